@@ -1,0 +1,178 @@
+"""Pins the oracle (oracle/affordance.py, oracle/densenet121.py) against vectors
+captured from the reference's own Python (tests/golden/reference_vectors.npz, made by
+oracle/make_golden.py).  CPU only.  Same torch CPU operators in the same order, so the
+expectation is bit-identical; a 1e-6 guard band is allowed for thread-count effects."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+import synthetic
+from oracle import affordance as orc
+
+MEAN, STD = 0.01, 0.03
+TOL = dict(rtol=2e-5, atol=2e-6)
+
+
+def crc(a):
+    return np.uint32(zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF)
+
+
+def probe_idx(n, k, tag):
+    return (synthetic.uniform(1234, "probe/" + tag, k) * n).astype(np.int64)
+
+
+def make_net(seed, out_ch=1, R=16):
+    net = orc.OracleNet(out_ch)
+    orc.load_numpy_state(net, synthetic.make_state_dict(orc.state_layout(out_ch), seed))
+    net.gnum_rotations = net.snum_rotations = R
+    net.train()
+    return net
+
+
+def scene_inputs(seed, mask_ids):
+    depth, masks = synthetic.heightmap_scene(seed)
+    m = sum(masks[i] for i in mask_ids)
+    return (orc.preprocess(depth, [MEAN] * 3, [STD] * 3),
+            orc.preprocess(depth * m, [MEAN] * 3, [STD] * 3))
+
+
+def test_state_layout_counts():
+    lay = orc.state_layout(1)
+    assert len(lay) == 2217                      # SURVEY.md section 5 (measured on the reference)
+    n_params = sum(int(np.prod(s)) for _, s, k in lay if k not in ("rm", "rv", "nbt"))
+    assert n_params == 24419256
+
+
+@pytest.mark.parametrize("size,R", [(640, 16), (1824, 32)])
+def test_g1_rotation_index_tables(golden, size, R):
+    for r in range(R):
+        idx = orc.rotation_index_map(r, R, size)
+        assert int((idx < 0).sum()) == int(golden["g1_oob_%d" % size][r])
+        assert crc(idx) == golden["g1_crc_%d" % size][r], "rotation %d" % r
+
+
+def test_g2_preprocess(golden):
+    depth, masks = synthetic.heightmap_scene(0)
+    rep = np.repeat(np.repeat(depth, 2, axis=0), 2, axis=1)
+    assert crc(rep) == golden["g2_zoom_crc"]     # ndimage.zoom(order=0, x2) == pixel replication
+    with np.errstate(all="ignore"):
+        lit = orc.preprocess(depth, [0.0] * 3, [0.0] * 3).numpy()
+    assert tuple(lit.shape) == tuple(golden["g2_literal_shape"])
+    assert int(np.isinf(lit).sum()) == int(golden["g2_literal_ninf"])
+    assert int(np.isnan(lit).sum()) == int(golden["g2_literal_nnan"])
+    assert crc(np.isinf(lit).astype(np.uint8)) == golden["g2_literal_infmask_crc"]
+
+
+def test_g3_trunk_stages(golden):
+    net = make_net(0)
+    x, _ = scene_inputs(0, [0])
+    feats = net.grasp_depth_trunk.features
+    with torch.no_grad():
+        t = orc.rotate(x, 3, 16)
+        for name, mod in feats.named_children():
+            t = mod(t)
+            if "g3_%s_stats" % name in golden.files:
+                a = t.numpy().astype(np.float64).ravel()
+                st = np.asarray([a.mean(), np.sqrt((a * a).sum()), np.abs(a).max()])
+                np.testing.assert_allclose(st, golden["g3_%s_stats" % name], rtol=1e-5, atol=1e-7)
+                pi = probe_idx(a.size, 32, "g3/" + name)
+                np.testing.assert_allclose(t.numpy().ravel()[pi], golden["g3_%s_probe" % name], **TOL)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_g4_q_values(golden, seed):
+    net = make_net(seed)
+    x, mx = scene_inputs(seed, [seed % 8])
+    _, mx2 = scene_inputs(seed, [1, 2])
+    for style, rots in ((0, (0, 3, 9)), (1, (5,))):
+        for r in rots:
+            q = orc.forward(net, x, mx, style, True, r)
+            assert torch.is_tensor(q) and tuple(q.shape) == (1, 1, 1, 1)
+            np.testing.assert_allclose(float(q), golden["g4_s%d_q%d" % (seed, style)][r], **TOL)
+    q2 = orc.forward(net, x, mx2, 2, True, -1)
+    assert isinstance(q2, list) and len(q2) == 1
+    np.testing.assert_allclose(float(q2[0]), golden["g4_s%d_q2" % seed][0], **TOL)
+
+
+def test_g4_branches_and_g7_bn_buffers(golden):
+    net = make_net(0)
+    x, mx = scene_inputs(0, [0])
+    qb = orc.forward(net, x, mx, 0, True, 5)
+    np.testing.assert_allclose(float(qb), golden["g4_branchB_style0_rot5"], **TOL)
+    np.testing.assert_allclose(float(qb), golden["g4_s0_q0"][5], **TOL)   # sweep element == branch B
+    qb1 = orc.forward(net, x, mx, 1, True, 7)
+    np.testing.assert_allclose(float(qb1), golden["g4_branchB_style1_rot7"], **TOL)
+    sd = net.state_dict()
+    keys = sorted(k[3:-3] for k in golden.files if k.startswith("g7_") and k.endswith("_rm"))
+    assert keys
+    for key in keys:
+        np.testing.assert_allclose(sd[key + ".running_mean"].numpy(), golden["g7_%s_rm" % key], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(sd[key + ".running_var"].numpy(), golden["g7_%s_rv" % key], rtol=1e-5, atol=1e-7)
+        assert int(sd[key + ".num_batches_tracked"]) == int(golden["g7_%s_nbt" % key])
+
+
+def test_g5_g6_training_steps(golden):
+    net = make_net(0)
+    target = orc.clone_target(net)
+    opt = orc.make_adam(net)
+    x, mx = scene_inputs(0, [0])
+    names = [n for n, _ in net.named_parameters()]
+    assert names == [str(s) for s in golden["g5_param_names"]]
+    for si, (style, rot, label) in enumerate([(0, 3, 0.4), (1, 9, 7.5), (2, 0, -3.0)]):
+        opt.zero_grad()
+        q = orc.forward(net, x, mx, style, False, rot)
+        loss = orc.huber(q[0, 0, 0, 0], label).sum()
+        loss.backward()
+        np.testing.assert_allclose(float(q), golden["g5_step%d_q" % si], **TOL)
+        np.testing.assert_allclose(float(loss), golden["g5_step%d_loss" % si], **TOL)
+        has = np.asarray([p.grad is not None for p in net.parameters()])
+        assert (has == golden["g5_step%d_hasgrad" % si]).all()
+        gn = np.asarray([float(p.grad.double().norm()) if p.grad is not None else 0.0 for p in net.parameters()])
+        np.testing.assert_allclose(gn, golden["g5_step%d_gradnorm" % si], rtol=1e-4, atol=1e-9)
+        params = dict(net.named_parameters())
+        pre = "g5_step%d_grad_" % si
+        for k in [k for k in golden.files if k.startswith(pre)]:
+            p = params[k[len(pre):]]
+            pi = probe_idx(p.numel(), 16, "g5/" + k[len(pre):])
+            np.testing.assert_allclose(p.grad.numpy().ravel()[pi], golden[k], rtol=1e-4, atol=1e-9)
+        opt.step()
+        pre = "g6_step%d_param_" % si
+        for k in [k for k in golden.files if k.startswith(pre)]:
+            p = params[k[len(pre):]]
+            pi = probe_idx(p.numel(), 16, "g6/" + k[len(pre):])
+            np.testing.assert_allclose(p.detach().numpy().ravel()[pi], golden[k], rtol=1e-6, atol=1e-9)
+    qt = orc.forward(target, x, mx, 0, True, 3)
+    qm = orc.forward(net, x, mx, 0, True, 3)
+    np.testing.assert_allclose(float(qt), golden["g4_target_rot3"], **TOL)
+    np.testing.assert_allclose(float(qm), golden["g4_model_after3_rot3"], rtol=1e-4, atol=1e-5)
+    assert abs(float(qt) - float(qm)) > 1e-4     # the two nets really have diverged
+
+
+def test_g8_reactive(golden):
+    net = make_net(0, out_ch=3, R=1)
+    x, mx = scene_inputs(0, [0])
+    out = orc.forward(net, x, mx, 0, True, -1)
+    np.testing.assert_allclose(out[0].numpy().ravel(), golden["g8_logits"], **TOL)
+    sm = torch.softmax(out[0].view(1, 3, 1, 1), 1).numpy()[0, 0, 0, 0]
+    np.testing.assert_allclose(sm, golden["g8_softmax0"], **TOL)
+    opt = orc.make_adam(net)
+    opt.zero_grad()
+    q = orc.forward(net, x, mx, 0, False, 0)
+    loss = orc.reactive_loss(q, 1)
+    loss.backward()
+    np.testing.assert_allclose(float(loss), golden["g8_loss"], **TOL)
+    gn = np.asarray([float(p.grad.double().norm()) if p.grad is not None else 0.0 for p in net.parameters()])
+    np.testing.assert_allclose(gn, golden["g8_gradnorm"], rtol=1e-4, atol=1e-9)
+
+
+def test_label_value_known_answers():
+    # code/trainer.py:238-274 reward arithmetic
+    assert orc.label_value("reinforcement", "grasp", 3, 0, 1, 0, 0.8, 0.5) == (1 + 0.5 * 0.8, 1)
+    assert orc.label_value("reinforcement", "grasp", 3, 0, 0, 0, 0.8, 0.5) == (0, 0)
+    assert orc.label_value("reinforcement", "suction", 1, 1, 0, 0, 0.8, 0.5) == (1, 1)
+    assert orc.label_value("reinforcement", "grasp_then_suction", 2, 0, 0, 2.5, 0.8, 0.5) == (2.5, 2.5)
+    assert orc.label_value("reinforcement", "grasp_then_suction", 3, 0, 0, 0.5, 0.8, 0.5) == (0.5 + 0.4, 0.5)
+    assert orc.label_value("reactive", "grasp", 3, 0, 0, 0, 0, 0.5) == (1, 0)
+    assert orc.label_value("reactive", "grasp_then_suction", 3, 0, 0, 2.5, 0, 0.5) == (0, 2.5)
