@@ -1,0 +1,575 @@
+// elem.cuh - the HBM-bound kernels around the MFMA convolutions: input
+// preparation (zoom/pad/normalise/rotate gather), weight repacking, max-pool forward
+// and backward, head feature assembly (norm5 + two-stream concat), the 20x20 value
+// convolution and its backward, losses, BN running-statistics update, Adam.
+#pragma once
+#include "gemm.cuh"
+
+namespace smg {
+
+// ------------------------------------------------------------------------------------
+// K1: fused Trainer.forward preprocessing (code/trainer.py:165-191) + per-stream
+// rotation (code/models.py:372-382) -> NHWC4 image (4th channel zero).
+//
+// The sampling arithmetic restates torch's CPU operators bit for bit (pinned by
+// golden vector G1): linspace(-1,1,S)[i] = fma(step, i, -1) for i < S/2 else
+// fma(-step, S-1-i, 1); affine_grid = fma(y, a01, x*a00) + a02; grid_sample nearest,
+// align_corners=True: rint(((g+1)/2)*(S-1)), zero outside [0, S-1].
+// ------------------------------------------------------------------------------------
+struct PrepArgs {
+    const float* images_nchw;   // [n_images][3][S][S] or null
+    const double* heightmaps;   // [n_images][hm][hm] or null
+    int hm, pad, S;
+    double mean, stdv;
+    const int* stream_image;
+    const float* stream_affine;
+    const int* stream_rotated;
+    float* img4;                // [streams][HWp][4]
+    int HWp;
+};
+
+__device__ __forceinline__ float lin_coord(int i, int S, float step) {
+    return (i < S / 2) ? fmaf(step, (float)i, -1.f) : fmaf(-step, (float)(S - 1 - i), 1.f);
+}
+
+__global__ void prep_rotate_kernel(const PrepArgs a) {
+    const int s = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int S = a.S;
+    if (p >= S * S) return;
+    const int y = p / S, x = p - y * S;
+    int sx = x, sy = y;
+    bool inside = true;
+    if (a.stream_rotated[s]) {
+        const float* th = a.stream_affine + 6 * s;
+        const float step = 2.0f / (float)(S - 1);
+        const float lx = lin_coord(x, S, step), ly = lin_coord(y, S, step);
+        const float gx = fmaf(ly, th[1], __fmul_rn(lx, th[0])) + th[2];
+        const float gy = fmaf(ly, th[4], __fmul_rn(lx, th[3])) + th[5];
+        const float fx = rintf(__fmul_rn(__fdiv_rn(__fadd_rn(gx, 1.f), 2.f), (float)(S - 1)));
+        const float fy = rintf(__fmul_rn(__fdiv_rn(__fadd_rn(gy, 1.f), 2.f), (float)(S - 1)));
+        inside = fx >= 0.f && fx <= (float)(S - 1) && fy >= 0.f && fy <= (float)(S - 1);
+        sx = (int)fx;
+        sy = (int)fy;
+    }
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (inside) {
+        const int img = a.stream_image[s];
+        if (a.images_nchw) {
+            const float* b = a.images_nchw + (int64_t)img * 3 * S * S + (int64_t)sy * S + sx;
+            out.x = b[0];
+            out.y = b[(int64_t)S * S];
+            out.z = b[(int64_t)2 * S * S];
+        } else {
+            const int hy = sy - a.pad, hx = sx - a.pad;
+            double v = 0.0;
+            if (hy >= 0 && hx >= 0 && hy < 2 * a.hm && hx < 2 * a.hm)
+                v = a.heightmaps[(int64_t)img * a.hm * a.hm + (hy >> 1) * a.hm + (hx >> 1)];
+            const float f = (float)((v - a.mean) / a.stdv);
+            out.x = out.y = out.z = f;
+        }
+    }
+    *reinterpret_cast<float4*>(a.img4 + ((int64_t)s * a.HWp + p) * 4) = out;
+}
+
+// ------------------------------------------------------------------------------------
+// Weight repack: reference layout [cout][cin][kh][kw] -> the K-major layouts the GEMM
+// B operand streams.  One launch for a whole trunk + head through a descriptor table.
+// ------------------------------------------------------------------------------------
+enum { PK_T1 = 0, PK_3F = 1, PK_3D = 2, PK_STEM = 3, PK_HEAD = 4 };
+struct PackDesc { int64_t src, dst; int cout, cin, mode, count; };
+
+__global__ void pack_weights_kernel(const PackDesc* descs, const float* params, float* packed) {
+    const PackDesc d = descs[blockIdx.y];
+    const float* s = params + d.src;
+    float* o = packed + d.dst;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.count; i += gridDim.x * blockDim.x) {
+        float v;
+        if (d.mode == PK_T1) {                 // dst[k][n] = src[n][k]
+            const int k = i / d.cout, n = i - k * d.cout;
+            v = s[(int64_t)n * d.cin + k];
+        } else if (d.mode == PK_3F) {          // dst[(tap*cin + c)][n] = src[n][c][tap]
+            const int r = i / d.cout, n = i - r * d.cout;
+            const int tap = r / d.cin, c = r - tap * d.cin;
+            v = s[((int64_t)n * d.cin + c) * 9 + tap];
+        } else if (d.mode == PK_3D) {          // dst[(tap*cout + n)][c] = src[n][c][tap]
+            const int r = i / d.cin, c = i - r * d.cin;
+            const int tap = r / d.cout, n = r - tap * d.cout;
+            v = s[((int64_t)n * d.cin + c) * 9 + tap];
+        } else if (d.mode == PK_STEM) {        // dst[(tap*4 + c)][n] (K padded to 224) = src[n][c][tap]
+            const int r = i / 64, n = i - r * 64;
+            const int tap = r >> 2, c = r & 3;
+            v = (c < 3 && tap < 49) ? s[((int64_t)n * 3 + c) * 49 + tap] : 0.f;
+        } else {                               // PK_HEAD: dst[o][tap][c] = src[o][c][tap]
+            const int taps = 400;
+            const int o_ = i / (taps * d.cin), r = i - o_ * taps * d.cin;
+            const int tap = r / d.cin, c = r - tap * d.cin;
+            v = s[((int64_t)o_ * d.cin + c) * taps + tap];
+        }
+        o[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// pool0: BN(norm0)+ReLU+MaxPool(3,2,1) of the stem output -> channels 0..63 of the
+// block-1 buffer, + their per-stream statistics, + argmax (for the backward).
+// Workgroup = 64 pooled pixels x 64 channels; thread = (channel quad, pixel slot).
+// ------------------------------------------------------------------------------------
+struct Pool0Args {
+    const float* stem; Plane ps;           // [n][HWp][64]
+    const double* ssum; const double* ssq;  // [n][64]
+    const float* gamma; const float* beta; float eps;
+    float* x1; int ldx; Plane po;
+    double* dsum; double* dsq; int dstride;
+    unsigned char* argmax;                  // [n][po.HWp][64]
+};
+
+__global__ __launch_bounds__(256) void pool0_kernel(const Pool0Args a) {
+    __shared__ float prm[128];
+    __shared__ float red[2][16][64];
+    const int n = blockIdx.y, t = threadIdx.x, cq = t & 15, slot = t >> 4;
+    if (t < 64) {
+        float mean, invstd;
+        bn_moments(a.ssum, a.ssq, (int64_t)n * 64 + t, 1.0 / (double)a.ps.HW, a.eps, mean, invstd);
+        const float sc = a.gamma[t] * invstd;
+        prm[t] = sc;
+        prm[64 + t] = a.beta[t] - mean * sc;
+    }
+    __syncthreads();
+    const float* sc = prm + 4 * cq;
+    const float* sh = prm + 64 + 4 * cq;
+    float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+        const int p = blockIdx.x * 64 + slot + 16 * i;
+        if (p >= a.po.HW) continue;
+        const int y = p / a.po.W, x = p - y * a.po.W;
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 9; ++k) {
+            const int yy = 2 * y - 1 + k / 3, xx = 2 * x - 1 + k % 3;
+            if ((unsigned)yy >= (unsigned)a.ps.H || (unsigned)xx >= (unsigned)a.ps.W) continue;
+            const float4 v = bnrelu4(ld4(a.stem + ((int64_t)n * a.ps.HWp + yy * a.ps.W + xx) * 64 + 4 * cq), sc, sh);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (vv[c] > best[c]) { best[c] = vv[c]; bi[c] = k; }
+        }
+        const int64_t o = (int64_t)n * a.po.HWp + p;
+        *reinterpret_cast<float4*>(a.x1 + o * a.ldx + 4 * cq) = make_float4(best[0], best[1], best[2], best[3]);
+        if (a.argmax) *reinterpret_cast<uchar4*>(a.argmax + o * 64 + 4 * cq) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { s[c] += best[c]; ss[c] += best[c] * best[c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { red[0][slot][4 * cq + c] = s[c]; red[1][slot][4 * cq + c] = ss[c]; }
+    __syncthreads();
+    if (t < 128) {
+        const int q = t >> 6, c = t & 63;
+        float tot = 0.f;
+        for (int k = 0; k < 16; ++k) tot += red[q][k][c];
+        atomicAdd((q ? a.dsq : a.dsum) + (int64_t)n * a.dstride + c, (double)tot);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Head feature assembly: F[pair] = concat(norm5(X4[a]), norm5(X4[b]))  (no ReLU after
+// norm5 - the reference calls .features directly, code/models.py:384-386) and the
+// per-(pair, channel) statistics the head's norm0 needs.
+// ------------------------------------------------------------------------------------
+struct FeatArgs {
+    const float* x4; Plane p4;              // [n][HWp][1024]
+    const double* xsum; const double* xsq;  // [n][1024]
+    const float* gamma; const float* beta; float eps;   // norm5
+    const int* pair_a; const int* pair_b;
+    float* F;                               // [pair][HWp][2048]
+    double* fsum; double* fsq;              // [pair][2048]
+    int chunk;
+};
+
+__global__ __launch_bounds__(256) void feat_kernel(const FeatArgs a) {
+    const int j = blockIdx.y, cq = blockIdx.x * 256 + threadIdx.x;   // channel quad of 2048/4
+    const int ch = 4 * cq, slot = ch >> 10, c5 = ch & 1023;
+    const int s = slot ? a.pair_b[j] : a.pair_a[j];
+    float sc[4], sh[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float mean, invstd;
+        bn_moments(a.xsum, a.xsq, (int64_t)s * 1024 + c5 + c, 1.0 / (double)a.p4.HW, a.eps, mean, invstd);
+        sc[c] = a.gamma[c5 + c] * invstd;
+        sh[c] = a.beta[c5 + c] - mean * sc[c];
+    }
+    float sm[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+    const int p0 = blockIdx.z * a.chunk;
+    const int p1 = min(p0 + a.chunk, a.p4.HW);
+    for (int p = p0; p < p1; ++p) {
+        const float4 v = ld4(a.x4 + ((int64_t)s * a.p4.HWp + p) * 1024 + c5);
+        float4 o;
+        o.x = fmaf(v.x, sc[0], sh[0]); o.y = fmaf(v.y, sc[1], sh[1]);
+        o.z = fmaf(v.z, sc[2], sh[2]); o.w = fmaf(v.w, sc[3], sh[3]);
+        *reinterpret_cast<float4*>(a.F + ((int64_t)j * a.p4.HWp + p) * 2048 + ch) = o;
+        sm[0] += o.x; sm[1] += o.y; sm[2] += o.z; sm[3] += o.w;
+        sq[0] += o.x * o.x; sq[1] += o.y * o.y; sq[2] += o.z * o.z; sq[3] += o.w * o.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        atomicAdd(a.fsum + (int64_t)j * 2048 + ch + c, (double)sm[c]);
+        atomicAdd(a.fsq + (int64_t)j * 2048 + ch + c, (double)sq[c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Value convolution: 20x20 valid conv over BN+ReLU(H1) (code/models.py:322,332).
+// One workgroup per output element; fixed summation order -> reproducible argmax.
+// ------------------------------------------------------------------------------------
+struct ValueArgs {
+    const float* h1; Plane p4;               // [pair][HWp][64]
+    const double* hsum; const double* hsq;   // [pair][64]
+    const float* gamma; const float* beta; float eps;
+    const float* w2p;                        // packed [out][400][64]
+    float* q; int out_ch, OH, OW;
+};
+
+__global__ __launch_bounds__(256) void value_conv_kernel(const ValueArgs a) {
+    __shared__ float prm[128];
+    __shared__ float red[256];
+    const int t = threadIdx.x, cq = t & 15, slot = t >> 4;
+    int id = blockIdx.x;
+    const int ox = id % a.OW; id /= a.OW;
+    const int oy = id % a.OH; id /= a.OH;
+    const int o = id % a.out_ch;
+    const int j = id / a.out_ch;
+    if (t < 64) {
+        float mean, invstd;
+        bn_moments(a.hsum, a.hsq, (int64_t)j * 64 + t, 1.0 / (double)a.p4.HW, a.eps, mean, invstd);
+        const float sc = a.gamma[t] * invstd;
+        prm[t] = sc;
+        prm[64 + t] = a.beta[t] - mean * sc;
+    }
+    __syncthreads();
+    float acc = 0.f;
+    for (int tap = slot; tap < 400; tap += 16) {
+        const int pix = (oy + tap / 20) * a.p4.W + ox + tap % 20;
+        const float4 v = bnrelu4(ld4(a.h1 + ((int64_t)j * a.p4.HWp + pix) * 64 + 4 * cq), prm + 4 * cq, prm + 64 + 4 * cq);
+        const float4 w = ld4(a.w2p + ((int64_t)o * 400 + tap) * 64 + 4 * cq);
+        acc = fmaf(v.x, w.x, acc); acc = fmaf(v.y, w.y, acc); acc = fmaf(v.z, w.z, acc); acc = fmaf(v.w, w.w, acc);
+    }
+    red[t] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        __syncthreads();
+    }
+    if (t == 0) a.q[blockIdx.x] = red[0];
+}
+
+// Backward of the value convolution + ReLU + BN(norm1) statistics:
+//   dact[p][c] = sum_{o,oy,ox} dq[o][oy][ox] * W[o][c][py-oy][px-ox]
+//   dy = dact * [BN(h1) > 0] -> DH1 ; sums of dy, dy*xhat per (pair, c);
+//   dW[o][c][tap] += dq * act.
+struct ValueBwdArgs {
+    const float* h1; Plane p4;
+    const double* hsum; const double* hsq;
+    const float* gamma; const float* beta; float eps;
+    const float* w2p;                         // packed [out][400][64]
+    const float* dq; int out_ch, OH, OW;
+    float* dh1;                               // [pair][HWp][64]
+    double* o1; double* o2;                   // [pair][64]
+    float* dbeta; float* dgamma;              // norm1 grads
+    float* dw2;                               // native [out][64][20][20]
+};
+
+__global__ __launch_bounds__(256) void value_bwd_kernel(const ValueBwdArgs a) {
+    __shared__ float prm[256];
+    __shared__ float red[2][16][64];
+    const int j = blockIdx.y, t = threadIdx.x, cq = t & 15, slot = t >> 4;
+    if (t < 64) {
+        float mean, invstd;
+        bn_moments(a.hsum, a.hsq, (int64_t)j * 64 + t, 1.0 / (double)a.p4.HW, a.eps, mean, invstd);
+        const float sc = a.gamma[t] * invstd;
+        prm[t] = sc; prm[64 + t] = a.beta[t] - mean * sc; prm[128 + t] = mean; prm[192 + t] = invstd;
+    }
+    __syncthreads();
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+        const int p = blockIdx.x * 64 + slot + 16 * i;
+        if (p >= a.p4.HW) continue;
+        const int py = p / a.p4.W, px = p - py * a.p4.W;
+        const int64_t row = (int64_t)j * a.p4.HWp + p;
+        const float4 hv = ld4(a.h1 + row * 64 + 4 * cq);
+        const float h[4] = {hv.x, hv.y, hv.z, hv.w};
+        float act[4], dact[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) act[c] = fmaxf(fmaf(h[c], prm[4 * cq + c], prm[64 + 4 * cq + c]), 0.f);
+        for (int o = 0; o < a.out_ch; ++o)
+            for (int oy = max(0, py - 19); oy <= min(py, a.OH - 1); ++oy)
+                for (int ox = max(0, px - 19); ox <= min(px, a.OW - 1); ++ox) {
+                    const float g = a.dq[(((int64_t)j * a.out_ch + o) * a.OH + oy) * a.OW + ox];
+                    if (g == 0.f) continue;
+                    const int tap = (py - oy) * 20 + (px - ox);
+                    const float4 w = ld4(a.w2p + ((int64_t)o * 400 + tap) * 64 + 4 * cq);
+                    dact[0] = fmaf(g, w.x, dact[0]); dact[1] = fmaf(g, w.y, dact[1]);
+                    dact[2] = fmaf(g, w.z, dact[2]); dact[3] = fmaf(g, w.w, dact[3]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        atomicAdd(a.dw2 + ((int64_t)o * 64 + 4 * cq + c) * 400 + tap, g * act[c]);
+                }
+        float dy[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            dy[c] = act[c] > 0.f ? dact[c] : 0.f;
+            s1[c] += dy[c];
+            s2[c] += dy[c] * ((h[c] - prm[128 + 4 * cq + c]) * prm[192 + 4 * cq + c]);
+        }
+        *reinterpret_cast<float4*>(a.dh1 + row * 64 + 4 * cq) = make_float4(dy[0], dy[1], dy[2], dy[3]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { red[0][slot][4 * cq + c] = s1[c]; red[1][slot][4 * cq + c] = s2[c]; }
+    __syncthreads();
+    if (t < 128) {
+        const int q = t >> 6, c = t & 63;
+        float tot = 0.f;
+        for (int k = 0; k < 16; ++k) tot += red[q][k][c];
+        atomicAdd((q ? a.o2 : a.o1) + (int64_t)j * 64 + c, (double)tot);
+        atomicAdd((q ? a.dgamma : a.dbeta) + c, tot);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// norm5 backward (no ReLU) fused with the head's norm0 backward and the two-stream
+// concat backward: for stream s, sum over every (pair, slot) that consumed its
+// features the BN-corrected gradient of F, then start the block-4 gradient buffer:
+//   G'_4[s] = gamma5 * dy5,  SA/SB += gamma5 * sums,  dbeta5/dgamma5 += sums.
+// ------------------------------------------------------------------------------------
+struct Norm5BwdArgs {
+    const float* DF; const float* F; Plane p4;      // [pair][HWp][2048]
+    const double* fsum; const double* fsq;          // F statistics [pair][2048]
+    const double* f1; const double* f2;             // sums of dy0, dy0*xhat [pair][2048]
+    const float* hgamma;                            // head norm0 gamma [2048]
+    const float* x4; const double* xsum; const double* xsq;   // [n][HWp][1024], [n][1024]
+    const float* gamma5; float eps;
+    const int* user_ptr; const int* user_pair; const int* user_slot;  // CSR over streams
+    float* G4;                                      // [n][HWp][1024]
+    double* SA; double* SB;                         // [n][1024]
+    float* dbeta5; float* dgamma5;
+    int chunk;
+};
+
+__global__ __launch_bounds__(256) void norm5_bwd_kernel(const Norm5BwdArgs a) {
+    const int s = blockIdx.y, c5 = 4 * threadIdx.x;      // 256 threads x 4 = 1024 channels
+    const int p0 = blockIdx.z * a.chunk, p1 = min(p0 + a.chunk, a.p4.HW);
+    const double inv = 1.0 / (double)a.p4.HW;
+    float mean5[4], inv5[4], g5[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bn_moments(a.xsum, a.xsq, (int64_t)s * 1024 + c5 + c, inv, a.eps, mean5[c], inv5[c]);
+        g5[c] = a.gamma5[c5 + c];
+    }
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    const int u0 = a.user_ptr[s], u1 = a.user_ptr[s + 1];
+    if (u0 == u1) {
+        for (int p = p0; p < p1; ++p)
+            *reinterpret_cast<float4*>(a.G4 + ((int64_t)s * a.p4.HWp + p) * 1024 + c5) = zero4();
+        return;
+    }
+    for (int u = u0; u < u1; ++u) {
+        const int j = a.user_pair[u], ch = a.user_slot[u] * 1024 + c5;
+        float ca[4], cb[4], cc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float mean, invstd;
+            bn_moments(a.fsum, a.fsq, (int64_t)j * 2048 + ch + c, inv, a.eps, mean, invstd);
+            const float q1 = (float)(a.f1[(int64_t)j * 2048 + ch + c] * inv);
+            const float q2 = (float)(a.f2[(int64_t)j * 2048 + ch + c] * inv);
+            const float gi = a.hgamma[ch + c] * invstd;
+            ca[c] = gi; cb[c] = -gi * invstd * q2; cc[c] = -gi * q1 + gi * invstd * q2 * mean;
+        }
+        for (int p = p0; p < p1; ++p) {
+            const int64_t fr = ((int64_t)j * a.p4.HWp + p) * 2048 + ch;
+            const float4 d = affine2(ld4(a.DF + fr), ld4(a.F + fr), ca, cb, cc);
+            const int64_t xr = ((int64_t)s * a.p4.HWp + p) * 1024 + c5;
+            const float4 xv = ld4(a.x4 + xr);
+            const float dd[4] = {d.x, d.y, d.z, d.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
+            float4 g = (u == u0) ? zero4() : ld4(a.G4 + xr);
+            g.x += g5[0] * dd[0]; g.y += g5[1] * dd[1]; g.z += g5[2] * dd[2]; g.w += g5[3] * dd[3];
+            *reinterpret_cast<float4*>(a.G4 + xr) = g;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { s1[c] += dd[c]; s2[c] += dd[c] * ((xx[c] - mean5[c]) * inv5[c]); }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        atomicAdd(a.SA + (int64_t)s * 1024 + c5 + c, (double)(g5[c] * s1[c]));
+        atomicAdd(a.SB + (int64_t)s * 1024 + c5 + c, (double)(g5[c] * s2[c]));
+        atomicAdd(a.dbeta5 + c5 + c, s1[c]);
+        atomicAdd(a.dgamma5 + c5 + c, s2[c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// pool0 + relu0 backward: route the (BN-corrected) gradient of block-1 channels 0..63
+// back through the 3x3/stride-2 max pool to the stem output, apply the ReLU mask of
+// norm0, and collect norm0's backward sums.  Gather form: each stem pixel looks at
+// the <= 4 pooled windows covering it and takes those whose argmax points at it.
+// ------------------------------------------------------------------------------------
+struct Pool0BwdArgs {
+    const float* G1; const float* X1; int ld1; Plane p1;     // block-1 buffers
+    const double* xsum; const double* xsq; int xstride;      // block-1 stats
+    const double* SA; const double* SB; int sstride;
+    const unsigned char* argmax;                             // [n][p1.HWp][64]
+    const float* stem; Plane ps;                             // raw stem output [n][HWp][64]
+    const double* ssum; const double* ssq;                   // [n][64]
+    const float* gamma; const float* beta; float eps;        // norm0
+    float* DY0;                                              // [n][ps.HWp][64]
+    double* o1; double* o2;                                  // [n][64]
+    float* dbeta; float* dgamma;
+};
+
+__global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArgs a) {
+    __shared__ float prm[7 * 64];
+    __shared__ float red[2][16][64];
+    const int n = blockIdx.y, t = threadIdx.x, cq = t & 15, slot = t >> 4;
+    if (t < 64) {
+        float mean, invstd;
+        bn_moments(a.ssum, a.ssq, (int64_t)n * 64 + t, 1.0 / (double)a.ps.HW, a.eps, mean, invstd);
+        const float sc = a.gamma[t] * invstd;
+        prm[t] = sc; prm[64 + t] = a.beta[t] - mean * sc; prm[128 + t] = mean; prm[192 + t] = invstd;
+        const double inv = 1.0 / (double)a.p1.HW;
+        float m1, i1;
+        bn_moments(a.xsum, a.xsq, (int64_t)n * a.xstride + t, inv, a.eps, m1, i1);
+        const float q1 = (float)(a.SA[(int64_t)n * a.sstride + t] * inv);
+        const float q2 = (float)(a.SB[(int64_t)n * a.sstride + t] * inv);
+        prm[256 + t] = i1; prm[320 + t] = -i1 * i1 * q2; prm[384 + t] = -i1 * q1 + i1 * i1 * q2 * m1;
+    }
+    __syncthreads();
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+        const int p = blockIdx.x * 64 + slot + 16 * i;
+        if (p >= a.ps.HW) continue;
+        const int y = p / a.ps.W, x = p - y * a.ps.W;
+        float g[4] = {0, 0, 0, 0};
+        const int py0 = y >> 1, py1 = (y + 1) >> 1, px0 = x >> 1, px1 = (x + 1) >> 1;
+        for (int wy = py0; wy <= py1; ++wy)
+            for (int wx = px0; wx <= px1; ++wx) {
+                if (wy >= a.p1.H || wx >= a.p1.W) continue;
+                const int k = (y - (2 * wy - 1)) * 3 + (x - (2 * wx - 1));   // my index inside that window
+                const int64_t pr = (int64_t)n * a.p1.HWp + wy * a.p1.W + wx;
+                const uchar4 am = *reinterpret_cast<const uchar4*>(a.argmax + pr * 64 + 4 * cq);
+                const int amv[4] = {am.x, am.y, am.z, am.w};
+                if (amv[0] != k && amv[1] != k && amv[2] != k && amv[3] != k) continue;
+                const float4 gv = affine2(ld4(a.G1 + pr * a.ld1 + 4 * cq), ld4(a.X1 + pr * a.ld1 + 4 * cq),
+                                          prm + 256 + 4 * cq, prm + 320 + 4 * cq, prm + 384 + 4 * cq);
+                const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (amv[c] == k) g[c] += gg[c];
+            }
+        const int64_t row = (int64_t)n * a.ps.HWp + p;
+        const float4 sv = ld4(a.stem + row * 64 + 4 * cq);
+        const float st[4] = {sv.x, sv.y, sv.z, sv.w};
+        float dy[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            dy[c] = fmaf(st[c], prm[4 * cq + c], prm[64 + 4 * cq + c]) > 0.f ? g[c] : 0.f;
+            s1[c] += dy[c];
+            s2[c] += dy[c] * ((st[c] - prm[128 + 4 * cq + c]) * prm[192 + 4 * cq + c]);
+        }
+        *reinterpret_cast<float4*>(a.DY0 + row * 64 + 4 * cq) = make_float4(dy[0], dy[1], dy[2], dy[3]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { red[0][slot][4 * cq + c] = s1[c]; red[1][slot][4 * cq + c] = s2[c]; }
+    __syncthreads();
+    if (t < 128) {
+        const int q = t >> 6, c = t & 63;
+        float tot = 0.f;
+        for (int k = 0; k < 16; ++k) tot += red[q][k][c];
+        atomicAdd((q ? a.o2 : a.o1) + (int64_t)n * 64 + c, (double)tot);
+        atomicAdd((q ? a.dgamma : a.dbeta) + c, tot);
+    }
+}
+
+// Zero the rows/columns of a gradient plane that an odd-sized 2x2/stride-2 average
+// pool never reads (they receive no gradient from the transition).
+__global__ void zero_uncovered_kernel(float* G, int ld, Plane p, int Hc, int Wc, int C) {
+    const int n = blockIdx.y;
+    const int64_t total = (int64_t)p.HW * (C / 4);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int pix = (int)(i / (C / 4)), cq = (int)(i - (int64_t)pix * (C / 4));
+        const int y = pix / p.W, x = pix - y * p.W;
+        if (y >= Hc || x >= Wc) *reinterpret_cast<float4*>(G + ((int64_t)n * p.HWp + pix) * ld + 4 * cq) = zero4();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Losses (code/trainer.py:345-348 Huber on element [0,0,0,0]; :296-299 +
+// code/utils.py:306-313 class-weighted cross entropy, weights {1,1,0}).
+// ------------------------------------------------------------------------------------
+__global__ void loss_kernel(int mode, const float* q, const float* labels, int n_pairs, int per_pair,
+                            float* loss, float* dq) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_pairs) return;
+    const float* qj = q + (int64_t)j * per_pair;
+    float* dj = dq + (int64_t)j * per_pair;
+    for (int i = 0; i < per_pair; ++i) dj[i] = 0.f;
+    if (mode == 0) {
+        const float d = qj[0] - labels[j];
+        if (fabsf(d) < 1.f) { loss[j] = 0.5f * (d * d); dj[0] = d; }
+        else { loss[j] = fabsf(d) - 0.5f; dj[0] = d > 0.f ? 1.f : -1.f; }
+    } else {
+        const int y = (int)labels[j];
+        const float m = fmaxf(qj[0], fmaxf(qj[1], qj[2]));
+        const float e0 = expf(qj[0] - m), e1 = expf(qj[1] - m), e2 = expf(qj[2] - m);
+        const float se = e0 + e1 + e2, lse = logf(se) + m;
+        const float wy = (y == 2) ? 0.f : 1.f;
+        loss[j] = wy * (lse - qj[y]) / wy;          // size_average: weighted mean over 1 element
+        const float sm[3] = {e0 / se, e1 / se, e2 / se};
+        for (int c = 0; c < 3; ++c) dj[c] = wy * (sm[c] - (c == y ? 1.f : 0.f)) / wy;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// BN running statistics: momentum 0.1, unbiased variance,
+// one update per entry of the reference-order sequence, num_batches_tracked += len.
+// ------------------------------------------------------------------------------------
+struct BnUpdDesc { int64_t rm, rv, nbt; int64_t stat_off; int stride, coff, C, count, head; };
+
+__global__ void bn_update_kernel(const BnUpdDesc* descs, const double* stats_sum, const double* stats_sq,
+                                 float* bufs, int64_t* nbt, const int* seq_trunk, int n_trunk,
+                                 const int* seq_head, int n_head) {
+    const BnUpdDesc d = descs[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int* seq = d.head ? seq_head : seq_trunk;
+    const int ns = d.head ? n_head : n_trunk;
+    if (c == 0 && ns > 0) nbt[d.nbt] += ns;
+    if (c >= d.C || ns == 0) return;
+    double rm = bufs[d.rm + c], rv = bufs[d.rv + c];
+    const double inv = 1.0 / (double)d.count;
+    for (int i = 0; i < ns; ++i) {
+        const int64_t idx = d.stat_off + (int64_t)seq[i] * d.stride + d.coff + c;
+        const double m = stats_sum[idx] * inv;
+        double var = stats_sq[idx] * inv - m * m;
+        var = var < 0 ? 0 : var;
+        const double unb = var * (double)d.count / (double)(d.count - 1);
+        rm = (double)(float)(0.1 * m + 0.9 * rm);
+        rv = (double)(float)(0.1 * unb + 0.9 * rv);
+    }
+    bufs[d.rm + c] = (float)rm;
+    bufs[d.rv + c] = (float)rv;
+}
+
+// ------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam, no amsgrad, no weight decay).
+// ------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                            float eps, float bc1, float bc2_sqrt) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);           // torch: exp_avg.lerp_(grad, 1-beta1)
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;           // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - (lr / bc1) * (mi / denom);
+    }
+}
+
+}  // namespace smg

@@ -1,0 +1,783 @@
+// engine.hip - host side of the MI355X affordance engine: workspace ownership, the
+// walk over DenseNet-121 (forward and backward) and the C ABI of include/smg_hip.h.
+//
+// Replaces, for one (trunk, head) of the reference model:
+//   reinforcement_net.forward / reactive_net.forward   code/models.py:361-586, :72-296
+//   loss.backward() of Trainer.backprop                code/trainer.py:350-351
+//   torch.optim.Adam.step                              code/trainer.py:383
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/smg_hip.h"
+#include "elem.cuh"
+#include "gemm.cuh"
+#include "plan.h"
+
+using namespace smg;
+
+// ------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_OK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail(-5, std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+    } while (0)
+
+static const Layout& layout_for(int head_out) {
+    static Layout L1 = build_layout(1);
+    static Layout L3 = build_layout(3);
+    return head_out == 3 ? L3 : L1;
+}
+
+// ------------------------------------------------------------------------------------
+// GEMM tile configurations (BM, BN, BK, waves M x N, A pixel-major?)
+// ------------------------------------------------------------------------------------
+using CfgP128x128 = GemmCfg<128, 128, 16, 2, 2, true>;    // 1x1 fwd, transitions, 3x3 dgrad
+using CfgP128x32 = GemmCfg<128, 32, 32, 4, 1, true>;      // 3x3 fwd (N = growth 32)
+using CfgP128x64 = GemmCfg<128, 64, 16, 2, 2, true>;      // stem, head conv0, 1x1 dgrad
+using CfgW32x128 = GemmCfg<32, 128, 32, 1, 4, false>;     // 3x3 wgrad (32 x 128 per tap)
+using CfgW128x64 = GemmCfg<128, 64, 16, 2, 2, false>;     // 1x1 wgrad (128 x cin)
+using CfgW128x128 = GemmCfg<128, 128, 16, 2, 2, false>;   // transition wgrad
+using CfgW64x64 = GemmCfg<64, 64, 16, 2, 2, false>;       // stem / head conv0 wgrad
+
+enum Kind {
+    K_STEM = 0, K_C1, K_C3, K_TRANS, K_HEAD0, K_D3, K_W3, K_D1, K_W1, K_TW, K_TD, K_SW, K_HW0, K_HD0, K_OTHER, K_COUNT
+};
+static const char* kKindNames[K_COUNT] = {"stem7x7_fwd", "conv1x1_fwd", "conv3x3_fwd", "transition_fwd", "head_conv0_fwd",
+                                          "conv3x3_dgrad", "conv3x3_wgrad", "conv1x1_dgrad", "conv1x1_wgrad",
+                                          "transition_wgrad", "transition_dgrad", "stem_wgrad", "head_conv0_wgrad",
+                                          "head_conv0_dgrad", "elementwise"};
+
+struct ProfRec { hipEvent_t a, b; int kind; double flops; };
+
+struct StatArr { int64_t off; int stride; };   // into a double arena: sum at off, sumsq at off + span
+
+// ------------------------------------------------------------------------------------
+// engine
+// ------------------------------------------------------------------------------------
+struct smg_engine {
+    int device = 0, S = 0, max_streams = 0, max_pairs = 0, head_out = 1;
+    Plane p_img, p_stem, p_blk[4];
+    int OH = 1, OW = 1;
+    const Layout* L = nullptr;
+
+    // activations
+    float* img4 = nullptr; float* stem = nullptr; float* X[4] = {}; float* Bt = nullptr;
+    std::vector<int64_t> bt_off[4];          // float offset of each layer's bottleneck buffer
+    unsigned char* argmax = nullptr;
+    float* F = nullptr; float* H1 = nullptr;
+    // gradients
+    float* G[4] = {}; float* D2 = nullptr; float* DY0 = nullptr; float* DH1 = nullptr; float* DF = nullptr;
+    // statistics arenas (doubles). fwd: [sum | sumsq] halves; bwd: [s1 | s2] halves
+    double* fstat = nullptr; int64_t fstat_span = 0;
+    double* bstat = nullptr; int64_t bstat_span = 0;
+    StatArr st_stem, st_X[4], st_F, st_H1; std::vector<StatArr> st_Bt[4];
+    StatArr bs_stem, bs_X[4], bs_F, bs_H1; std::vector<StatArr> bs_Bt[4];
+    // packed weights
+    float* packed = nullptr; int64_t packed_floats = 0;
+    PackDesc* d_pack = nullptr; std::vector<PackDesc> h_pack[3]; std::vector<PackDesc> h_pack_head[3];
+    int64_t pk_conv0 = 0, pk_head0 = 0, pk_head1 = 0;
+    std::vector<int64_t> pk_c1[4], pk_c2f[4], pk_c2d[4]; int64_t pk_t[3] = {};
+    int max_pack = 0;
+    // bn update descriptors
+    BnUpdDesc* d_bnupd = nullptr; std::vector<BnUpdDesc> h_bnupd;
+    // small device arrays for the batch description
+    int* d_ints = nullptr; float* d_floats = nullptr; int ints_cap = 0, floats_cap = 0;
+    // last forward
+    bool have_fwd = false; int f_trunk = 0, f_head = 0, f_streams = 0, f_pairs = 0;
+    int* d_stream_image = nullptr; int* d_stream_rot = nullptr; int* d_pair_a = nullptr; int* d_pair_b = nullptr;
+    int* d_seq_t = nullptr; int* d_seq_h = nullptr; int* d_user_ptr = nullptr; int* d_user_pair = nullptr; int* d_user_slot = nullptr;
+    float* d_affine = nullptr;
+    int64_t workspace_bytes = 0;
+    // profiling
+    bool prof = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> ev_pool;
+    double prof_ms[K_COUNT] = {}; int64_t prof_n[K_COUNT] = {}; double prof_flops[K_COUNT] = {};
+};
+
+static Plane make_plane(int H, int W) {
+    Plane p; p.H = H; p.W = W; p.HW = H * W; p.HWp = (p.HW + 127) / 128 * 128; return p;
+}
+
+template <class T>
+static int dev_alloc(smg_engine* e, T** out, int64_t count) {
+    void* p = nullptr;
+    hipError_t err = hipMalloc(&p, (size_t)count * sizeof(T));
+    if (err != hipSuccess) return fail(-12, std::string("hipMalloc ") + std::to_string(count * sizeof(T)) + " B: " + hipGetErrorString(err));
+    e->workspace_bytes += count * (int64_t)sizeof(T);
+    *out = (T*)p;
+    return 0;
+}
+#define ALLOC(ptr, count) do { int _r = dev_alloc(e, &(ptr), (count)); if (_r) return _r; } while (0)
+
+// ------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------
+static hipEvent_t prof_event(smg_engine* e) {
+    if (!e->ev_pool.empty()) { hipEvent_t ev = e->ev_pool.back(); e->ev_pool.pop_back(); return ev; }
+    hipEvent_t ev; (void)hipEventCreate(&ev); return ev;
+}
+struct ProfScope {
+    smg_engine* e; hipStream_t st; int kind; double flops; hipEvent_t a{}, b{};
+    ProfScope(smg_engine* e_, hipStream_t s, int k, double f) : e(e_), st(s), kind(k), flops(f) {
+        if (e->prof) { a = prof_event(e); b = prof_event(e); (void)hipEventRecord(a, st); }
+    }
+    ~ProfScope() {
+        if (e->prof) { (void)hipEventRecord(b, st); e->recs.push_back({a, b, kind, flops}); }
+    }
+};
+
+template <class P>
+static void launch_gemm(smg_engine* e, hipStream_t st, const P& p, dim3 grid, int kind, double flops) {
+    const size_t smem = (size_t)(P::Cfg::TILE_FLOATS + p.param_floats()) * sizeof(float);
+    ProfScope ps(e, st, kind, flops);
+    hipLaunchKernelGGL(gemm_kernel<P>, grid, dim3(256), smem, st, p);
+}
+
+// ------------------------------------------------------------------------------------
+// creation
+// ------------------------------------------------------------------------------------
+static int engine_build(smg_engine* e) {
+    const Layout& L = *e->L;
+    const int NS = e->max_streams, NP = e->max_pairs;
+    const int S = e->S;
+    const int H1 = (S - 1) / 2 + 1, H2 = (H1 - 1) / 2 + 1;
+    e->p_img = make_plane(S, S);
+    e->p_stem = make_plane(H1, H1);
+    int h = H2;
+    for (int b = 0; b < 4; ++b) { e->p_blk[b] = make_plane(h, h); h /= 2; }
+    e->OH = e->OW = e->p_blk[3].H - kHeadKernel + 1;
+    if (e->OH < 1) return fail(-22, "input_size too small for the 20x20 value head");
+
+    ALLOC(e->img4, (int64_t)NS * e->p_img.HWp * 4);
+    ALLOC(e->stem, (int64_t)NS * e->p_stem.HWp * 64);
+    ALLOC(e->DY0, (int64_t)NS * e->p_stem.HWp * 64);
+    ALLOC(e->argmax, (int64_t)NS * e->p_blk[0].HWp * 64);
+    int64_t bt_total = 0;
+    for (int b = 0; b < 4; ++b) {
+        ALLOC(e->X[b], (int64_t)NS * e->p_blk[b].HWp * kBlockCtot[b]);
+        ALLOC(e->G[b], (int64_t)NS * e->p_blk[b].HWp * kBlockCtot[b]);
+        for (int i = 0; i < kBlockLayers[b]; ++i) {
+            e->bt_off[b].push_back(bt_total);
+            bt_total += (int64_t)NS * e->p_blk[b].HWp * kBottleneck;
+        }
+    }
+    ALLOC(e->Bt, bt_total);
+    ALLOC(e->D2, (int64_t)NS * e->p_blk[0].HWp * kBottleneck);
+    ALLOC(e->F, (int64_t)NP * e->p_blk[3].HWp * 2 * kFeat);
+    ALLOC(e->DF, (int64_t)NP * e->p_blk[3].HWp * 2 * kFeat);
+    ALLOC(e->H1, (int64_t)NP * e->p_blk[3].HWp * kHeadMid);
+    ALLOC(e->DH1, (int64_t)NP * e->p_blk[3].HWp * kHeadMid);
+
+    // statistic arenas: identical carving for forward (sum, sumsq) and backward (s1, s2)
+    int64_t off = 0;
+    auto carve = [&](int n, int stride) { StatArr s{off, stride}; off += (int64_t)n * stride; return s; };
+    e->st_stem = carve(NS, 64);
+    for (int b = 0; b < 4; ++b) e->st_X[b] = carve(NS, kBlockCtot[b]);
+    for (int b = 0; b < 4; ++b)
+        for (int i = 0; i < kBlockLayers[b]; ++i) e->st_Bt[b].push_back(carve(NS, kBottleneck));
+    e->st_F = carve(NP, 2 * kFeat);
+    e->st_H1 = carve(NP, kHeadMid);
+    e->fstat_span = e->bstat_span = off;
+    e->bs_stem = e->st_stem; e->bs_F = e->st_F; e->bs_H1 = e->st_H1;
+    for (int b = 0; b < 4; ++b) { e->bs_X[b] = e->st_X[b]; e->bs_Bt[b] = e->st_Bt[b]; }
+    ALLOC(e->fstat, 2 * off);
+    ALLOC(e->bstat, 2 * off);
+
+    // packed weights + descriptor tables (one table per trunk, one per head)
+    int64_t pk = 0;
+    auto add_pack = [&](std::vector<PackDesc>& v, int64_t src, int cout, int cin, int mode, int64_t count) {
+        PackDesc d; d.src = src; d.dst = pk; d.cout = cout; d.cin = cin; d.mode = mode; d.count = (int)count;
+        v.push_back(d); int64_t at = pk; pk += count; return at;
+    };
+    for (int t = 0; t < 3; ++t) {
+        pk = 0;   // every trunk packs into the same region (only one trunk is active per forward)
+        const TrunkRef& T = L.trunk[t];
+        std::vector<PackDesc>& v = e->h_pack[t];
+        e->pk_conv0 = add_pack(v, T.conv0.w, 64, 3, PK_STEM, 224 * 64);
+        for (int b = 0; b < 4; ++b) {
+            if (t == 0) { e->pk_c1[b].clear(); e->pk_c2f[b].clear(); e->pk_c2d[b].clear(); }
+            for (size_t i = 0; i < T.layers[b].size(); ++i) {
+                const DenseLayerRef& d = T.layers[b][i];
+                int64_t a1 = add_pack(v, d.c1.w, kBottleneck, d.cin, PK_T1, d.c1.count());
+                int64_t a2 = add_pack(v, d.c2.w, kGrowth, kBottleneck, PK_3F, d.c2.count());
+                int64_t a3 = add_pack(v, d.c2.w, kGrowth, kBottleneck, PK_3D, d.c2.count());
+                if (t == 0) { e->pk_c1[b].push_back(a1); e->pk_c2f[b].push_back(a2); e->pk_c2d[b].push_back(a3); }
+            }
+            if (b < 3) e->pk_t[b] = add_pack(v, T.tconv[b].w, T.tconv[b].cout, T.tconv[b].cin, PK_T1, T.tconv[b].count());
+        }
+    }
+    const int64_t trunk_pk = pk;
+    for (int hd = 0; hd < 3; ++hd) {
+        pk = trunk_pk;
+        const HeadRef& H = L.head[hd];
+        std::vector<PackDesc>& v = e->h_pack_head[hd];
+        e->pk_head0 = add_pack(v, H.c0.w, kHeadMid, 2 * kFeat, PK_T1, H.c0.count());
+        e->pk_head1 = add_pack(v, H.c1.w, e->head_out, kHeadMid, PK_HEAD, H.c1.count());
+    }
+    e->packed_floats = pk;
+    ALLOC(e->packed, pk);
+    e->max_pack = (int)(e->h_pack[0].size() + e->h_pack_head[0].size());
+    ALLOC(e->d_pack, e->max_pack);
+    ALLOC(e->d_bnupd, 128);
+
+    // batch description
+    const int R = NS > NP ? NS : NP;
+    ALLOC(e->d_stream_image, NS); ALLOC(e->d_stream_rot, NS); ALLOC(e->d_affine, 6 * NS);
+    ALLOC(e->d_pair_a, NP); ALLOC(e->d_pair_b, NP);
+    ALLOC(e->d_seq_t, 4 * R + 16); ALLOC(e->d_seq_h, 4 * R + 16);
+    ALLOC(e->d_user_ptr, NS + 1); ALLOC(e->d_user_pair, 2 * NP); ALLOC(e->d_user_slot, 2 * NP);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------
+static inline double* fsum(smg_engine* e, const StatArr& s) { return e->fstat + s.off; }
+static inline double* fsq(smg_engine* e, const StatArr& s) { return e->fstat + e->fstat_span + s.off; }
+static inline double* b1(smg_engine* e, const StatArr& s) { return e->bstat + s.off; }
+static inline double* b2(smg_engine* e, const StatArr& s) { return e->bstat + e->bstat_span + s.off; }
+
+static const float kEps = 1e-5f;
+
+static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, const smg_batch* B,
+                      float* q_out, hipStream_t st) {
+    const Layout& L = *e->L;
+    const TrunkRef& T = L.trunk[trunk_id];
+    const HeadRef& Hd = L.head[head_id];
+    const int NS = B->n_streams, NP = B->n_pairs;
+    if (NS < 1 || NS > e->max_streams || NP < 1 || NP > e->max_pairs) return fail(-22, "batch exceeds engine capacity");
+    if (!B->images_nchw_dev && !B->heightmaps_dev) return fail(-22, "no input images");
+    for (int s = 0; s < NS; ++s)
+        if (B->stream_image[s] < 0 || B->stream_image[s] >= B->n_images) return fail(-22, "stream_image out of range");
+    for (int j = 0; j < NP; ++j)
+        if (B->pair_a[j] < 0 || B->pair_a[j] >= NS || B->pair_b[j] < 0 || B->pair_b[j] >= NS) return fail(-22, "pair index out of range");
+    const int n_seq_t = B->bn_seq_trunk ? B->n_bn_seq_trunk : 0, n_seq_h = B->bn_seq_head ? B->n_bn_seq_head : 0;
+    const int R = e->max_streams > e->max_pairs ? e->max_streams : e->max_pairs;
+    if (n_seq_t > 4 * R + 16 || n_seq_h > 4 * R + 16) return fail(-22, "bn sequence too long");
+    int pad = 0;
+    if (B->heightmaps_dev) {
+        pad = (e->S - 2 * B->hm_size) / 2;
+        if (pad < 0 || 2 * B->hm_size + 2 * pad != e->S) return fail(-22, "heightmap size does not match engine input_size");
+    }
+
+    // batch description -> device
+    HIP_OK(hipMemcpyAsync(e->d_stream_image, B->stream_image, NS * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(e->d_stream_rot, B->stream_rotated, NS * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(e->d_affine, B->stream_affine, 6 * NS * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(e->d_pair_a, B->pair_a, NP * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(e->d_pair_b, B->pair_b, NP * sizeof(int), hipMemcpyHostToDevice, st));
+    if (n_seq_t) HIP_OK(hipMemcpyAsync(e->d_seq_t, B->bn_seq_trunk, n_seq_t * sizeof(int), hipMemcpyHostToDevice, st));
+    if (n_seq_h) HIP_OK(hipMemcpyAsync(e->d_seq_h, B->bn_seq_head, n_seq_h * sizeof(int), hipMemcpyHostToDevice, st));
+    {   // users of each stream's features (CSR), for the backward
+        std::vector<int> ptr(NS + 1, 0), up, us;
+        for (int s = 0; s < NS; ++s) {
+            for (int j = 0; j < NP; ++j) {
+                if (B->pair_a[j] == s) { up.push_back(j); us.push_back(0); }
+                if (B->pair_b[j] == s) { up.push_back(j); us.push_back(1); }
+            }
+            ptr[s + 1] = (int)up.size();
+        }
+        HIP_OK(hipMemcpyAsync(e->d_user_ptr, ptr.data(), (NS + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(e->d_user_pair, up.data(), up.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(e->d_user_slot, us.data(), us.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_OK(hipStreamSynchronize(st));   // host vectors go out of scope
+    }
+    HIP_OK(hipMemsetAsync(e->fstat, 0, 2 * e->fstat_span * sizeof(double), st));
+
+    // weights -> K-major packs
+    {
+        std::vector<PackDesc> v = e->h_pack[trunk_id];
+        v.insert(v.end(), e->h_pack_head[head_id].begin(), e->h_pack_head[head_id].end());
+        HIP_OK(hipMemcpyAsync(e->d_pack, v.data(), v.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
+        HIP_OK(hipStreamSynchronize(st));
+        ProfScope ps(e, st, K_OTHER, 0);
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(64, (unsigned)v.size()), dim3(256), 0, st, e->d_pack, net->params, e->packed);
+    }
+    const float* P = net->params;
+
+    {   // K1 input preparation
+        PrepArgs a;
+        a.images_nchw = B->images_nchw_dev; a.heightmaps = B->heightmaps_dev; a.hm = B->hm_size; a.pad = pad; a.S = e->S;
+        a.mean = B->image_mean; a.stdv = B->image_std;
+        a.stream_image = e->d_stream_image; a.stream_affine = e->d_affine; a.stream_rotated = e->d_stream_rot;
+        a.img4 = e->img4; a.HWp = e->p_img.HWp;
+        ProfScope ps(e, st, K_OTHER, 0);
+        hipLaunchKernelGGL(prep_rotate_kernel, dim3((e->S * e->S + 255) / 256, NS), dim3(256), 0, st, a);
+    }
+    {   // stem conv0 7x7/2
+        FwdConvP<CfgP128x64, F_STEM> p{};
+        p.src = e->img4; p.lds_ = 4; p.ps = e->p_img; p.po = e->p_stem; p.K = 0;
+        p.w = e->packed + e->pk_conv0; p.ldw = 64; p.N = 64;
+        p.dst = e->stem; p.ldd = 64; p.dcoff = 0;
+        p.dsum = fsum(e, e->st_stem); p.dsq = fsq(e, e->st_stem); p.dstride = 64; p.eps = kEps;
+        launch_gemm(e, st, p, dim3(NS * e->p_stem.HWp / 128, 1), K_STEM, 2.0 * NS * e->p_stem.HW * 64 * 147);
+    }
+    {   // norm0 + relu0 + pool0
+        Pool0Args a;
+        a.stem = e->stem; a.ps = e->p_stem; a.ssum = fsum(e, e->st_stem); a.ssq = fsq(e, e->st_stem);
+        a.gamma = P + T.norm0.w; a.beta = P + T.norm0.b; a.eps = kEps;
+        a.x1 = e->X[0]; a.ldx = kBlockCtot[0]; a.po = e->p_blk[0];
+        a.dsum = fsum(e, e->st_X[0]); a.dsq = fsq(e, e->st_X[0]); a.dstride = kBlockCtot[0];
+        a.argmax = e->argmax;
+        ProfScope ps(e, st, K_OTHER, 0);
+        hipLaunchKernelGGL(pool0_kernel, dim3(e->p_blk[0].HWp / 64, NS), dim3(256), 0, st, a);
+    }
+    for (int b = 0; b < 4; ++b) {
+        const Plane pl = e->p_blk[b];
+        const int Ct = kBlockCtot[b];
+        for (size_t i = 0; i < T.layers[b].size(); ++i) {
+            const DenseLayerRef& d = T.layers[b][i];
+            float* bt = e->Bt + e->bt_off[b][i];
+            {   // norm1 + relu + conv1 (1x1, cin -> 128)
+                FwdConvP<CfgP128x128, F_ONE> p{};
+                p.src = e->X[b]; p.lds_ = Ct; p.ps = pl; p.po = pl; p.K = d.cin;
+                p.ssum = fsum(e, e->st_X[b]); p.ssq = fsq(e, e->st_X[b]); p.sstride = Ct;
+                p.gamma = P + d.n1.w; p.beta = P + d.n1.b; p.eps = kEps;
+                p.w = e->packed + e->pk_c1[b][i]; p.ldw = kBottleneck; p.N = kBottleneck;
+                p.dst = bt; p.ldd = kBottleneck; p.dcoff = 0;
+                p.dsum = fsum(e, e->st_Bt[b][i]); p.dsq = fsq(e, e->st_Bt[b][i]); p.dstride = kBottleneck;
+                launch_gemm(e, st, p, dim3(NS * pl.HWp / 128, 1), K_C1, 2.0 * NS * pl.HW * d.cin * kBottleneck);
+            }
+            {   // norm2 + relu + conv2 (3x3, 128 -> 32), appended to the block buffer
+                FwdConvP<CfgP128x32, F_THREE> p{};
+                p.src = bt; p.lds_ = kBottleneck; p.ps = pl; p.po = pl; p.K = kBottleneck;
+                p.ssum = fsum(e, e->st_Bt[b][i]); p.ssq = fsq(e, e->st_Bt[b][i]); p.sstride = kBottleneck;
+                p.gamma = P + d.n2.w; p.beta = P + d.n2.b; p.eps = kEps;
+                p.w = e->packed + e->pk_c2f[b][i]; p.ldw = kGrowth; p.N = kGrowth;
+                p.dst = e->X[b]; p.ldd = Ct; p.dcoff = d.cin;
+                p.dsum = fsum(e, e->st_X[b]); p.dsq = fsq(e, e->st_X[b]); p.dstride = Ct;
+                launch_gemm(e, st, p, dim3(NS * pl.HWp / 128, 1), K_C3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+            }
+        }
+        if (b < 3) {   // transition: norm + relu + (avgpool2 commuted in front of) conv 1x1
+            const Plane pn = e->p_blk[b + 1];
+            FwdConvP<CfgP128x128, F_POOL> p{};
+            p.src = e->X[b]; p.lds_ = Ct; p.ps = pl; p.po = pn; p.K = Ct;
+            p.ssum = fsum(e, e->st_X[b]); p.ssq = fsq(e, e->st_X[b]); p.sstride = Ct;
+            p.gamma = P + T.tnorm[b].w; p.beta = P + T.tnorm[b].b; p.eps = kEps;
+            p.w = e->packed + e->pk_t[b]; p.ldw = Ct / 2; p.N = Ct / 2;
+            p.dst = e->X[b + 1]; p.ldd = kBlockCtot[b + 1]; p.dcoff = 0;
+            p.dsum = fsum(e, e->st_X[b + 1]); p.dsq = fsq(e, e->st_X[b + 1]); p.dstride = kBlockCtot[b + 1];
+            launch_gemm(e, st, p, dim3(NS * pn.HWp / 128, (Ct / 2) / 128), K_TRANS, 2.0 * NS * pn.HW * Ct * (Ct / 2));
+        }
+    }
+    const Plane p4 = e->p_blk[3];
+    {   // norm5 + two-stream concat
+        FeatArgs a;
+        a.x4 = e->X[3]; a.p4 = p4; a.xsum = fsum(e, e->st_X[3]); a.xsq = fsq(e, e->st_X[3]);
+        a.gamma = P + T.norm5.w; a.beta = P + T.norm5.b; a.eps = kEps;
+        a.pair_a = e->d_pair_a; a.pair_b = e->d_pair_b; a.F = e->F;
+        a.fsum = fsum(e, e->st_F); a.fsq = fsq(e, e->st_F); a.chunk = 64;
+        ProfScope ps(e, st, K_OTHER, 0);
+        hipLaunchKernelGGL(feat_kernel, dim3(2, NP, (p4.HW + 63) / 64), dim3(256), 0, st, a);
+    }
+    {   // head norm0 + relu + conv0 (1x1, 2048 -> 64)
+        FwdConvP<CfgP128x64, F_ONE> p{};
+        p.src = e->F; p.lds_ = 2 * kFeat; p.ps = p4; p.po = p4; p.K = 2 * kFeat;
+        p.ssum = fsum(e, e->st_F); p.ssq = fsq(e, e->st_F); p.sstride = 2 * kFeat;
+        p.gamma = P + Hd.n0.w; p.beta = P + Hd.n0.b; p.eps = kEps;
+        p.w = e->packed + e->pk_head0; p.ldw = kHeadMid; p.N = kHeadMid;
+        p.dst = e->H1; p.ldd = kHeadMid; p.dcoff = 0;
+        p.dsum = fsum(e, e->st_H1); p.dsq = fsq(e, e->st_H1); p.dstride = kHeadMid;
+        launch_gemm(e, st, p, dim3(NP * p4.HWp / 128, 1), K_HEAD0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid);
+    }
+    {   // head norm1 + relu + conv1 (20x20 valid)
+        ValueArgs a;
+        a.h1 = e->H1; a.p4 = p4; a.hsum = fsum(e, e->st_H1); a.hsq = fsq(e, e->st_H1);
+        a.gamma = P + Hd.n1.w; a.beta = P + Hd.n1.b; a.eps = kEps;
+        a.w2p = e->packed + e->pk_head1; a.q = q_out; a.out_ch = e->head_out; a.OH = e->OH; a.OW = e->OW;
+        ProfScope ps(e, st, K_OTHER, 0);
+        hipLaunchKernelGGL(value_conv_kernel, dim3(NP * e->head_out * e->OH * e->OW), dim3(256), 0, st, a);
+    }
+    if (n_seq_t || n_seq_h) {   // BN running statistics, in the reference's update order
+        std::vector<BnUpdDesc> v;
+        auto add = [&](const BnRef& r, const StatArr& s, int coff, int count, int head) {
+            BnUpdDesc d; d.rm = r.rm; d.rv = r.rv; d.nbt = r.nbt; d.stat_off = s.off; d.stride = s.stride; d.coff = coff;
+            d.C = r.C; d.count = count; d.head = head; v.push_back(d);
+        };
+        add(T.norm0, e->st_stem, 0, e->p_stem.HW, 0);
+        for (int b = 0; b < 4; ++b) {
+            for (size_t i = 0; i < T.layers[b].size(); ++i) {
+                add(T.layers[b][i].n1, e->st_X[b], 0, e->p_blk[b].HW, 0);
+                add(T.layers[b][i].n2, e->st_Bt[b][i], 0, e->p_blk[b].HW, 0);
+            }
+            if (b < 3) add(T.tnorm[b], e->st_X[b], 0, e->p_blk[b].HW, 0);
+        }
+        add(T.norm5, e->st_X[3], 0, p4.HW, 0);
+        add(Hd.n0, e->st_F, 0, p4.HW, 1);
+        add(Hd.n1, e->st_H1, 0, p4.HW, 1);
+        HIP_OK(hipMemcpyAsync(e->d_bnupd, v.data(), v.size() * sizeof(BnUpdDesc), hipMemcpyHostToDevice, st));
+        HIP_OK(hipStreamSynchronize(st));
+        ProfScope ps(e, st, K_OTHER, 0);
+        hipLaunchKernelGGL(bn_update_kernel, dim3(8, (unsigned)v.size()), dim3(256), 0, st, e->d_bnupd,
+                           e->fstat, e->fstat + e->fstat_span, net->bufs, net->nbt, e->d_seq_t, n_seq_t, e->d_seq_h, n_seq_h);
+    }
+    HIP_OK(hipGetLastError());
+    e->have_fwd = true; e->f_trunk = trunk_id; e->f_head = head_id; e->f_streams = NS; e->f_pairs = NP;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------
+static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t st) {
+    if (!e->have_fwd) return fail(-22, "smg_backward without a preceding smg_forward");
+    if (!net->grads) return fail(-22, "net.grads is NULL");
+    const Layout& L = *e->L;
+    const TrunkRef& T = L.trunk[e->f_trunk];
+    const HeadRef& Hd = L.head[e->f_head];
+    const int NS = e->f_streams, NP = e->f_pairs;
+    const float* P = net->params;
+    float* Gr = net->grads;
+    const Plane p4 = e->p_blk[3];
+    HIP_OK(hipMemsetAsync(e->bstat, 0, 2 * e->bstat_span * sizeof(double), st));
+
+    {   // value conv backward + relu1 + norm1 sums
+        ValueBwdArgs a;
+        a.h1 = e->H1; a.p4 = p4; a.hsum = fsum(e, e->st_H1); a.hsq = fsq(e, e->st_H1);
+        a.gamma = P + Hd.n1.w; a.beta = P + Hd.n1.b; a.eps = kEps; a.w2p = e->packed + e->pk_head1;
+        a.dq = dq; a.out_ch = e->head_out; a.OH = e->OH; a.OW = e->OW; a.dh1 = e->DH1;
+        a.o1 = b1(e, e->bs_H1); a.o2 = b2(e, e->bs_H1); a.dbeta = Gr + Hd.n1.b; a.dgamma = Gr + Hd.n1.w; a.dw2 = Gr + Hd.c1.w;
+        ProfScope ps(e, st, K_OTHER, 0);
+        hipLaunchKernelGGL(value_bwd_kernel, dim3((p4.HW + 63) / 64, NP), dim3(256), 0, st, a);
+    }
+    const int chunk4 = 128;
+    const int cps4 = (p4.HWp + chunk4 - 1) / chunk4;
+    {   // head conv0 weight gradient
+        BwdWeightP<CfgW64x64, W_ONE, C_IDENT> p{};
+        p.gbuf = e->DH1; p.ldg = kHeadMid; p.gcoff = 0; p.xbuf = e->H1; p.ldx = kHeadMid; p.xcoff = 0; p.pa = p4; p.MA = kHeadMid;
+        p.xsum = fsum(e, e->st_H1); p.xsq = fsq(e, e->st_H1); p.xstride = kHeadMid;
+        p.s1 = b1(e, e->bs_H1); p.s2 = b2(e, e->bs_H1); p.sstride = kHeadMid; p.scoff = 0; p.agamma = P + Hd.n1.w;
+        p.bbuf = e->F; p.ldb = 2 * kFeat; p.pb = p4; p.NB = 2 * kFeat;
+        p.bsum = fsum(e, e->st_F); p.bsq = fsq(e, e->st_F); p.bstride = 2 * kFeat; p.bgamma = P + Hd.n0.w; p.bbeta = P + Hd.n0.b;
+        p.eps = kEps; p.chunk = chunk4; p.chunks_per_stream = cps4; p.n_chunks = NP * cps4;
+        p.dw = Gr + Hd.c0.w; p.ldw_out = 2 * kFeat;
+        launch_gemm(e, st, p, dim3(1, 2 * kFeat / 64, NP * cps4), K_HW0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid);
+    }
+    {   // head conv0 data gradient + relu0 + norm0 sums
+        BwdDataP<CfgP128x128, false, E_STORE> p{};
+        p.gbuf = e->DH1; p.ldg = kHeadMid; p.gcoff = 0; p.xbuf = e->H1; p.ldx = kHeadMid; p.xcoff = 0; p.pa = p4; p.KA = kHeadMid;
+        p.xsum = fsum(e, e->st_H1); p.xsq = fsq(e, e->st_H1); p.xstride = kHeadMid;
+        p.s1 = b1(e, e->bs_H1); p.s2 = b2(e, e->bs_H1); p.sstride = kHeadMid; p.scoff = 0; p.agamma = P + Hd.n1.w;
+        p.w = P + Hd.c0.w; p.ldw = 2 * kFeat; p.N = 2 * kFeat;
+        p.mbuf = e->F; p.ldm = 2 * kFeat; p.mcoff = 0; p.pm = p4;
+        p.msum = fsum(e, e->st_F); p.msq = fsq(e, e->st_F); p.mstride = 2 * kFeat; p.egamma = P + Hd.n0.w; p.ebeta = P + Hd.n0.b;
+        p.dst = e->DF; p.ldd = 2 * kFeat; p.dcoff = 0;
+        p.o1 = b1(e, e->bs_F); p.o2 = b2(e, e->bs_F); p.ostride = 2 * kFeat; p.ocoff = 0;
+        p.dbeta = Gr + Hd.n0.b; p.dgamma = Gr + Hd.n0.w; p.eps = kEps;
+        launch_gemm(e, st, p, dim3(NP * p4.HWp / 128, 2 * kFeat / 128), K_HD0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid);
+    }
+    {   // head norm0 backward + concat backward + norm5 backward -> G'_4
+        Norm5BwdArgs a;
+        a.DF = e->DF; a.F = e->F; a.p4 = p4; a.fsum = fsum(e, e->st_F); a.fsq = fsq(e, e->st_F);
+        a.f1 = b1(e, e->bs_F); a.f2 = b2(e, e->bs_F); a.hgamma = P + Hd.n0.w;
+        a.x4 = e->X[3]; a.xsum = fsum(e, e->st_X[3]); a.xsq = fsq(e, e->st_X[3]); a.gamma5 = P + T.norm5.w; a.eps = kEps;
+        a.user_ptr = e->d_user_ptr; a.user_pair = e->d_user_pair; a.user_slot = e->d_user_slot;
+        a.G4 = e->G[3]; a.SA = b1(e, e->bs_X[3]); a.SB = b2(e, e->bs_X[3]);
+        a.dbeta5 = Gr + T.norm5.b; a.dgamma5 = Gr + T.norm5.w; a.chunk = 16;
+        ProfScope ps(e, st, K_OTHER, 0);
+        hipLaunchKernelGGL(norm5_bwd_kernel, dim3(1, NS, (p4.HW + 15) / 16), dim3(256), 0, st, a);
+    }
+    for (int b = 3; b >= 0; --b) {
+        const Plane pl = e->p_blk[b];
+        const int Ct = kBlockCtot[b];
+        const int chunk = 1024;
+        const int cps = (pl.HWp + chunk - 1) / chunk;
+        for (int i = (int)T.layers[b].size() - 1; i >= 0; --i) {
+            const DenseLayerRef& d = T.layers[b][i];
+            float* bt = e->Bt + e->bt_off[b][i];
+            {   // conv2 (3x3) data gradient -> dy of relu2/norm2 (D2) + norm2 sums
+                BwdDataP<CfgP128x128, true, E_STORE> p{};
+                p.gbuf = e->G[b]; p.ldg = Ct; p.gcoff = d.cin; p.xbuf = e->X[b]; p.ldx = Ct; p.xcoff = d.cin; p.pa = pl; p.KA = kGrowth;
+                p.xsum = fsum(e, e->st_X[b]); p.xsq = fsq(e, e->st_X[b]); p.xstride = Ct;
+                p.s1 = b1(e, e->bs_X[b]); p.s2 = b2(e, e->bs_X[b]); p.sstride = Ct; p.scoff = d.cin; p.agamma = nullptr;
+                p.w = e->packed + e->pk_c2d[b][i]; p.ldw = kBottleneck; p.N = kBottleneck;
+                p.mbuf = bt; p.ldm = kBottleneck; p.mcoff = 0; p.pm = pl;
+                p.msum = fsum(e, e->st_Bt[b][i]); p.msq = fsq(e, e->st_Bt[b][i]); p.mstride = kBottleneck;
+                p.egamma = P + d.n2.w; p.ebeta = P + d.n2.b;
+                p.dst = e->D2; p.ldd = kBottleneck; p.dcoff = 0;
+                p.o1 = b1(e, e->bs_Bt[b][i]); p.o2 = b2(e, e->bs_Bt[b][i]); p.ostride = kBottleneck; p.ocoff = 0;
+                p.dbeta = Gr + d.n2.b; p.dgamma = Gr + d.n2.w; p.eps = kEps;
+                launch_gemm(e, st, p, dim3(NS * pl.HWp / 128, 1), K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+            }
+            {   // conv2 weight gradient
+                BwdWeightP<CfgW32x128, W_THREE, C_3x3> p{};
+                p.gbuf = e->G[b]; p.ldg = Ct; p.gcoff = d.cin; p.xbuf = e->X[b]; p.ldx = Ct; p.xcoff = d.cin; p.pa = pl; p.MA = kGrowth;
+                p.xsum = fsum(e, e->st_X[b]); p.xsq = fsq(e, e->st_X[b]); p.xstride = Ct;
+                p.s1 = b1(e, e->bs_X[b]); p.s2 = b2(e, e->bs_X[b]); p.sstride = Ct; p.scoff = d.cin; p.agamma = nullptr;
+                p.bbuf = bt; p.ldb = kBottleneck; p.pb = pl; p.NB = kBottleneck;
+                p.bsum = fsum(e, e->st_Bt[b][i]); p.bsq = fsq(e, e->st_Bt[b][i]); p.bstride = kBottleneck;
+                p.bgamma = P + d.n2.w; p.bbeta = P + d.n2.b; p.eps = kEps;
+                p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
+                p.dw = Gr + d.c2.w; p.ldw_out = kBottleneck * 9;
+                launch_gemm(e, st, p, dim3(1, 1, 9 * NS * cps), K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+            }
+            {   // conv1 (1x1) data gradient -> relu1/norm1 backward accumulated into G'
+                BwdDataP<CfgP128x64, false, E_ACCUM> p{};
+                p.gbuf = e->D2; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = bt; p.ldx = kBottleneck; p.xcoff = 0; p.pa = pl; p.KA = kBottleneck;
+                p.xsum = fsum(e, e->st_Bt[b][i]); p.xsq = fsq(e, e->st_Bt[b][i]); p.xstride = kBottleneck;
+                p.s1 = b1(e, e->bs_Bt[b][i]); p.s2 = b2(e, e->bs_Bt[b][i]); p.sstride = kBottleneck; p.scoff = 0; p.agamma = P + d.n2.w;
+                p.w = P + d.c1.w; p.ldw = d.cin; p.N = d.cin;
+                p.mbuf = e->X[b]; p.ldm = Ct; p.mcoff = 0; p.pm = pl;
+                p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct;
+                p.egamma = P + d.n1.w; p.ebeta = P + d.n1.b;
+                p.dst = e->G[b]; p.ldd = Ct; p.dcoff = 0;
+                p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.ocoff = 0;
+                p.dbeta = Gr + d.n1.b; p.dgamma = Gr + d.n1.w; p.eps = kEps;
+                launch_gemm(e, st, p, dim3(NS * pl.HWp / 128, (d.cin + 63) / 64), K_D1, 2.0 * NS * pl.HW * d.cin * kBottleneck);
+            }
+            {   // conv1 weight gradient
+                BwdWeightP<CfgW128x64, W_ONE, C_IDENT> p{};
+                p.gbuf = e->D2; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = bt; p.ldx = kBottleneck; p.xcoff = 0; p.pa = pl; p.MA = kBottleneck;
+                p.xsum = fsum(e, e->st_Bt[b][i]); p.xsq = fsq(e, e->st_Bt[b][i]); p.xstride = kBottleneck;
+                p.s1 = b1(e, e->bs_Bt[b][i]); p.s2 = b2(e, e->bs_Bt[b][i]); p.sstride = kBottleneck; p.scoff = 0; p.agamma = P + d.n2.w;
+                p.bbuf = e->X[b]; p.ldb = Ct; p.pb = pl; p.NB = d.cin;
+                p.bsum = fsum(e, e->st_X[b]); p.bsq = fsq(e, e->st_X[b]); p.bstride = Ct;
+                p.bgamma = P + d.n1.w; p.bbeta = P + d.n1.b; p.eps = kEps;
+                p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
+                p.dw = Gr + d.c1.w; p.ldw_out = d.cin;
+                launch_gemm(e, st, p, dim3(1, (d.cin + 63) / 64, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck);
+            }
+        }
+        if (b > 0) {   // transition b-1: X[b-1] (all channels) -> X[b][:, 0:C0]
+            const Plane pp = e->p_blk[b - 1];
+            const int Cp = kBlockCtot[b - 1], C0 = kBlockCin[b];
+            {
+                BwdWeightP<CfgW128x128, W_POOL, C_IDENT> p{};
+                p.gbuf = e->G[b]; p.ldg = Ct; p.gcoff = 0; p.xbuf = e->X[b]; p.ldx = Ct; p.xcoff = 0; p.pa = pl; p.MA = C0;
+                p.xsum = fsum(e, e->st_X[b]); p.xsq = fsq(e, e->st_X[b]); p.xstride = Ct;
+                p.s1 = b1(e, e->bs_X[b]); p.s2 = b2(e, e->bs_X[b]); p.sstride = Ct; p.scoff = 0; p.agamma = nullptr;
+                p.bbuf = e->X[b - 1]; p.ldb = Cp; p.pb = pp; p.NB = Cp;
+                p.bsum = fsum(e, e->st_X[b - 1]); p.bsq = fsq(e, e->st_X[b - 1]); p.bstride = Cp;
+                p.bgamma = P + T.tnorm[b - 1].w; p.bbeta = P + T.tnorm[b - 1].b; p.eps = kEps;
+                p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
+                p.dw = Gr + T.tconv[b - 1].w; p.ldw_out = Cp;
+                launch_gemm(e, st, p, dim3(C0 / 128, Cp / 128, NS * cps), K_TW, 2.0 * NS * pl.HW * Cp * C0);
+            }
+            if (pp.H != 2 * pl.H || pp.W != 2 * pl.W) {
+                ProfScope ps(e, st, K_OTHER, 0);
+                hipLaunchKernelGGL(zero_uncovered_kernel, dim3(256, NS), dim3(256), 0, st, e->G[b - 1], Cp, pp, 2 * pl.H, 2 * pl.W, Cp);
+            }
+            {
+                BwdDataP<CfgP128x128, false, E_UNPOOL> p{};
+                p.gbuf = e->G[b]; p.ldg = Ct; p.gcoff = 0; p.xbuf = e->X[b]; p.ldx = Ct; p.xcoff = 0; p.pa = pl; p.KA = C0;
+                p.xsum = fsum(e, e->st_X[b]); p.xsq = fsq(e, e->st_X[b]); p.xstride = Ct;
+                p.s1 = b1(e, e->bs_X[b]); p.s2 = b2(e, e->bs_X[b]); p.sstride = Ct; p.scoff = 0; p.agamma = nullptr;
+                p.w = P + T.tconv[b - 1].w; p.ldw = Cp; p.N = Cp;
+                p.mbuf = e->X[b - 1]; p.ldm = Cp; p.mcoff = 0; p.pm = pp;
+                p.msum = fsum(e, e->st_X[b - 1]); p.msq = fsq(e, e->st_X[b - 1]); p.mstride = Cp;
+                p.egamma = P + T.tnorm[b - 1].w; p.ebeta = P + T.tnorm[b - 1].b;
+                p.dst = e->G[b - 1]; p.ldd = Cp; p.dcoff = 0;
+                p.o1 = b1(e, e->bs_X[b - 1]); p.o2 = b2(e, e->bs_X[b - 1]); p.ostride = Cp; p.ocoff = 0;
+                p.dbeta = Gr + T.tnorm[b - 1].b; p.dgamma = Gr + T.tnorm[b - 1].w; p.eps = kEps;
+                launch_gemm(e, st, p, dim3(NS * pl.HWp / 128, Cp / 128), K_TD, 2.0 * NS * pl.HW * Cp * C0);
+            }
+        }
+    }
+    {   // pool0 / relu0 backward + norm0 sums
+        Pool0BwdArgs a;
+        a.G1 = e->G[0]; a.X1 = e->X[0]; a.ld1 = kBlockCtot[0]; a.p1 = e->p_blk[0];
+        a.xsum = fsum(e, e->st_X[0]); a.xsq = fsq(e, e->st_X[0]); a.xstride = kBlockCtot[0];
+        a.SA = b1(e, e->bs_X[0]); a.SB = b2(e, e->bs_X[0]); a.sstride = kBlockCtot[0];
+        a.argmax = e->argmax; a.stem = e->stem; a.ps = e->p_stem;
+        a.ssum = fsum(e, e->st_stem); a.ssq = fsq(e, e->st_stem);
+        a.gamma = P + T.norm0.w; a.beta = P + T.norm0.b; a.eps = kEps;
+        a.DY0 = e->DY0; a.o1 = b1(e, e->bs_stem); a.o2 = b2(e, e->bs_stem);
+        a.dbeta = Gr + T.norm0.b; a.dgamma = Gr + T.norm0.w;
+        ProfScope ps(e, st, K_OTHER, 0);
+        hipLaunchKernelGGL(pool0_bwd_kernel, dim3(e->p_stem.HWp / 64, NS), dim3(256), 0, st, a);
+    }
+    {   // conv0 weight gradient (no data gradient: the image needs none)
+        const Plane ps_ = e->p_stem;
+        const int chunk = 2048, cps = (ps_.HWp + chunk - 1) / chunk;
+        BwdWeightP<CfgW64x64, W_STEM, C_STEM> p{};
+        p.gbuf = e->DY0; p.ldg = 64; p.gcoff = 0; p.xbuf = e->stem; p.ldx = 64; p.xcoff = 0; p.pa = ps_; p.MA = 64;
+        p.xsum = fsum(e, e->st_stem); p.xsq = fsq(e, e->st_stem); p.xstride = 64;
+        p.s1 = b1(e, e->bs_stem); p.s2 = b2(e, e->bs_stem); p.sstride = 64; p.scoff = 0; p.agamma = P + T.norm0.w;
+        p.bbuf = e->img4; p.ldb = 4; p.pb = e->p_img; p.NB = 196;
+        p.eps = kEps; p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
+        p.dw = Gr + T.conv0.w; p.ldw_out = 147;
+        launch_gemm(e, st, p, dim3(1, 4, NS * cps), K_SW, 2.0 * NS * ps_.HW * 64 * 147);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------
+extern "C" {
+
+const char* smg_last_error(void) { return g_err.c_str(); }
+int smg_version(void) { return 1; }
+
+int smg_layout_count(int head_out) { return (int)layout_for(head_out).entries.size(); }
+int64_t smg_layout_param_floats(int head_out) { return layout_for(head_out).n_params; }
+int64_t smg_layout_buffer_floats(int head_out) { return layout_for(head_out).n_bufs; }
+int64_t smg_layout_nbt_count(int head_out) { return layout_for(head_out).n_nbt; }
+int smg_layout_entry(int head_out, int index, char* name, int name_cap, int* kind, int64_t* offset, int* ndim, int64_t shape[4]) {
+    const Layout& L = layout_for(head_out);
+    if (index < 0 || index >= (int)L.entries.size()) return fail(-22, "layout index out of range");
+    const LayoutEntry& en = L.entries[index];
+    if (name && name_cap > 0) { std::strncpy(name, en.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (kind) *kind = en.kind;
+    if (offset) *offset = en.offset;
+    if (ndim) *ndim = en.ndim;
+    if (shape) for (int i = 0; i < 4; ++i) shape[i] = en.shape[i];
+    return 0;
+}
+int smg_layout_trunk_range(int head_out, int trunk_id, int64_t* offset, int64_t* count) {
+    if (trunk_id < 0 || trunk_id > 2) return fail(-22, "trunk_id");
+    const TrunkRef& T = layout_for(head_out).trunk[trunk_id];
+    *offset = T.p_begin; *count = T.p_feat_end - T.p_begin; return 0;
+}
+int smg_layout_head_range(int head_out, int head_id, int64_t* offset, int64_t* count) {
+    if (head_id < 0 || head_id > 2) return fail(-22, "head_id");
+    const HeadRef& H = layout_for(head_out).head[head_id];
+    *offset = H.p_begin; *count = H.p_end - H.p_begin; return 0;
+}
+
+int smg_engine_create(int device, int input_size, int max_streams, int max_pairs, int head_out, smg_engine** out) {
+    if (!out) return fail(-22, "out is NULL");
+    if (head_out != 1 && head_out != 3) return fail(-22, "head_out must be 1 or 3");
+    if (input_size < 640 || max_streams < 1 || max_pairs < 1) return fail(-22, "bad engine dimensions");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(-19, "no HIP device available: the affordance engine needs an MI355X");
+    if (device < 0 || device >= ndev) return fail(-22, "device index out of range");
+    HIP_OK(hipSetDevice(device));
+    smg_engine* e = new smg_engine();
+    e->device = device; e->S = input_size; e->max_streams = max_streams; e->max_pairs = max_pairs; e->head_out = head_out;
+    e->L = &layout_for(head_out);
+    int r = engine_build(e);
+    if (r) { smg_engine_destroy(e); return r; }
+    *out = e;
+    return 0;
+}
+
+void smg_engine_destroy(smg_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    void* ptrs[] = {e->img4, e->stem, e->DY0, e->argmax, e->X[0], e->X[1], e->X[2], e->X[3], e->G[0], e->G[1], e->G[2], e->G[3],
+                    e->Bt, e->D2, e->F, e->DF, e->H1, e->DH1, e->fstat, e->bstat, e->packed, e->d_pack, e->d_bnupd,
+                    e->d_stream_image, e->d_stream_rot, e->d_affine, e->d_pair_a, e->d_pair_b, e->d_seq_t, e->d_seq_h,
+                    e->d_user_ptr, e->d_user_pair, e->d_user_slot};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& r : e->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    delete e;
+}
+
+int64_t smg_engine_workspace_bytes(const smg_engine* e) { return e ? e->workspace_bytes : 0; }
+
+int smg_engine_geometry(const smg_engine* e, int H[6], int HWp[6]) {
+    if (!e) return fail(-22, "engine is NULL");
+    const Plane* pl[6] = {&e->p_img, &e->p_stem, &e->p_blk[0], &e->p_blk[1], &e->p_blk[2], &e->p_blk[3]};
+    for (int i = 0; i < 6; ++i) { H[i] = pl[i]->H; HWp[i] = pl[i]->HWp; }
+    return 0;
+}
+
+int smg_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, const smg_batch* batch, float* q_out_dev, void* stream) {
+    if (!e || !net || !batch || !q_out_dev) return fail(-22, "NULL argument");
+    if (!net->params || !net->bufs || !net->nbt) return fail(-22, "net arrays are NULL");
+    if (trunk_id < 0 || trunk_id > 2 || head_id < 0 || head_id > 2) return fail(-22, "trunk_id / head_id out of range");
+    HIP_OK(hipSetDevice(e->device));
+    return do_forward(e, net, trunk_id, head_id, batch, q_out_dev, (hipStream_t)stream);
+}
+
+int smg_loss(smg_engine* e, int mode, const float* q_dev, const float* labels_dev, int n_pairs, float* loss_dev, float* dq_dev, void* stream) {
+    if (!e || !q_dev || !labels_dev || !loss_dev || !dq_dev) return fail(-22, "NULL argument");
+    if (mode == 1 && e->head_out != 3) return fail(-22, "cross-entropy loss needs a 3-class head");
+    HIP_OK(hipSetDevice(e->device));
+    const int per_pair = e->head_out * e->OH * e->OW;
+    hipLaunchKernelGGL(loss_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, (hipStream_t)stream, mode, q_dev, labels_dev, n_pairs, per_pair, loss_dev, dq_dev);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int smg_backward(smg_engine* e, const smg_net* net, const float* dq_dev, void* stream) {
+    if (!e || !net || !dq_dev) return fail(-22, "NULL argument");
+    HIP_OK(hipSetDevice(e->device));
+    return do_backward(e, net, dq_dev, (hipStream_t)stream);
+}
+
+int smg_adam_step(float* params, const float* grads, float* m, float* v, int64_t offset, int64_t count, int step, float lr,
+                  float beta1, float beta2, float eps, void* stream) {
+    if (!params || !grads || !m || !v || count < 0 || step < 1) return fail(-22, "bad Adam arguments");
+    const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)std::sqrt(bc2);
+    if (count == 0) return 0;
+    int blocks = (int)((count + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params + offset, grads + offset, m + offset, v + offset,
+                       count, step_size, beta1, beta2, eps, 1.0f, bc2_sqrt);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int64_t smg_debug_read(smg_engine* e, const char* name, float* host_out, int64_t cap, void* stream) {
+    if (!e || !name) return fail(-22, "NULL argument");
+    const int NS = e->max_streams, NP = e->max_pairs;
+    const float* src = nullptr; int64_t n = 0;
+    std::string s(name);
+    if (s == "img") { src = e->img4; n = (int64_t)NS * e->p_img.HWp * 4; }
+    else if (s == "stem") { src = e->stem; n = (int64_t)NS * e->p_stem.HWp * 64; }
+    else if (s == "dy0") { src = e->DY0; n = (int64_t)NS * e->p_stem.HWp * 64; }
+    else if (s == "feat") { src = e->F; n = (int64_t)NP * e->p_blk[3].HWp * 2 * kFeat; }
+    else if (s == "h1") { src = e->H1; n = (int64_t)NP * e->p_blk[3].HWp * kHeadMid; }
+    else if (s == "df") { src = e->DF; n = (int64_t)NP * e->p_blk[3].HWp * 2 * kFeat; }
+    else if (s.size() == 2 && (s[0] == 'x' || s[0] == 'g') && s[1] >= '1' && s[1] <= '4') {
+        const int b = s[1] - '1';
+        src = s[0] == 'x' ? e->X[b] : e->G[b]; n = (int64_t)NS * e->p_blk[b].HWp * kBlockCtot[b];
+    } else if (s.size() >= 4 && s.substr(0, 2) == "bt") {   // "bt<block>_<layer>" 1-based
+        int b = 0, i = 0;
+        if (std::sscanf(name, "bt%d_%d", &b, &i) != 2 || b < 1 || b > 4 || i < 1 || i > kBlockLayers[b - 1]) return fail(-22, "bad bt name");
+        src = e->Bt + e->bt_off[b - 1][i - 1]; n = (int64_t)NS * e->p_blk[b - 1].HWp * kBottleneck;
+    } else return fail(-22, "unknown debug buffer");
+    if (!host_out) return n;
+    if (cap < n) n = cap;
+    HIP_OK(hipSetDevice(e->device));
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    HIP_OK(hipMemcpy(host_out, src, n * sizeof(float), hipMemcpyDeviceToHost));
+    return n;
+}
+
+int smg_profile_enable(smg_engine* e, int on) {
+    if (!e) return fail(-22, "engine is NULL");
+    e->prof = on != 0;
+    for (auto& r : e->recs) { e->ev_pool.push_back(r.a); e->ev_pool.push_back(r.b); }
+    e->recs.clear();
+    for (int k = 0; k < K_COUNT; ++k) { e->prof_ms[k] = 0; e->prof_n[k] = 0; e->prof_flops[k] = 0; }
+    return 0;
+}
+
+int smg_profile_kinds(void) { return K_COUNT; }
+const char* smg_profile_kind_name(int kind) { return (kind >= 0 && kind < K_COUNT) ? kKindNames[kind] : ""; }
+
+// Drains the recorded events (synchronises them) and returns the totals of one kind.
+int smg_profile_read(smg_engine* e, int kind, double* ms, int64_t* launches, double* flops) {
+    if (!e || kind < 0 || kind >= K_COUNT) return fail(-22, "bad profile query");
+    for (auto& r : e->recs) {
+        float t = 0.f;
+        (void)hipEventSynchronize(r.b);
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { e->prof_ms[r.kind] += t; e->prof_n[r.kind] += 1; e->prof_flops[r.kind] += r.flops; }
+        e->ev_pool.push_back(r.a); e->ev_pool.push_back(r.b);
+    }
+    e->recs.clear();
+    if (ms) *ms = e->prof_ms[kind];
+    if (launches) *launches = e->prof_n[kind];
+    if (flops) *flops = e->prof_flops[kind];
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,668 @@
+// gemm.cuh - one fp32-MFMA implicit-GEMM kernel template for gfx950 and the
+// policies (operand fetchers + epilogues) that turn it into every convolution
+// forward / data-gradient / weight-gradient of the DenseNet-121 affordance path.
+//
+//   D[i][j] = sum_r A(i, r) * B(r, j)       v_mfma_f32_32x32x2_f32 (exact fp32)
+//
+// Data layout: activations are NHWC fp32, one "plane" of HWp = roundup(H*W, 128)
+// pixel rows per stream, so a 128-row tile never straddles two streams and a dense
+// block is ONE buffer [stream][pixel][Ctot] that every layer appends 32 channels to
+// (torch.cat of code/models.py:386 / torchvision _DenseBlock disappears).
+//
+// LDS tiles are k-major: As[k][m], Bs[k][n], so the MFMA operand reads
+// (lane l -> A[i = l&31][k = l>>5]) are 32 consecutive floats per half-wave:
+// conflict-free ds_read_b32.  Pixel-major operands (conv forward / data gradient)
+// are transposed on the way in with scalar ds_write_b32 into rows of odd length
+// (BM+1); channel-major operands (weights, and both operands of a weight gradient)
+// go in with one ds_write_b128 per float4.
+//
+// BatchNorm (training mode, per stream - SURVEY.md section 7) is never a kernel of
+// its own: the producer's epilogue accumulates per-(stream, channel) sum / sum of
+// squares with fp64 atomics, and every consumer turns them into scale/shift in its
+// prologue (into LDS) and applies BN + ReLU while staging the operand.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace smg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Plane { int H, W, HW, HWp; };
+
+template <int BM_, int BN_, int BK_, int WM_, int WN_, bool AT_>
+struct GemmCfg {
+    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
+    static constexpr bool AT = AT_;  // A tile arrives pixel-major and is transposed into LDS
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    static_assert(TM >= 1 && TN >= 1 && TM * WM * 32 == BM && TN * WN * 32 == BN, "tile shape");
+    static constexpr int LDA = AT ? BM + 1 : BM + 4;
+    static constexpr int LDB = BN + 4;
+    static constexpr int A_FLOATS = BK * LDA, B_FLOATS = BK * LDB;
+    static constexpr int A_Q = AT ? BK / 4 : BM / 4;       // float4 per tile line
+    static constexpr int A_LINES = AT ? BM : BK;
+    static constexpr int A_STEP = 256 / A_Q;
+    static constexpr int A_N = (A_LINES + A_STEP - 1) / A_STEP;
+    static constexpr int B_Q = BN / 4;
+    static constexpr int B_STEP = 256 / B_Q;
+    static constexpr int B_N = (BK + B_STEP - 1) / B_STEP;
+    static constexpr int TILE_FLOATS = 2 * A_FLOATS + 2 * B_FLOATS;
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+__device__ __forceinline__ void bn_moments(const double* sum, const double* sq, int64_t idx, double inv_cnt, float eps,
+                                           float& mean, float& invstd) {
+    const double m = sum[idx] * inv_cnt;
+    double var = sq[idx] * inv_cnt - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    mean = (float)m;
+    invstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__device__ __forceinline__ float4 bnrelu4(float4 v, const float* sc, const float* sh) {
+    float4 r;
+    r.x = fmaxf(fmaf(v.x, sc[0], sh[0]), 0.f);
+    r.y = fmaxf(fmaf(v.y, sc[1], sh[1]), 0.f);
+    r.z = fmaxf(fmaf(v.z, sc[2], sh[2]), 0.f);
+    r.w = fmaxf(fmaf(v.w, sc[3], sh[3]), 0.f);
+    return r;
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// v = g*a + x*b + c, per channel (BN backward folded into an operand fetch)
+__device__ __forceinline__ float4 affine2(float4 g, float4 x, const float* a, const float* b, const float* c) {
+    float4 r;
+    r.x = fmaf(g.x, a[0], fmaf(x.x, b[0], c[0]));
+    r.y = fmaf(g.y, a[1], fmaf(x.y, b[1], c[1]));
+    r.z = fmaf(g.z, a[2], fmaf(x.z, b[2], c[2]));
+    r.w = fmaf(g.w, a[3], fmaf(x.w, b[3], c[3]));
+    return r;
+}
+
+// Sum per-lane column partials over the rows of the whole workgroup tile.
+// v[q][tn]: this lane's partial for column (wn0 + tn*32 + l31) of quantity q.
+// On return threads t < BN hold the totals of column t in out[q].
+template <class C, int NQ>
+__device__ __forceinline__ void block_col_reduce(float (&v)[NQ][C::TN], float* red, float (&out)[NQ]) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
+    const int wm = wave / C::WN, wn0 = (wave % C::WN) * C::TN * 32;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) v[q][tn] += __shfl_xor(v[q][tn], 32);
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn) red[(q * C::WM + wm) * C::BN + wn0 + tn * 32 + l31] = v[q][tn];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        float s = 0.f;
+        if (t < C::BN) {
+#pragma unroll
+            for (int w = 0; w < C::WM; ++w) s += red[(q * C::WM + w) * C::BN + t];
+        }
+        out[q] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// The kernel.
+// ------------------------------------------------------------------------------------
+template <class P>
+__global__ __launch_bounds__(256) void gemm_kernel(const P p) {
+    using C = typename P::Cfg;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * C::A_FLOATS;
+    float* sp = smem + C::TILE_FLOATS;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm0 = (wave / C::WN) * C::TM * 32, wn0 = (wave % C::WN) * C::TN * 32;
+
+    typename P::Ctx ctx;
+    p.init(ctx, sp);
+    __syncthreads();
+    const int KT = p.ktiles(ctx);
+
+    f32x16 acc[C::TM][C::TN];
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int aq = t % C::A_Q, al = t / C::A_Q;
+    const int bq = t % C::B_Q, bl = t / C::B_Q;
+    float4 ra[C::A_N], rb[C::B_N];
+    typename P::ARow arow[C::A_N];
+    if constexpr (C::AT) {
+#pragma unroll
+        for (int i = 0; i < C::A_N; ++i) p.a_row_init(ctx, arow[i], al + i * C::A_STEP);
+    }
+
+    auto g_load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < C::A_N; ++i) {
+            if constexpr (C::AT) {
+                ra[i] = p.a_fetch(ctx, arow[i], kt, aq, sp);
+            } else {
+                const int kr = al + i * C::A_STEP;
+                ra[i] = (kr < C::BK) ? p.a_fetch_d(ctx, kt, kr, aq, sp) : zero4();
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::B_N; ++i) {
+            const int kr = bl + i * C::B_STEP;
+            rb[i] = (kr < C::BK) ? p.b_fetch(ctx, kt, kr, bq, sp) : zero4();
+        }
+    };
+    auto s_store = [&](int buf) {
+        float* A = As + buf * C::A_FLOATS;
+        float* B = Bs + buf * C::B_FLOATS;
+#pragma unroll
+        for (int i = 0; i < C::A_N; ++i) {
+            if constexpr (C::AT) {
+                const int row = al + i * C::A_STEP;
+                A[(aq * 4 + 0) * C::LDA + row] = ra[i].x;
+                A[(aq * 4 + 1) * C::LDA + row] = ra[i].y;
+                A[(aq * 4 + 2) * C::LDA + row] = ra[i].z;
+                A[(aq * 4 + 3) * C::LDA + row] = ra[i].w;
+            } else {
+                const int kr = al + i * C::A_STEP;
+                if (kr < C::BK) *reinterpret_cast<float4*>(&A[kr * C::LDA + aq * 4]) = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::B_N; ++i) {
+            const int kr = bl + i * C::B_STEP;
+            if (kr < C::BK) *reinterpret_cast<float4*>(&B[kr * C::LDB + bq * 4]) = rb[i];
+        }
+    };
+
+    if (KT > 0) {
+        g_load(0);
+        s_store(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) g_load(kt + 1);  // global loads in flight across the MFMA block
+        const float* A = As + buf * C::A_FLOATS + wm0 + l31;
+        const float* B = Bs + buf * C::B_FLOATS + wn0 + l31;
+#pragma unroll
+        for (int kk = 0; kk < C::BK / 2; ++kk) {
+            float a[C::TM], b[C::TN];
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i) a[i] = A[(2 * kk + half) * C::LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j) b[j] = B[(2 * kk + half) * C::LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < KT) s_store(buf ^ 1);
+        __syncthreads();
+    }
+    p.epilogue(ctx, acc, smem, sp);
+}
+
+// Accumulator element (tm, tn, reg) of this lane sits at tile row / column:
+//   row = wm0 + tm*32 + (reg&3) + 8*(reg>>2) + 4*half,  col = wn0 + tn*32 + l31
+#define SMG_ACC_ROW(wm0, tm, reg, half) ((wm0) + (tm)*32 + ((reg)&3) + 8 * ((reg) >> 2) + 4 * (half))
+
+// ------------------------------------------------------------------------------------
+// Forward convolution policy.
+//   F_ONE   1x1 conv over BN+ReLU(src)                      (bottleneck conv1, head conv0)
+//   F_THREE 3x3 pad-1 conv over BN+ReLU(src), K-tiles walk (tap, channel)
+//   F_POOL  1x1 conv over avgpool2x2(BN+ReLU(src))          (transition; pool commutes
+//           with the pointwise conv, so it is applied first: 4x fewer MACs)
+//   F_STEM  7x7 stride-2 pad-3 conv over the NHWC4 input image (no BN)
+// Epilogue: store raw output + per-(stream, channel) sum / sum-of-squares (fp64 atomics).
+// ------------------------------------------------------------------------------------
+enum { F_ONE = 0, F_THREE = 1, F_POOL = 2, F_STEM = 3 };
+
+template <class Cfg_, int MODE>
+struct FwdConvP {
+    using Cfg = Cfg_;
+    const float* src; int lds_;
+    Plane ps, po;
+    int K;
+    const double* ssum; const double* ssq; int sstride;
+    const float* gamma; const float* beta;
+    float eps;
+    const float* w; int ldw; int N;
+    float* dst; int ldd; int dcoff;
+    double* dsum; double* dsq; int dstride;
+
+    struct Ctx { int n, m0, n0; };
+    struct ARow { int y, x; bool valid; };
+
+    __host__ __device__ int param_floats() const { return MODE == F_STEM ? 0 : 2 * K; }
+
+    __device__ void init(Ctx& c, float* sp) const {
+        c.m0 = blockIdx.x * Cfg::BM;
+        c.n0 = blockIdx.y * Cfg::BN;
+        c.n = c.m0 / po.HWp;
+        if constexpr (MODE != F_STEM) {
+            const double inv = 1.0 / (double)ps.HW;
+            for (int k = threadIdx.x; k < K; k += 256) {
+                float mean, invstd;
+                bn_moments(ssum, ssq, (int64_t)c.n * sstride + k, inv, eps, mean, invstd);
+                const float sc = gamma[k] * invstd;
+                sp[k] = sc;
+                sp[K + k] = beta[k] - mean * sc;
+            }
+        }
+    }
+    __device__ int ktiles(const Ctx&) const {
+        if constexpr (MODE == F_THREE) return 9 * (K / Cfg::BK);
+        else if constexpr (MODE == F_STEM) return 224 / Cfg::BK;
+        else return K / Cfg::BK;
+    }
+    __device__ void a_row_init(const Ctx& c, ARow& r, int line) const {
+        const int p = c.m0 + line - c.n * po.HWp;
+        r.valid = p < po.HW;
+        r.y = p / po.W;
+        r.x = p - r.y * po.W;
+    }
+    __device__ float4 a_fetch(const Ctx& c, const ARow& r, int kt, int q, const float* sp) const {
+        if constexpr (MODE == F_ONE) {
+            if (!r.valid) return zero4();
+            const int ch = kt * Cfg::BK + 4 * q;
+            const float4 v = ld4(src + ((int64_t)c.n * ps.HWp + r.y * ps.W + r.x) * lds_ + ch);
+            return bnrelu4(v, sp + ch, sp + K + ch);
+        } else if constexpr (MODE == F_THREE) {
+            const int kpt = K / Cfg::BK;
+            const int tap = kt / kpt;
+            const int ch = (kt - tap * kpt) * Cfg::BK + 4 * q;
+            const int yy = r.y + tap / 3 - 1, xx = r.x + tap % 3 - 1;
+            if (!r.valid || (unsigned)yy >= (unsigned)ps.H || (unsigned)xx >= (unsigned)ps.W) return zero4();
+            const float4 v = ld4(src + ((int64_t)c.n * ps.HWp + yy * ps.W + xx) * lds_ + ch);
+            return bnrelu4(v, sp + ch, sp + K + ch);
+        } else if constexpr (MODE == F_POOL) {
+            if (!r.valid) return zero4();
+            const int ch = kt * Cfg::BK + 4 * q;
+            const float* b = src + ((int64_t)c.n * ps.HWp + (2 * r.y) * ps.W + 2 * r.x) * lds_ + ch;
+            const float* sc = sp + ch;
+            const float* sh = sp + K + ch;
+            float4 s = bnrelu4(ld4(b), sc, sh);
+            s = add4(s, bnrelu4(ld4(b + lds_), sc, sh));
+            s = add4(s, bnrelu4(ld4(b + (int64_t)ps.W * lds_), sc, sh));
+            s = add4(s, bnrelu4(ld4(b + (int64_t)(ps.W + 1) * lds_), sc, sh));
+            return make_float4(s.x * 0.25f, s.y * 0.25f, s.z * 0.25f, s.w * 0.25f);
+        } else {
+            const int tap = kt * (Cfg::BK / 4) + q;
+            const int yy = 2 * r.y + tap / 7 - 3, xx = 2 * r.x + tap % 7 - 3;
+            if (!r.valid || tap >= 49 || (unsigned)yy >= (unsigned)ps.H || (unsigned)xx >= (unsigned)ps.W) return zero4();
+            return ld4(src + ((int64_t)c.n * ps.HWp + yy * ps.W + xx) * 4);
+        }
+    }
+    __device__ float4 a_fetch_d(const Ctx&, int, int, int, const float*) const { return zero4(); }
+    __device__ float4 b_fetch(const Ctx& c, int kt, int kr, int q, const float*) const {
+        const int col = c.n0 + 4 * q;
+        if (col >= N) return zero4();
+        return ld4(w + (int64_t)(kt * Cfg::BK + kr) * ldw + col);
+    }
+    __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, float*) const {
+        const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
+        const int wm0 = (wave / Cfg::WN) * Cfg::TM * 32, wn0 = (wave % Cfg::WN) * Cfg::TN * 32;
+        float v[2][Cfg::TN];
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) v[0][j] = v[1][j] = 0.f;
+        const int pbase = c.m0 - c.n * po.HWp;
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) {
+                const int col = c.n0 + wn0 + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = SMG_ACC_ROW(wm0, i, r, half);
+                    if (pbase + row < po.HW && col < N) {
+                        const float x = acc[i][j][r];
+                        dst[(int64_t)(c.m0 + row) * ldd + dcoff + col] = x;
+                        v[0][j] += x;
+                        v[1][j] += x * x;
+                    }
+                }
+            }
+        float tot[2];
+        block_col_reduce<Cfg, 2>(v, smem, tot);
+        if (t < Cfg::BN && c.n0 + t < N) {
+            const int64_t si = (int64_t)c.n * dstride + dcoff + c.n0 + t;
+            atomicAdd(dsum + si, (double)tot[0]);
+            atomicAdd(dsq + si, (double)tot[1]);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// Data-gradient policy (pixel-major A, transposed into LDS).
+//   A(m, r)  = g*a[r] + x*b[r] + c[r]     the BN-backward-corrected upstream gradient:
+//              g from the gradient buffer, x from the raw activation the BN normalised.
+//              With SHIFT3 the reduction walks (tap, channel) and the pixel is shifted
+//              (transposed 3x3 convolution).
+//   B(r, j)  = weights, row-major [K][N].
+//   Epilogue = ReLU + BN backward of the BN that FEEDS this convolution's input
+//              (mask source `mbuf`), in one of three forms:
+//     E_STORE  dst = dy; per-stream sums of dy and dy*xhat           (-> next fetch)
+//     E_ACCUM  dst += gamma*dy; per-stream sums weighted by gamma    (dense-block G')
+//     E_UNPOOL as E_ACCUM with plain stores to the 4 pixels each pooled pixel covers
+//   and always dbeta += sum dy, dgamma += sum dy*xhat.
+// ------------------------------------------------------------------------------------
+enum { E_STORE = 0, E_ACCUM = 1, E_UNPOOL = 2 };
+
+template <class Cfg_, bool SHIFT3, int EMODE>
+struct BwdDataP {
+    using Cfg = Cfg_;
+    const float* gbuf; int ldg; int gcoff;
+    const float* xbuf; int ldx; int xcoff;
+    Plane pa;
+    int KA;
+    const double* xsum; const double* xsq; int xstride;
+    const double* s1; const double* s2; int sstride; int scoff;
+    const float* agamma;
+    const float* w; int ldw; int N;
+    const float* mbuf; int ldm; int mcoff; Plane pm;
+    const double* msum; const double* msq; int mstride;
+    const float* egamma; const float* ebeta;
+    float* dst; int ldd; int dcoff;
+    double* o1; double* o2; int ostride; int ocoff;
+    float* dbeta; float* dgamma;
+    float eps;
+
+    struct Ctx { int n, m0, n0; };
+    struct ARow { int y, x; bool valid; };
+
+    __host__ __device__ int param_floats() const { return 3 * KA + 5 * Cfg::BN; }
+
+    __device__ void init(Ctx& c, float* sp) const {
+        c.m0 = blockIdx.x * Cfg::BM;
+        c.n0 = blockIdx.y * Cfg::BN;
+        c.n = c.m0 / pa.HWp;
+        const double inv = 1.0 / (double)pa.HW;
+        for (int k = threadIdx.x; k < KA; k += 256) {
+            float mean, invstd;
+            bn_moments(xsum, xsq, (int64_t)c.n * xstride + xcoff + k, inv, eps, mean, invstd);
+            const float g = agamma ? agamma[k] : 1.f;
+            const float q1 = (float)(s1[(int64_t)c.n * sstride + scoff + k] * inv);
+            const float q2 = (float)(s2[(int64_t)c.n * sstride + scoff + k] * inv);
+            const float gi = g * invstd;
+            sp[k] = gi;
+            sp[KA + k] = -gi * invstd * q2;
+            sp[2 * KA + k] = -gi * q1 + gi * invstd * q2 * mean;
+        }
+        float* ep = sp + 3 * KA;
+        const double minv = 1.0 / (double)pm.HW;
+        for (int j = threadIdx.x; j < Cfg::BN; j += 256) {
+            const int col = c.n0 + j;
+            float mean = 0.f, invstd = 0.f, g = 0.f, b = 0.f;
+            if (col < N) {
+                bn_moments(msum, msq, (int64_t)c.n * mstride + mcoff + col, minv, eps, mean, invstd);
+                g = egamma[col];
+                b = ebeta[col];
+            }
+            const float sc = g * invstd;
+            ep[j] = sc;
+            ep[Cfg::BN + j] = b - mean * sc;
+            ep[2 * Cfg::BN + j] = mean;
+            ep[3 * Cfg::BN + j] = invstd;
+            ep[4 * Cfg::BN + j] = g;
+        }
+    }
+    __device__ int ktiles(const Ctx&) const { return (SHIFT3 ? 9 : 1) * (KA / Cfg::BK); }
+    __device__ void a_row_init(const Ctx& c, ARow& r, int line) const {
+        const int p = c.m0 + line - c.n * pa.HWp;
+        r.valid = p < pa.HW;
+        r.y = p / pa.W;
+        r.x = p - r.y * pa.W;
+    }
+    __device__ float4 a_fetch(const Ctx& c, const ARow& r, int kt, int q, const float* sp) const {
+        int ch, yy = r.y, xx = r.x;
+        if constexpr (SHIFT3) {
+            const int kpt = KA / Cfg::BK;
+            const int tap = kt / kpt;
+            ch = (kt - tap * kpt) * Cfg::BK + 4 * q;
+            yy = r.y + 1 - tap / 3;
+            xx = r.x + 1 - tap % 3;
+            if (!r.valid || (unsigned)yy >= (unsigned)pa.H || (unsigned)xx >= (unsigned)pa.W) return zero4();
+        } else {
+            ch = kt * Cfg::BK + 4 * q;
+            if (!r.valid) return zero4();
+        }
+        const int64_t pix = (int64_t)c.n * pa.HWp + yy * pa.W + xx;
+        const float4 g = ld4(gbuf + pix * ldg + gcoff + ch);
+        const float4 x = ld4(xbuf + pix * ldx + xcoff + ch);
+        return affine2(g, x, sp + ch, sp + KA + ch, sp + 2 * KA + ch);
+    }
+    __device__ float4 a_fetch_d(const Ctx&, int, int, int, const float*) const { return zero4(); }
+    __device__ float4 b_fetch(const Ctx& c, int kt, int kr, int q, const float*) const {
+        const int col = c.n0 + 4 * q;
+        if (col >= N) return zero4();
+        return ld4(w + (int64_t)(kt * Cfg::BK + kr) * ldw + col);
+    }
+    __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, float* sp) const {
+        const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
+        const int wm0 = (wave / Cfg::WN) * Cfg::TM * 32, wn0 = (wave % Cfg::WN) * Cfg::TN * 32;
+        const float* ep = sp + 3 * KA;
+        float v[2][Cfg::TN];
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) v[0][j] = v[1][j] = 0.f;
+        const int pbase = c.m0 - c.n * pa.HWp;
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) {
+            const int cj = wn0 + j * 32 + l31;
+            const int col = c.n0 + cj;
+            const bool cok = col < N;
+            const float sc = ep[cj], sh = ep[Cfg::BN + cj], mean = ep[2 * Cfg::BN + cj], invstd = ep[3 * Cfg::BN + cj];
+            const float gam = ep[4 * Cfg::BN + cj];
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = SMG_ACC_ROW(wm0, i, r, half);
+                    const int p = pbase + row;
+                    if (p < pa.HW && cok) {
+                        if constexpr (EMODE == E_UNPOOL) {
+                            const int y = p / pa.W, x = p - y * pa.W;
+                            const float up = 0.25f * acc[i][j][r];
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) {
+                                const int64_t pix = (int64_t)c.n * pm.HWp + (2 * y + (d >> 1)) * pm.W + 2 * x + (d & 1);
+                                const float xv = mbuf[pix * ldm + mcoff + col];
+                                const float dy = fmaf(xv, sc, sh) > 0.f ? up : 0.f;
+                                dst[pix * ldd + dcoff + col] = gam * dy;
+                                v[0][j] += dy;
+                                v[1][j] += dy * ((xv - mean) * invstd);
+                            }
+                        } else {
+                            const int64_t pix = (int64_t)c.m0 + row;
+                            const float xv = mbuf[pix * ldm + mcoff + col];
+                            const float dy = fmaf(xv, sc, sh) > 0.f ? acc[i][j][r] : 0.f;
+                            if constexpr (EMODE == E_STORE) {
+                                dst[pix * ldd + dcoff + col] = dy;
+                            } else {
+                                float* d = dst + pix * ldd + dcoff + col;
+                                *d = *d + gam * dy;
+                            }
+                            v[0][j] += dy;
+                            v[1][j] += dy * ((xv - mean) * invstd);
+                        }
+                    }
+                }
+        }
+        float tot[2];
+        block_col_reduce<Cfg, 2>(v, smem, tot);
+        if (t < Cfg::BN && c.n0 + t < N) {
+            const int col = c.n0 + t;
+            const float wgt = (EMODE == E_STORE) ? 1.f : ep[4 * Cfg::BN + t];
+            const int64_t oi = (int64_t)c.n * ostride + ocoff + col;
+            atomicAdd(o1 + oi, (double)(wgt * tot[0]));
+            atomicAdd(o2 + oi, (double)(wgt * tot[1]));
+            atomicAdd(dbeta + col, tot[0]);
+            atomicAdd(dgamma + col, tot[1]);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// Weight-gradient policy (both operands channel-major; reduction over pixels).
+//   dW[i][j] += sum_p A(p, i) * B(p, j) over the pixels of one z-chunk of one stream.
+//   A(p, i) = g*a[i] + x*b[i] + c[i]        (BN-backward-corrected output gradient)
+//   B(p, j) = the convolution's input as the forward saw it, recomputed:
+//     W_ONE BN+ReLU(bbuf) | W_THREE the same at the tap-shifted pixel |
+//     W_POOL avgpool2x2(BN+ReLU(bbuf)) | W_STEM the NHWC4 image at the 7x7/stride-2 tap
+//   Epilogue: fp32 atomicAdd into the gradient array in the reference's native
+//   [cout][cin][kh][kw] layout (C_IDENT / C_3x3 / C_STEM index maps).
+// ------------------------------------------------------------------------------------
+enum { W_ONE = 0, W_THREE = 1, W_POOL = 2, W_STEM = 3 };
+enum { C_IDENT = 0, C_3x3 = 1, C_STEM = 2 };
+
+template <class Cfg_, int BMODE, int CMAP>
+struct BwdWeightP {
+    using Cfg = Cfg_;
+    const float* gbuf; int ldg; int gcoff;
+    const float* xbuf; int ldx; int xcoff;
+    Plane pa; int MA;
+    const double* xsum; const double* xsq; int xstride;
+    const double* s1; const double* s2; int sstride; int scoff;
+    const float* agamma;
+    const float* bbuf; int ldb; Plane pb; int NB;
+    const double* bsum; const double* bsq; int bstride;
+    const float* bgamma; const float* bbeta;
+    float eps;
+    int chunk, chunks_per_stream, n_chunks;   // blockIdx.z = tap * n_chunks + chunk index
+    float* dw; int ldw_out;
+
+    struct Ctx { int n, p0, m0, n0, tap, kt; };
+    struct ARow { int dummy; };
+
+    __host__ __device__ int param_floats() const { return 3 * Cfg::BM + 2 * Cfg::BN; }
+
+    __device__ void init(Ctx& c, float* sp) const {
+        c.m0 = blockIdx.x * Cfg::BM;
+        c.n0 = blockIdx.y * Cfg::BN;
+        const int z = blockIdx.z;
+        c.tap = z / n_chunks;
+        const int ci = z - c.tap * n_chunks;
+        c.n = ci / chunks_per_stream;
+        c.p0 = (ci - c.n * chunks_per_stream) * chunk;
+        int len = pa.HWp - c.p0;
+        len = len < chunk ? len : chunk;
+        c.kt = len / Cfg::BK;
+        const double inv = 1.0 / (double)pa.HW;
+        for (int k = threadIdx.x; k < Cfg::BM; k += 256) {
+            const int ch = c.m0 + k;
+            float a = 0.f, b = 0.f, cc = 0.f;
+            if (ch < MA) {
+                float mean, invstd;
+                bn_moments(xsum, xsq, (int64_t)c.n * xstride + xcoff + ch, inv, eps, mean, invstd);
+                const float g = agamma ? agamma[ch] : 1.f;
+                const float q1 = (float)(s1[(int64_t)c.n * sstride + scoff + ch] * inv);
+                const float q2 = (float)(s2[(int64_t)c.n * sstride + scoff + ch] * inv);
+                const float gi = g * invstd;
+                a = gi;
+                b = -gi * invstd * q2;
+                cc = -gi * q1 + gi * invstd * q2 * mean;
+            }
+            sp[k] = a;
+            sp[Cfg::BM + k] = b;
+            sp[2 * Cfg::BM + k] = cc;
+        }
+        if constexpr (BMODE != W_STEM) {
+            float* bp = sp + 3 * Cfg::BM;
+            const double binv = 1.0 / (double)pb.HW;
+            for (int j = threadIdx.x; j < Cfg::BN; j += 256) {
+                const int ch = c.n0 + j;
+                float sc = 0.f, sh = 0.f;
+                if (ch < NB) {
+                    float mean, invstd;
+                    bn_moments(bsum, bsq, (int64_t)c.n * bstride + ch, binv, eps, mean, invstd);
+                    sc = bgamma[ch] * invstd;
+                    sh = bbeta[ch] - mean * sc;
+                }
+                bp[j] = sc;
+                bp[Cfg::BN + j] = sh;
+            }
+        }
+    }
+    __device__ int ktiles(const Ctx& c) const { return c.kt; }
+    __device__ void a_row_init(const Ctx&, ARow&, int) const {}
+    __device__ float4 a_fetch(const Ctx&, const ARow&, int, int, const float*) const { return zero4(); }
+    __device__ float4 a_fetch_d(const Ctx& c, int kt, int kr, int q, const float* sp) const {
+        const int p = c.p0 + kt * Cfg::BK + kr;
+        const int ch = c.m0 + 4 * q;
+        if (p >= pa.HW || ch >= MA) return zero4();
+        const int64_t pix = (int64_t)c.n * pa.HWp + p;
+        const float4 g = ld4(gbuf + pix * ldg + gcoff + ch);
+        const float4 x = ld4(xbuf + pix * ldx + xcoff + ch);
+        return affine2(g, x, sp + 4 * q, sp + Cfg::BM + 4 * q, sp + 2 * Cfg::BM + 4 * q);
+    }
+    __device__ float4 b_fetch(const Ctx& c, int kt, int kr, int q, const float* sp) const {
+        const int p = c.p0 + kt * Cfg::BK + kr;
+        const int ch = c.n0 + 4 * q;
+        if (p >= pa.HW || ch >= NB) return zero4();
+        const float* sc = sp + 3 * Cfg::BM + 4 * q;
+        const float* sh = sc + Cfg::BN;
+        if constexpr (BMODE == W_ONE) {
+            return bnrelu4(ld4(bbuf + ((int64_t)c.n * pb.HWp + p) * ldb + ch), sc, sh);
+        } else if constexpr (BMODE == W_THREE) {
+            const int y = p / pa.W, x = p - y * pa.W;
+            const int yy = y + c.tap / 3 - 1, xx = x + c.tap % 3 - 1;
+            if ((unsigned)yy >= (unsigned)pb.H || (unsigned)xx >= (unsigned)pb.W) return zero4();
+            return bnrelu4(ld4(bbuf + ((int64_t)c.n * pb.HWp + yy * pb.W + xx) * ldb + ch), sc, sh);
+        } else if constexpr (BMODE == W_POOL) {
+            const int y = p / pa.W, x = p - y * pa.W;
+            const float* b = bbuf + ((int64_t)c.n * pb.HWp + (2 * y) * pb.W + 2 * x) * ldb + ch;
+            float4 s = bnrelu4(ld4(b), sc, sh);
+            s = add4(s, bnrelu4(ld4(b + ldb), sc, sh));
+            s = add4(s, bnrelu4(ld4(b + (int64_t)pb.W * ldb), sc, sh));
+            s = add4(s, bnrelu4(ld4(b + (int64_t)(pb.W + 1) * ldb), sc, sh));
+            return make_float4(s.x * 0.25f, s.y * 0.25f, s.z * 0.25f, s.w * 0.25f);
+        } else {
+            const int tap = ch >> 2;
+            const int y = p / pa.W, x = p - y * pa.W;
+            const int yy = 2 * y + tap / 7 - 3, xx = 2 * x + tap % 7 - 3;
+            if (tap >= 49 || (unsigned)yy >= (unsigned)pb.H || (unsigned)xx >= (unsigned)pb.W) return zero4();
+            return ld4(bbuf + ((int64_t)c.n * pb.HWp + yy * pb.W + xx) * 4);
+        }
+    }
+    __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float*, float*) const {
+        const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
+        const int wm0 = (wave / Cfg::WN) * Cfg::TM * 32, wn0 = (wave % Cfg::WN) * Cfg::TN * 32;
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) {
+                const int col = c.n0 + wn0 + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = c.m0 + SMG_ACC_ROW(wm0, i, r, half);
+                    if (row < MA && col < NB) {
+                        int64_t idx;
+                        if constexpr (CMAP == C_IDENT) idx = (int64_t)row * ldw_out + col;
+                        else if constexpr (CMAP == C_3x3) idx = (int64_t)row * ldw_out + col * 9 + c.tap;
+                        else {
+                            const int tap = col >> 2, cc = col & 3;
+                            if (cc == 3 || tap >= 49) continue;
+                            idx = (int64_t)row * ldw_out + cc * 49 + tap;
+                        }
+                        atomicAdd(dw + idx, acc[i][j][r]);
+                    }
+                }
+            }
+    }
+};
+
+}  // namespace smg

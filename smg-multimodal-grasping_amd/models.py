@@ -1,0 +1,298 @@
+"""MI355X-native stand-ins for the reference's `models.reinforcement_net` and
+`models.reactive_net` (/root/reference/code/models.py:301-586 and :15-296).
+
+Same constructor, attributes, forward() signature, return types per branch and
+state_dict keys (2217 entries, torchvision densenet121 naming) - so
+`from models import reactive_net, reinforcement_net` (code/trainer.py:10) and
+snapshot load/save (code/logger.py:121-125, code/main.py:104,353) keep working - but
+forward() is one call into libsmg_hip.so (hand-written HIP for gfx950), not a chain
+of torch ops.  All parameters are views into ONE flat fp32 buffer whose layout the
+C library defines (smg_hip.layout), so Adam and the gradient all-reduce are single
+passes over contiguous memory.
+
+What forward() does NOT do: run on CPU.  The reference itself only builds its
+sampling grids under `if self.use_cuda` (models.py:377-382); here a missing GPU or
+missing libsmg_hip.so raises instead of silently computing something else.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import smg_hip
+
+# style -> (trunk_id, head_id) in layout order (suction, grasp, gs).
+# Style 2 deliberately uses suctionnet_val: code/models.py:434,507,582.
+STYLE_TRUNK = (1, 0, 2)
+STYLE_HEAD = (1, 0, 0)
+_PROB_ATTR = ("gra_prob", "suc_prob", "gs_prob")
+
+_ENGINES = {}
+
+
+def get_engine(device, input_size, head_out, n_streams, n_pairs):
+    """Engines (activation / gradient workspaces) are cached per (device, S, head_out)
+    and regrown when a call needs more streams than the cached one holds."""
+    key = (device, input_size, head_out)
+    eng = _ENGINES.get(key)
+    if eng is None or eng.max_streams < n_streams or eng.max_pairs < n_pairs:
+        cap_s = max(n_streams, eng.max_streams if eng else 0, 17)
+        cap_p = max(n_pairs, eng.max_pairs if eng else 0, 16)
+        if eng is not None:
+            eng.close()
+        torch.cuda.synchronize(device)
+        eng = smg_hip.Engine(device, input_size, cap_s, cap_p, head_out)
+        _ENGINES[key] = eng
+    return eng
+
+
+def release_engines():
+    for e in _ENGINES.values():
+        e.close()
+    _ENGINES.clear()
+
+
+def rotation_theta(rotate_idx, num_rotations):
+    """2x3 float32 affine matrix of code/models.py:372-376 (float64 trig, then .float())."""
+    t = np.radians(rotate_idx * (360 / num_rotations))
+    a = np.asarray([[np.cos(-t), np.sin(-t), 0], [-np.sin(-t), np.cos(-t), 0]])
+    return a.astype(np.float32).reshape(6)
+
+
+class _Node(nn.Module):
+    """Parameter container; only exists to reproduce the reference's key hierarchy."""
+
+
+class _EngineFn(torch.autograd.Function):
+    """Lets the reference's own Trainer.backprop (`loss.backward()`,
+    code/trainer.py:350-351) drive smg_backward through autograd."""
+
+    @staticmethod
+    def forward(ctx, hook, net, q, token):
+        ctx.net, ctx.token = net, token
+        return q.clone()
+
+    @staticmethod
+    def backward(ctx, dq):
+        ctx.net._engine_backward(ctx.token, dq.contiguous())
+        return None, None, None, None
+
+
+class _AffordanceNet(nn.Module):
+    HEAD_OUT = 1
+
+    def __init__(self, use_cuda):
+        super(_AffordanceNet, self).__init__()
+        self.use_cuda = use_cuda
+        self.gnum_rotations = 1     # code/models.py:312-313, :25-26
+        self.snum_rotations = 1
+        self._layout = smg_hip.layout(self.HEAD_OUT)
+        L = smg_hip.lib()
+        self._flat_params = torch.zeros(L.smg_layout_param_floats(self.HEAD_OUT), dtype=torch.float32)
+        self._flat_bufs = torch.zeros(L.smg_layout_buffer_floats(self.HEAD_OUT), dtype=torch.float32)
+        self._flat_nbt = torch.zeros(L.smg_layout_nbt_count(self.HEAD_OUT), dtype=torch.int64)
+        self._flat_grads = None
+        self._entries = []          # (tensor-or-param, kind, offset, shape)
+        for name, kind, off, shape in self._layout:
+            parts = name.split(".")
+            node = self
+            for p in parts[:-1]:
+                if p not in node._modules:
+                    node.add_module(p, _Node())
+                node = node._modules[p]
+            n = int(np.prod(shape)) if shape else 1
+            if kind == 0:
+                t = nn.Parameter(self._flat_params[off:off + n].view(shape))
+                node.register_parameter(parts[-1], t)
+            elif kind in (1, 2):
+                t = self._flat_bufs[off:off + n].view(shape)
+                node.register_buffer(parts[-1], t)
+            else:
+                t = self._flat_nbt[off:off + 1].view(())
+                node.register_buffer(parts[-1], t)
+            self._entries.append((node, parts[-1], kind, off, n, shape))
+        self._init_weights()
+        self.gra_prob = []          # code/models.py:356-358
+        self.suc_prob = []
+        self.gs_prob = []
+        self._saved = None
+        self._autograd_hook = None
+
+    # ---- initialisation ------------------------------------------------------------------
+    def _init_weights(self):
+        """Heads: kaiming-normal convs, BN gamma=1 beta=0 (code/models.py:347-353).
+        Trunks: the reference loads ImageNet weights (densenet121(pretrained=True),
+        :308-310) which cannot be fetched offline; load a snapshot with load_state_dict.
+        Until then the trunks get torch's default Conv2d/BatchNorm2d/Linear init."""
+        with torch.no_grad():
+            for node, leaf, kind, off, n, shape in self._entries:
+                t = getattr(node, leaf)
+                if kind == 0 and len(shape) == 4:
+                    nn.init.kaiming_normal_(t)
+                elif kind == 0 and len(shape) == 2:
+                    nn.init.normal_(t, 0.0, 0.01)
+                elif kind == 0 and leaf == "weight":
+                    t.fill_(1.0)
+                elif kind == 0:
+                    t.zero_()
+                elif kind == 2:
+                    t.fill_(1.0)
+
+    # ---- storage management ----------------------------------------------------------------
+    def _rebind(self):
+        for node, leaf, kind, off, n, shape in self._entries:
+            if kind == 0:
+                p = node._parameters[leaf]
+                p.data = self._flat_params[off:off + n].view(shape)
+                p.grad = None
+            elif kind in (1, 2):
+                node._buffers[leaf] = self._flat_bufs[off:off + n].view(shape)
+            else:
+                node._buffers[leaf] = self._flat_nbt[off:off + 1].view(())
+
+    def _apply(self, fn, recurse=True):
+        self._flat_params = fn(self._flat_params)
+        self._flat_bufs = fn(self._flat_bufs)
+        nbt = fn(self._flat_nbt)
+        self._flat_nbt = nbt if nbt.dtype == torch.int64 else nbt.to(torch.int64)
+        if self._flat_params.dtype != torch.float32:
+            raise TypeError("the affordance engine computes in fp32 (reference: apex O0, code/trainer.py:101)")
+        self._flat_grads = None
+        self._rebind()
+        return self
+
+    def __deepcopy__(self, memo):
+        new = type(self)(self.use_cuda)
+        new._flat_params = self._flat_params.clone()
+        new._flat_bufs = self._flat_bufs.clone()
+        new._flat_nbt = self._flat_nbt.clone()
+        new._rebind()
+        new.gnum_rotations, new.snum_rotations = self.gnum_rotations, self.snum_rotations
+        return new
+
+    def train(self, mode=True):
+        if not mode:
+            raise NotImplementedError("the reference never leaves training-mode BatchNorm (code/trainer.py:95); "
+                                      "eval-mode statistics are not part of this path")
+        return self
+
+    def flat_grads(self):
+        if self._flat_grads is None or self._flat_grads.device != self._flat_params.device:
+            self._flat_grads = torch.zeros_like(self._flat_params)
+        return self._flat_grads
+
+    def zero_grad(self, set_to_none=True):
+        if self._flat_grads is not None:
+            self._flat_grads.zero_()
+        for p in self.parameters():
+            p.grad = None
+
+    def expose_grads(self, trunk_id, head_id):
+        """Make p.grad views of the flat gradient buffer for the parameters the last
+        backward touched (everything else stays None, like torch>=2 zero_grad)."""
+        t0, tn = smg_hip.trunk_range(self.HEAD_OUT, trunk_id)
+        h0, hn = smg_hip.head_range(self.HEAD_OUT, head_id)
+        g = self.flat_grads()
+        for node, leaf, kind, off, n, shape in self._entries:
+            if kind == 0 and (t0 <= off < t0 + tn or h0 <= off < h0 + hn):
+                node._parameters[leaf].grad = g[off:off + n].view(shape)
+
+    def _net_struct(self, with_grads):
+        net = smg_hip.SmgNet()
+        net.params = self._flat_params.data_ptr()
+        net.grads = self.flat_grads().data_ptr() if with_grads else None
+        net.bufs = self._flat_bufs.data_ptr()
+        net.nbt = self._flat_nbt.data_ptr()
+        return net
+
+    # ---- engine calls ----------------------------------------------------------------------
+    def _require_gpu(self):
+        if not self.use_cuda or not self._flat_params.is_cuda:
+            raise RuntimeError("the affordance network runs only on an MI355X through libsmg_hip.so; construct it with "
+                               "use_cuda=True and call .cuda() (the reference has no CPU path either: "
+                               "code/models.py:377-385)")
+
+    def run(self, style, rotations, num_rot, images_nchw=None, heightmaps=None, mean=0.0, std=1.0,
+            keep_for_backward=False, update_bn=True):
+        """Evaluate len(rotations) (rotation, mask) samples of one scene: image 0 is the
+        depth image (rotated per sample), image 1 the masked depth image (never rotated,
+        so its trunk pass is computed once - the reference recomputes it per rotation,
+        code/models.py:385).  Returns a cuda tensor [len(rotations), out, OH, OW]."""
+        self._require_gpu()
+        dev = self._flat_params.device
+        R = len(rotations)
+        if images_nchw is not None:
+            S = int(images_nchw.shape[-1])
+            src = dict(images_nchw=images_nchw.data_ptr(), n_images=2)
+        else:
+            hm = int(heightmaps.shape[-1])
+            diag = np.ceil(float(2 * hm) * np.sqrt(2) / 32) * 32          # code/trainer.py:169-171
+            S = 2 * hm + 2 * int((diag - 2 * hm) / 2)
+            src = dict(heightmaps=heightmaps.data_ptr(), hm_size=hm, mean=float(mean), std=float(std), n_images=2)
+        eng = get_engine(dev.index or 0, S, self.HEAD_OUT, R + 1, R)
+        q = torch.empty((R, self.HEAD_OUT, eng.OH, eng.OW), dtype=torch.float32, device=dev)
+        aff = np.concatenate([rotation_theta(r, num_rot) for r in rotations] + [rotation_theta(0, 1)])
+        seq_t = None
+        seq_h = None
+        if update_bn:   # reference order: trunk(rot r), trunk(mask), head(r) for each r
+            seq_t = np.stack([np.arange(R), np.full(R, R)], axis=1).reshape(-1)
+            seq_h = np.arange(R)
+        trunk_id, head_id = STYLE_TRUNK[style], STYLE_HEAD[style]
+        net = self._net_struct(keep_for_backward)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        token = eng.forward(net, trunk_id, head_id, q.data_ptr(), stream,
+                            stream_image=[0] * R + [1], stream_affine=aff, stream_rotated=[1] * R + [0],
+                            pair_a=list(range(R)), pair_b=[R] * R, bn_seq_trunk=seq_t, bn_seq_head=seq_h, **src)
+        self._saved = (eng, token, trunk_id, head_id) if keep_for_backward else None
+        return q
+
+    def _engine_backward(self, token, dq):
+        if self._saved is None or self._saved[1] != token or self._saved[0].forward_id != token:
+            raise RuntimeError("backward: the activations of that forward are gone (another forward ran on the engine)")
+        eng, _, trunk_id, head_id = self._saved
+        stream = torch.cuda.current_stream(dq.device).cuda_stream
+        eng.backward(self._net_struct(True), dq.data_ptr(), stream)
+        self.expose_grads(trunk_id, head_id)
+
+    # ---- the reference interface -------------------------------------------------------------
+    def forward(self, input_depth_data, m_input_depth_data, style=0, is_volatile=False, specific_rotation=-1):
+        """code/models.py:361 (reinforcement_net) / :72 (reactive_net)."""
+        self._require_gpu()
+        dev = self._flat_params.device
+        imgs = torch.cat((input_depth_data, m_input_depth_data), dim=0).to(device=dev, dtype=torch.float32).contiguous()
+        if is_volatile and specific_rotation == -1:                     # branch A, models.py:363-437
+            if style == 0:
+                rots, num = list(range(self.gnum_rotations)), self.gnum_rotations
+            elif style == 1:
+                rots, num = list(range(self.snum_rotations)), self.snum_rotations
+            else:
+                rots, num = [0], self.gnum_rotations
+            q = self.run(style, rots, num, images_nchw=imgs)
+            return [q[i:i + 1] for i in range(len(rots))]
+        rot = 0 if style == 2 else specific_rotation                    # models.py:418,446,469 (gnum for style 1 too)
+        if is_volatile:                                                 # branch B, models.py:439-510
+            return self.run(style, [rot], self.gnum_rotations, images_nchw=imgs)
+        q = self.run(style, [rot], self.gnum_rotations, images_nchw=imgs, keep_for_backward=True)   # branch C, :513-586
+        if self._autograd_hook is None or self._autograd_hook.device != dev:
+            self._autograd_hook = torch.zeros(1, device=dev, requires_grad=True)
+        out = _EngineFn.apply(self._autograd_hook, self, q, self._saved[1])
+        self.gra_prob, self.suc_prob, self.gs_prob = [], [], []
+        setattr(self, _PROB_ATTR[style], out)
+        return out
+
+
+class reinforcement_net(_AffordanceNet):
+    """code/models.py:301-586: three DenseNet-121 trunks + three 1-channel Q heads."""
+    HEAD_OUT = 1
+
+    def __init__(self, use_cuda):
+        super(reinforcement_net, self).__init__(use_cuda)
+
+
+class reactive_net(_AffordanceNet):
+    """code/models.py:15-296: the same with 3-class heads."""
+    HEAD_OUT = 3
+
+    def __init__(self, use_cuda):
+        super(reactive_net, self).__init__(use_cuda)

@@ -1,0 +1,243 @@
+"""MI355X-native stand-in for the reference's `trainer.Trainer`
+(/root/reference/code/trainer.py:17-384): same constructor, attributes and
+forward / get_label_value / backprop signatures and return types, so
+`from trainer import Trainer` (code/main.py:17) keeps working - but every network
+evaluation, the Huber / cross-entropy loss, the backward pass and the Adam step run
+in libsmg_hip.so (hand-written HIP for gfx950).
+
+Differences that are deliberate and documented:
+  * image_mean / image_std are constructor arguments (default 0.01 / 0.03); the
+    released constants are [0,0,0] / [0,0,0] (code/trainer.py:176-177) which makes
+    every network input inf/NaN.  `literal_reference=True` reproduces that.
+  * the masked stream's trunk pass is computed once per sweep instead of once per
+    rotation (code/models.py:385 sits inside the rotation loop); results are identical.
+  * no CPU mode: without a GPU (or with force_cpu=True) the first forward raises.
+"""
+import copy
+
+import numpy as np
+import torch
+
+import smg_hip
+from models import STYLE_HEAD, STYLE_TRUNK, reactive_net, reinforcement_net
+
+_ACTION_STYLE = {"grasp": 0, "suction": 1, "grasp_then_suction": 2}
+
+
+class FusedAdam(object):
+    """torch.optim.Adam(lr=1e-4, betas=(0.9,0.999), eps=1e-8, weight_decay=0)
+    (code/trainer.py:99) over the model's flat parameter buffer.  Like torch >= 2
+    (zero_grad(set_to_none=True)) only parameters that received a gradient in this
+    step are updated: the engine reports which (trunk, head) segments those are."""
+
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+        self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
+        self.m = None
+        self.v = None
+        self.steps = {}
+
+    def zero_grad(self, set_to_none=True):
+        self.model.zero_grad()
+
+    def _segments(self):
+        if self.model._saved is None:
+            return []
+        _, _, trunk_id, head_id = self.model._saved
+        return [("trunk%d" % trunk_id, smg_hip.trunk_range(self.model.HEAD_OUT, trunk_id)),
+                ("head%d" % head_id, smg_hip.head_range(self.model.HEAD_OUT, head_id))]
+
+    def step(self, segments=None):
+        model = self.model
+        p = model._flat_params
+        if self.m is None or self.m.device != p.device:
+            self.m = torch.zeros_like(p)
+            self.v = torch.zeros_like(p)
+        stream = torch.cuda.current_stream(p.device).cuda_stream
+        for name, (off, n) in (segments if segments is not None else self._segments()):
+            self.steps[name] = self.steps.get(name, 0) + 1
+            smg_hip.adam_step(p.data_ptr(), model.flat_grads().data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                              off, n, self.steps[name], self.lr, self.betas[0], self.betas[1], self.eps, stream)
+
+
+class Trainer(object):
+    def __init__(self, method, future_reward_discount, load_snapshot, snapshot_file, force_cpu,
+                 image_mean=0.01, image_std=0.03, literal_reference=False):
+        self.method = method
+        # code/trainer.py:22-31
+        if torch.cuda.is_available() and not force_cpu:
+            print("CUDA detected. Running with GPU acceleration.")
+            self.use_cuda = True
+        elif force_cpu:
+            print("CUDA detected, but overriding with option '--cpu'. Running with only CPU.")
+            self.use_cuda = False
+        else:
+            print("CUDA is *NOT* detected. Running with only CPU.")
+            self.use_cuda = False
+        self.image_mean = 0.0 if literal_reference else float(image_mean)
+        self.image_std = 0.0 if literal_reference else float(image_std)
+
+        if self.method == 'reactive':                                   # code/trainer.py:34-69
+            self.model = reactive_net(self.use_cuda)
+            if load_snapshot:
+                self.model.load_state_dict(torch.load(snapshot_file))
+                print('Pre-trained model snapshot loaded from: %s' % (snapshot_file))
+            if self.use_cuda:
+                self.model = self.model.cuda()
+        elif self.method == 'reinforcement':                            # code/trainer.py:72-92
+            self.model = reinforcement_net(self.use_cuda)
+            self.model_target = copy.deepcopy(self.model)
+            self.model_target.load_state_dict(self.model.state_dict())
+            self.future_reward_discount = future_reward_discount
+            if load_snapshot:
+                self.model.load_state_dict(torch.load(snapshot_file))
+                print('Pre-trained model snapshot loaded from: %s' % (snapshot_file))
+            if self.use_cuda:
+                self.model = self.model.cuda()
+                self.model_target = self.model_target.cuda()
+        else:
+            raise ValueError("method must be 'reactive' or 'reinforcement'")
+
+        self.model.train()                                              # code/trainer.py:95
+        self.optimizer = FusedAdam(self.model)                          # code/trainer.py:99
+        self.iteration = 0
+        # code/trainer.py:105-114
+        self.executed_action_log = []
+        self.label_value_log = []
+        self.reward_value_log = []
+        self.predicted_value_log = []
+        self.use_heuristic_log = []
+        self.is_exploit_log = []
+        self.clearance_log = []
+        self.grasping_type_log = []
+        self.episode_success_log = []
+        self.training_loss_log = []
+
+    # ---- network evaluation -----------------------------------------------------------------
+    def _heightmaps_to_device(self, depth_heightmap, m_depth_heightmap):
+        hm = np.stack([np.asarray(depth_heightmap, dtype=np.float64), np.asarray(m_depth_heightmap, dtype=np.float64)])
+        if hm.ndim != 3 or hm.shape[1] != hm.shape[2]:
+            raise ValueError("heightmaps must be square 2-D arrays")
+        dev = self.model._flat_params.device
+        return torch.from_numpy(np.ascontiguousarray(hm)).to(dev)
+
+    def _evaluate(self, model, depth_heightmap, m_depth_heightmap, style, is_volatile, specific_rotation):
+        """Rotation selection of reinforcement_net.forward / reactive_net.forward
+        (code/models.py:363-586) on the heightmap fast path: the x2 zoom, padding,
+        3-channel replication and normalisation of code/trainer.py:165-191 happen inside
+        the engine's input kernel."""
+        model._require_gpu()
+        hm = self._heightmaps_to_device(depth_heightmap, m_depth_heightmap)
+        if is_volatile and specific_rotation == -1:
+            if style == 0:
+                rots, num = list(range(model.gnum_rotations)), model.gnum_rotations
+            elif style == 1:
+                rots, num = list(range(model.snum_rotations)), model.snum_rotations
+            else:
+                rots, num = [0], model.gnum_rotations
+        else:
+            rots, num = [0 if style == 2 else specific_rotation], model.gnum_rotations
+        return model.run(style, rots, num, heightmaps=hm, mean=self.image_mean, std=self.image_std,
+                         keep_for_backward=not is_volatile)
+
+    def forward(self, depth_heightmap, m_depth_heightmap, style=0, is_volatile=False, is_target=False, specific_rotation=-1):
+        """code/trainer.py:162-209.  Returns np.ndarray float64 of length R (reinforcement)
+        or a python float P(success) (reactive, :195-199)."""
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if self.method == 'reactive':
+                q = self._evaluate(self.model, depth_heightmap, m_depth_heightmap, style, is_volatile, specific_rotation)
+                self._last_q = q
+                logits = q[0].reshape(1, 3, 1, 1)
+                return torch.softmax(logits, dim=1).cpu().numpy()[0, 0, 0][0]
+            model = self.model_target if is_target else self.model
+            q = self._evaluate(model, depth_heightmap, m_depth_heightmap, style, is_volatile, specific_rotation)
+            self._last_q = q
+            if q.shape[2] * q.shape[3] != 1:
+                raise NotImplementedError("dense Q maps (input larger than 640) cannot be returned through the "
+                                          "reference's scalar-per-rotation array (code/trainer.py:205-207)")
+            return q.reshape(-1).cpu().numpy().astype(np.float64)
+
+    def get_label_value(self, primitive_action, objects_number,
+                        suction_success, grasp_success, gs_success,
+                        depth_heightmap, mask_depth, objects_mask,
+                        bestg_id, bests_id, bestgs_g_id, bestgs_s_id,
+                        exploit_action, bestg_conf, bests_conf, bestgs_conf):
+        """code/trainer.py:212-274."""
+        if self.method == 'reactive':
+            label_value = 0
+            if primitive_action == 'suction':
+                success_value = suction_success
+                if not suction_success:
+                    label_value = 1
+            elif primitive_action == 'grasp':
+                success_value = grasp_success
+                if not grasp_success:
+                    label_value = 1
+            elif primitive_action == 'grasp_then_suction':
+                success_value = gs_success
+                label_value = 0 if gs_success == 2.5 else 1
+            print('Label value: %d' % (label_value))
+            return label_value, success_value
+
+        current_reward = 0
+        if primitive_action == 'suction':
+            current_reward = suction_success
+        elif primitive_action == 'grasp':
+            current_reward = grasp_success
+        elif primitive_action == 'grasp_then_suction':
+            current_reward = gs_success
+        if suction_success == 0 and grasp_success == 0 and gs_success == 0:
+            future_reward = 0
+        elif (objects_number == 1 and suction_success == 1) or (objects_number == 1 and grasp_success == 1) or \
+                (objects_number == 2 and gs_success == 2.5):
+            future_reward = 0
+        else:
+            if exploit_action == 'grasp':
+                m = depth_heightmap * mask_depth[bestg_id[0]]
+                future_reward = self.forward(depth_heightmap, m, style=0, is_volatile=True, is_target=True, specific_rotation=bestg_id[1])[0]
+            elif exploit_action == 'suction':
+                m = depth_heightmap * mask_depth[bests_id[0]]
+                future_reward = self.forward(depth_heightmap, m, style=1, is_volatile=True, is_target=True, specific_rotation=bests_id[1])[0]
+            elif exploit_action == 'grasp_then_suction':
+                m = depth_heightmap * (mask_depth[bestgs_g_id[0]] + mask_depth[bestgs_s_id[0]])
+                future_reward = self.forward(depth_heightmap, m, style=2, is_volatile=True, is_target=True, specific_rotation=bestgs_g_id[1])[0]
+        expected_reward = current_reward + self.future_reward_discount * future_reward
+        print('Expected reward: %f + %f x %f = %f' % (current_reward, self.future_reward_discount, future_reward, expected_reward))
+        return expected_reward, current_reward
+
+    def backprop(self, depth_heightmap, primitive_action,
+                 bestg_id, bests_id, bestgs_g_id, bestgs_s_id,
+                 label_value, objects_mask, sro_best, gro_best, bestgs_num):
+        """code/trainer.py:278-384: one sample, one optimizer step; returns a 0-d array."""
+        mask_depth = objects_mask.copy()
+        objects_mask.shape = (objects_mask.shape[0], objects_mask.shape[1], objects_mask.shape[2], 1)   # trainer.py:288,336
+        style = _ACTION_STYLE[primitive_action]
+        if style == 0:
+            m = depth_heightmap * mask_depth[bestg_id[0]]
+            rot = bestg_id[1]
+        elif style == 1:
+            m = depth_heightmap * mask_depth[bests_id[0]]
+            rot = bests_id[1]
+        else:
+            m = depth_heightmap * (mask_depth[bestgs_g_id[0]] + mask_depth[bestgs_s_id[0]])
+            rot = bestgs_g_id[1]
+        loss_value = self.train_step(depth_heightmap, m, style, rot, label_value)
+        print('Training loss: %f' % (loss_value))
+        return loss_value
+
+    def train_step(self, depth_heightmap, m_depth_heightmap, style, rotation, label_value):
+        """zero_grad -> forward (branch C) -> loss -> backward -> Adam, all on the device;
+        the only host synchronisation is reading the loss back (as code/trainer.py:352 does)."""
+        model = self.model
+        self.optimizer.zero_grad()
+        q = self._evaluate(model, depth_heightmap, m_depth_heightmap, style, False, rotation)
+        dev = q.device
+        eng, token, trunk_id, head_id = model._saved
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        labels = torch.tensor([float(label_value)], dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dq = torch.empty_like(q)
+        eng.loss(0 if self.method == 'reinforcement' else 1, q.data_ptr(), labels.data_ptr(), 1, loss.data_ptr(), dq.data_ptr(), stream)
+        model._engine_backward(token, dq)
+        self.optimizer.step()
+        setattr(model, ("gra_prob", "suc_prob", "gs_prob")[style], q)
+        return np.asarray(loss.cpu().numpy()[0])
