@@ -36,41 +36,26 @@ def main(what):
     NS = eng.max_streams
     H, HWp = eng.H, eng.HWp
     feats = on.grasp_depth_trunk.features
-    stages = {}
-    hooks = []
-    for name in ("conv0", "pool0", "denseblock1", "transition1", "denseblock2", "transition2", "denseblock3",
-                 "transition3", "denseblock4", "norm5"):
-        hooks.append(getattr(feats, name).register_forward_hook(lambda m, i, o, name=name: stages.__setitem__(name, o.detach().numpy()[0])))
-    hooks.append(feats.denseblock1.denselayer1.conv1.register_forward_hook(lambda m, i, o: stages.__setitem__("b1l1c1", o.detach().numpy()[0])))
-    hooks.append(feats.denseblock1.denselayer1.conv2.register_forward_hook(lambda m, i, o: stages.__setitem__("b1l1c2", o.detach().numpy()[0])))
-    with torch.no_grad():
-        rx = orc.rotate(x, rot, R)
-        qo = orc.forward(on, x, mx, 0, True, rot)
-    for h in hooks:
-        h.remove()
-    # the hooks saw both trunk passes; the LAST call was the masked stream -> rerun rotated only
-    stages_m = dict(stages)
-    stages.clear()
-    hooks = []
-    for name in ("conv0", "pool0", "denseblock1", "transition1", "denseblock2", "transition2", "denseblock3",
-                 "transition3", "denseblock4", "norm5"):
-        hooks.append(getattr(feats, name).register_forward_hook(lambda m, i, o, name=name: stages.__setitem__(name, o.detach().numpy()[0])))
-    hooks.append(feats.denseblock1.denselayer1.conv1.register_forward_hook(lambda m, i, o: stages.__setitem__("b1l1c1", o.detach().numpy()[0])))
-    hooks.append(feats.denseblock1.denselayer1.conv2.register_forward_hook(lambda m, i, o: stages.__setitem__("b1l1c2", o.detach().numpy()[0])))
-    on2 = oracle_net(0)
-    on2.grasp_depth_trunk.features.load_state_dict(feats.state_dict())
-    with torch.no_grad():
+
+    def capture(inp):
         import copy
         f2 = copy.deepcopy(feats)
-        for h in hooks:
-            h.remove()
-        hooks = []
+        out = {}
         for name in ("conv0", "pool0", "denseblock1", "transition1", "denseblock2", "transition2", "denseblock3",
                      "transition3", "denseblock4", "norm5"):
-            hooks.append(getattr(f2, name).register_forward_hook(lambda m, i, o, name=name: stages.__setitem__(name, o.detach().numpy()[0])))
-        hooks.append(f2.denseblock1.denselayer1.conv1.register_forward_hook(lambda m, i, o: stages.__setitem__("b1l1c1", o.detach().numpy()[0])))
-        hooks.append(f2.denseblock1.denselayer1.conv2.register_forward_hook(lambda m, i, o: stages.__setitem__("b1l1c2", o.detach().numpy()[0])))
-        f2(rx)
+            getattr(f2, name).register_forward_hook(lambda m, i, o, name=name: out.__setitem__(name, o.detach().numpy()[0]))
+        f2.denseblock1.denselayer1.conv1.register_forward_hook(lambda m, i, o: out.__setitem__("b1l1c1", o.detach().numpy()[0]))
+        f2.denseblock1.denselayer1.conv2.register_forward_hook(lambda m, i, o: out.__setitem__("b1l1c2", o.detach().numpy()[0]))
+        with torch.no_grad():
+            f2(inp)
+        return out
+
+    with torch.no_grad():
+        rx = orc.rotate(x, rot, R)
+    stages = capture(rx)
+    stages_m = capture(mx)
+    with torch.no_grad():
+        qo = orc.forward(on, x, mx, 0, True, rot)
     print("oracle q", float(qo), " product q", float(qp), " abs diff %.3e" % abs(float(qo) - float(qp)))
 
     img = eng.debug_read("img")
