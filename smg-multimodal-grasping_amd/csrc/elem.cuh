@@ -126,7 +126,7 @@ struct Pool0Args {
 
 __global__ __launch_bounds__(256) void pool0_kernel(const Pool0Args a) {
     __shared__ float prm[128];
-    __shared__ float red[2][16][64];
+    __shared__ double red[2][16][64];
     const int n = blockIdx.y, t = threadIdx.x, cq = t & 15, slot = t >> 4;
     if (t < 64) {
         float mean, invstd;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void pool0_kernel(const Pool0Args a) {
     __syncthreads();
     const float* sc = prm + 4 * cq;
     const float* sh = prm + 64 + 4 * cq;
-    float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
     for (int i = 0; i < 4; ++i) {
         const int p = blockIdx.x * 64 + slot + 16 * i;
         if (p >= a.po.HW) continue;
@@ -158,16 +158,16 @@ __global__ __launch_bounds__(256) void pool0_kernel(const Pool0Args a) {
         *reinterpret_cast<float4*>(a.x1 + o * a.ldx + 4 * cq) = make_float4(best[0], best[1], best[2], best[3]);
         if (a.argmax) *reinterpret_cast<uchar4*>(a.argmax + o * 64 + 4 * cq) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { s[c] += best[c]; ss[c] += best[c] * best[c]; }
+        for (int c = 0; c < 4; ++c) { s[c] += (double)best[c]; ss[c] += (double)best[c] * (double)best[c]; }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) { red[0][slot][4 * cq + c] = s[c]; red[1][slot][4 * cq + c] = ss[c]; }
     __syncthreads();
     if (t < 128) {
         const int q = t >> 6, c = t & 63;
-        float tot = 0.f;
+        double tot = 0.0;
         for (int k = 0; k < 16; ++k) tot += red[q][k][c];
-        atomicAdd((q ? a.dsq : a.dsum) + (int64_t)n * a.dstride + c, (double)tot);
+        atomicAdd((q ? a.dsq : a.dsum) + (int64_t)n * a.dstride + c, tot);
     }
 }
 
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void feat_kernel(const FeatArgs a) {
         sc[c] = a.gamma[c5 + c] * invstd;
         sh[c] = a.beta[c5 + c] - mean * sc[c];
     }
-    float sm[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+    double sm[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
     const int p0 = blockIdx.z * a.chunk;
     const int p1 = min(p0 + a.chunk, a.p4.HW);
     for (int p = p0; p < p1; ++p) {
@@ -207,13 +207,14 @@ __global__ __launch_bounds__(256) void feat_kernel(const FeatArgs a) {
         o.x = fmaf(v.x, sc[0], sh[0]); o.y = fmaf(v.y, sc[1], sh[1]);
         o.z = fmaf(v.z, sc[2], sh[2]); o.w = fmaf(v.w, sc[3], sh[3]);
         *reinterpret_cast<float4*>(a.F + ((int64_t)j * a.p4.HWp + p) * 2048 + ch) = o;
-        sm[0] += o.x; sm[1] += o.y; sm[2] += o.z; sm[3] += o.w;
-        sq[0] += o.x * o.x; sq[1] += o.y * o.y; sq[2] += o.z * o.z; sq[3] += o.w * o.w;
+        const double od[4] = {(double)o.x, (double)o.y, (double)o.z, (double)o.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { sm[c] += od[c]; sq[c] += od[c] * od[c]; }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        atomicAdd(a.fsum + (int64_t)j * 2048 + ch + c, (double)sm[c]);
-        atomicAdd(a.fsq + (int64_t)j * 2048 + ch + c, (double)sq[c]);
+        atomicAdd(a.fsum + (int64_t)j * 2048 + ch + c, sm[c]);
+        atomicAdd(a.fsq + (int64_t)j * 2048 + ch + c, sq[c]);
     }
 }
 

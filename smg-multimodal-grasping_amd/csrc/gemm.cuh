@@ -85,8 +85,8 @@ __device__ __forceinline__ float4 affine2(float4 g, float4 x, const float* a, co
 // Sum per-lane column partials over the rows of the whole workgroup tile.
 // v[q][tn]: this lane's partial for column (wn0 + tn*32 + l31) of quantity q.
 // On return threads t < BN hold the totals of column t in out[q].
-template <class C, int NQ>
-__device__ __forceinline__ void block_col_reduce(float (&v)[NQ][C::TN], float* red, float (&out)[NQ]) {
+template <class C, int NQ, class T>
+__device__ __forceinline__ void block_col_reduce(T (&v)[NQ][C::TN], T* red, T (&out)[NQ]) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
     const int wm = wave / C::WN, wn0 = (wave % C::WN) * C::TN * 32;
 #pragma unroll
@@ -103,7 +103,7 @@ __device__ __forceinline__ void block_col_reduce(float (&v)[NQ][C::TN], float* r
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        float s = 0.f;
+        T s = 0;
         if (t < C::BN) {
 #pragma unroll
             for (int w = 0; w < C::WM; ++w) s += red[(q * C::WM + w) * C::BN + t];
@@ -317,9 +317,11 @@ struct FwdConvP {
     __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, float*) const {
         const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
         const int wm0 = (wave / Cfg::WN) * Cfg::TM * 32, wn0 = (wave % Cfg::WN) * Cfg::TN * 32;
-        float v[2][Cfg::TN];
+        // fp64 in-lane accumulation: E[x^2] - mean^2 must survive near-constant channels
+        // (the masked stream is mostly background).
+        double v[2][Cfg::TN];
 #pragma unroll
-        for (int j = 0; j < Cfg::TN; ++j) v[0][j] = v[1][j] = 0.f;
+        for (int j = 0; j < Cfg::TN; ++j) v[0][j] = v[1][j] = 0.0;
         const int pbase = c.m0 - c.n * po.HWp;
 #pragma unroll
         for (int i = 0; i < Cfg::TM; ++i)
@@ -332,17 +334,18 @@ struct FwdConvP {
                     if (pbase + row < po.HW && col < N) {
                         const float x = acc[i][j][r];
                         dst[(int64_t)(c.m0 + row) * ldd + dcoff + col] = x;
-                        v[0][j] += x;
-                        v[1][j] += x * x;
+                        const double xd = (double)x;
+                        v[0][j] += xd;
+                        v[1][j] += xd * xd;
                     }
                 }
             }
-        float tot[2];
-        block_col_reduce<Cfg, 2>(v, smem, tot);
+        double tot[2];
+        block_col_reduce<Cfg, 2, double>(v, reinterpret_cast<double*>(smem), tot);
         if (t < Cfg::BN && c.n0 + t < N) {
             const int64_t si = (int64_t)c.n * dstride + dcoff + c.n0 + t;
-            atomicAdd(dsum + si, (double)tot[0]);
-            atomicAdd(dsq + si, (double)tot[1]);
+            atomicAdd(dsum + si, tot[0]);
+            atomicAdd(dsq + si, tot[1]);
         }
     }
 };
@@ -503,7 +506,7 @@ struct BwdDataP {
                 }
         }
         float tot[2];
-        block_col_reduce<Cfg, 2>(v, smem, tot);
+        block_col_reduce<Cfg, 2, float>(v, smem, tot);
         if (t < Cfg::BN && c.n0 + t < N) {
             const int col = c.n0 + t;
             const float wgt = (EMODE == E_STORE) ? 1.f : ep[4 * Cfg::BN + t];

@@ -224,6 +224,34 @@ class Trainer(object):
         print('Training loss: %f' % (loss_value))
         return loss_value
 
+    def train_batch(self, depth_heightmap, m_depth_heightmap, style, rotations, labels, grad_sync=None, return_q=False):
+        """Batched form of backprop for one scene: every rotation in `rotations` is a training
+        sample (forward as branch C, Huber / CE against labels[i]); the gradient of the SUM of
+        the losses is accumulated in one backward pass (the masked stream's trunk is walked once
+        with the summed gradient - exact, the trunk is linear in its output gradient), then ONE
+        Adam step.  Equals len(rotations) reference backprop calls with the optimizer step
+        deferred to the end.  `grad_sync(model, trunk_id, head_id)` is the data-parallel hook
+        (parallel.allreduce_grads) called between backward and Adam.  Returns the loss vector."""
+        model = self.model
+        self.optimizer.zero_grad()
+        model._require_gpu()
+        hm = self._heightmaps_to_device(depth_heightmap, m_depth_heightmap)
+        num = model.gnum_rotations                     # code/models.py:522,545,568 (gnum for every style)
+        rots = [0 if style == 2 else int(r) for r in rotations]
+        q = model.run(style, rots, num, heightmaps=hm, mean=self.image_mean, std=self.image_std, keep_for_backward=True)
+        dev = q.device
+        eng, token, trunk_id, head_id = model._saved
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        lab = torch.as_tensor(np.asarray(labels, dtype=np.float32), device=dev)
+        loss = torch.empty(len(rots), dtype=torch.float32, device=dev)
+        dq = torch.empty_like(q)
+        eng.loss(0 if self.method == 'reinforcement' else 1, q.data_ptr(), lab.data_ptr(), len(rots), loss.data_ptr(), dq.data_ptr(), stream)
+        model._engine_backward(token, dq)
+        if grad_sync is not None:
+            grad_sync(model, trunk_id, head_id)
+        self.optimizer.step()
+        return (loss, q) if return_q else loss
+
     def train_step(self, depth_heightmap, m_depth_heightmap, style, rotation, label_value):
         """zero_grad -> forward (branch C) -> loss -> backward -> Adam, all on the device;
         the only host synchronisation is reading the loss back (as code/trainer.py:352 does)."""

@@ -1,0 +1,142 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol
+include/smg_hip.h declares, its state layout equals the reference's state_dict
+layout, and the host-side mirror (models.py / trainer.py) behaves like the
+reference's interface up to the point where the GPU is needed - where it must fail
+loudly instead of falling back to anything."""
+import copy
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import REPO, orc
+
+import smg_hip
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "smg_hip.h")).read()
+    declared = set(re.findall(r"\b(smg_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"smg_engine", "smg_net", "smg_batch"}
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(smg_hip.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libsmg_hip.so does not export " + name
+    assert declared == set(smg_hip.EXPORTS)
+
+
+def test_layout_matches_reference_state_dict():
+    for out_ch in (1, 3):
+        lay = smg_hip.layout(out_ch)
+        ref = orc.state_layout(out_ch)
+        assert [n for n, _, _, _ in lay] == [n for n, _, _ in ref]
+        assert [tuple(s) for _, _, _, s in lay] == [tuple(s) for _, s, _ in ref]
+    L = smg_hip.lib()
+    assert L.smg_layout_count(1) == 2217
+    assert L.smg_layout_param_floats(1) == 24419256
+    off, n = smg_hip.trunk_range(1, 1)
+    hoff, hn = smg_hip.head_range(1, 1)
+    assert n == 6953856 and hn == 160896
+
+
+def test_model_state_dict_roundtrip_and_flat_views():
+    import models
+    net = models.reinforcement_net(False)
+    o = orc.OracleNet(1)
+    assert list(net.state_dict().keys()) == list(o.state_dict().keys())
+    net.load_state_dict(o.state_dict())
+    for k, v in o.state_dict().items():
+        assert torch.equal(net.state_dict()[k], v), k
+    # parameters are views of ONE flat buffer
+    p = dict(net.named_parameters())["grasp_depth_trunk.features.denseblock2.denselayer3.conv2.weight"]
+    base = net._flat_params
+    assert p.data_ptr() >= base.data_ptr() and p.data_ptr() < base.data_ptr() + base.numel() * 4
+    p.data.fill_(7.0)
+    assert float((base == 7.0).sum()) == p.numel()
+    # deepcopy gives an independent buffer (Trainer.__init__: copy.deepcopy(self.model), code/trainer.py:74)
+    t = copy.deepcopy(net)
+    t._flat_params.zero_()
+    assert float(p.sum()) == 7.0 * p.numel()
+    # head init follows code/models.py:347-353
+    net2 = models.reinforcement_net(False)
+    sd = net2.state_dict()
+    assert float(sd["graspnet_val.grasp-val-norm0.weight"].min()) == 1.0
+    assert float(sd["graspnet_val.grasp-val-norm0.bias"].abs().max()) == 0.0
+    w = sd["suctionnet_val.suction-val-conv0.weight"]
+    assert abs(float(w.std()) - np.sqrt(2.0 / 2048)) < 2e-3
+
+
+def test_no_cpu_fallback():
+    import models
+    from trainer import Trainer
+    net = models.reinforcement_net(False)
+    with pytest.raises(RuntimeError):
+        net.forward(torch.zeros(1, 3, 640, 640), torch.zeros(1, 3, 640, 640), 0, True, -1)
+    if not torch.cuda.is_available():
+        with pytest.raises(smg_hip.SmgError):
+            smg_hip.Engine(0, 640, 2, 1, 1)
+        tr = Trainer('reinforcement', 0.5, False, None, False)
+        assert tr.use_cuda is False and tr.iteration == 0 and tr.method == 'reinforcement'
+        for log in ("executed_action_log", "label_value_log", "reward_value_log", "predicted_value_log", "use_heuristic_log",
+                    "is_exploit_log", "clearance_log", "grasping_type_log", "episode_success_log", "training_loss_log"):
+            assert getattr(tr, log) == []
+        with pytest.raises(RuntimeError):
+            tr.forward(np.zeros((224, 224)), np.zeros((224, 224)), 0, True)
+
+
+def test_trainer_reward_arithmetic_matches_oracle():
+    """get_label_value without network evaluation (zero-future cases + reactive labels)."""
+    from trainer import Trainer
+    tr = Trainer('reinforcement', 0.5, False, None, True)
+    z = np.zeros((224, 224))
+    m = np.zeros((2, 224, 224))
+    for args in (("grasp", 3, 0, 0, 0), ("suction", 1, 1, 0, 0), ("grasp", 1, 0, 1, 0), ("grasp_then_suction", 2, 0, 0, 2.5)):
+        got = tr.get_label_value(args[0], args[1], args[2], args[3], args[4], z, m, m, (0, 0), (0, 0), (0, 0), (0, 0), 'grasp', 0, 0, 0)
+        want = orc.label_value("reinforcement", args[0], args[1], args[2], args[3], args[4], 123.0, 0.5)
+        assert got == want
+    tr3 = Trainer('reactive', 0.5, False, None, True)
+    for args in (("grasp", 3, 0, 0, 0), ("grasp", 3, 0, 1, 0), ("suction", 3, 1, 0, 0), ("grasp_then_suction", 3, 0, 0, 2.5),
+                 ("grasp_then_suction", 3, 0, 0, 0.5)):
+        got = tr3.get_label_value(args[0], args[1], args[2], args[3], args[4], z, m, m, (0, 0), (0, 0), (0, 0), (0, 0), 'grasp', 0, 0, 0)
+        want = orc.label_value("reactive", args[0], args[1], args[2], args[3], args[4], 0, 0.5)
+        assert got == want
+
+
+def test_rotation_theta_matches_reference_matrix():
+    import models
+    for R in (16, 32):
+        for r in range(R):
+            assert np.array_equal(models.rotation_theta(r, R), orc.rotation_matrix(r, R).numpy().reshape(6))
+
+
+def test_input_kernel_formula_restated_in_numpy(golden):
+    """The closed-form sampling arithmetic the HIP input kernel uses (elem.cuh
+    prep_rotate_kernel), evaluated in numpy with exact fma emulation, reproduces torch's
+    affine_grid + grid_sample(nearest) index maps (golden G1) bit for bit."""
+    import zlib
+    import models
+
+    def fma(a, b, c):
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+    S, R = 640, 16
+    i = np.arange(S)
+    step = np.float32(2.0) / np.float32(S - 1)
+    lin = np.where(i < S // 2,
+                   (np.float64(-1) + np.float64(step) * i).astype(np.float32),
+                   (np.float64(1) - np.float64(step) * (S - 1 - i)).astype(np.float32)).astype(np.float32)
+    X = np.broadcast_to(lin[None, :], (S, S)).astype(np.float32)
+    Y = np.broadcast_to(lin[:, None], (S, S)).astype(np.float32)
+    for r in range(R):
+        th = models.rotation_theta(r, R)
+        gx = fma(Y, np.full_like(Y, th[1]), (X * th[0]).astype(np.float32)) + th[2]
+        gy = fma(Y, np.full_like(Y, th[4]), (X * th[3]).astype(np.float32)) + th[5]
+        fx = np.rint(((gx + np.float32(1)) / np.float32(2)) * np.float32(S - 1))
+        fy = np.rint(((gy + np.float32(1)) / np.float32(2)) * np.float32(S - 1))
+        ok = (fx >= 0) & (fx <= S - 1) & (fy >= 0) & (fy <= S - 1)
+        idx = (fy.astype(np.int64) * S + fx.astype(np.int64)).astype(np.int32)
+        idx[~ok] = -1
+        assert np.uint32(zlib.crc32(idx.tobytes()) & 0xFFFFFFFF) == golden["g1_crc_640"][r], r

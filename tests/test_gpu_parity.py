@@ -1,0 +1,293 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through
+the C ABI (libsmg_hip.so via smg_hip.py), against
+  * the golden vectors captured from the reference (tests/golden/reference_vectors.npz),
+  * the oracle (oracle/affordance.py, PyTorch-CPU) on the same seeded inputs.
+
+Tolerances
+  * rotation / preprocessing gathers: bit-exact;
+  * Q values: SURVEY.md 8c / north_star: |dq| <= 1e-3 * max(|q|, 1e-2 * max|q|), argmax exact;
+  * gradients: fp32 training-mode BN on these inputs is ill-conditioned - the PyTorch-CPU
+    fp32 oracle itself deviates from an fp64 evaluation by ~5e-3 (median) to 3e-2 per
+    tensor - so each tensor's error against the fp64 oracle must stay within
+    3x the fp32 oracle's own error (+ a floor), not within a fixed epsilon.
+"""
+import copy
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import MEAN, STD, nhwc_plane, oracle_net, orc, probe_idx, q_close, scene, scene_tensors
+
+pytestmark = pytest.mark.gpu
+
+
+def crc(a):
+    return np.uint32(zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF)
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the gpu-marked tests must run on the MI355X box")
+    import smg_hip
+    smg_hip.lib()   # raises if libsmg_hip.so is missing
+    return torch.device("cuda:0")
+
+
+def product_net(seed, out_ch=1, R=16):
+    from helpers import product_net as pn
+    return pn(seed, out_ch, R)
+
+
+def engine_of(net, S=640):
+    import models
+    return models._ENGINES[(0, S, net.HEAD_OUT)]
+
+
+# ---------------------------------------------------------------------------------------
+def test_g1_rotation_gather_bit_exact(gpu, golden):
+    """K1 against golden G1 (CRC of torch's grid_sample index map) for all 16 rotations."""
+    net = product_net(0)
+    S = 640
+    idx_img = (torch.arange(S * S, dtype=torch.float32).reshape(1, 1, S, S) + 1.0).repeat(1, 3, 1, 1)
+    net.forward(idx_img, idx_img, 0, True, -1)
+    eng = engine_of(net)
+    img = eng.debug_read("img")
+    for r in range(16):
+        a = nhwc_plane(img, eng.max_streams, eng.HWp[0], 4, S, S, r)
+        idx = (a[0].astype(np.int64) - 1).astype(np.int32)
+        assert int((idx < 0).sum()) == int(golden["g1_oob_640"][r])
+        assert crc(idx) == golden["g1_crc_640"][r], "rotation %d" % r
+        assert (a[0] == a[1]).all() and (a[0] == a[2]).all() and (a[3] == 0).all()
+
+
+def test_g2_heightmap_preprocess_bit_exact(gpu):
+    """Engine heightmap path (zoom x2, pad, normalise, replicate) == oracle preprocess + rotate."""
+    from trainer import Trainer
+    tr = Trainer('reinforcement', 0.5, False, None, False)
+    tr.model.gnum_rotations = tr.model.snum_rotations = 16
+    d, dm = scene(0, [0])
+    tr.forward(d, dm, 0, True, False, 5)
+    eng = engine_of(tr.model)
+    img = eng.debug_read("img")
+    x, mx = scene_tensors(0, [0])
+    a = nhwc_plane(img, eng.max_streams, eng.HWp[0], 4, 640, 640, 0)
+    assert (a[:3] == orc.rotate(x, 5, 16).numpy()[0]).all()
+    a = nhwc_plane(img, eng.max_streams, eng.HWp[0], 4, 640, 640, 1)
+    assert (a[:3] == mx.numpy()[0]).all()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_g4_q_sweeps_vs_reference(gpu, golden, seed):
+    """16-rotation sweeps of styles 0/1 and the ES pass against the reference's values."""
+    net = product_net(seed)
+    x, mx = scene_tensors(seed, [seed % 8])
+    _, mx2 = scene_tensors(seed, [1, 2])
+    for style in (0, 1):
+        out = net.forward(x, mx, style, True, -1)
+        assert isinstance(out, list) and len(out) == 16 and tuple(out[0].shape) == (1, 1, 1, 1)
+        q = np.asarray([float(t) for t in out])
+        ref = golden["g4_s%d_q%d" % (seed, style)]
+        ok, worst = q_close(q, ref)
+        assert ok, "style %d worst |dq| %.3e" % (style, worst)
+        assert int(q.argmax()) == int(ref.argmax())
+    out = net.forward(x, mx2, 2, True, -1)
+    assert isinstance(out, list) and len(out) == 1
+    ok, worst = q_close([float(out[0])], golden["g4_s%d_q2" % seed], scale=np.abs(golden["g4_s%d_q0" % seed]).max())
+    assert ok, worst
+
+
+def test_g4_branch_b_and_g7_bn_buffers(gpu, golden):
+    net = product_net(0)
+    x, mx = scene_tensors(0, [0])
+    qb = net.forward(x, mx, 0, True, 5)
+    assert torch.is_tensor(qb) and tuple(qb.shape) == (1, 1, 1, 1)
+    assert q_close([float(qb)], golden["g4_branchB_style0_rot5"], scale=1.1)[0]
+    qb1 = net.forward(x, mx, 1, True, 7)
+    assert q_close([float(qb1)], golden["g4_branchB_style1_rot7"], scale=1.1)[0]
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    keys = sorted(k[3:-3] for k in golden.files if k.startswith("g7_") and k.endswith("_rm"))
+    for key in keys:
+        np.testing.assert_allclose(sd[key + ".running_mean"].numpy(), golden["g7_%s_rm" % key], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(sd[key + ".running_var"].numpy(), golden["g7_%s_rv" % key], rtol=2e-4, atol=2e-5)
+        assert int(sd[key + ".num_batches_tracked"]) == int(golden["g7_%s_nbt" % key])
+
+
+def test_sweep_bn_update_order(gpu):
+    """A 2-rotation sweep updates trunk BN buffers 4 times and head buffers twice
+    (SURVEY.md Appendix B), exactly like the oracle's sequential schedule."""
+    net = product_net(1, R=2)
+    on = oracle_net(1, R=2)
+    x, mx = scene_tensors(1, [2])
+    net.forward(x, mx, 0, True, -1)
+    orc.forward(on, x, mx, 0, True, -1)
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    so = on.state_dict()
+    assert int(sd["grasp_depth_trunk.features.norm0.num_batches_tracked"]) == 4
+    assert int(sd["graspnet_val.grasp-val-norm0.num_batches_tracked"]) == 2
+    assert int(sd["suction_depth_trunk.features.norm0.num_batches_tracked"]) == 0
+    for k in ("grasp_depth_trunk.features.norm0", "grasp_depth_trunk.features.denseblock3.denselayer7.norm2",
+              "grasp_depth_trunk.features.transition1.norm", "graspnet_val.grasp-val-norm1"):
+        np.testing.assert_allclose(sd[k + ".running_mean"].numpy(), so[k + ".running_mean"].numpy(), rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(sd[k + ".running_var"].numpy(), so[k + ".running_var"].numpy(), rtol=2e-4, atol=2e-5)
+
+
+def _fp64_truth(on, rx, mx, style, label):
+    o64 = copy.deepcopy(on).double()
+    o64.zero_grad()
+    trunk = getattr(o64, orc.STYLE_TRUNK[style]).features
+    head = getattr(o64, orc.STYLE_HEAD[style])
+    q = head(torch.cat((trunk(rx.double()), trunk(mx.double())), 1))
+    orc.huber(q[0, 0, 0, 0], label).sum().backward()
+    return float(q), {n: p.grad for n, p in o64.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("style,rot,label", [(0, 3, 0.4), (1, 9, 7.5)])
+def test_g5_backward_gradients(gpu, golden, style, rot, label):
+    """Every one of the 368 gradient tensors of a train step (both Huber branches)."""
+    on = oracle_net(0)
+    x, mx = scene_tensors(0, [0])
+    rx = orc.rotate(x, rot, 16)
+    q64, g64 = _fp64_truth(on, rx, mx, style, label)
+    on.zero_grad()
+    qo = orc.forward(on, x, mx, style, False, rot)
+    orc.huber(qo[0, 0, 0, 0], label).sum().backward()
+    net = product_net(0)
+    net.zero_grad()
+    qp = net.forward(x, mx, style, False, rot)
+    d = qp[0, 0, 0, 0] - label
+    loss = 0.5 * d ** 2 if abs(float(d.detach())) < 1 else abs(d) - 0.5       # code/trainer.py:345-348
+    loss.backward()                                                            # autograd -> smg_backward
+    assert abs(float(qp.detach()) - q64) <= 1e-3 * max(abs(q64), 1e-2)
+    po = dict(on.named_parameters())
+    gmax = max(float(g.norm()) for g in g64.values())
+    n_checked = 0
+    for name, p in net.named_parameters():
+        if name not in g64:
+            assert p.grad is None, "unexpected gradient on " + name
+            continue
+        assert p.grad is not None, "missing gradient on " + name
+        t = g64[name].numpy()
+        e_prod = np.sqrt(((p.grad.cpu().double().numpy() - t) ** 2).sum())
+        e_orc = np.sqrt(((po[name].grad.double().numpy() - t) ** 2).sum())
+        nrm = np.sqrt((t * t).sum())
+        assert e_prod <= 3.0 * e_orc + 2e-3 * nrm + 1e-6 * gmax, \
+            "%s: |err| %.3e vs fp32-oracle |err| %.3e, |g| %.3e" % (name, e_prod, e_orc, nrm)
+        n_checked += 1
+    assert n_checked == 368
+    # the same tensors the reference produced gradients for
+    has = golden["g5_step0_hasgrad"] if style == 0 else None
+    if has is not None:
+        mine = np.asarray([p.grad is not None for p in net.parameters()])
+        assert (mine == has).all()
+
+
+def test_g5_g6_trainer_steps_vs_reference(gpu, golden):
+    """Trainer.backprop x3 (grasp, suction, grasp_then_suction): q, loss and Adam-updated
+    weights against the reference's own trajectory; then the diverged target network."""
+    from trainer import Trainer
+    import synthetic
+    tr = Trainer('reinforcement', 0.5, False, None, False)
+    sd = synthetic.make_state_dict(orc.state_layout(1), 0)
+    tr.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    tr.model_target.load_state_dict(tr.model.state_dict())
+    for m in (tr.model, tr.model_target):
+        m.gnum_rotations = m.snum_rotations = 16
+    depth, masks = synthetic.heightmap_scene(0)
+    actions = [("grasp", 3, 0.4), ("suction", 9, 7.5), ("grasp_then_suction", 0, -3.0)]
+    for si, (action, rot, label) in enumerate(actions):
+        om = masks.copy()
+        loss = tr.backprop(depth, action, (0, rot), (0, rot), (0, rot), (0, rot), label, om, None, None, None)
+        assert om.ndim == 4                                       # in-place reshape, code/trainer.py:336
+        assert isinstance(loss, np.ndarray) and loss.shape == ()
+        style = {"grasp": 0, "suction": 1, "grasp_then_suction": 2}[action]
+        q = float((tr.model.gra_prob, tr.model.suc_prob, tr.model.gs_prob)[style].reshape(-1)[0])
+        # style 2 masks with objects 0+0 here; the golden run used mask 0 for every step
+        if action != "grasp_then_suction":
+            assert abs(q - float(golden["g5_step%d_q" % si])) <= 2e-3 * max(abs(float(golden["g5_step%d_q" % si])), 0.1)
+            assert abs(float(loss) - float(golden["g5_step%d_loss" % si])) <= 2e-3 * max(float(golden["g5_step%d_loss" % si]), 0.1)
+            # Adam: on a segment's first step every weight moves by +-lr (sign of its gradient), so a
+            # probe can only be off by a full 2e-4 where fp32 noise flips the sign of a ~zero gradient
+            params = dict(tr.model.named_parameters())
+            pre = "g6_step%d_param_" % si
+            diffs = []
+            for k in [k for k in golden.files if k.startswith(pre)]:
+                p = params[k[len(pre):]]
+                pi = probe_idx(p.numel(), 16, "g6/" + k[len(pre):])
+                diffs.append(np.abs(p.detach().cpu().numpy().ravel()[pi] - golden[k]))
+            diffs = np.concatenate(diffs)
+            assert diffs.max() <= 2.1e-4 and (diffs < 2e-6).mean() >= 0.9, diffs
+    d = depth
+    qt = tr.forward(d, d * masks[0], 0, True, True, 3)
+    assert isinstance(qt, np.ndarray) and qt.shape == (1,) and qt.dtype == np.float64
+    assert q_close(qt, [golden["g4_target_rot3"]], scale=1.1)[0]      # target net never moved
+    qm = tr.forward(d, d * masks[0], 0, True, False, 3)
+    assert abs(qm[0] - qt[0]) > 1e-4                                   # model has
+
+
+def test_get_label_value_uses_target_network(gpu):
+    from trainer import Trainer
+    import synthetic
+    tr = Trainer('reinforcement', 0.5, False, None, False)
+    for m in (tr.model, tr.model_target):
+        m.gnum_rotations = m.snum_rotations = 16
+    depth, masks = synthetic.heightmap_scene(1)
+    fut = tr.forward(depth, depth * masks[2], 0, True, True, 4)[0]
+    exp, cur = tr.get_label_value('grasp', 3, 0, 1, 0, depth, masks, masks, (2, 4), (2, 4), (2, 4), (2, 4),
+                                  'grasp', 0, 0, 0)
+    assert cur == 1 and abs(exp - (1 + 0.5 * fut)) < 1e-9
+    exp, cur = tr.get_label_value('grasp', 3, 0, 0, 0, depth, masks, masks, (2, 4), (2, 4), (2, 4), (2, 4), 'grasp', 0, 0, 0)
+    assert (exp, cur) == (0, 0)
+
+
+def test_g8_reactive(gpu, golden):
+    """Config 1: reactive_net, 1 rotation; logits, softmax, weighted CE and its gradients."""
+    from trainer import Trainer
+    import synthetic
+    tr = Trainer('reactive', 0.5, False, None, False)
+    sd = synthetic.make_state_dict(orc.state_layout(3), 0)
+    tr.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    x, mx = scene_tensors(0, [0])
+    out = tr.model.forward(x, mx, 0, True, -1)
+    assert isinstance(out, list) and tuple(out[0].shape) == (1, 3, 1, 1)
+    ok, worst = q_close(out[0].cpu().numpy().ravel(), golden["g8_logits"])
+    assert ok, worst
+    depth, masks = synthetic.heightmap_scene(0)
+    p0 = tr.forward(depth, depth * masks[0], 0, True, False, -1)
+    assert isinstance(p0, (float, np.floating)) and abs(p0 - float(golden["g8_softmax0"])) < 1e-3
+    loss = tr.backprop(depth, 'grasp', (0, 0), (0, 0), (0, 0), (0, 0), 1, masks.copy(), None, None, None)
+    assert abs(float(loss) - float(golden["g8_loss"])) < 2e-3
+
+
+def test_model_api_errors(gpu):
+    import models
+    net = models.reinforcement_net(True)      # not moved to the GPU
+    with pytest.raises(RuntimeError):
+        net.forward(torch.zeros(1, 3, 640, 640), torch.zeros(1, 3, 640, 640), 0, True, -1)
+    with pytest.raises(NotImplementedError):
+        net.eval()
+    net = net.cuda()
+    q = net.forward(torch.zeros(1, 3, 640, 640), torch.zeros(1, 3, 640, 640), 0, False, 0)
+    net.forward(torch.zeros(1, 3, 640, 640), torch.zeros(1, 3, 640, 640), 0, True, 0)   # overwrites the saved activations
+    with pytest.raises(RuntimeError):
+        q.sum().backward()
+
+
+def test_snapshot_roundtrip(gpu, tmp_path):
+    """Logger.save_model pattern (code/logger.py:121-125): model.cpu().state_dict() -> file -> load."""
+    import models
+    net = product_net(2)
+    x, mx = scene_tensors(2, [1])
+    q0 = float(net.forward(x, mx, 0, True, 2))
+    f = str(tmp_path / "snap.pth")
+    torch.save(net.cpu().state_dict(), f)
+    net = net.cuda()
+    other = models.reinforcement_net(True)
+    other.load_state_dict(torch.load(f))
+    other = other.cuda()
+    other.gnum_rotations = other.snum_rotations = 16
+    assert len(other.state_dict()) == 2217
+    # BN buffers changed by the first forward do not enter a training-mode forward
+    assert abs(float(other.forward(x, mx, 0, True, 2)) - q0) < 1e-6
