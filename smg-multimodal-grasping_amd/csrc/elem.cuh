@@ -125,19 +125,17 @@ struct Pool0Args {
 };
 
 __global__ __launch_bounds__(256) void pool0_kernel(const Pool0Args a) {
-    __shared__ float prm[128];
+    __shared__ float prm[192];
     __shared__ double red[2][16][64];
     const int n = blockIdx.y, t = threadIdx.x, cq = t & 15, slot = t >> 4;
     if (t < 64) {
         float mean, invstd;
         bn_moments(a.ssum, a.ssq, (int64_t)n * 64 + t, 1.0 / (double)a.ps.HW, a.eps, mean, invstd);
-        const float sc = a.gamma[t] * invstd;
-        prm[t] = sc;
-        prm[64 + t] = a.beta[t] - mean * sc;
+        prm[t] = mean;
+        prm[64 + t] = a.gamma[t] * invstd;
+        prm[128 + t] = a.beta[t];
     }
     __syncthreads();
-    const float* sc = prm + 4 * cq;
-    const float* sh = prm + 64 + 4 * cq;
     double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
     for (int i = 0; i < 4; ++i) {
         const int p = blockIdx.x * 64 + slot + 16 * i;
@@ -148,7 +146,7 @@ __global__ __launch_bounds__(256) void pool0_kernel(const Pool0Args a) {
         for (int k = 0; k < 9; ++k) {
             const int yy = 2 * y - 1 + k / 3, xx = 2 * x - 1 + k % 3;
             if ((unsigned)yy >= (unsigned)a.ps.H || (unsigned)xx >= (unsigned)a.ps.W) continue;
-            const float4 v = bnrelu4(ld4(a.stem + ((int64_t)n * a.ps.HWp + yy * a.ps.W + xx) * 64 + 4 * cq), sc, sh);
+            const float4 v = bnrelu4(ld4(a.stem + ((int64_t)n * a.ps.HWp + yy * a.ps.W + xx) * 64 + 4 * cq), prm + 4 * cq, 64);
             const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -190,13 +188,13 @@ __global__ __launch_bounds__(256) void feat_kernel(const FeatArgs a) {
     const int j = blockIdx.y, cq = blockIdx.x * 256 + threadIdx.x;   // channel quad of 2048/4
     const int ch = 4 * cq, slot = ch >> 10, c5 = ch & 1023;
     const int s = slot ? a.pair_b[j] : a.pair_a[j];
-    float sc[4], sh[4];
+    float mu[4], sc[4], be[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        float mean, invstd;
-        bn_moments(a.xsum, a.xsq, (int64_t)s * 1024 + c5 + c, 1.0 / (double)a.p4.HW, a.eps, mean, invstd);
+        float invstd;
+        bn_moments(a.xsum, a.xsq, (int64_t)s * 1024 + c5 + c, 1.0 / (double)a.p4.HW, a.eps, mu[c], invstd);
         sc[c] = a.gamma[c5 + c] * invstd;
-        sh[c] = a.beta[c5 + c] - mean * sc[c];
+        be[c] = a.beta[c5 + c];
     }
     double sm[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
     const int p0 = blockIdx.z * a.chunk;
@@ -204,8 +202,8 @@ __global__ __launch_bounds__(256) void feat_kernel(const FeatArgs a) {
     for (int p = p0; p < p1; ++p) {
         const float4 v = ld4(a.x4 + ((int64_t)s * a.p4.HWp + p) * 1024 + c5);
         float4 o;
-        o.x = fmaf(v.x, sc[0], sh[0]); o.y = fmaf(v.y, sc[1], sh[1]);
-        o.z = fmaf(v.z, sc[2], sh[2]); o.w = fmaf(v.w, sc[3], sh[3]);
+        o.x = bn1(v.x, mu[0], sc[0], be[0]); o.y = bn1(v.y, mu[1], sc[1], be[1]);
+        o.z = bn1(v.z, mu[2], sc[2], be[2]); o.w = bn1(v.w, mu[3], sc[3], be[3]);
         *reinterpret_cast<float4*>(a.F + ((int64_t)j * a.p4.HWp + p) * 2048 + ch) = o;
         const double od[4] = {(double)o.x, (double)o.y, (double)o.z, (double)o.w};
 #pragma unroll
@@ -231,7 +229,7 @@ struct ValueArgs {
 };
 
 __global__ __launch_bounds__(256) void value_conv_kernel(const ValueArgs a) {
-    __shared__ float prm[128];
+    __shared__ float prm[192];
     __shared__ float red[256];
     const int t = threadIdx.x, cq = t & 15, slot = t >> 4;
     int id = blockIdx.x;
@@ -242,15 +240,15 @@ __global__ __launch_bounds__(256) void value_conv_kernel(const ValueArgs a) {
     if (t < 64) {
         float mean, invstd;
         bn_moments(a.hsum, a.hsq, (int64_t)j * 64 + t, 1.0 / (double)a.p4.HW, a.eps, mean, invstd);
-        const float sc = a.gamma[t] * invstd;
-        prm[t] = sc;
-        prm[64 + t] = a.beta[t] - mean * sc;
+        prm[t] = mean;
+        prm[64 + t] = a.gamma[t] * invstd;
+        prm[128 + t] = a.beta[t];
     }
     __syncthreads();
     float acc = 0.f;
     for (int tap = slot; tap < 400; tap += 16) {
         const int pix = (oy + tap / 20) * a.p4.W + ox + tap % 20;
-        const float4 v = bnrelu4(ld4(a.h1 + ((int64_t)j * a.p4.HWp + pix) * 64 + 4 * cq), prm + 4 * cq, prm + 64 + 4 * cq);
+        const float4 v = bnrelu4(ld4(a.h1 + ((int64_t)j * a.p4.HWp + pix) * 64 + 4 * cq), prm + 4 * cq, 64);
         const float4 w = ld4(a.w2p + ((int64_t)o * 400 + tap) * 64 + 4 * cq);
         acc = fmaf(v.x, w.x, acc); acc = fmaf(v.y, w.y, acc); acc = fmaf(v.z, w.z, acc); acc = fmaf(v.w, w.w, acc);
     }
@@ -286,8 +284,7 @@ __global__ __launch_bounds__(256) void value_bwd_kernel(const ValueBwdArgs a) {
     if (t < 64) {
         float mean, invstd;
         bn_moments(a.hsum, a.hsq, (int64_t)j * 64 + t, 1.0 / (double)a.p4.HW, a.eps, mean, invstd);
-        const float sc = a.gamma[t] * invstd;
-        prm[t] = sc; prm[64 + t] = a.beta[t] - mean * sc; prm[128 + t] = mean; prm[192 + t] = invstd;
+        prm[t] = a.gamma[t] * invstd; prm[64 + t] = a.beta[t]; prm[128 + t] = mean; prm[192 + t] = invstd;
     }
     __syncthreads();
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
@@ -300,7 +297,7 @@ __global__ __launch_bounds__(256) void value_bwd_kernel(const ValueBwdArgs a) {
         const float h[4] = {hv.x, hv.y, hv.z, hv.w};
         float act[4], dact[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) act[c] = fmaxf(fmaf(h[c], prm[4 * cq + c], prm[64 + 4 * cq + c]), 0.f);
+        for (int c = 0; c < 4; ++c) act[c] = fmaxf(bn1(h[c], prm[128 + 4 * cq + c], prm[4 * cq + c], prm[64 + 4 * cq + c]), 0.f);
         for (int o = 0; o < a.out_ch; ++o)
             for (int oy = max(0, py - 19); oy <= min(py, a.OH - 1); ++oy)
                 for (int ox = max(0, px - 19); ox <= min(px, a.OW - 1); ++ox) {
@@ -374,19 +371,20 @@ __global__ __launch_bounds__(256) void norm5_bwd_kernel(const Norm5BwdArgs a) {
     }
     for (int u = u0; u < u1; ++u) {
         const int j = a.user_pair[u], ch = a.user_slot[u] * 1024 + c5;
-        float ca[4], cb[4], cc[4];
+        float cf[16];   // a[4], q1[4], mean[4], k[4]
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float mean, invstd;
             bn_moments(a.fsum, a.fsq, (int64_t)j * 2048 + ch + c, inv, a.eps, mean, invstd);
-            const float q1 = (float)(a.f1[(int64_t)j * 2048 + ch + c] * inv);
             const float q2 = (float)(a.f2[(int64_t)j * 2048 + ch + c] * inv);
-            const float gi = a.hgamma[ch + c] * invstd;
-            ca[c] = gi; cb[c] = -gi * invstd * q2; cc[c] = -gi * q1 + gi * invstd * q2 * mean;
+            cf[c] = a.hgamma[ch + c] * invstd;
+            cf[4 + c] = (float)(a.f1[(int64_t)j * 2048 + ch + c] * inv);
+            cf[8 + c] = mean;
+            cf[12 + c] = invstd * q2;
         }
         for (int p = p0; p < p1; ++p) {
             const int64_t fr = ((int64_t)j * a.p4.HWp + p) * 2048 + ch;
-            const float4 d = affine2(ld4(a.DF + fr), ld4(a.F + fr), ca, cb, cc);
+            const float4 d = affine2(ld4(a.DF + fr), ld4(a.F + fr), cf, 4);
             const int64_t xr = ((int64_t)s * a.p4.HWp + p) * 1024 + c5;
             const float4 xv = ld4(a.x4 + xr);
             const float dd[4] = {d.x, d.y, d.z, d.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
@@ -426,20 +424,19 @@ struct Pool0BwdArgs {
 };
 
 __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArgs a) {
-    __shared__ float prm[7 * 64];
+    __shared__ float prm[8 * 64];
     __shared__ float red[2][16][64];
     const int n = blockIdx.y, t = threadIdx.x, cq = t & 15, slot = t >> 4;
     if (t < 64) {
         float mean, invstd;
         bn_moments(a.ssum, a.ssq, (int64_t)n * 64 + t, 1.0 / (double)a.ps.HW, a.eps, mean, invstd);
-        const float sc = a.gamma[t] * invstd;
-        prm[t] = sc; prm[64 + t] = a.beta[t] - mean * sc; prm[128 + t] = mean; prm[192 + t] = invstd;
+        prm[t] = a.gamma[t] * invstd; prm[64 + t] = a.beta[t]; prm[128 + t] = mean; prm[192 + t] = invstd;
         const double inv = 1.0 / (double)a.p1.HW;
         float m1, i1;
         bn_moments(a.xsum, a.xsq, (int64_t)n * a.xstride + t, inv, a.eps, m1, i1);
         const float q1 = (float)(a.SA[(int64_t)n * a.sstride + t] * inv);
         const float q2 = (float)(a.SB[(int64_t)n * a.sstride + t] * inv);
-        prm[256 + t] = i1; prm[320 + t] = -i1 * i1 * q2; prm[384 + t] = -i1 * q1 + i1 * i1 * q2 * m1;
+        prm[256 + t] = i1; prm[320 + t] = q1; prm[384 + t] = m1; prm[448 + t] = i1 * q2;
     }
     __syncthreads();
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
@@ -458,7 +455,7 @@ __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArgs a) {
                 const int amv[4] = {am.x, am.y, am.z, am.w};
                 if (amv[0] != k && amv[1] != k && amv[2] != k && amv[3] != k) continue;
                 const float4 gv = affine2(ld4(a.G1 + pr * a.ld1 + 4 * cq), ld4(a.X1 + pr * a.ld1 + 4 * cq),
-                                          prm + 256 + 4 * cq, prm + 320 + 4 * cq, prm + 384 + 4 * cq);
+                                          prm + 256 + 4 * cq, 64);
                 const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -470,7 +467,7 @@ __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArgs a) {
         float dy[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            dy[c] = fmaf(st[c], prm[4 * cq + c], prm[64 + 4 * cq + c]) > 0.f ? g[c] : 0.f;
+            dy[c] = bn1(st[c], prm[128 + 4 * cq + c], prm[4 * cq + c], prm[64 + 4 * cq + c]) > 0.f ? g[c] : 0.f;
             s1[c] += dy[c];
             s2[c] += dy[c] * ((st[c] - prm[128 + 4 * cq + c]) * prm[192 + 4 * cq + c]);
         }

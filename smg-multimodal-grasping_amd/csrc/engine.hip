@@ -41,13 +41,19 @@ static const Layout& layout_for(int head_out) {
 // ------------------------------------------------------------------------------------
 // GEMM tile configurations (BM, BN, BK, waves M x N, A pixel-major?)
 // ------------------------------------------------------------------------------------
-using CfgP128x128 = GemmCfg<128, 128, 16, 2, 2, true>;    // 1x1 fwd, transitions, 3x3 dgrad
-using CfgP128x32 = GemmCfg<128, 32, 32, 4, 1, true>;      // 3x3 fwd (N = growth 32)
-using CfgP128x64 = GemmCfg<128, 64, 16, 2, 2, true>;      // stem, head conv0, 1x1 dgrad
-using CfgW32x128 = GemmCfg<32, 128, 32, 1, 4, false>;     // 3x3 wgrad (32 x 128 per tap)
-using CfgW128x64 = GemmCfg<128, 64, 16, 2, 2, false>;     // 1x1 wgrad (128 x cin)
-using CfgW128x128 = GemmCfg<128, 128, 16, 2, 2, false>;   // transition wgrad
-using CfgW64x64 = GemmCfg<64, 64, 16, 2, 2, false>;       // stem / head conv0 wgrad
+// big stages (pixel planes that are multiples of 128 rows)
+using CfgP128x128 = GemmCfg<128, 128, 16, 2, 2, 1, true>;    // 1x1 fwd, transitions, 3x3 dgrad
+using CfgP128x32 = GemmCfg<128, 32, 32, 4, 1, 1, true>;      // 3x3 fwd (N = growth 32)
+using CfgP128x64 = GemmCfg<128, 64, 16, 2, 2, 1, true>;      // stem, head conv0, 1x1 dgrad
+// small stages (late blocks: few pixels per stream -> 64-row tiles, 4x the workgroups)
+using CfgP64x64 = GemmCfg<64, 64, 32, 2, 2, 1, true>;        // 1x1 fwd / dgrad, transitions
+using CfgP64x128 = GemmCfg<64, 128, 16, 2, 2, 1, true>;      // 3x3 dgrad
+using CfgP64x32 = GemmCfg<64, 32, 64, 2, 1, 2, true>;        // 3x3 fwd, k-tile split over 2 waves
+// weight gradients (reduction over pixels)
+using CfgW32x128 = GemmCfg<32, 128, 32, 1, 4, 1, false>;     // 3x3 wgrad (32 x 128 per tap)
+using CfgW128x64 = GemmCfg<128, 64, 16, 2, 2, 1, false>;     // 1x1 wgrad (128 x cin)
+using CfgW128x128 = GemmCfg<128, 128, 16, 2, 2, 1, false>;   // transition wgrad
+using CfgW64x64 = GemmCfg<64, 64, 16, 2, 2, 1, false>;       // stem / head conv0 wgrad
 
 enum Kind {
     K_STEM = 0, K_C1, K_C3, K_TRANS, K_HEAD0, K_D3, K_W3, K_D1, K_W1, K_TW, K_TD, K_SW, K_HW0, K_HD0, K_OTHER, K_COUNT
@@ -104,7 +110,7 @@ struct smg_engine {
 };
 
 static Plane make_plane(int H, int W) {
-    Plane p; p.H = H; p.W = W; p.HW = H * W; p.HWp = (p.HW + 127) / 128 * 128; return p;
+    Plane p; p.H = H; p.W = W; p.HW = H * W; p.HWp = (p.HW + 63) / 64 * 64; return p;
 }
 
 template <class T>
@@ -314,12 +320,16 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
         hipLaunchKernelGGL(prep_rotate_kernel, dim3((e->S * e->S + 255) / 256, NS), dim3(256), 0, st, a);
     }
     {   // stem conv0 7x7/2
-        FwdConvP<CfgP128x64, F_STEM> p{};
+        auto run = [&](auto tag) {
+                using Cfg = decltype(tag);
+                FwdConvP<Cfg, F_STEM> p{};
         p.src = e->img4; p.lds_ = 4; p.ps = e->p_img; p.po = e->p_stem; p.K = 0;
         p.w = e->packed + e->pk_conv0; p.ldw = 64; p.N = 64;
         p.dst = e->stem; p.ldd = 64; p.dcoff = 0;
         p.dsum = fsum(e, e->st_stem); p.dsq = fsq(e, e->st_stem); p.dstride = 64; p.eps = kEps;
-        launch_gemm(e, st, p, dim3(NS * e->p_stem.HWp / 128, 1), K_STEM, 2.0 * NS * e->p_stem.HW * 64 * 147);
+        launch_gemm(e, st, p, dim3(NS * e->p_stem.HWp / Cfg::BM, 1), K_STEM, 2.0 * NS * e->p_stem.HW * 64 * 147);
+            };
+            if (e->p_stem.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
     }
     {   // norm0 + relu0 + pool0
         Pool0Args a;
@@ -338,36 +348,48 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
             const DenseLayerRef& d = T.layers[b][i];
             float* bt = e->Bt + e->bt_off[b][i];
             {   // norm1 + relu + conv1 (1x1, cin -> 128)
-                FwdConvP<CfgP128x128, F_ONE> p{};
+                auto run = [&](auto tag) {
+                using Cfg = decltype(tag);
+                FwdConvP<Cfg, F_ONE> p{};
                 p.src = e->X[b]; p.lds_ = Ct; p.ps = pl; p.po = pl; p.K = d.cin;
                 p.ssum = fsum(e, e->st_X[b]); p.ssq = fsq(e, e->st_X[b]); p.sstride = Ct;
                 p.gamma = P + d.n1.w; p.beta = P + d.n1.b; p.eps = kEps;
                 p.w = e->packed + e->pk_c1[b][i]; p.ldw = kBottleneck; p.N = kBottleneck;
                 p.dst = bt; p.ldd = kBottleneck; p.dcoff = 0;
                 p.dsum = fsum(e, e->st_Bt[b][i]); p.dsq = fsq(e, e->st_Bt[b][i]); p.dstride = kBottleneck;
-                launch_gemm(e, st, p, dim3(NS * pl.HWp / 128, 1), K_C1, 2.0 * NS * pl.HW * d.cin * kBottleneck);
+                launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, kBottleneck / Cfg::BN), K_C1, 2.0 * NS * pl.HW * d.cin * kBottleneck);
+            };
+            if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x64{});
             }
             {   // norm2 + relu + conv2 (3x3, 128 -> 32), appended to the block buffer
-                FwdConvP<CfgP128x32, F_THREE> p{};
+                auto run = [&](auto tag) {
+                using Cfg = decltype(tag);
+                FwdConvP<Cfg, F_THREE> p{};
                 p.src = bt; p.lds_ = kBottleneck; p.ps = pl; p.po = pl; p.K = kBottleneck;
                 p.ssum = fsum(e, e->st_Bt[b][i]); p.ssq = fsq(e, e->st_Bt[b][i]); p.sstride = kBottleneck;
                 p.gamma = P + d.n2.w; p.beta = P + d.n2.b; p.eps = kEps;
                 p.w = e->packed + e->pk_c2f[b][i]; p.ldw = kGrowth; p.N = kGrowth;
                 p.dst = e->X[b]; p.ldd = Ct; p.dcoff = d.cin;
                 p.dsum = fsum(e, e->st_X[b]); p.dsq = fsq(e, e->st_X[b]); p.dstride = Ct;
-                launch_gemm(e, st, p, dim3(NS * pl.HWp / 128, 1), K_C3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+                launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, 1), K_C3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+            };
+            if (pl.HWp % 128 == 0) run(CfgP128x32{}); else run(CfgP64x32{});
             }
         }
         if (b < 3) {   // transition: norm + relu + (avgpool2 commuted in front of) conv 1x1
             const Plane pn = e->p_blk[b + 1];
-            FwdConvP<CfgP128x128, F_POOL> p{};
+            auto run = [&](auto tag) {
+                using Cfg = decltype(tag);
+                FwdConvP<Cfg, F_POOL> p{};
             p.src = e->X[b]; p.lds_ = Ct; p.ps = pl; p.po = pn; p.K = Ct;
             p.ssum = fsum(e, e->st_X[b]); p.ssq = fsq(e, e->st_X[b]); p.sstride = Ct;
             p.gamma = P + T.tnorm[b].w; p.beta = P + T.tnorm[b].b; p.eps = kEps;
             p.w = e->packed + e->pk_t[b]; p.ldw = Ct / 2; p.N = Ct / 2;
             p.dst = e->X[b + 1]; p.ldd = kBlockCtot[b + 1]; p.dcoff = 0;
             p.dsum = fsum(e, e->st_X[b + 1]); p.dsq = fsq(e, e->st_X[b + 1]); p.dstride = kBlockCtot[b + 1];
-            launch_gemm(e, st, p, dim3(NS * pn.HWp / 128, (Ct / 2) / 128), K_TRANS, 2.0 * NS * pn.HW * Ct * (Ct / 2));
+            launch_gemm(e, st, p, dim3(NS * pn.HWp / Cfg::BM, (Ct / 2) / Cfg::BN), K_TRANS, 2.0 * NS * pn.HW * Ct * (Ct / 2));
+            };
+            if (pn.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x64{});
         }
     }
     const Plane p4 = e->p_blk[3];
@@ -381,14 +403,18 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
         hipLaunchKernelGGL(feat_kernel, dim3(2, NP, (p4.HW + 63) / 64), dim3(256), 0, st, a);
     }
     {   // head norm0 + relu + conv0 (1x1, 2048 -> 64)
-        FwdConvP<CfgP128x64, F_ONE> p{};
+        auto run = [&](auto tag) {
+                using Cfg = decltype(tag);
+                FwdConvP<Cfg, F_ONE> p{};
         p.src = e->F; p.lds_ = 2 * kFeat; p.ps = p4; p.po = p4; p.K = 2 * kFeat;
         p.ssum = fsum(e, e->st_F); p.ssq = fsq(e, e->st_F); p.sstride = 2 * kFeat;
         p.gamma = P + Hd.n0.w; p.beta = P + Hd.n0.b; p.eps = kEps;
         p.w = e->packed + e->pk_head0; p.ldw = kHeadMid; p.N = kHeadMid;
         p.dst = e->H1; p.ldd = kHeadMid; p.dcoff = 0;
         p.dsum = fsum(e, e->st_H1); p.dsq = fsq(e, e->st_H1); p.dstride = kHeadMid;
-        launch_gemm(e, st, p, dim3(NP * p4.HWp / 128, 1), K_HEAD0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid);
+        launch_gemm(e, st, p, dim3(NP * p4.HWp / Cfg::BM, 1), K_HEAD0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid);
+            };
+            if (p4.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
     }
     {   // head norm1 + relu + conv1 (20x20 valid)
         ValueArgs a;
@@ -464,7 +490,9 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
         launch_gemm(e, st, p, dim3(1, 2 * kFeat / 64, NP * cps4), K_HW0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid);
     }
     {   // head conv0 data gradient + relu0 + norm0 sums
-        BwdDataP<CfgP128x128, false, E_STORE> p{};
+        auto run = [&](auto tag) {
+                using Cfg = decltype(tag);
+                BwdDataP<Cfg, false, E_STORE> p{};
         p.gbuf = e->DH1; p.ldg = kHeadMid; p.gcoff = 0; p.xbuf = e->H1; p.ldx = kHeadMid; p.xcoff = 0; p.pa = p4; p.KA = kHeadMid;
         p.xsum = fsum(e, e->st_H1); p.xsq = fsq(e, e->st_H1); p.xstride = kHeadMid;
         p.s1 = b1(e, e->bs_H1); p.s2 = b2(e, e->bs_H1); p.sstride = kHeadMid; p.scoff = 0; p.agamma = P + Hd.n1.w;
@@ -474,7 +502,9 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
         p.dst = e->DF; p.ldd = 2 * kFeat; p.dcoff = 0;
         p.o1 = b1(e, e->bs_F); p.o2 = b2(e, e->bs_F); p.ostride = 2 * kFeat; p.ocoff = 0;
         p.dbeta = Gr + Hd.n0.b; p.dgamma = Gr + Hd.n0.w; p.eps = kEps;
-        launch_gemm(e, st, p, dim3(NP * p4.HWp / 128, 2 * kFeat / 128), K_HD0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid);
+        launch_gemm(e, st, p, dim3(NP * p4.HWp / Cfg::BM, 2 * kFeat / Cfg::BN), K_HD0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid);
+            };
+            if (p4.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
     }
     {   // head norm0 backward + concat backward + norm5 backward -> G'_4
         Norm5BwdArgs a;
@@ -496,7 +526,9 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
             const DenseLayerRef& d = T.layers[b][i];
             float* bt = e->Bt + e->bt_off[b][i];
             {   // conv2 (3x3) data gradient -> dy of relu2/norm2 (D2) + norm2 sums
-                BwdDataP<CfgP128x128, true, E_STORE> p{};
+                auto run = [&](auto tag) {
+                using Cfg = decltype(tag);
+                BwdDataP<Cfg, true, E_STORE> p{};
                 p.gbuf = e->G[b]; p.ldg = Ct; p.gcoff = d.cin; p.xbuf = e->X[b]; p.ldx = Ct; p.xcoff = d.cin; p.pa = pl; p.KA = kGrowth;
                 p.xsum = fsum(e, e->st_X[b]); p.xsq = fsq(e, e->st_X[b]); p.xstride = Ct;
                 p.s1 = b1(e, e->bs_X[b]); p.s2 = b2(e, e->bs_X[b]); p.sstride = Ct; p.scoff = d.cin; p.agamma = nullptr;
@@ -507,7 +539,9 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 p.dst = e->D2; p.ldd = kBottleneck; p.dcoff = 0;
                 p.o1 = b1(e, e->bs_Bt[b][i]); p.o2 = b2(e, e->bs_Bt[b][i]); p.ostride = kBottleneck; p.ocoff = 0;
                 p.dbeta = Gr + d.n2.b; p.dgamma = Gr + d.n2.w; p.eps = kEps;
-                launch_gemm(e, st, p, dim3(NS * pl.HWp / 128, 1), K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+                launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, kBottleneck / Cfg::BN), K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+            };
+            if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
             }
             {   // conv2 weight gradient
                 BwdWeightP<CfgW32x128, W_THREE, C_3x3> p{};
@@ -522,7 +556,9 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 launch_gemm(e, st, p, dim3(1, 1, 9 * NS * cps), K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
             }
             {   // conv1 (1x1) data gradient -> relu1/norm1 backward accumulated into G'
-                BwdDataP<CfgP128x64, false, E_ACCUM> p{};
+                auto run = [&](auto tag) {
+                using Cfg = decltype(tag);
+                BwdDataP<Cfg, false, E_ACCUM> p{};
                 p.gbuf = e->D2; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = bt; p.ldx = kBottleneck; p.xcoff = 0; p.pa = pl; p.KA = kBottleneck;
                 p.xsum = fsum(e, e->st_Bt[b][i]); p.xsq = fsq(e, e->st_Bt[b][i]); p.xstride = kBottleneck;
                 p.s1 = b1(e, e->bs_Bt[b][i]); p.s2 = b2(e, e->bs_Bt[b][i]); p.sstride = kBottleneck; p.scoff = 0; p.agamma = P + d.n2.w;
@@ -533,7 +569,9 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 p.dst = e->G[b]; p.ldd = Ct; p.dcoff = 0;
                 p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.ocoff = 0;
                 p.dbeta = Gr + d.n1.b; p.dgamma = Gr + d.n1.w; p.eps = kEps;
-                launch_gemm(e, st, p, dim3(NS * pl.HWp / 128, (d.cin + 63) / 64), K_D1, 2.0 * NS * pl.HW * d.cin * kBottleneck);
+                launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, (d.cin + Cfg::BN - 1) / Cfg::BN), K_D1, 2.0 * NS * pl.HW * d.cin * kBottleneck);
+            };
+            if (pl.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
             }
             {   // conv1 weight gradient
                 BwdWeightP<CfgW128x64, W_ONE, C_IDENT> p{};
@@ -568,7 +606,9 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 hipLaunchKernelGGL(zero_uncovered_kernel, dim3(256, NS), dim3(256), 0, st, e->G[b - 1], Cp, pp, 2 * pl.H, 2 * pl.W, Cp);
             }
             {
-                BwdDataP<CfgP128x128, false, E_UNPOOL> p{};
+                auto run = [&](auto tag) {
+                using Cfg = decltype(tag);
+                BwdDataP<Cfg, false, E_UNPOOL> p{};
                 p.gbuf = e->G[b]; p.ldg = Ct; p.gcoff = 0; p.xbuf = e->X[b]; p.ldx = Ct; p.xcoff = 0; p.pa = pl; p.KA = C0;
                 p.xsum = fsum(e, e->st_X[b]); p.xsq = fsq(e, e->st_X[b]); p.xstride = Ct;
                 p.s1 = b1(e, e->bs_X[b]); p.s2 = b2(e, e->bs_X[b]); p.sstride = Ct; p.scoff = 0; p.agamma = nullptr;
@@ -579,7 +619,9 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 p.dst = e->G[b - 1]; p.ldd = Cp; p.dcoff = 0;
                 p.o1 = b1(e, e->bs_X[b - 1]); p.o2 = b2(e, e->bs_X[b - 1]); p.ostride = Cp; p.ocoff = 0;
                 p.dbeta = Gr + T.tnorm[b - 1].b; p.dgamma = Gr + T.tnorm[b - 1].w; p.eps = kEps;
-                launch_gemm(e, st, p, dim3(NS * pl.HWp / 128, Cp / 128), K_TD, 2.0 * NS * pl.HW * Cp * C0);
+                launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, Cp / Cfg::BN), K_TD, 2.0 * NS * pl.HW * Cp * C0);
+            };
+            if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
             }
         }
     }

@@ -30,13 +30,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct Plane { int H, W, HW, HWp; };
 
-template <int BM_, int BN_, int BK_, int WM_, int WN_, bool AT_>
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int WK_, bool AT_>
 struct GemmCfg {
-    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
+    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, WK = WK_;
     static constexpr bool AT = AT_;  // A tile arrives pixel-major and is transposed into LDS
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    // 4 waves: WM x WN of them tile the output, WK of them split every k-tile (in-block
+    // split-K for the small late stages, reduced through LDS before the epilogue)
+    static_assert(WM * WN * WK == 4, "4 waves per workgroup");
     static constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     static_assert(TM >= 1 && TN >= 1 && TM * WM * 32 == BM && TN * WN * 32 == BN, "tile shape");
+    static constexpr int KK = BK / 2 / WK;                   // MFMA k-steps per wave per k-tile
+    static_assert(KK >= 1 && KK * 2 * WK == BK, "k split");
     static constexpr int LDA = AT ? BM + 1 : BM + 4;
     static constexpr int LDB = BN + 4;
     static constexpr int A_FLOATS = BK * LDA, B_FLOATS = BK * LDB;
@@ -47,7 +51,9 @@ struct GemmCfg {
     static constexpr int B_Q = BN / 4;
     static constexpr int B_STEP = 256 / B_Q;
     static constexpr int B_N = (BK + B_STEP - 1) / B_STEP;
-    static constexpr int TILE_FLOATS = 2 * A_FLOATS + 2 * B_FLOATS;
+    static constexpr int RED_FLOATS = (WK - 1) * WM * WN * TM * TN * 16 * 64;
+    static constexpr int TILE_FLOATS = (2 * A_FLOATS + 2 * B_FLOATS) > RED_FLOATS ? (2 * A_FLOATS + 2 * B_FLOATS) : RED_FLOATS;
+    static constexpr int AB_FLOATS = 2 * A_FLOATS + 2 * B_FLOATS;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -62,23 +68,37 @@ __device__ __forceinline__ void bn_moments(const double* sum, const double* sq, 
     invstd = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-__device__ __forceinline__ float4 bnrelu4(float4 v, const float* sc, const float* sh) {
+// BN + ReLU in the centered form (x - mean) * (gamma * invstd) + beta: no cancellation
+// between x*scale and a pre-folded shift on near-constant channels.
+// prm points at {mean[4]...}, scale at prm + stride, beta at prm + 2*stride.
+__device__ __forceinline__ float bn1(float x, float mean, float sc, float beta) { return fmaf(x - mean, sc, beta); }
+__device__ __forceinline__ float4 bnrelu4(float4 v, const float* prm, int stride) {
+    const float* sc = prm + stride;
+    const float* be = prm + 2 * stride;
     float4 r;
-    r.x = fmaxf(fmaf(v.x, sc[0], sh[0]), 0.f);
-    r.y = fmaxf(fmaf(v.y, sc[1], sh[1]), 0.f);
-    r.z = fmaxf(fmaf(v.z, sc[2], sh[2]), 0.f);
-    r.w = fmaxf(fmaf(v.w, sc[3], sh[3]), 0.f);
+    r.x = fmaxf(bn1(v.x, prm[0], sc[0], be[0]), 0.f);
+    r.y = fmaxf(bn1(v.y, prm[1], sc[1], be[1]), 0.f);
+    r.z = fmaxf(bn1(v.z, prm[2], sc[2], be[2]), 0.f);
+    r.w = fmaxf(bn1(v.w, prm[3], sc[3], be[3]), 0.f);
     return r;
 }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-// v = g*a + x*b + c, per channel (BN backward folded into an operand fetch)
-__device__ __forceinline__ float4 affine2(float4 g, float4 x, const float* a, const float* b, const float* c) {
+// BN backward folded into an operand fetch, centered form:
+//   v = a * ((g - q1) - (x - mean) * k),   a = gamma*invstd, q1 = mean(dy), k = invstd * mean(dy*xhat)
+// prm -> a[4]; q1 at prm + stride; mean at prm + 2*stride; k at prm + 3*stride.
+__device__ __forceinline__ float bnb1(float g, float x, float a, float q1, float mean, float k) {
+    return a * fmaf(-(x - mean), k, g - q1);
+}
+__device__ __forceinline__ float4 affine2(float4 g, float4 x, const float* prm, int stride) {
+    const float* q1 = prm + stride;
+    const float* mu = prm + 2 * stride;
+    const float* k = prm + 3 * stride;
     float4 r;
-    r.x = fmaf(g.x, a[0], fmaf(x.x, b[0], c[0]));
-    r.y = fmaf(g.y, a[1], fmaf(x.y, b[1], c[1]));
-    r.z = fmaf(g.z, a[2], fmaf(x.z, b[2], c[2]));
-    r.w = fmaf(g.w, a[3], fmaf(x.w, b[3], c[3]));
+    r.x = bnb1(g.x, x.x, prm[0], q1[0], mu[0], k[0]);
+    r.y = bnb1(g.y, x.y, prm[1], q1[1], mu[1], k[1]);
+    r.z = bnb1(g.z, x.z, prm[2], q1[2], mu[2], k[2]);
+    r.w = bnb1(g.w, x.w, prm[3], q1[3], mu[3], k[3]);
     return r;
 }
 
@@ -88,13 +108,15 @@ __device__ __forceinline__ float4 affine2(float4 g, float4 x, const float* a, co
 template <class C, int NQ, class T>
 __device__ __forceinline__ void block_col_reduce(T (&v)[NQ][C::TN], T* red, T (&out)[NQ]) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
-    const int wm = wave / C::WN, wn0 = (wave % C::WN) * C::TN * 32;
+    const int wmn = wave % (C::WM * C::WN);
+    const int wm = wmn / C::WN, wn0 = (wmn % C::WN) * C::TN * 32;
+    const bool owner = wave < C::WM * C::WN;            // wk == 0
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int tn = 0; tn < C::TN; ++tn) v[q][tn] += __shfl_xor(v[q][tn], 32);
     __syncthreads();
-    if (half == 0) {
+    if (half == 0 && owner) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -125,10 +147,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const P p) {
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int wm0 = (wave / C::WN) * C::TM * 32, wn0 = (wave % C::WN) * C::TN * 32;
+    const int wk = wave / (C::WM * C::WN), wmn = wave % (C::WM * C::WN);
+    const int wm0 = (wmn / C::WN) * C::TM * 32, wn0 = (wmn % C::WN) * C::TN * 32;
 
     typename P::Ctx ctx;
-    p.init(ctx, sp);
+    if (!p.init(ctx, sp)) return;          // tile made of padding rows only (block-uniform)
     __syncthreads();
     const int KT = p.ktiles(ctx);
 
@@ -144,10 +167,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const P p) {
     const int bq = t % C::B_Q, bl = t / C::B_Q;
     float4 ra[C::A_N], rb[C::B_N];
     typename P::ARow arow[C::A_N];
+    typename P::DRow da[C::A_N], db[C::B_N];
     if constexpr (C::AT) {
 #pragma unroll
         for (int i = 0; i < C::A_N; ++i) p.a_row_init(ctx, arow[i], al + i * C::A_STEP);
+    } else {
+#pragma unroll
+        for (int i = 0; i < C::A_N; ++i) p.d_init(ctx, da[i], al + i * C::A_STEP);
     }
+#pragma unroll
+    for (int i = 0; i < C::B_N; ++i) p.d_init(ctx, db[i], bl + i * C::B_STEP);
 
     auto g_load = [&](int kt) {
 #pragma unroll
@@ -156,13 +185,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const P p) {
                 ra[i] = p.a_fetch(ctx, arow[i], kt, aq, sp);
             } else {
                 const int kr = al + i * C::A_STEP;
-                ra[i] = (kr < C::BK) ? p.a_fetch_d(ctx, kt, kr, aq, sp) : zero4();
+                ra[i] = (kr < C::BK) ? p.a_fetch_d(ctx, da[i], kt, kr, aq, sp) : zero4();
+                p.d_next(ctx, da[i]);
             }
         }
 #pragma unroll
         for (int i = 0; i < C::B_N; ++i) {
             const int kr = bl + i * C::B_STEP;
-            rb[i] = (kr < C::BK) ? p.b_fetch(ctx, kt, kr, bq, sp) : zero4();
+            rb[i] = (kr < C::BK) ? p.b_fetch(ctx, db[i], kt, kr, bq, sp) : zero4();
+            p.d_next(ctx, db[i]);
         }
     };
     auto s_store = [&](int buf) {
@@ -196,25 +227,57 @@ __global__ __launch_bounds__(256) void gemm_kernel(const P p) {
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < KT) g_load(kt + 1);  // global loads in flight across the MFMA block
-        const float* A = As + buf * C::A_FLOATS + wm0 + l31;
-        const float* B = Bs + buf * C::B_FLOATS + wn0 + l31;
+        const float* A = As + buf * C::A_FLOATS + (wk * C::KK * 2 + half) * C::LDA + wm0 + l31;
+        const float* B = Bs + buf * C::B_FLOATS + (wk * C::KK * 2 + half) * C::LDB + wn0 + l31;
+        // All operand fragments of this wave's k-slice first (one LDS round trip per k-tile,
+        // not one per MFMA k-step), then the MFMAs back to back.
+        float af[C::KK][C::TM], bf[C::KK][C::TN];
 #pragma unroll
-        for (int kk = 0; kk < C::BK / 2; ++kk) {
-            float a[C::TM], b[C::TN];
+        for (int kk = 0; kk < C::KK; ++kk) {
 #pragma unroll
-            for (int i = 0; i < C::TM; ++i) a[i] = A[(2 * kk + half) * C::LDA + i * 32];
+            for (int i = 0; i < C::TM; ++i) af[kk][i] = A[2 * kk * C::LDA + i * 32];
 #pragma unroll
-            for (int j = 0; j < C::TN; ++j) b[j] = B[(2 * kk + half) * C::LDB + j * 32];
+            for (int j = 0; j < C::TN; ++j) bf[kk][j] = B[2 * kk * C::LDB + j * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep every ds_read ahead of the MFMA block (hipcc re-interleaves them otherwise)
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk)
 #pragma unroll
             for (int i = 0; i < C::TM; ++i)
 #pragma unroll
                 for (int j = 0; j < C::TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < KT) s_store(buf ^ 1);
         __syncthreads();
     }
-    p.epilogue(ctx, acc, smem, sp);
+    if constexpr (C::WK > 1) {              // in-block split-K: fold the partial tiles into the wk == 0 waves
+        constexpr int PER = C::TM * C::TN * 16 * 64;
+        if (wk > 0) {
+            float* r = smem + ((wk - 1) * C::WM * C::WN + wmn) * PER + lane;
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) r[((i * C::TN + j) * 16 + q) * 64] = acc[i][j][q];
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int w = 1; w < C::WK; ++w) {
+                const float* r = smem + ((w - 1) * C::WM * C::WN + wmn) * PER + lane;
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) acc[i][j][q] += r[((i * C::TN + j) * 16 + q) * 64];
+            }
+        }
+        __syncthreads();
+    }
+    p.epilogue(ctx, acc, smem, sp, wk == 0);
 }
 
 // Accumulator element (tm, tn, reg) of this lane sits at tile row / column:
@@ -247,24 +310,29 @@ struct FwdConvP {
 
     struct Ctx { int n, m0, n0; };
     struct ARow { int y, x; bool valid; };
+    struct DRow {};
 
-    __host__ __device__ int param_floats() const { return MODE == F_STEM ? 0 : 2 * K; }
+    __host__ __device__ int param_floats() const { return MODE == F_STEM ? 0 : 3 * K; }
 
-    __device__ void init(Ctx& c, float* sp) const {
+    __device__ bool init(Ctx& c, float* sp) const {
         c.m0 = blockIdx.x * Cfg::BM;
         c.n0 = blockIdx.y * Cfg::BN;
         c.n = c.m0 / po.HWp;
+        if (c.m0 - c.n * po.HWp >= po.HW) return false;
         if constexpr (MODE != F_STEM) {
             const double inv = 1.0 / (double)ps.HW;
             for (int k = threadIdx.x; k < K; k += 256) {
                 float mean, invstd;
                 bn_moments(ssum, ssq, (int64_t)c.n * sstride + k, inv, eps, mean, invstd);
-                const float sc = gamma[k] * invstd;
-                sp[k] = sc;
-                sp[K + k] = beta[k] - mean * sc;
+                sp[k] = mean;
+                sp[K + k] = gamma[k] * invstd;
+                sp[2 * K + k] = beta[k];
             }
         }
+        return true;
     }
+    __device__ void d_init(const Ctx&, DRow&, int) const {}
+    __device__ void d_next(const Ctx&, DRow&) const {}
     __device__ int ktiles(const Ctx&) const {
         if constexpr (MODE == F_THREE) return 9 * (K / Cfg::BK);
         else if constexpr (MODE == F_STEM) return 224 / Cfg::BK;
@@ -281,7 +349,7 @@ struct FwdConvP {
             if (!r.valid) return zero4();
             const int ch = kt * Cfg::BK + 4 * q;
             const float4 v = ld4(src + ((int64_t)c.n * ps.HWp + r.y * ps.W + r.x) * lds_ + ch);
-            return bnrelu4(v, sp + ch, sp + K + ch);
+            return bnrelu4(v, sp + ch, K);
         } else if constexpr (MODE == F_THREE) {
             const int kpt = K / Cfg::BK;
             const int tap = kt / kpt;
@@ -289,17 +357,16 @@ struct FwdConvP {
             const int yy = r.y + tap / 3 - 1, xx = r.x + tap % 3 - 1;
             if (!r.valid || (unsigned)yy >= (unsigned)ps.H || (unsigned)xx >= (unsigned)ps.W) return zero4();
             const float4 v = ld4(src + ((int64_t)c.n * ps.HWp + yy * ps.W + xx) * lds_ + ch);
-            return bnrelu4(v, sp + ch, sp + K + ch);
+            return bnrelu4(v, sp + ch, K);
         } else if constexpr (MODE == F_POOL) {
             if (!r.valid) return zero4();
             const int ch = kt * Cfg::BK + 4 * q;
             const float* b = src + ((int64_t)c.n * ps.HWp + (2 * r.y) * ps.W + 2 * r.x) * lds_ + ch;
-            const float* sc = sp + ch;
-            const float* sh = sp + K + ch;
-            float4 s = bnrelu4(ld4(b), sc, sh);
-            s = add4(s, bnrelu4(ld4(b + lds_), sc, sh));
-            s = add4(s, bnrelu4(ld4(b + (int64_t)ps.W * lds_), sc, sh));
-            s = add4(s, bnrelu4(ld4(b + (int64_t)(ps.W + 1) * lds_), sc, sh));
+            const float* pr = sp + ch;
+            float4 s = bnrelu4(ld4(b), pr, K);
+            s = add4(s, bnrelu4(ld4(b + lds_), pr, K));
+            s = add4(s, bnrelu4(ld4(b + (int64_t)ps.W * lds_), pr, K));
+            s = add4(s, bnrelu4(ld4(b + (int64_t)(ps.W + 1) * lds_), pr, K));
             return make_float4(s.x * 0.25f, s.y * 0.25f, s.z * 0.25f, s.w * 0.25f);
         } else {
             const int tap = kt * (Cfg::BK / 4) + q;
@@ -308,15 +375,15 @@ struct FwdConvP {
             return ld4(src + ((int64_t)c.n * ps.HWp + yy * ps.W + xx) * 4);
         }
     }
-    __device__ float4 a_fetch_d(const Ctx&, int, int, int, const float*) const { return zero4(); }
-    __device__ float4 b_fetch(const Ctx& c, int kt, int kr, int q, const float*) const {
+    __device__ float4 a_fetch_d(const Ctx&, const DRow&, int, int, int, const float*) const { return zero4(); }
+    __device__ float4 b_fetch(const Ctx& c, const DRow&, int kt, int kr, int q, const float*) const {
         const int col = c.n0 + 4 * q;
         if (col >= N) return zero4();
         return ld4(w + (int64_t)(kt * Cfg::BK + kr) * ldw + col);
     }
-    __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, float*) const {
-        const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
-        const int wm0 = (wave / Cfg::WN) * Cfg::TM * 32, wn0 = (wave % Cfg::WN) * Cfg::TN * 32;
+    __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, float*, bool active) const {
+        const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
+        const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
         // fp64 in-lane accumulation: E[x^2] - mean^2 must survive near-constant channels
         // (the masked stream is mostly background).
         double v[2][Cfg::TN];
@@ -331,7 +398,7 @@ struct FwdConvP {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = SMG_ACC_ROW(wm0, i, r, half);
-                    if (pbase + row < po.HW && col < N) {
+                    if (active && pbase + row < po.HW && col < N) {
                         const float x = acc[i][j][r];
                         dst[(int64_t)(c.m0 + row) * ldd + dcoff + col] = x;
                         const double xd = (double)x;
@@ -387,13 +454,17 @@ struct BwdDataP {
 
     struct Ctx { int n, m0, n0; };
     struct ARow { int y, x; bool valid; };
+    struct DRow {};
 
-    __host__ __device__ int param_floats() const { return 3 * KA + 5 * Cfg::BN; }
+    __host__ __device__ int param_floats() const { return 4 * KA + 5 * Cfg::BN; }
 
-    __device__ void init(Ctx& c, float* sp) const {
+    __device__ void d_init(const Ctx&, DRow&, int) const {}
+    __device__ void d_next(const Ctx&, DRow&) const {}
+    __device__ bool init(Ctx& c, float* sp) const {
         c.m0 = blockIdx.x * Cfg::BM;
         c.n0 = blockIdx.y * Cfg::BN;
         c.n = c.m0 / pa.HWp;
+        if (c.m0 - c.n * pa.HWp >= pa.HW) return false;
         const double inv = 1.0 / (double)pa.HW;
         for (int k = threadIdx.x; k < KA; k += 256) {
             float mean, invstd;
@@ -401,12 +472,12 @@ struct BwdDataP {
             const float g = agamma ? agamma[k] : 1.f;
             const float q1 = (float)(s1[(int64_t)c.n * sstride + scoff + k] * inv);
             const float q2 = (float)(s2[(int64_t)c.n * sstride + scoff + k] * inv);
-            const float gi = g * invstd;
-            sp[k] = gi;
-            sp[KA + k] = -gi * invstd * q2;
-            sp[2 * KA + k] = -gi * q1 + gi * invstd * q2 * mean;
+            sp[k] = g * invstd;
+            sp[KA + k] = q1;
+            sp[2 * KA + k] = mean;
+            sp[3 * KA + k] = invstd * q2;
         }
-        float* ep = sp + 3 * KA;
+        float* ep = sp + 4 * KA;
         const double minv = 1.0 / (double)pm.HW;
         for (int j = threadIdx.x; j < Cfg::BN; j += 256) {
             const int col = c.n0 + j;
@@ -416,13 +487,13 @@ struct BwdDataP {
                 g = egamma[col];
                 b = ebeta[col];
             }
-            const float sc = g * invstd;
-            ep[j] = sc;
-            ep[Cfg::BN + j] = b - mean * sc;
+            ep[j] = g * invstd;
+            ep[Cfg::BN + j] = b;
             ep[2 * Cfg::BN + j] = mean;
             ep[3 * Cfg::BN + j] = invstd;
             ep[4 * Cfg::BN + j] = g;
         }
+        return true;
     }
     __device__ int ktiles(const Ctx&) const { return (SHIFT3 ? 9 : 1) * (KA / Cfg::BK); }
     __device__ void a_row_init(const Ctx& c, ARow& r, int line) const {
@@ -447,18 +518,18 @@ struct BwdDataP {
         const int64_t pix = (int64_t)c.n * pa.HWp + yy * pa.W + xx;
         const float4 g = ld4(gbuf + pix * ldg + gcoff + ch);
         const float4 x = ld4(xbuf + pix * ldx + xcoff + ch);
-        return affine2(g, x, sp + ch, sp + KA + ch, sp + 2 * KA + ch);
+        return affine2(g, x, sp + ch, KA);
     }
-    __device__ float4 a_fetch_d(const Ctx&, int, int, int, const float*) const { return zero4(); }
-    __device__ float4 b_fetch(const Ctx& c, int kt, int kr, int q, const float*) const {
+    __device__ float4 a_fetch_d(const Ctx&, const DRow&, int, int, int, const float*) const { return zero4(); }
+    __device__ float4 b_fetch(const Ctx& c, const DRow&, int kt, int kr, int q, const float*) const {
         const int col = c.n0 + 4 * q;
         if (col >= N) return zero4();
         return ld4(w + (int64_t)(kt * Cfg::BK + kr) * ldw + col);
     }
-    __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, float* sp) const {
-        const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
-        const int wm0 = (wave / Cfg::WN) * Cfg::TM * 32, wn0 = (wave % Cfg::WN) * Cfg::TN * 32;
-        const float* ep = sp + 3 * KA;
+    __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, float* sp, bool active) const {
+        const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
+        const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
+        const float* ep = sp + 4 * KA;
         float v[2][Cfg::TN];
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) v[0][j] = v[1][j] = 0.f;
@@ -476,7 +547,7 @@ struct BwdDataP {
                 for (int r = 0; r < 16; ++r) {
                     const int row = SMG_ACC_ROW(wm0, i, r, half);
                     const int p = pbase + row;
-                    if (p < pa.HW && cok) {
+                    if (active && p < pa.HW && cok) {
                         if constexpr (EMODE == E_UNPOOL) {
                             const int y = p / pa.W, x = p - y * pa.W;
                             const float up = 0.25f * acc[i][j][r];
@@ -484,7 +555,7 @@ struct BwdDataP {
                             for (int d = 0; d < 4; ++d) {
                                 const int64_t pix = (int64_t)c.n * pm.HWp + (2 * y + (d >> 1)) * pm.W + 2 * x + (d & 1);
                                 const float xv = mbuf[pix * ldm + mcoff + col];
-                                const float dy = fmaf(xv, sc, sh) > 0.f ? up : 0.f;
+                                const float dy = bn1(xv, mean, sc, sh) > 0.f ? up : 0.f;
                                 dst[pix * ldd + dcoff + col] = gam * dy;
                                 v[0][j] += dy;
                                 v[1][j] += dy * ((xv - mean) * invstd);
@@ -492,7 +563,7 @@ struct BwdDataP {
                         } else {
                             const int64_t pix = (int64_t)c.m0 + row;
                             const float xv = mbuf[pix * ldm + mcoff + col];
-                            const float dy = fmaf(xv, sc, sh) > 0.f ? acc[i][j][r] : 0.f;
+                            const float dy = bn1(xv, mean, sc, sh) > 0.f ? acc[i][j][r] : 0.f;
                             if constexpr (EMODE == E_STORE) {
                                 dst[pix * ldd + dcoff + col] = dy;
                             } else {
@@ -550,10 +621,21 @@ struct BwdWeightP {
 
     struct Ctx { int n, p0, m0, n0, tap, kt; };
     struct ARow { int dummy; };
+    struct DRow { int p, y, x; };     // the pixel this staging slot reads, advanced BK per k-tile
 
-    __host__ __device__ int param_floats() const { return 3 * Cfg::BM + 2 * Cfg::BN; }
+    __host__ __device__ int param_floats() const { return 4 * Cfg::BM + 3 * Cfg::BN; }
 
-    __device__ void init(Ctx& c, float* sp) const {
+    __device__ void d_init(const Ctx& c, DRow& r, int kr) const {
+        r.p = c.p0 + kr;
+        r.y = r.p / pa.W;
+        r.x = r.p - r.y * pa.W;
+    }
+    __device__ void d_next(const Ctx&, DRow& r) const {
+        r.p += Cfg::BK;
+        r.x += Cfg::BK;
+        while (r.x >= pa.W) { r.x -= pa.W; ++r.y; }
+    }
+    __device__ bool init(Ctx& c, float* sp) const {
         c.m0 = blockIdx.x * Cfg::BM;
         c.n0 = blockIdx.y * Cfg::BN;
         const int z = blockIdx.z;
@@ -561,89 +643,84 @@ struct BwdWeightP {
         const int ci = z - c.tap * n_chunks;
         c.n = ci / chunks_per_stream;
         c.p0 = (ci - c.n * chunks_per_stream) * chunk;
+        if (c.p0 >= pa.HW) return false;
         int len = pa.HWp - c.p0;
         len = len < chunk ? len : chunk;
         c.kt = len / Cfg::BK;
         const double inv = 1.0 / (double)pa.HW;
         for (int k = threadIdx.x; k < Cfg::BM; k += 256) {
             const int ch = c.m0 + k;
-            float a = 0.f, b = 0.f, cc = 0.f;
+            float a = 0.f, q1 = 0.f, mean = 0.f, kk = 0.f;
             if (ch < MA) {
-                float mean, invstd;
+                float invstd;
                 bn_moments(xsum, xsq, (int64_t)c.n * xstride + xcoff + ch, inv, eps, mean, invstd);
                 const float g = agamma ? agamma[ch] : 1.f;
-                const float q1 = (float)(s1[(int64_t)c.n * sstride + scoff + ch] * inv);
+                q1 = (float)(s1[(int64_t)c.n * sstride + scoff + ch] * inv);
                 const float q2 = (float)(s2[(int64_t)c.n * sstride + scoff + ch] * inv);
-                const float gi = g * invstd;
-                a = gi;
-                b = -gi * invstd * q2;
-                cc = -gi * q1 + gi * invstd * q2 * mean;
+                a = g * invstd;
+                kk = invstd * q2;
             }
             sp[k] = a;
-            sp[Cfg::BM + k] = b;
-            sp[2 * Cfg::BM + k] = cc;
+            sp[Cfg::BM + k] = q1;
+            sp[2 * Cfg::BM + k] = mean;
+            sp[3 * Cfg::BM + k] = kk;
         }
         if constexpr (BMODE != W_STEM) {
-            float* bp = sp + 3 * Cfg::BM;
+            float* bp = sp + 4 * Cfg::BM;
             const double binv = 1.0 / (double)pb.HW;
             for (int j = threadIdx.x; j < Cfg::BN; j += 256) {
                 const int ch = c.n0 + j;
-                float sc = 0.f, sh = 0.f;
+                float mean = 0.f, invstd = 0.f, sc = 0.f, be = 0.f;
                 if (ch < NB) {
-                    float mean, invstd;
                     bn_moments(bsum, bsq, (int64_t)c.n * bstride + ch, binv, eps, mean, invstd);
                     sc = bgamma[ch] * invstd;
-                    sh = bbeta[ch] - mean * sc;
+                    be = bbeta[ch];
                 }
-                bp[j] = sc;
-                bp[Cfg::BN + j] = sh;
+                bp[j] = mean;
+                bp[Cfg::BN + j] = sc;
+                bp[2 * Cfg::BN + j] = be;
             }
         }
+        return true;
     }
     __device__ int ktiles(const Ctx& c) const { return c.kt; }
     __device__ void a_row_init(const Ctx&, ARow&, int) const {}
     __device__ float4 a_fetch(const Ctx&, const ARow&, int, int, const float*) const { return zero4(); }
-    __device__ float4 a_fetch_d(const Ctx& c, int kt, int kr, int q, const float* sp) const {
-        const int p = c.p0 + kt * Cfg::BK + kr;
+    __device__ float4 a_fetch_d(const Ctx& c, const DRow& r, int, int, int q, const float* sp) const {
         const int ch = c.m0 + 4 * q;
-        if (p >= pa.HW || ch >= MA) return zero4();
-        const int64_t pix = (int64_t)c.n * pa.HWp + p;
+        if (r.p >= pa.HW || ch >= MA) return zero4();
+        const int64_t pix = (int64_t)c.n * pa.HWp + r.p;
         const float4 g = ld4(gbuf + pix * ldg + gcoff + ch);
         const float4 x = ld4(xbuf + pix * ldx + xcoff + ch);
-        return affine2(g, x, sp + 4 * q, sp + Cfg::BM + 4 * q, sp + 2 * Cfg::BM + 4 * q);
+        return affine2(g, x, sp + 4 * q, Cfg::BM);
     }
-    __device__ float4 b_fetch(const Ctx& c, int kt, int kr, int q, const float* sp) const {
-        const int p = c.p0 + kt * Cfg::BK + kr;
+    __device__ float4 b_fetch(const Ctx& c, const DRow& r, int, int, int q, const float* sp) const {
         const int ch = c.n0 + 4 * q;
-        if (p >= pa.HW || ch >= NB) return zero4();
-        const float* sc = sp + 3 * Cfg::BM + 4 * q;
-        const float* sh = sc + Cfg::BN;
+        if (r.p >= pa.HW || ch >= NB) return zero4();
+        const float* pr = sp + 4 * Cfg::BM + 4 * q;
         if constexpr (BMODE == W_ONE) {
-            return bnrelu4(ld4(bbuf + ((int64_t)c.n * pb.HWp + p) * ldb + ch), sc, sh);
+            return bnrelu4(ld4(bbuf + ((int64_t)c.n * pb.HWp + r.p) * ldb + ch), pr, Cfg::BN);
         } else if constexpr (BMODE == W_THREE) {
-            const int y = p / pa.W, x = p - y * pa.W;
-            const int yy = y + c.tap / 3 - 1, xx = x + c.tap % 3 - 1;
+            const int yy = r.y + c.tap / 3 - 1, xx = r.x + c.tap % 3 - 1;
             if ((unsigned)yy >= (unsigned)pb.H || (unsigned)xx >= (unsigned)pb.W) return zero4();
-            return bnrelu4(ld4(bbuf + ((int64_t)c.n * pb.HWp + yy * pb.W + xx) * ldb + ch), sc, sh);
+            return bnrelu4(ld4(bbuf + ((int64_t)c.n * pb.HWp + yy * pb.W + xx) * ldb + ch), pr, Cfg::BN);
         } else if constexpr (BMODE == W_POOL) {
-            const int y = p / pa.W, x = p - y * pa.W;
-            const float* b = bbuf + ((int64_t)c.n * pb.HWp + (2 * y) * pb.W + 2 * x) * ldb + ch;
-            float4 s = bnrelu4(ld4(b), sc, sh);
-            s = add4(s, bnrelu4(ld4(b + ldb), sc, sh));
-            s = add4(s, bnrelu4(ld4(b + (int64_t)pb.W * ldb), sc, sh));
-            s = add4(s, bnrelu4(ld4(b + (int64_t)(pb.W + 1) * ldb), sc, sh));
+            const float* b = bbuf + ((int64_t)c.n * pb.HWp + (2 * r.y) * pb.W + 2 * r.x) * ldb + ch;
+            float4 s = bnrelu4(ld4(b), pr, Cfg::BN);
+            s = add4(s, bnrelu4(ld4(b + ldb), pr, Cfg::BN));
+            s = add4(s, bnrelu4(ld4(b + (int64_t)pb.W * ldb), pr, Cfg::BN));
+            s = add4(s, bnrelu4(ld4(b + (int64_t)(pb.W + 1) * ldb), pr, Cfg::BN));
             return make_float4(s.x * 0.25f, s.y * 0.25f, s.z * 0.25f, s.w * 0.25f);
         } else {
             const int tap = ch >> 2;
-            const int y = p / pa.W, x = p - y * pa.W;
-            const int yy = 2 * y + tap / 7 - 3, xx = 2 * x + tap % 7 - 3;
+            const int yy = 2 * r.y + tap / 7 - 3, xx = 2 * r.x + tap % 7 - 3;
             if (tap >= 49 || (unsigned)yy >= (unsigned)pb.H || (unsigned)xx >= (unsigned)pb.W) return zero4();
             return ld4(bbuf + ((int64_t)c.n * pb.HWp + yy * pb.W + xx) * 4);
         }
     }
-    __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float*, float*) const {
-        const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
-        const int wm0 = (wave / Cfg::WN) * Cfg::TM * 32, wn0 = (wave % Cfg::WN) * Cfg::TN * 32;
+    __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float*, float*, bool active) const {
+        const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
+        const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
 #pragma unroll
         for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -652,7 +729,7 @@ struct BwdWeightP {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = c.m0 + SMG_ACC_ROW(wm0, i, r, half);
-                    if (row < MA && col < NB) {
+                    if (active && row < MA && col < NB) {
                         int64_t idx;
                         if constexpr (CMAP == C_IDENT) idx = (int64_t)row * ldw_out + col;
                         else if constexpr (CMAP == C_3x3) idx = (int64_t)row * ldw_out + col * 9 + c.tap;
