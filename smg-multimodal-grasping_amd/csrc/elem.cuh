@@ -485,6 +485,48 @@ __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------
+// BN backward applied once: out = a*((g - q1) - (x - mean)*k) for a C-channel slice
+// of one stream's plane (C = 32: the finalized gradient of a dense layer's output
+// slice; C = 128: the gradient of a bottleneck through norm2).  The data- and
+// weight-gradient GEMMs that follow then stream ONE array instead of two.
+// ------------------------------------------------------------------------------------
+struct BnBwdApplyArgs {
+    const float* g; int ldg, gcoff;
+    const float* x; int ldx, xcoff;
+    Plane pl; int C;
+    const double* xsum; const double* xsq; int xstride;
+    const double* s1; const double* s2; int sstride, scoff;
+    const float* gamma; float eps;
+    float* out; int ldo;
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs a) {
+    __shared__ float prm[4 * 128];
+    const int n = blockIdx.y, t = threadIdx.x;
+    if (t < a.C) {
+        const double inv = 1.0 / (double)a.pl.HW;
+        float mean, invstd;
+        bn_moments(a.xsum, a.xsq, (int64_t)n * a.xstride + a.xcoff + t, inv, a.eps, mean, invstd);
+        const float q2 = (float)(a.s2[(int64_t)n * a.sstride + a.scoff + t] * inv);
+        prm[t] = (a.gamma ? a.gamma[t] : 1.f) * invstd;
+        prm[a.C + t] = (float)(a.s1[(int64_t)n * a.sstride + a.scoff + t] * inv);
+        prm[2 * a.C + t] = mean;
+        prm[3 * a.C + t] = invstd * q2;
+    }
+    __syncthreads();
+    const int qpr = a.C / 4;                      // float4 per row
+    const int rows_per_pass = 256 / qpr;
+    const int cq = t % qpr;
+    const int r0 = blockIdx.x * 64;
+    for (int r = r0 + t / qpr; r < r0 + 64 && r < a.pl.HW; r += rows_per_pass) {
+        const int64_t pix = (int64_t)n * a.pl.HWp + r;
+        const float4 g = ld4(a.g + pix * a.ldg + a.gcoff + 4 * cq);
+        const float4 x = ld4(a.x + pix * a.ldx + a.xcoff + 4 * cq);
+        *reinterpret_cast<float4*>(a.out + pix * a.ldo + 4 * cq) = affine2(g, x, prm + 4 * cq, a.C);
+    }
+}
+
 // Zero the rows/columns of a gradient plane that an odd-sized 2x2/stride-2 average
 // pool never reads (they receive no gradient from the transition).
 __global__ void zero_uncovered_kernel(float* G, int ld, Plane p, int Hc, int Wc, int C) {

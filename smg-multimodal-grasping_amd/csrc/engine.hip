@@ -16,6 +16,7 @@
 #include "../../include/smg_hip.h"
 #include "elem.cuh"
 #include "gemm.cuh"
+#include "halo.cuh"
 #include "plan.h"
 
 using namespace smg;
@@ -82,7 +83,7 @@ struct smg_engine {
     unsigned char* argmax = nullptr;
     float* F = nullptr; float* H1 = nullptr;
     // gradients
-    float* G[4] = {}; float* D2 = nullptr; float* DY0 = nullptr; float* DH1 = nullptr; float* DF = nullptr;
+    float* G[4] = {}; float* GS = nullptr; float* D2 = nullptr; float* DY0 = nullptr; float* DH1 = nullptr; float* DF = nullptr;
     // statistics arenas (doubles). fwd: [sum | sumsq] halves; bwd: [s1 | s2] halves
     double* fstat = nullptr; int64_t fstat_span = 0;
     double* bstat = nullptr; int64_t bstat_span = 0;
@@ -178,6 +179,7 @@ static int engine_build(smg_engine* e) {
     }
     ALLOC(e->Bt, bt_total);
     ALLOC(e->D2, (int64_t)NS * e->p_blk[0].HWp * kBottleneck);
+    ALLOC(e->GS, (int64_t)NS * e->p_blk[0].HWp * kGrowth);
     ALLOC(e->F, (int64_t)NP * e->p_blk[3].HWp * 2 * kFeat);
     ALLOC(e->DF, (int64_t)NP * e->p_blk[3].HWp * 2 * kFeat);
     ALLOC(e->H1, (int64_t)NP * e->p_blk[3].HWp * kHeadMid);
@@ -361,19 +363,37 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
             };
             if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x64{});
             }
-            {   // norm2 + relu + conv2 (3x3, 128 -> 32), appended to the block buffer
+            if (pl.H % HALO_T == 0 && pl.W % HALO_T == 0) {
+                // norm2 + relu + conv2 (3x3, 128 -> 32) with an LDS-resident input halo (halo.cuh)
+                Halo3x3FwdArgs a;
+                a.src = bt; a.lds_ = kBottleneck; a.pl = pl; a.C = kBottleneck;
+                a.ssum = fsum(e, e->st_Bt[b][i]); a.ssq = fsq(e, e->st_Bt[b][i]); a.sstride = kBottleneck;
+                a.gamma = P + d.n2.w; a.beta = P + d.n2.b; a.eps = kEps;
+                a.w = e->packed + e->pk_c2f[b][i];
+                a.dst = e->X[b]; a.ldd = Ct; a.dcoff = d.cin;
+                a.dsum = fsum(e, e->st_X[b]); a.dsq = fsq(e, e->st_X[b]); a.dstride = Ct;
+                a.tiles_x = pl.W / HALO_T;
+                const size_t smem = (size_t)(2 * 5512 + 2 * HALO_B_FLOATS + 3 * kBottleneck) * sizeof(float);
+                static bool attr_set = false;
+                if (!attr_set) {
+                    HIP_OK(hipFuncSetAttribute((const void*)conv3x3_halo_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                    attr_set = true;
+                }
+                ProfScope ps(e, st, K_C3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+                hipLaunchKernelGGL(conv3x3_halo_fwd_kernel, dim3((pl.H / HALO_T) * (pl.W / HALO_T), NS), dim3(256), smem, st, a);
+            } else {   // norm2 + relu + conv2 (3x3, 128 -> 32), appended to the block buffer (generic implicit GEMM)
                 auto run = [&](auto tag) {
-                using Cfg = decltype(tag);
-                FwdConvP<Cfg, F_THREE> p{};
-                p.src = bt; p.lds_ = kBottleneck; p.ps = pl; p.po = pl; p.K = kBottleneck;
-                p.ssum = fsum(e, e->st_Bt[b][i]); p.ssq = fsq(e, e->st_Bt[b][i]); p.sstride = kBottleneck;
-                p.gamma = P + d.n2.w; p.beta = P + d.n2.b; p.eps = kEps;
-                p.w = e->packed + e->pk_c2f[b][i]; p.ldw = kGrowth; p.N = kGrowth;
-                p.dst = e->X[b]; p.ldd = Ct; p.dcoff = d.cin;
-                p.dsum = fsum(e, e->st_X[b]); p.dsq = fsq(e, e->st_X[b]); p.dstride = Ct;
-                launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, 1), K_C3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
-            };
-            if (pl.HWp % 128 == 0) run(CfgP128x32{}); else run(CfgP64x32{});
+                    using Cfg = decltype(tag);
+                    FwdConvP<Cfg, F_THREE> p{};
+                    p.src = bt; p.lds_ = kBottleneck; p.ps = pl; p.po = pl; p.K = kBottleneck;
+                    p.ssum = fsum(e, e->st_Bt[b][i]); p.ssq = fsq(e, e->st_Bt[b][i]); p.sstride = kBottleneck;
+                    p.gamma = P + d.n2.w; p.beta = P + d.n2.b; p.eps = kEps;
+                    p.w = e->packed + e->pk_c2f[b][i]; p.ldw = kGrowth; p.N = kGrowth;
+                    p.dst = e->X[b]; p.ldd = Ct; p.dcoff = d.cin;
+                    p.dsum = fsum(e, e->st_X[b]); p.dsq = fsq(e, e->st_X[b]); p.dstride = Ct;
+                    launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, 1), K_C3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+                };
+                if (pl.HWp % 128 == 0) run(CfgP128x32{}); else run(CfgP64x32{});
             }
         }
         if (b < 3) {   // transition: norm + relu + (avgpool2 commuted in front of) conv 1x1
@@ -455,6 +475,16 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
 // ------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------
+// Pixel-chunk size of a weight-gradient launch: enough workgroups to fill the chip
+// (~768) but no more - every workgroup ends with one fp32 atomicAdd per output element.
+static void pick_chunk(const Plane& pl, int n_planes, int tiles_per_chunk, int& chunk, int& cps) {
+    const int want = (768 + tiles_per_chunk - 1) / tiles_per_chunk;
+    cps = (want + n_planes - 1) / n_planes;
+    if (cps < 1) cps = 1;
+    chunk = ((pl.HWp + cps - 1) / cps + 63) / 64 * 64;
+    cps = (pl.HWp + chunk - 1) / chunk;
+}
+
 static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t st) {
     if (!e->have_fwd) return fail(-22, "smg_backward without a preceding smg_forward");
     if (!net->grads) return fail(-22, "net.grads is NULL");
@@ -476,8 +506,8 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
         ProfScope ps(e, st, K_OTHER, 0);
         hipLaunchKernelGGL(value_bwd_kernel, dim3((p4.HW + 63) / 64, NP), dim3(256), 0, st, a);
     }
-    const int chunk4 = 128;
-    const int cps4 = (p4.HWp + chunk4 - 1) / chunk4;
+    int chunk4, cps4;
+    pick_chunk(p4, NP, 2 * kFeat / 64, chunk4, cps4);
     {   // head conv0 weight gradient
         BwdWeightP<CfgW64x64, W_ONE, C_IDENT> p{};
         p.gbuf = e->DH1; p.ldg = kHeadMid; p.gcoff = 0; p.xbuf = e->H1; p.ldx = kHeadMid; p.xcoff = 0; p.pa = p4; p.MA = kHeadMid;
@@ -520,34 +550,39 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
     for (int b = 3; b >= 0; --b) {
         const Plane pl = e->p_blk[b];
         const int Ct = kBlockCtot[b];
-        const int chunk = 1024;
-        const int cps = (pl.HWp + chunk - 1) / chunk;
         for (int i = (int)T.layers[b].size() - 1; i >= 0; --i) {
             const DenseLayerRef& d = T.layers[b][i];
             float* bt = e->Bt + e->bt_off[b][i];
+            {   // finalize this layer's output-slice gradient once: GS = invstd*(G' - SA/n - xhat*SB/n)
+                BnBwdApplyArgs a;
+                a.g = e->G[b]; a.ldg = Ct; a.gcoff = d.cin; a.x = e->X[b]; a.ldx = Ct; a.xcoff = d.cin; a.pl = pl; a.C = kGrowth;
+                a.xsum = fsum(e, e->st_X[b]); a.xsq = fsq(e, e->st_X[b]); a.xstride = Ct;
+                a.s1 = b1(e, e->bs_X[b]); a.s2 = b2(e, e->bs_X[b]); a.sstride = Ct; a.scoff = d.cin; a.gamma = nullptr; a.eps = kEps;
+                a.out = e->GS; a.ldo = kGrowth;
+                ProfScope ps(e, st, K_OTHER, 0);
+                hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(pl.HWp / 64, NS), dim3(256), 0, st, a);
+            }
             {   // conv2 (3x3) data gradient -> dy of relu2/norm2 (D2) + norm2 sums
                 auto run = [&](auto tag) {
-                using Cfg = decltype(tag);
-                BwdDataP<Cfg, true, E_STORE> p{};
-                p.gbuf = e->G[b]; p.ldg = Ct; p.gcoff = d.cin; p.xbuf = e->X[b]; p.ldx = Ct; p.xcoff = d.cin; p.pa = pl; p.KA = kGrowth;
-                p.xsum = fsum(e, e->st_X[b]); p.xsq = fsq(e, e->st_X[b]); p.xstride = Ct;
-                p.s1 = b1(e, e->bs_X[b]); p.s2 = b2(e, e->bs_X[b]); p.sstride = Ct; p.scoff = d.cin; p.agamma = nullptr;
-                p.w = e->packed + e->pk_c2d[b][i]; p.ldw = kBottleneck; p.N = kBottleneck;
-                p.mbuf = bt; p.ldm = kBottleneck; p.mcoff = 0; p.pm = pl;
-                p.msum = fsum(e, e->st_Bt[b][i]); p.msq = fsq(e, e->st_Bt[b][i]); p.mstride = kBottleneck;
-                p.egamma = P + d.n2.w; p.ebeta = P + d.n2.b;
-                p.dst = e->D2; p.ldd = kBottleneck; p.dcoff = 0;
-                p.o1 = b1(e, e->bs_Bt[b][i]); p.o2 = b2(e, e->bs_Bt[b][i]); p.ostride = kBottleneck; p.ocoff = 0;
-                p.dbeta = Gr + d.n2.b; p.dgamma = Gr + d.n2.w; p.eps = kEps;
-                launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, kBottleneck / Cfg::BN), K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
-            };
-            if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
+                    using Cfg = decltype(tag);
+                    BwdDataP<Cfg, true, E_STORE> p{};
+                    p.gbuf = e->GS; p.ldg = kGrowth; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kGrowth;
+                    p.w = e->packed + e->pk_c2d[b][i]; p.ldw = kBottleneck; p.N = kBottleneck;
+                    p.mbuf = bt; p.ldm = kBottleneck; p.mcoff = 0; p.pm = pl;
+                    p.msum = fsum(e, e->st_Bt[b][i]); p.msq = fsq(e, e->st_Bt[b][i]); p.mstride = kBottleneck;
+                    p.egamma = P + d.n2.w; p.ebeta = P + d.n2.b;
+                    p.dst = e->D2; p.ldd = kBottleneck; p.dcoff = 0;
+                    p.o1 = b1(e, e->bs_Bt[b][i]); p.o2 = b2(e, e->bs_Bt[b][i]); p.ostride = kBottleneck; p.ocoff = 0;
+                    p.dbeta = Gr + d.n2.b; p.dgamma = Gr + d.n2.w; p.eps = kEps;
+                    launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, kBottleneck / Cfg::BN), K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+                };
+                if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
             }
             {   // conv2 weight gradient
+                int chunk, cps;
+                pick_chunk(pl, NS, 9, chunk, cps);
                 BwdWeightP<CfgW32x128, W_THREE, C_3x3> p{};
-                p.gbuf = e->G[b]; p.ldg = Ct; p.gcoff = d.cin; p.xbuf = e->X[b]; p.ldx = Ct; p.xcoff = d.cin; p.pa = pl; p.MA = kGrowth;
-                p.xsum = fsum(e, e->st_X[b]); p.xsq = fsq(e, e->st_X[b]); p.xstride = Ct;
-                p.s1 = b1(e, e->bs_X[b]); p.s2 = b2(e, e->bs_X[b]); p.sstride = Ct; p.scoff = d.cin; p.agamma = nullptr;
+                p.gbuf = e->GS; p.ldg = kGrowth; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kGrowth;
                 p.bbuf = bt; p.ldb = kBottleneck; p.pb = pl; p.NB = kBottleneck;
                 p.bsum = fsum(e, e->st_Bt[b][i]); p.bsq = fsq(e, e->st_Bt[b][i]); p.bstride = kBottleneck;
                 p.bgamma = P + d.n2.w; p.bbeta = P + d.n2.b; p.eps = kEps;
@@ -555,29 +590,36 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 p.dw = Gr + d.c2.w; p.ldw_out = kBottleneck * 9;
                 launch_gemm(e, st, p, dim3(1, 1, 9 * NS * cps), K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
             }
+            {   // norm2 backward applied once, in place: D2 <- gamma2*invstd*(dy - s1/n - xhat*s2/n)
+                BnBwdApplyArgs a;
+                a.g = e->D2; a.ldg = kBottleneck; a.gcoff = 0; a.x = bt; a.ldx = kBottleneck; a.xcoff = 0; a.pl = pl; a.C = kBottleneck;
+                a.xsum = fsum(e, e->st_Bt[b][i]); a.xsq = fsq(e, e->st_Bt[b][i]); a.xstride = kBottleneck;
+                a.s1 = b1(e, e->bs_Bt[b][i]); a.s2 = b2(e, e->bs_Bt[b][i]); a.sstride = kBottleneck; a.scoff = 0;
+                a.gamma = P + d.n2.w; a.eps = kEps; a.out = e->D2; a.ldo = kBottleneck;
+                ProfScope ps(e, st, K_OTHER, 0);
+                hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(pl.HWp / 64, NS), dim3(256), 0, st, a);
+            }
             {   // conv1 (1x1) data gradient -> relu1/norm1 backward accumulated into G'
                 auto run = [&](auto tag) {
-                using Cfg = decltype(tag);
-                BwdDataP<Cfg, false, E_ACCUM> p{};
-                p.gbuf = e->D2; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = bt; p.ldx = kBottleneck; p.xcoff = 0; p.pa = pl; p.KA = kBottleneck;
-                p.xsum = fsum(e, e->st_Bt[b][i]); p.xsq = fsq(e, e->st_Bt[b][i]); p.xstride = kBottleneck;
-                p.s1 = b1(e, e->bs_Bt[b][i]); p.s2 = b2(e, e->bs_Bt[b][i]); p.sstride = kBottleneck; p.scoff = 0; p.agamma = P + d.n2.w;
-                p.w = P + d.c1.w; p.ldw = d.cin; p.N = d.cin;
-                p.mbuf = e->X[b]; p.ldm = Ct; p.mcoff = 0; p.pm = pl;
-                p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct;
-                p.egamma = P + d.n1.w; p.ebeta = P + d.n1.b;
-                p.dst = e->G[b]; p.ldd = Ct; p.dcoff = 0;
-                p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.ocoff = 0;
-                p.dbeta = Gr + d.n1.b; p.dgamma = Gr + d.n1.w; p.eps = kEps;
-                launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, (d.cin + Cfg::BN - 1) / Cfg::BN), K_D1, 2.0 * NS * pl.HW * d.cin * kBottleneck);
-            };
-            if (pl.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
+                    using Cfg = decltype(tag);
+                    BwdDataP<Cfg, false, E_ACCUM> p{};
+                    p.gbuf = e->D2; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kBottleneck;
+                    p.w = P + d.c1.w; p.ldw = d.cin; p.N = d.cin;
+                    p.mbuf = e->X[b]; p.ldm = Ct; p.mcoff = 0; p.pm = pl;
+                    p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct;
+                    p.egamma = P + d.n1.w; p.ebeta = P + d.n1.b;
+                    p.dst = e->G[b]; p.ldd = Ct; p.dcoff = 0;
+                    p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.ocoff = 0;
+                    p.dbeta = Gr + d.n1.b; p.dgamma = Gr + d.n1.w; p.eps = kEps;
+                    launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, (d.cin + Cfg::BN - 1) / Cfg::BN), K_D1, 2.0 * NS * pl.HW * d.cin * kBottleneck);
+                };
+                if (pl.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
             }
             {   // conv1 weight gradient
+                int chunk, cps;
+                pick_chunk(pl, NS, (d.cin + 63) / 64, chunk, cps);
                 BwdWeightP<CfgW128x64, W_ONE, C_IDENT> p{};
-                p.gbuf = e->D2; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = bt; p.ldx = kBottleneck; p.xcoff = 0; p.pa = pl; p.MA = kBottleneck;
-                p.xsum = fsum(e, e->st_Bt[b][i]); p.xsq = fsq(e, e->st_Bt[b][i]); p.xstride = kBottleneck;
-                p.s1 = b1(e, e->bs_Bt[b][i]); p.s2 = b2(e, e->bs_Bt[b][i]); p.sstride = kBottleneck; p.scoff = 0; p.agamma = P + d.n2.w;
+                p.gbuf = e->D2; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck;
                 p.bbuf = e->X[b]; p.ldb = Ct; p.pb = pl; p.NB = d.cin;
                 p.bsum = fsum(e, e->st_X[b]); p.bsq = fsq(e, e->st_X[b]); p.bstride = Ct;
                 p.bgamma = P + d.n1.w; p.bbeta = P + d.n1.b; p.eps = kEps;
@@ -590,6 +632,8 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
             const Plane pp = e->p_blk[b - 1];
             const int Cp = kBlockCtot[b - 1], C0 = kBlockCin[b];
             {
+                int chunk, cps;
+                pick_chunk(pl, NS, (C0 / 128) * (Cp / 128), chunk, cps);
                 BwdWeightP<CfgW128x128, W_POOL, C_IDENT> p{};
                 p.gbuf = e->G[b]; p.ldg = Ct; p.gcoff = 0; p.xbuf = e->X[b]; p.ldx = Ct; p.xcoff = 0; p.pa = pl; p.MA = C0;
                 p.xsum = fsum(e, e->st_X[b]); p.xsq = fsq(e, e->st_X[b]); p.xstride = Ct;
@@ -640,7 +684,8 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
     }
     {   // conv0 weight gradient (no data gradient: the image needs none)
         const Plane ps_ = e->p_stem;
-        const int chunk = 2048, cps = (ps_.HWp + chunk - 1) / chunk;
+        int chunk, cps;
+        pick_chunk(ps_, NS, 4, chunk, cps);
         BwdWeightP<CfgW64x64, W_STEM, C_STEM> p{};
         p.gbuf = e->DY0; p.ldg = 64; p.gcoff = 0; p.xbuf = e->stem; p.ldx = 64; p.xcoff = 0; p.pa = ps_; p.MA = 64;
         p.xsum = fsum(e, e->st_stem); p.xsq = fsq(e, e->st_stem); p.xstride = 64;
@@ -710,7 +755,7 @@ void smg_engine_destroy(smg_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     void* ptrs[] = {e->img4, e->stem, e->DY0, e->argmax, e->X[0], e->X[1], e->X[2], e->X[3], e->G[0], e->G[1], e->G[2], e->G[3],
-                    e->Bt, e->D2, e->F, e->DF, e->H1, e->DH1, e->fstat, e->bstat, e->packed, e->d_pack, e->d_bnupd,
+                    e->Bt, e->D2, e->GS, e->F, e->DF, e->H1, e->DH1, e->fstat, e->bstat, e->packed, e->d_pack, e->d_bnupd,
                     e->d_stream_image, e->d_stream_rot, e->d_affine, e->d_pair_a, e->d_pair_b, e->d_seq_t, e->d_seq_h,
                     e->d_user_ptr, e->d_user_pair, e->d_user_slot};
     for (void* p : ptrs) if (p) (void)hipFree(p);

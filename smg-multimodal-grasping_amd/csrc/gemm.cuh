@@ -466,7 +466,7 @@ struct BwdDataP {
         c.n = c.m0 / pa.HWp;
         if (c.m0 - c.n * pa.HWp >= pa.HW) return false;
         const double inv = 1.0 / (double)pa.HW;
-        for (int k = threadIdx.x; k < KA; k += 256) {
+        for (int k = threadIdx.x; xbuf && k < KA; k += 256) {
             float mean, invstd;
             bn_moments(xsum, xsq, (int64_t)c.n * xstride + xcoff + k, inv, eps, mean, invstd);
             const float g = agamma ? agamma[k] : 1.f;
@@ -517,6 +517,7 @@ struct BwdDataP {
         }
         const int64_t pix = (int64_t)c.n * pa.HWp + yy * pa.W + xx;
         const float4 g = ld4(gbuf + pix * ldg + gcoff + ch);
+        if (!xbuf) return g;               // gradient already BN-corrected (bn_bwd_apply_kernel)
         const float4 x = ld4(xbuf + pix * ldx + xcoff + ch);
         return affine2(g, x, sp + ch, KA);
     }
@@ -648,7 +649,7 @@ struct BwdWeightP {
         len = len < chunk ? len : chunk;
         c.kt = len / Cfg::BK;
         const double inv = 1.0 / (double)pa.HW;
-        for (int k = threadIdx.x; k < Cfg::BM; k += 256) {
+        for (int k = threadIdx.x; xbuf && k < Cfg::BM; k += 256) {
             const int ch = c.m0 + k;
             float a = 0.f, q1 = 0.f, mean = 0.f, kk = 0.f;
             if (ch < MA) {
@@ -691,6 +692,7 @@ struct BwdWeightP {
         if (r.p >= pa.HW || ch >= MA) return zero4();
         const int64_t pix = (int64_t)c.n * pa.HWp + r.p;
         const float4 g = ld4(gbuf + pix * ldg + gcoff + ch);
+        if (!xbuf) return g;
         const float4 x = ld4(xbuf + pix * ldx + xcoff + ch);
         return affine2(g, x, sp + 4 * q, Cfg::BM);
     }
