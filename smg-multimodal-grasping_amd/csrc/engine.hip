@@ -373,7 +373,7 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
                 a.dst = e->X[b]; a.ldd = Ct; a.dcoff = d.cin;
                 a.dsum = fsum(e, e->st_X[b]); a.dsq = fsq(e, e->st_X[b]); a.dstride = Ct;
                 a.tiles_x = pl.W / HALO_T;
-                const size_t smem = (size_t)(2 * 5512 + 2 * HALO_B_FLOATS + 3 * kBottleneck) * sizeof(float);
+                const size_t smem = (size_t)(HALO_A_PAD + HALO_B_FLOATS + 3 * kBottleneck) * sizeof(float);
                 static bool attr_set = false;
                 if (!attr_set) {
                     HIP_OK(hipFuncSetAttribute((const void*)conv3x3_halo_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -562,7 +562,18 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 ProfScope ps(e, st, K_OTHER, 0);
                 hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(pl.HWp / 64, NS), dim3(256), 0, st, a);
             }
-            {   // conv2 (3x3) data gradient -> dy of relu2/norm2 (D2) + norm2 sums
+            if (pl.H % HALO_T == 0 && pl.W % HALO_T == 0) {
+                // conv2 (3x3) data gradient with the gradient halo resident in LDS (halo.cuh)
+                Halo3x3DgradArgs a;
+                a.g = e->GS; a.pl = pl; a.w = e->packed + e->pk_c2d[b][i]; a.C = kBottleneck;
+                a.mbuf = bt; a.msum = fsum(e, e->st_Bt[b][i]); a.msq = fsq(e, e->st_Bt[b][i]); a.mstride = kBottleneck;
+                a.gamma = P + d.n2.w; a.beta = P + d.n2.b; a.eps = kEps;
+                a.dst = e->D2; a.o1 = b1(e, e->bs_Bt[b][i]); a.o2 = b2(e, e->bs_Bt[b][i]); a.ostride = kBottleneck;
+                a.dbeta = Gr + d.n2.b; a.dgamma = Gr + d.n2.w; a.tiles_x = pl.W / HALO_T;
+                const size_t smem = (size_t)(HD_A_FLOATS + HD_B_FLOATS + 4 * kBottleneck + 256) * sizeof(float);
+                ProfScope ps(e, st, K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+                hipLaunchKernelGGL(conv3x3_halo_dgrad_kernel, dim3((pl.H / HALO_T) * (pl.W / HALO_T), NS), dim3(256), smem, st, a);
+            } else {   // conv2 (3x3) data gradient -> dy of relu2/norm2 (D2) + norm2 sums (generic implicit GEMM)
                 auto run = [&](auto tag) {
                     using Cfg = decltype(tag);
                     BwdDataP<Cfg, true, E_STORE> p{};
@@ -578,9 +589,27 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 };
                 if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
             }
-            {   // conv2 weight gradient
-                int chunk, cps;
-                pick_chunk(pl, NS, 9, chunk, cps);
+            if (pl.H % HALO_T == 0 && pl.W % HALO_T == 0) {
+                // conv2 weight gradient with the activation halo resident in LDS (halo.cuh)
+                Halo3x3WgradArgs a;
+                a.g = e->GS; a.pl = pl; a.src = bt; a.C = kBottleneck;
+                a.ssum = fsum(e, e->st_Bt[b][i]); a.ssq = fsq(e, e->st_Bt[b][i]); a.sstride = kBottleneck;
+                a.gamma = P + d.n2.w; a.beta = P + d.n2.b; a.eps = kEps;
+                a.dw = Gr + d.c2.w; a.tiles_x = pl.W / HALO_T; a.n_tiles = (pl.H / HALO_T) * (pl.W / HALO_T);
+                int groups = (768 + 4 * NS - 1) / (4 * NS);                 // ~768 workgroups
+                if (groups > a.n_tiles) groups = a.n_tiles;
+                a.tiles_per_wg = (a.n_tiles + groups - 1) / groups;
+                groups = (a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+                const size_t smem = (size_t)(HW_B_FLOATS + HW_A_FLOATS + 96) * sizeof(float);
+                static bool attr_set = false;
+                if (!attr_set) {
+                    HIP_OK(hipFuncSetAttribute((const void*)conv3x3_halo_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                    attr_set = true;
+                }
+                ProfScope ps(e, st, K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+                hipLaunchKernelGGL(conv3x3_halo_wgrad_kernel, dim3(groups, kBottleneck / 32, NS), dim3(256), smem, st, a);
+            } else {   // conv2 weight gradient (generic implicit GEMM, one launch slice per tap)
+                const int chunk = 1024, cps = (pl.HWp + chunk - 1) / chunk;   // load-bound: wants many workgroups
                 BwdWeightP<CfgW32x128, W_THREE, C_3x3> p{};
                 p.gbuf = e->GS; p.ldg = kGrowth; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kGrowth;
                 p.bbuf = bt; p.ldb = kBottleneck; p.pb = pl; p.NB = kBottleneck;

@@ -11,9 +11,11 @@
 //   out[p][n] = sum_{tap, c} relu(bn(in[p + d(tap)][c])) * W[n][c][tap]
 //
 // 4 waves, wave w owns pixel rows 4w..4w+3 (two 32x32 MFMA tiles: 2 rows x 16 cols
-// each) x all 32 output channels.  LDS: A[2][324 px][17] (pixel-major, odd stride ->
-// conflict-free fragment reads), B[2][9*16][32].  Double-buffered over channel chunks;
-// operand fragments of tap t+1 are fetched while the MFMAs of tap t run.
+// each) x all 32 output channels.  LDS: A[324 px][17] (pixel-major, odd stride ->
+// conflict-free fragment reads), B[9*16][32]: 42 KB, so 2-3 workgroups share a CU and
+// one's staging / epilogue hides under another's MFMAs.  The next chunk is prefetched
+// into registers during the MFMAs; operand fragments of tap t+1 are fetched while the
+// MFMAs of tap t run.
 #pragma once
 #include "gemm.cuh"
 
@@ -36,15 +38,16 @@ constexpr int HALO_PX = HALO_W * HALO_W;   // 324
 constexpr int HALO_CK = 16;                // channels per chunk
 constexpr int HALO_LDA = HALO_CK + 1;      // 17
 constexpr int HALO_A_FLOATS = HALO_PX * HALO_LDA;          // 5508
+constexpr int HALO_A_PAD = 5512;                             // keeps B 16-byte aligned
 constexpr int HALO_B_FLOATS = 9 * HALO_CK * 32;            // 4608
 constexpr int HALO_A_N = (HALO_PX * (HALO_CK / 4) + 255) / 256;   // float4 per thread: 6
 constexpr int HALO_B_N = (9 * HALO_CK * 8 + 255) / 256;           // 5
 
 __global__ __launch_bounds__(256) void conv3x3_halo_fwd_kernel(const Halo3x3FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                   // [2][HALO_A_FLOATS] (+pad to 16 B)
-    float* Bs = smem + 2 * 5512;                        // [2][HALO_B_FLOATS]
-    float* prm = Bs + 2 * HALO_B_FLOATS;                // mean | scale | beta, C each
+    float* As = smem;                                   // [HALO_A_FLOATS] (+pad to 16 B)
+    float* Bs = smem + HALO_A_PAD;                      // [HALO_B_FLOATS]
+    float* prm = Bs + HALO_B_FLOATS;                    // mean | scale | beta, C each
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
     const int n = blockIdx.y;
     const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
@@ -91,9 +94,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_fwd_kernel(const Halo3x3FwdA
             rb[i] = (idx < 9 * HALO_CK * 8) ? ld4(a.w + ((int64_t)(tap * C + c0 + cc)) * 32 + 4 * q) : zero4();
         }
     };
-    auto s_store = [&](int buf, int chunk) {
-        float* A = As + buf * 5512;
-        float* B = Bs + buf * HALO_B_FLOATS;
+    auto s_store = [&](int chunk) {
+        float* A = As;
+        float* B = Bs;
         const int c0 = chunk * HALO_CK;
 #pragma unroll
         for (int i = 0; i < HALO_A_N; ++i) {
@@ -125,13 +128,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_fwd_kernel(const Halo3x3FwdA
     const int NCH = C / HALO_CK;
     __syncthreads();                 // prm visible
     g_load(0);
-    s_store(0, 0);
+    s_store(0);
     __syncthreads();
     for (int ch = 0; ch < NCH; ++ch) {
-        const int buf = ch & 1;
         if (ch + 1 < NCH) g_load(ch + 1);
-        const float* A = As + buf * 5512;
-        const float* B = Bs + buf * HALO_B_FLOATS;
+        const float* A = As;
+        const float* B = Bs;
         float fa[2][8][2], fb[2][8];
         auto frag = [&](int set, int tap) {
             const int toff = ((tap / 3) * HALO_W + (tap % 3)) * HALO_LDA;
@@ -155,8 +157,11 @@ __global__ __launch_bounds__(256) void conv3x3_halo_fwd_kernel(const Halo3x3FwdA
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (ch + 1 < NCH) s_store(buf ^ 1, ch + 1);
-        __syncthreads();
+        __syncthreads();                          // every wave is done reading this chunk
+        if (ch + 1 < NCH) {
+            s_store(ch + 1);
+            __syncthreads();
+        }
     }
 
     // epilogue: raw output + per-(stream, channel) sum / sum of squares (fp64)
@@ -183,6 +188,280 @@ __global__ __launch_bounds__(256) void conv3x3_halo_fwd_kernel(const Halo3x3FwdA
         const int q = t >> 5, c = t & 31;
         const double tot = red[q * 128 + c] + red[q * 128 + 32 + c] + red[q * 128 + 64 + c] + red[q * 128 + 96 + c];
         atomicAdd((q ? a.dsq : a.dsum) + (int64_t)n * a.dstride + a.dcoff + c, tot);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------
+// 3x3 data gradient (transposed convolution) with the gradient halo resident in LDS:
+//   dc[p][c] = sum_{tap, n} g[p - d(tap)][n] * W[n][c][tap]          (g: [pixel][32])
+// followed by the ReLU mask and BN(norm2) backward sums of the bottleneck (the same
+// epilogue as BwdDataP/E_STORE).  The 18x18x32 halo of g is staged once per workgroup;
+// the weights of one (32-channel output chunk, tap row) - 12 KB - are streamed through
+// LDS 12 times, prefetched into registers under the MFMAs.  57 KB LDS -> 2 workgroups/CU.
+// ------------------------------------------------------------------------------------
+struct Halo3x3DgradArgs {
+    const float* g; Plane pl;                        // [n][HWp][32] finalized output gradient
+    const float* w;                                  // packed [(tap*32 + n)][C]
+    int C;                                           // bottleneck channels (128)
+    const float* mbuf;                               // raw bottleneck [n][HWp][C] (mask + xhat source)
+    const double* msum; const double* msq; int mstride;
+    const float* gamma; const float* beta; float eps;
+    float* dst;                                      // dy [n][HWp][C]
+    double* o1; double* o2; int ostride;             // per-stream sums [n][C]
+    float* dbeta; float* dgamma;
+    int tiles_x;
+};
+
+constexpr int HD_LDA = 33;
+constexpr int HD_A_FLOATS = HALO_PX * HD_LDA;               // 10692
+constexpr int HD_B_FLOATS = 3 * 32 * 32;                    // one tap row x 32 n x 32 c
+constexpr int HD_A_N = (HALO_PX * 8 + 255) / 256;           // 11 float4 per thread
+constexpr int HD_B_N = HD_B_FLOATS / 4 / 256;               // 3
+
+__global__ __launch_bounds__(256) void conv3x3_halo_dgrad_kernel(const Halo3x3DgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                   // [324][33]
+    float* Bs = smem + HD_A_FLOATS;                     // [96][32]   (10692 % 4 == 0)
+    float* prm = Bs + HD_B_FLOATS;                      // scale | beta | mean | invstd, C each
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
+    const int n = blockIdx.y;
+    const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
+    const int y0 = ty * HALO_T, x0 = tx * HALO_T;
+    const int C = a.C;
+    {
+        const double inv = 1.0 / (double)a.pl.HW;
+        for (int k = t; k < C; k += 256) {
+            float mean, invstd;
+            bn_moments(a.msum, a.msq, (int64_t)n * a.mstride + k, inv, a.eps, mean, invstd);
+            prm[k] = a.gamma[k] * invstd;
+            prm[C + k] = a.beta[k];
+            prm[2 * C + k] = mean;
+            prm[3 * C + k] = invstd;
+        }
+    }
+    // gradient halo (plain values, zero outside the image)
+    const float* g_n = a.g + (int64_t)n * a.pl.HWp * 32;
+#pragma unroll
+    for (int i = 0; i < HD_A_N; ++i) {
+        const int idx = t + 256 * i;
+        if (idx < HALO_PX * 8) {
+            const int hp = idx >> 3, q = idx & 7;
+            const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+            const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+            float4 v = zero4();
+            if ((unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W) v = ld4(g_n + (int64_t)(iy * a.pl.W + ix) * 32 + 4 * q);
+            float* d = As + hp * HD_LDA + 4 * q;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    }
+    float4 rb[HD_B_N];
+    auto g_load = [&](int stage) {            // stage = cchunk*3 + tap row
+        const int cc0 = (stage / 3) * 32, dy = stage % 3;
+#pragma unroll
+        for (int i = 0; i < HD_B_N; ++i) {
+            const int idx = t + 256 * i;      // 768 float4: row = idx >> 3 (dx*32 + nn), q = idx & 7
+            const int row = idx >> 3, q = idx & 7;
+            rb[i] = ld4(a.w + (int64_t)((dy * 3) * 32 + row) * C + cc0 + 4 * q);
+        }
+    };
+    auto s_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < HD_B_N; ++i) *reinterpret_cast<float4*>(Bs + (t + 256 * i) * 4) = rb[i];
+    };
+    int abase[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) abase[m] = ((4 * wave + 2 * m + (l31 >> 4)) * HALO_W + (l31 & 15)) * HD_LDA + half;
+    const int bbase = half * 32 + l31;
+
+    g_load(0);
+    s_store();
+    __syncthreads();
+    f32x16 acc[2];
+    for (int stage = 0; stage < 12; ++stage) {
+        const int dy = stage % 3;
+        if (dy == 0) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        }
+        if (stage + 1 < 12) g_load(stage + 1);
+        float fa[2][8][2], fb[2][8];
+        // output pixel (ry, rx), tap (dy, dx) reads g at halo (ry + 2 - dy, rx + 2 - dx)
+        auto frag = [&](int set, int step) {          // step = dx*2 + (n half): 16 n per step
+            const int dx = step >> 1, nh = step & 1;
+            const int toff = ((2 - dy) * HALO_W + (2 - dx)) * HD_LDA + nh * 16;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                fa[set][kk][0] = As[abase[0] + toff + 2 * kk];
+                fa[set][kk][1] = As[abase[1] + toff + 2 * kk];
+                fb[set][kk] = Bs[(dx * 32 + nh * 16 + 2 * kk) * 32 + bbase];
+            }
+        };
+        frag(0, 0);
+#pragma unroll
+        for (int step = 0; step < 6; ++step) {
+            const int set = step & 1;
+            if (step + 1 < 6) frag(set ^ 1, step + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][kk][0], fb[set][kk], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][kk][1], fb[set][kk], acc[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                          // B of this stage fully consumed
+        if (stage + 1 < 12) s_store();
+        if (dy == 2) {
+            // epilogue of output-channel chunk cc0: ReLU mask, store dy, BN(norm2) backward sums
+            const int c = (stage / 3) * 32 + l31;
+            const float sc = prm[c], be = prm[C + c], mean = prm[2 * C + c], invstd = prm[3 * C + c];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int py = y0 + 4 * wave + 2 * m + (i >> 4), px = x0 + (i & 15);
+                    const int64_t pix = (int64_t)n * a.pl.HWp + py * a.pl.W + px;
+                    const float xv = a.mbuf[pix * C + c];
+                    const float dyv = bn1(xv, mean, sc, be) > 0.f ? acc[m][r] : 0.f;
+                    a.dst[pix * C + c] = dyv;
+                    s1 += dyv;
+                    s2 += dyv * ((xv - mean) * invstd);
+                }
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            float* red = prm + 4 * C;                 // [2][4][32]
+            if (half == 0) { red[wave * 32 + l31] = s1; red[128 + wave * 32 + l31] = s2; }
+            __syncthreads();
+            if (t < 64) {
+                const int q = t >> 5, cc = t & 31;
+                const float tot = red[q * 128 + cc] + red[q * 128 + 32 + cc] + red[q * 128 + 64 + cc] + red[q * 128 + 96 + cc];
+                const int ch = (stage / 3) * 32 + cc;
+                atomicAdd((q ? a.o2 : a.o1) + (int64_t)n * a.ostride + ch, (double)tot);
+                atomicAdd((q ? a.dgamma : a.dbeta) + ch, tot);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+
+// ------------------------------------------------------------------------------------
+// 3x3 weight gradient with the activation halo resident in LDS:
+//   dW[n][c][tap] += sum_p g[p][n] * relu(bn(in[p + d(tap)][c]))
+// A workgroup owns (a run of 16x16 pixel tiles of one stream) x (a 32-channel chunk of
+// c).  Per tile it stages the 18x18x32 activation halo (BN+ReLU applied once) and the
+// 256x32 gradient tile; every wave then walks its own 64 pixels as the MFMA reduction
+// dimension and accumulates ALL nine taps (9 accumulator tiles) by shifting the halo
+// read address - the operands are fetched once for 9 taps instead of once per tap.
+// The accumulators persist across the run of tiles; one LDS-reduced atomic flush at
+// the end (9216 atomics per workgroup).
+// ------------------------------------------------------------------------------------
+struct Halo3x3WgradArgs {
+    const float* g; Plane pl;                        // [n][HWp][32] finalized output gradient
+    const float* src; int C;                         // raw bottleneck [n][HWp][C]
+    const double* ssum; const double* ssq; int sstride;
+    const float* gamma; const float* beta; float eps;
+    float* dw;                                       // [32][C][3][3] native layout
+    int tiles_x, n_tiles, tiles_per_wg;
+};
+
+constexpr int HW_B_FLOATS = HALO_PX * 32;          // 10368
+constexpr int HW_A_FLOATS = 256 * 32;              // 8192
+constexpr int HW_B_N = (HALO_PX * 8 + 255) / 256;  // 11
+constexpr int HW_A_N = 8;
+
+__global__ __launch_bounds__(256) void conv3x3_halo_wgrad_kernel(const Halo3x3WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Bh = smem;                                   // [324][32] activation halo
+    float* Ag = smem + HW_B_FLOATS;                     // [256][32] gradient tile
+    float* prm = Ag + HW_A_FLOATS;                      // mean | scale | beta (32 each)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
+    const int n = blockIdx.z, cc0 = blockIdx.y * 32;
+    const int C = a.C;
+    if (t < 32) {
+        float mean, invstd;
+        bn_moments(a.ssum, a.ssq, (int64_t)n * a.sstride + cc0 + t, 1.0 / (double)a.pl.HW, a.eps, mean, invstd);
+        prm[t] = mean;
+        prm[32 + t] = a.gamma[cc0 + t] * invstd;
+        prm[64 + t] = a.beta[cc0 + t];
+    }
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    const float* src_n = a.src + (int64_t)n * a.pl.HWp * C + cc0;
+    const float* g_n = a.g + (int64_t)n * a.pl.HWp * 32;
+    const int tile0 = blockIdx.x * a.tiles_per_wg;
+    const int tile1 = min(tile0 + a.tiles_per_wg, a.n_tiles);
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const int y0 = ty * HALO_T, x0 = tx * HALO_T;
+        __syncthreads();                              // previous tile fully consumed (and prm visible)
+#pragma unroll
+        for (int i = 0; i < HW_B_N; ++i) {
+            const int idx = t + 256 * i;
+            if (idx < HALO_PX * 8) {
+                const int hp = idx >> 3, q = idx & 7;
+                const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+                const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+                float4 v = zero4();
+                if ((unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W)
+                    v = bnrelu4(ld4(src_n + (int64_t)(iy * a.pl.W + ix) * C + 4 * q), prm + 4 * q, 32);
+                *reinterpret_cast<float4*>(Bh + hp * 32 + 4 * q) = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < HW_A_N; ++i) {
+            const int idx = t + 256 * i;
+            const int px = idx >> 3, q = idx & 7;
+            const int64_t pix = (int64_t)(y0 + (px >> 4)) * a.pl.W + x0 + (px & 15);
+            *reinterpret_cast<float4*>(Ag + px * 32 + 4 * q) = ld4(g_n + pix * 32 + 4 * q);
+        }
+        __syncthreads();
+        // wave w reduces over its 64 pixels (rows 4w..4w+3); lane half selects the pixel parity
+        float fa[2], fb[2][9];
+        auto frag = [&](int set, int kk) {
+            const int pw = 2 * kk + half;
+            const int ry = 4 * wave + (pw >> 4), rx = pw & 15;
+            fa[set] = Ag[(ry * 16 + rx) * 32 + l31];
+            const float* b = Bh + (ry * HALO_W + rx) * 32 + l31;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) fb[set][tap] = b[((tap / 3) * HALO_W + (tap % 3)) * 32];
+        };
+        frag(0, 0);
+#pragma unroll 2
+        for (int kk = 0; kk < 32; ++kk) {
+            const int set = kk & 1;
+            if (kk + 1 < 32) frag(set ^ 1, kk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set], fb[set][tap], acc[tap], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // flush: per tap, fold the four waves' tiles through LDS and add into the gradient
+    float* red = smem;                                  // [4][16][64]
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[tap][r];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = t + 256 * k;                  // e = r*64 + lane'
+            const int r = e >> 6, ln = e & 63;
+            const float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+            const int nn = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), cc = ln & 31;
+            atomicAdd(a.dw + ((int64_t)nn * C + cc0 + cc) * 9 + tap, v);
+        }
     }
 }
 
