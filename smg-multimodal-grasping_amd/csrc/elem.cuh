@@ -518,12 +518,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs 
     const int qpr = a.C / 4;                      // float4 per row
     const int rows_per_pass = 256 / qpr;
     const int cq = t % qpr;
-    const int r0 = blockIdx.x * 64;
-    for (int r = r0 + t / qpr; r < r0 + 64 && r < a.pl.HW; r += rows_per_pass) {
-        const int64_t pix = (int64_t)n * a.pl.HWp + r;
-        const float4 g = ld4(a.g + pix * a.ldg + a.gcoff + 4 * cq);
-        const float4 x = ld4(a.x + pix * a.ldx + a.xcoff + 4 * cq);
-        *reinterpret_cast<float4*>(a.out + pix * a.ldo + 4 * cq) = affine2(g, x, prm + 4 * cq, a.C);
+    const int r0 = blockIdx.x * 64 + t / qpr;
+    // 64 rows per workgroup: up to 8 row slots per thread; loads of all slots first (the output may
+    // alias the gradient input - it does for the in-place norm2 case - so they cannot be hoisted
+    // past the stores by the compiler)
+    float4 gv[8], xv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int r = r0 + k * rows_per_pass;
+        const bool ok = k * rows_per_pass < 64 && r < a.pl.HW;
+        const int64_t pix = (int64_t)n * a.pl.HWp + (ok ? r : 0);
+        gv[k] = ok ? ld4(a.g + pix * a.ldg + a.gcoff + 4 * cq) : zero4();
+        xv[k] = ok ? ld4(a.x + pix * a.ldx + a.xcoff + 4 * cq) : zero4();
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int r = r0 + k * rows_per_pass;
+        if (k * rows_per_pass < 64 && r < a.pl.HW) {
+            const int64_t pix = (int64_t)n * a.pl.HWp + r;
+            *reinterpret_cast<float4*>(a.out + pix * a.ldo + 4 * cq) = affine2(gv[k], xv[k], prm + 4 * cq, a.C);
+        }
     }
 }
 

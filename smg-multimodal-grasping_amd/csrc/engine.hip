@@ -694,7 +694,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 p.dbeta = Gr + T.tnorm[b - 1].b; p.dgamma = Gr + T.tnorm[b - 1].w; p.eps = kEps;
                 launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, Cp / Cfg::BN), K_TD, 2.0 * NS * pl.HW * Cp * C0);
             };
-            if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
+            run(CfgP64x128{});   // the 128-row variant of the unpool epilogue spills registers
             }
         }
     }

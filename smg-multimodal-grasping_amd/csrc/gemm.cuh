@@ -543,39 +543,60 @@ struct BwdDataP {
             const float sc = ep[cj], sh = ep[Cfg::BN + cj], mean = ep[2 * Cfg::BN + cj], invstd = ep[3 * Cfg::BN + cj];
             const float gam = ep[4 * Cfg::BN + cj];
 #pragma unroll
-            for (int i = 0; i < Cfg::TM; ++i)
+            for (int i = 0; i < Cfg::TM; ++i) {
+                // Two passes per 32x32 accumulator tile: every load first (16..64 of them in
+                // flight), then the math and the stores.  Interleaving them serialises on one
+                // memory round trip per element, because the stores may alias the loads.
+                constexpr int NL = (EMODE == E_UNPOOL) ? 4 : 1;
+                constexpr int RB = (EMODE == E_UNPOOL) ? 8 : 16;      // accumulator rows per batch (bounds live registers)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = SMG_ACC_ROW(wm0, i, r, half);
-                    const int p = pbase + row;
-                    if (active && p < pa.HW && cok) {
+                for (int rb = 0; rb < 16; rb += RB) {
+                    float xv[RB][NL], gold[RB];
+                    int pix0[RB];                                     // first pixel row of the element (fits int: streams*HWp)
+                    bool ok[RB];
+#pragma unroll
+                    for (int q = 0; q < RB; ++q) {
+                        const int r = rb + q;
+                        const int row = SMG_ACC_ROW(wm0, i, r, half);
+                        const int p = pbase + row;
+                        ok[q] = active && p < pa.HW && cok;
+                        gold[q] = 0.f;
                         if constexpr (EMODE == E_UNPOOL) {
                             const int y = p / pa.W, x = p - y * pa.W;
-                            const float up = 0.25f * acc[i][j][r];
+                            pix0[q] = c.n * pm.HWp + (2 * y) * pm.W + 2 * x;
 #pragma unroll
-                            for (int d = 0; d < 4; ++d) {
-                                const int64_t pix = (int64_t)c.n * pm.HWp + (2 * y + (d >> 1)) * pm.W + 2 * x + (d & 1);
-                                const float xv = mbuf[pix * ldm + mcoff + col];
-                                const float dy = bn1(xv, mean, sc, sh) > 0.f ? up : 0.f;
-                                dst[pix * ldd + dcoff + col] = gam * dy;
-                                v[0][j] += dy;
-                                v[1][j] += dy * ((xv - mean) * invstd);
-                            }
+                            for (int d = 0; d < 4; ++d)
+                                xv[q][d] = ok[q] ? mbuf[(int64_t)(pix0[q] + (d >> 1) * pm.W + (d & 1)) * ldm + mcoff + col] : 0.f;
                         } else {
-                            const int64_t pix = (int64_t)c.m0 + row;
-                            const float xv = mbuf[pix * ldm + mcoff + col];
-                            const float dy = bn1(xv, mean, sc, sh) > 0.f ? acc[i][j][r] : 0.f;
-                            if constexpr (EMODE == E_STORE) {
-                                dst[pix * ldd + dcoff + col] = dy;
-                            } else {
-                                float* d = dst + pix * ldd + dcoff + col;
-                                *d = *d + gam * dy;
-                            }
-                            v[0][j] += dy;
-                            v[1][j] += dy * ((xv - mean) * invstd);
+                            pix0[q] = c.m0 + row;
+                            xv[q][0] = ok[q] ? mbuf[(int64_t)pix0[q] * ldm + mcoff + col] : 0.f;
+                            if constexpr (EMODE == E_ACCUM) gold[q] = ok[q] ? dst[(int64_t)pix0[q] * ldd + dcoff + col] : 0.f;
                         }
                     }
+#pragma unroll
+                    for (int q = 0; q < RB; ++q) {
+                        if (!ok[q]) continue;
+                        const float av = acc[i][j][rb + q];
+                        if constexpr (EMODE == E_UNPOOL) {
+                            const float up = 0.25f * av;
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) {
+                                const float dy = bn1(xv[q][d], mean, sc, sh) > 0.f ? up : 0.f;
+                                dst[(int64_t)(pix0[q] + (d >> 1) * pm.W + (d & 1)) * ldd + dcoff + col] = gam * dy;
+                                v[0][j] += dy;
+                                v[1][j] += dy * ((xv[q][d] - mean) * invstd);
+                            }
+                        } else {
+                            const float dy = bn1(xv[q][0], mean, sc, sh) > 0.f ? av : 0.f;
+                            if constexpr (EMODE == E_STORE) dst[(int64_t)pix0[q] * ldd + dcoff + col] = dy;
+                            else dst[(int64_t)pix0[q] * ldd + dcoff + col] = gold[q] + gam * dy;
+                            v[0][j] += dy;
+                            v[1][j] += dy * ((xv[q][0] - mean) * invstd);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);    // one batch of loads in flight at a time
                 }
+            }
         }
         float tot[2];
         block_col_reduce<Cfg, 2, float>(v, smem, tot);

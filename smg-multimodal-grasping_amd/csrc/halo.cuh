@@ -242,17 +242,24 @@ __global__ __launch_bounds__(256) void conv3x3_halo_dgrad_kernel(const Halo3x3Dg
     }
     // gradient halo (plain values, zero outside the image)
     const float* g_n = a.g + (int64_t)n * a.pl.HWp * 32;
+    {
+        float4 rv[HD_A_N];
 #pragma unroll
-    for (int i = 0; i < HD_A_N; ++i) {
-        const int idx = t + 256 * i;
-        if (idx < HALO_PX * 8) {
+        for (int i = 0; i < HD_A_N; ++i) {            // every load in flight before the first LDS store
+            const int idx = t + 256 * i;
             const int hp = idx >> 3, q = idx & 7;
             const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
             const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-            float4 v = zero4();
-            if ((unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W) v = ld4(g_n + (int64_t)(iy * a.pl.W + ix) * 32 + 4 * q);
-            float* d = As + hp * HD_LDA + 4 * q;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            const bool ok = idx < HALO_PX * 8 && (unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W;
+            rv[i] = ok ? ld4(g_n + (int64_t)(iy * a.pl.W + ix) * 32 + 4 * q) : zero4();
+        }
+#pragma unroll
+        for (int i = 0; i < HD_A_N; ++i) {
+            const int idx = t + 256 * i;
+            if (idx < HALO_PX * 8) {
+                float* d = As + (idx >> 3) * HD_LDA + 4 * (idx & 7);
+                d[0] = rv[i].x; d[1] = rv[i].y; d[2] = rv[i].z; d[3] = rv[i].w;
+            }
         }
     }
     float4 rb[HD_B_N];
@@ -319,18 +326,25 @@ __global__ __launch_bounds__(256) void conv3x3_halo_dgrad_kernel(const Halo3x3Dg
             const int c = (stage / 3) * 32 + l31;
             const float sc = prm[c], be = prm[C + c], mean = prm[2 * C + c], invstd = prm[3 * C + c];
             float s1 = 0.f, s2 = 0.f;
+            float xv[2][16];
+            int64_t pixv[2][16];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 2; ++m)       // all 32 mask-source loads first (stores below may alias them)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
                     const int py = y0 + 4 * wave + 2 * m + (i >> 4), px = x0 + (i & 15);
-                    const int64_t pix = (int64_t)n * a.pl.HWp + py * a.pl.W + px;
-                    const float xv = a.mbuf[pix * C + c];
-                    const float dyv = bn1(xv, mean, sc, be) > 0.f ? acc[m][r] : 0.f;
-                    a.dst[pix * C + c] = dyv;
+                    pixv[m][r] = (int64_t)n * a.pl.HWp + py * a.pl.W + px;
+                    xv[m][r] = a.mbuf[pixv[m][r] * C + c];
+                }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float dyv = bn1(xv[m][r], mean, sc, be) > 0.f ? acc[m][r] : 0.f;
+                    a.dst[pixv[m][r] * C + c] = dyv;
                     s1 += dyv;
-                    s2 += dyv * ((xv - mean) * invstd);
+                    s2 += dyv * ((xv[m][r] - mean) * invstd);
                 }
             s1 += __shfl_xor(s1, 32);
             s2 += __shfl_xor(s2, 32);
@@ -403,25 +417,39 @@ __global__ __launch_bounds__(256) void conv3x3_halo_wgrad_kernel(const Halo3x3Wg
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         const int y0 = ty * HALO_T, x0 = tx * HALO_T;
         __syncthreads();                              // previous tile fully consumed (and prm visible)
+        {
+            float4 rv[HW_B_N], rg[HW_A_N];
+            bool okv[HW_B_N];
 #pragma unroll
-        for (int i = 0; i < HW_B_N; ++i) {
-            const int idx = t + 256 * i;
-            if (idx < HALO_PX * 8) {
+            for (int i = 0; i < HW_B_N; ++i) {        // all 19 loads in flight, then transform + store
+                const int idx = t + 256 * i;
                 const int hp = idx >> 3, q = idx & 7;
                 const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
                 const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-                float4 v = zero4();
-                if ((unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W)
-                    v = bnrelu4(ld4(src_n + (int64_t)(iy * a.pl.W + ix) * C + 4 * q), prm + 4 * q, 32);
-                *reinterpret_cast<float4*>(Bh + hp * 32 + 4 * q) = v;
+                okv[i] = idx < HALO_PX * 8 && (unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W;
+                rv[i] = okv[i] ? ld4(src_n + (int64_t)(iy * a.pl.W + ix) * C + 4 * q) : zero4();
             }
-        }
 #pragma unroll
-        for (int i = 0; i < HW_A_N; ++i) {
-            const int idx = t + 256 * i;
-            const int px = idx >> 3, q = idx & 7;
-            const int64_t pix = (int64_t)(y0 + (px >> 4)) * a.pl.W + x0 + (px & 15);
-            *reinterpret_cast<float4*>(Ag + px * 32 + 4 * q) = ld4(g_n + pix * 32 + 4 * q);
+            for (int i = 0; i < HW_A_N; ++i) {
+                const int idx = t + 256 * i;
+                const int px = idx >> 3, q = idx & 7;
+                const int64_t pix = (int64_t)(y0 + (px >> 4)) * a.pl.W + x0 + (px & 15);
+                rg[i] = ld4(g_n + pix * 32 + 4 * q);
+            }
+#pragma unroll
+            for (int i = 0; i < HW_B_N; ++i) {
+                const int idx = t + 256 * i;
+                if (idx < HALO_PX * 8) {
+                    const int q = idx & 7;
+                    const float4 v = okv[i] ? bnrelu4(rv[i], prm + 4 * q, 32) : zero4();   // zero padding AFTER bn+relu
+                    *reinterpret_cast<float4*>(Bh + (idx >> 3) * 32 + 4 * q) = v;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < HW_A_N; ++i) {
+                const int idx = t + 256 * i;
+                *reinterpret_cast<float4*>(Ag + (idx >> 3) * 32 + 4 * (idx & 7)) = rg[i];
+            }
         }
         __syncthreads();
         // wave w reduces over its 64 pixels (rows 4w..4w+3); lane half selects the pixel parity
