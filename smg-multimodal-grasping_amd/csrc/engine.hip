@@ -83,7 +83,7 @@ struct smg_engine {
     unsigned char* argmax = nullptr;
     float* F = nullptr; float* H1 = nullptr;
     // gradients
-    float* G[4] = {}; float* GS = nullptr; float* D2 = nullptr; float* DY0 = nullptr; float* DH1 = nullptr; float* DF = nullptr;
+    float* G[4] = {}; float* GS = nullptr; float* D2 = nullptr; float* part = nullptr; int64_t part_floats = 0; float* DY0 = nullptr; float* DH1 = nullptr; float* DF = nullptr;
     // statistics arenas (doubles). fwd: [sum | sumsq] halves; bwd: [s1 | s2] halves
     double* fstat = nullptr; int64_t fstat_span = 0;
     double* bstat = nullptr; int64_t bstat_span = 0;
@@ -149,6 +149,26 @@ static void launch_gemm(smg_engine* e, hipStream_t st, const P& p, dim3 grid, in
     hipLaunchKernelGGL(gemm_kernel<P>, grid, dim3(256), smem, st, p);
 }
 
+// Weight-gradient launch: partial tiles to the workspace + one reduce kernel (falls back to
+// atomics if the workspace is too small for this launch).
+template <class P>
+static void launch_wgrad(smg_engine* e, hipStream_t st, P& p, dim3 grid, int kind, double flops, int taps, int cmap, bool use_part = true) {
+    using C = typename P::Cfg;
+    const int64_t ldp = (int64_t)grid.y * C::BN, rowsp = (int64_t)grid.x * C::BM;
+    const int64_t need = (int64_t)grid.z * rowsp * ldp;
+    p.part = (use_part && need <= e->part_floats) ? e->part : nullptr;
+    launch_gemm(e, st, p, grid, kind, flops);
+    if (p.part) {
+        ReduceArgs r;
+        r.part = e->part; r.Z = p.n_chunks; r.taps = taps; r.rows = p.MA; r.cols = p.NB; r.ldp = (int)ldp;
+        r.z_stride = rowsp * ldp; r.tap_stride = (int64_t)p.n_chunks * rowsp * ldp;
+        r.dw = p.dw; r.ldw_out = p.ldw_out; r.cmap = cmap;
+        const int total = taps * p.MA * p.NB;
+        ProfScope ps(e, st, kind, 0);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((total + 255) / 256), dim3(256), 0, st, r);
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // creation
 // ------------------------------------------------------------------------------------
@@ -180,6 +200,8 @@ static int engine_build(smg_engine* e) {
     ALLOC(e->Bt, bt_total);
     ALLOC(e->D2, (int64_t)NS * e->p_blk[0].HWp * kBottleneck);
     ALLOC(e->GS, (int64_t)NS * e->p_blk[0].HWp * kGrowth);
+    e->part_floats = (int64_t)24 << 20;   // 96 MB of partial weight-gradient tiles
+    ALLOC(e->part, e->part_floats);
     ALLOC(e->F, (int64_t)NP * e->p_blk[3].HWp * 2 * kFeat);
     ALLOC(e->DF, (int64_t)NP * e->p_blk[3].HWp * 2 * kFeat);
     ALLOC(e->H1, (int64_t)NP * e->p_blk[3].HWp * kHeadMid);
@@ -517,7 +539,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
         p.bsum = fsum(e, e->st_F); p.bsq = fsq(e, e->st_F); p.bstride = 2 * kFeat; p.bgamma = P + Hd.n0.w; p.bbeta = P + Hd.n0.b;
         p.eps = kEps; p.chunk = chunk4; p.chunks_per_stream = cps4; p.n_chunks = NP * cps4;
         p.dw = Gr + Hd.c0.w; p.ldw_out = 2 * kFeat;
-        launch_gemm(e, st, p, dim3(1, 2 * kFeat / 64, NP * cps4), K_HW0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid);
+        launch_wgrad(e, st, p, dim3(1, 2 * kFeat / 64, NP * cps4), K_HW0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid, 1, C_IDENT);
     }
     {   // head conv0 data gradient + relu0 + norm0 sums
         auto run = [&](auto tag) {
@@ -595,19 +617,28 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 a.g = e->GS; a.pl = pl; a.src = bt; a.C = kBottleneck;
                 a.ssum = fsum(e, e->st_Bt[b][i]); a.ssq = fsq(e, e->st_Bt[b][i]); a.sstride = kBottleneck;
                 a.gamma = P + d.n2.w; a.beta = P + d.n2.b; a.eps = kEps;
-                a.dw = Gr + d.c2.w; a.tiles_x = pl.W / HALO_T; a.n_tiles = (pl.H / HALO_T) * (pl.W / HALO_T);
+                a.part = e->part; a.tiles_x = pl.W / HALO_T; a.n_tiles = (pl.H / HALO_T) * (pl.W / HALO_T);
                 int groups = (768 + 4 * NS - 1) / (4 * NS);                 // ~768 workgroups
                 if (groups > a.n_tiles) groups = a.n_tiles;
                 a.tiles_per_wg = (a.n_tiles + groups - 1) / groups;
                 groups = (a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+                if ((int64_t)groups * NS * 9 * 32 * kBottleneck > e->part_floats) return fail(-12, "partial-gradient workspace too small");
                 const size_t smem = (size_t)(HW_B_FLOATS + HW_A_FLOATS + 96) * sizeof(float);
                 static bool attr_set = false;
                 if (!attr_set) {
                     HIP_OK(hipFuncSetAttribute((const void*)conv3x3_halo_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
                     attr_set = true;
                 }
-                ProfScope ps(e, st, K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
-                hipLaunchKernelGGL(conv3x3_halo_wgrad_kernel, dim3(groups, kBottleneck / 32, NS), dim3(256), smem, st, a);
+                {
+                    ProfScope ps(e, st, K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+                    hipLaunchKernelGGL(conv3x3_halo_wgrad_kernel, dim3(groups, kBottleneck / 32, NS), dim3(256), smem, st, a);
+                }
+                ReduceArgs r;
+                r.part = e->part; r.Z = groups * NS; r.taps = 9; r.rows = kGrowth; r.cols = kBottleneck; r.ldp = kBottleneck;
+                r.z_stride = (int64_t)9 * kGrowth * kBottleneck; r.tap_stride = (int64_t)kGrowth * kBottleneck;
+                r.dw = Gr + d.c2.w; r.ldw_out = kBottleneck * 9; r.cmap = C_3x3;
+                ProfScope ps(e, st, K_W3, 0);
+                hipLaunchKernelGGL(reduce_partials_kernel, dim3((9 * kGrowth * kBottleneck + 255) / 256), dim3(256), 0, st, r);
             } else {   // conv2 weight gradient (generic implicit GEMM, one launch slice per tap)
                 const int chunk = 1024, cps = (pl.HWp + chunk - 1) / chunk;   // load-bound: wants many workgroups
                 BwdWeightP<CfgW32x128, W_THREE, C_3x3> p{};
@@ -617,7 +648,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 p.bgamma = P + d.n2.w; p.bbeta = P + d.n2.b; p.eps = kEps;
                 p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
                 p.dw = Gr + d.c2.w; p.ldw_out = kBottleneck * 9;
-                launch_gemm(e, st, p, dim3(1, 1, 9 * NS * cps), K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+                launch_wgrad(e, st, p, dim3(1, 1, 9 * NS * cps), K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth, 9, C_3x3);
             }
             {   // norm2 backward applied once, in place: D2 <- gamma2*invstd*(dy - s1/n - xhat*s2/n)
                 BnBwdApplyArgs a;
@@ -654,7 +685,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 p.bgamma = P + d.n1.w; p.bbeta = P + d.n1.b; p.eps = kEps;
                 p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
                 p.dw = Gr + d.c1.w; p.ldw_out = d.cin;
-                launch_gemm(e, st, p, dim3(1, (d.cin + 63) / 64, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck);
+                launch_wgrad(e, st, p, dim3(1, (d.cin + 63) / 64, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck, 1, C_IDENT, false);   // measured: atomics beat partials here
             }
         }
         if (b > 0) {   // transition b-1: X[b-1] (all channels) -> X[b][:, 0:C0]
@@ -672,7 +703,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 p.bgamma = P + T.tnorm[b - 1].w; p.bbeta = P + T.tnorm[b - 1].b; p.eps = kEps;
                 p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
                 p.dw = Gr + T.tconv[b - 1].w; p.ldw_out = Cp;
-                launch_gemm(e, st, p, dim3(C0 / 128, Cp / 128, NS * cps), K_TW, 2.0 * NS * pl.HW * Cp * C0);
+                launch_wgrad(e, st, p, dim3(C0 / 128, Cp / 128, NS * cps), K_TW, 2.0 * NS * pl.HW * Cp * C0, 1, C_IDENT);
             }
             if (pp.H != 2 * pl.H || pp.W != 2 * pl.W) {
                 ProfScope ps(e, st, K_OTHER, 0);
@@ -722,7 +753,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
         p.bbuf = e->img4; p.ldb = 4; p.pb = e->p_img; p.NB = 196;
         p.eps = kEps; p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
         p.dw = Gr + T.conv0.w; p.ldw_out = 147;
-        launch_gemm(e, st, p, dim3(1, 4, NS * cps), K_SW, 2.0 * NS * ps_.HW * 64 * 147);
+        launch_wgrad(e, st, p, dim3(1, 4, NS * cps), K_SW, 2.0 * NS * ps_.HW * 64 * 147, 1, C_STEM);
     }
     HIP_OK(hipGetLastError());
     return 0;
@@ -784,7 +815,7 @@ void smg_engine_destroy(smg_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     void* ptrs[] = {e->img4, e->stem, e->DY0, e->argmax, e->X[0], e->X[1], e->X[2], e->X[3], e->G[0], e->G[1], e->G[2], e->G[3],
-                    e->Bt, e->D2, e->GS, e->F, e->DF, e->H1, e->DH1, e->fstat, e->bstat, e->packed, e->d_pack, e->d_bnupd,
+                    e->Bt, e->D2, e->GS, e->part, e->F, e->DF, e->H1, e->DH1, e->fstat, e->bstat, e->packed, e->d_pack, e->d_bnupd,
                     e->d_stream_image, e->d_stream_rot, e->d_affine, e->d_pair_a, e->d_pair_b, e->d_seq_t, e->d_seq_h,
                     e->d_user_ptr, e->d_user_pair, e->d_user_slot};
     for (void* p : ptrs) if (p) (void)hipFree(p);

@@ -640,6 +640,8 @@ struct BwdWeightP {
     float eps;
     int chunk, chunks_per_stream, n_chunks;   // blockIdx.z = tap * n_chunks + chunk index
     float* dw; int ldw_out;
+    float* part;                              // if set: partial tiles [z][gridDim.x*BM][gridDim.y*BN] (plain stores,
+                                              // summed by reduce_partials_kernel) instead of fp32 atomics into dw
 
     struct Ctx { int n, p0, m0, n0, tap, kt; };
     struct ARow { int dummy; };
@@ -753,6 +755,10 @@ struct BwdWeightP {
                 for (int r = 0; r < 16; ++r) {
                     const int row = c.m0 + SMG_ACC_ROW(wm0, i, r, half);
                     if (active && row < MA && col < NB) {
+                        if (part) {
+                            part[((int64_t)blockIdx.z * (gridDim.x * Cfg::BM) + row) * (gridDim.y * Cfg::BN) + col] = acc[i][j][r];
+                            continue;
+                        }
                         int64_t idx;
                         if constexpr (CMAP == C_IDENT) idx = (int64_t)row * ldw_out + col;
                         else if constexpr (CMAP == C_3x3) idx = (int64_t)row * ldw_out + col * 9 + c.tap;
@@ -767,5 +773,40 @@ struct BwdWeightP {
             }
     }
 };
+
+// Sum the partial weight-gradient tiles of one launch over its pixel chunks and add the
+// result into the gradient array (reference layout).  Deterministic, no atomics.
+//   value(tap, row, col) = sum_z part[tap*tap_stride + z*z_stride + row*ldp + col]
+struct ReduceArgs {
+    const float* part; int Z, taps, rows, cols, ldp; int64_t z_stride, tap_stride;
+    float* dw; int ldw_out, cmap;
+};
+__global__ void reduce_partials_kernel(const ReduceArgs a) {
+    const int total = a.taps * a.rows * a.cols;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int tap = e / (a.rows * a.cols);
+        const int rc = e - tap * a.rows * a.cols;
+        const int row = rc / a.cols, col = rc - row * a.cols;
+        const float* p = a.part + tap * a.tap_stride + (int64_t)row * a.ldp + col;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int z = 0;
+        for (; z + 3 < a.Z; z += 4) {
+            s0 += p[(int64_t)z * a.z_stride];
+            s1 += p[(int64_t)(z + 1) * a.z_stride];
+            s2 += p[(int64_t)(z + 2) * a.z_stride];
+            s3 += p[(int64_t)(z + 3) * a.z_stride];
+        }
+        for (; z < a.Z; ++z) s0 += p[(int64_t)z * a.z_stride];
+        int64_t idx;
+        if (a.cmap == C_IDENT) idx = (int64_t)row * a.ldw_out + col;
+        else if (a.cmap == C_3x3) idx = (int64_t)row * a.ldw_out + col * 9 + tap;
+        else {
+            const int t7 = col >> 2, cc = col & 3;
+            if (cc == 3 || t7 >= 49) continue;
+            idx = (int64_t)row * a.ldw_out + cc * 49 + t7;
+        }
+        a.dw[idx] += (s0 + s1) + (s2 + s3);
+    }
+}
 
 }  // namespace smg

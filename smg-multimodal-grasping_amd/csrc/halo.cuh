@@ -372,15 +372,16 @@ __global__ __launch_bounds__(256) void conv3x3_halo_dgrad_kernel(const Halo3x3Dg
 // 256x32 gradient tile; every wave then walks its own 64 pixels as the MFMA reduction
 // dimension and accumulates ALL nine taps (9 accumulator tiles) by shifting the halo
 // read address - the operands are fetched once for 9 taps instead of once per tap.
-// The accumulators persist across the run of tiles; one LDS-reduced atomic flush at
-// the end (9216 atomics per workgroup).
+// The accumulators persist across the run of tiles; at the end the four waves' tiles
+// are folded through LDS and written (plain stores) to a partial buffer that
+// reduce_partials_kernel sums over workgroups - fp32 atomics here cost ~3 ms/step.
 // ------------------------------------------------------------------------------------
 struct Halo3x3WgradArgs {
     const float* g; Plane pl;                        // [n][HWp][32] finalized output gradient
     const float* src; int C;                         // raw bottleneck [n][HWp][C]
     const double* ssum; const double* ssq; int sstride;
     const float* gamma; const float* beta; float eps;
-    float* dw;                                       // [32][C][3][3] native layout
+    float* part;                                     // partial sums [gridDim.x*gridDim.z][9][32][C]
     int tiles_x, n_tiles, tiles_per_wg;
 };
 
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_wgrad_kernel(const Halo3x3Wg
             const int r = e >> 6, ln = e & 63;
             const float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
             const int nn = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), cc = ln & 31;
-            atomicAdd(a.dw + ((int64_t)nn * C + cc0 + cc) * 9 + tap, v);
+            a.part[((((int64_t)blockIdx.x * gridDim.z + n) * 9 + tap) * 32 + nn) * C + cc0 + cc] = v;
         }
     }
 }
