@@ -83,7 +83,9 @@ struct smg_engine {
     unsigned char* argmax = nullptr;
     float* F = nullptr; float* H1 = nullptr;
     // gradients
-    float* G[4] = {}; float* GS = nullptr; float* D2 = nullptr; float* part = nullptr; int64_t part_floats = 0; float* DY0 = nullptr; float* DH1 = nullptr; float* DF = nullptr;
+    float* G[4] = {}; float* GS[2] = {}; float* D2[2] = {}; float* part = nullptr; int64_t part_floats = 0;
+    // second stream for the weight-gradient kernels (independent of the data-gradient chain)
+    hipStream_t side = nullptr; hipEvent_t ev_gs[2] = {}, ev_d2[2] = {}, ev_side[2] = {}, ev_misc = nullptr, ev_end = nullptr; float* DY0 = nullptr; float* DH1 = nullptr; float* DF = nullptr;
     // statistics arenas (doubles). fwd: [sum | sumsq] halves; bwd: [s1 | s2] halves
     double* fstat = nullptr; int64_t fstat_span = 0;
     double* bstat = nullptr; int64_t bstat_span = 0;
@@ -198,8 +200,16 @@ static int engine_build(smg_engine* e) {
         }
     }
     ALLOC(e->Bt, bt_total);
-    ALLOC(e->D2, (int64_t)NS * e->p_blk[0].HWp * kBottleneck);
-    ALLOC(e->GS, (int64_t)NS * e->p_blk[0].HWp * kGrowth);
+    for (int k = 0; k < 2; ++k) {   // double-buffered so the main stream never waits for the side stream's previous layer
+        ALLOC(e->D2[k], (int64_t)NS * e->p_blk[0].HWp * kBottleneck);
+        ALLOC(e->GS[k], (int64_t)NS * e->p_blk[0].HWp * kGrowth);
+        HIP_OK(hipEventCreateWithFlags(&e->ev_gs[k], hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&e->ev_d2[k], hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&e->ev_side[k], hipEventDisableTiming));
+    }
+    HIP_OK(hipEventCreateWithFlags(&e->ev_misc, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&e->ev_end, hipEventDisableTiming));
+    HIP_OK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
     e->part_floats = (int64_t)24 << 20;   // 96 MB of partial weight-gradient tiles
     ALLOC(e->part, e->part_floats);
     ALLOC(e->F, (int64_t)NP * e->p_blk[3].HWp * 2 * kFeat);
@@ -518,6 +528,17 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
     float* Gr = net->grads;
     const Plane p4 = e->p_blk[3];
     HIP_OK(hipMemsetAsync(e->bstat, 0, 2 * e->bstat_span * sizeof(double), st));
+    // Weight-gradient kernels only read what the data-gradient chain produces and write disjoint
+    // gradient ranges, so they run on a second stream beside it (their MFMA/L2-bound phases overlap the
+    // HBM-bound epilogues of the data-gradient kernels).  While profiling everything is serialised on
+    // `st` so that per-kernel durations stay clean.
+    const hipStream_t s2 = e->prof ? st : e->side;
+    auto fork = [&](hipEvent_t ev) -> int {      // side stream continues after everything enqueued on st so far
+        HIP_OK(hipEventRecord(ev, st));
+        HIP_OK(hipStreamWaitEvent(s2, ev, 0));
+        return 0;
+    };
+    int layer_no = 0;
 
     {   // value conv backward + relu1 + norm1 sums
         ValueBwdArgs a;
@@ -539,7 +560,8 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
         p.bsum = fsum(e, e->st_F); p.bsq = fsq(e, e->st_F); p.bstride = 2 * kFeat; p.bgamma = P + Hd.n0.w; p.bbeta = P + Hd.n0.b;
         p.eps = kEps; p.chunk = chunk4; p.chunks_per_stream = cps4; p.n_chunks = NP * cps4;
         p.dw = Gr + Hd.c0.w; p.ldw_out = 2 * kFeat;
-        launch_wgrad(e, st, p, dim3(1, 2 * kFeat / 64, NP * cps4), K_HW0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid, 1, C_IDENT);
+        if (fork(e->ev_misc)) return -5;
+        launch_wgrad(e, s2, p, dim3(1, 2 * kFeat / 64, NP * cps4), K_HW0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid, 1, C_IDENT);
     }
     {   // head conv0 data gradient + relu0 + norm0 sums
         auto run = [&](auto tag) {
@@ -575,22 +597,28 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
         for (int i = (int)T.layers[b].size() - 1; i >= 0; --i) {
             const DenseLayerRef& d = T.layers[b][i];
             float* bt = e->Bt + e->bt_off[b][i];
+            const int db = layer_no & 1;
+            float* GSb = e->GS[db];
+            float* D2b = e->D2[db];
+            if (layer_no >= 2) HIP_OK(hipStreamWaitEvent(st, e->ev_side[db], 0));   // side stream done with these buffers (2 layers ago)
+            ++layer_no;
             {   // finalize this layer's output-slice gradient once: GS = invstd*(G' - SA/n - xhat*SB/n)
                 BnBwdApplyArgs a;
                 a.g = e->G[b]; a.ldg = Ct; a.gcoff = d.cin; a.x = e->X[b]; a.ldx = Ct; a.xcoff = d.cin; a.pl = pl; a.C = kGrowth;
                 a.xsum = fsum(e, e->st_X[b]); a.xsq = fsq(e, e->st_X[b]); a.xstride = Ct;
                 a.s1 = b1(e, e->bs_X[b]); a.s2 = b2(e, e->bs_X[b]); a.sstride = Ct; a.scoff = d.cin; a.gamma = nullptr; a.eps = kEps;
-                a.out = e->GS; a.ldo = kGrowth;
+                a.out = GSb; a.ldo = kGrowth;
                 ProfScope ps(e, st, K_OTHER, 0);
                 hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(pl.HWp / 64, NS), dim3(256), 0, st, a);
             }
+            if (fork(e->ev_gs[db])) return -5;
             if (pl.H % HALO_T == 0 && pl.W % HALO_T == 0) {
                 // conv2 (3x3) data gradient with the gradient halo resident in LDS (halo.cuh)
                 Halo3x3DgradArgs a;
-                a.g = e->GS; a.pl = pl; a.w = e->packed + e->pk_c2d[b][i]; a.C = kBottleneck;
+                a.g = GSb; a.pl = pl; a.w = e->packed + e->pk_c2d[b][i]; a.C = kBottleneck;
                 a.mbuf = bt; a.msum = fsum(e, e->st_Bt[b][i]); a.msq = fsq(e, e->st_Bt[b][i]); a.mstride = kBottleneck;
                 a.gamma = P + d.n2.w; a.beta = P + d.n2.b; a.eps = kEps;
-                a.dst = e->D2; a.o1 = b1(e, e->bs_Bt[b][i]); a.o2 = b2(e, e->bs_Bt[b][i]); a.ostride = kBottleneck;
+                a.dst = D2b; a.o1 = b1(e, e->bs_Bt[b][i]); a.o2 = b2(e, e->bs_Bt[b][i]); a.ostride = kBottleneck;
                 a.dbeta = Gr + d.n2.b; a.dgamma = Gr + d.n2.w; a.tiles_x = pl.W / HALO_T;
                 const size_t smem = (size_t)(HD_A_FLOATS + HD_B_FLOATS + 4 * kBottleneck + 256) * sizeof(float);
                 ProfScope ps(e, st, K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
@@ -599,12 +627,12 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 auto run = [&](auto tag) {
                     using Cfg = decltype(tag);
                     BwdDataP<Cfg, true, E_STORE> p{};
-                    p.gbuf = e->GS; p.ldg = kGrowth; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kGrowth;
+                    p.gbuf = GSb; p.ldg = kGrowth; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kGrowth;
                     p.w = e->packed + e->pk_c2d[b][i]; p.ldw = kBottleneck; p.N = kBottleneck;
                     p.mbuf = bt; p.ldm = kBottleneck; p.mcoff = 0; p.pm = pl;
                     p.msum = fsum(e, e->st_Bt[b][i]); p.msq = fsq(e, e->st_Bt[b][i]); p.mstride = kBottleneck;
                     p.egamma = P + d.n2.w; p.ebeta = P + d.n2.b;
-                    p.dst = e->D2; p.ldd = kBottleneck; p.dcoff = 0;
+                    p.dst = D2b; p.ldd = kBottleneck; p.dcoff = 0;
                     p.o1 = b1(e, e->bs_Bt[b][i]); p.o2 = b2(e, e->bs_Bt[b][i]); p.ostride = kBottleneck; p.ocoff = 0;
                     p.dbeta = Gr + d.n2.b; p.dgamma = Gr + d.n2.w; p.eps = kEps;
                     launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, kBottleneck / Cfg::BN), K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
@@ -614,7 +642,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
             if (pl.H % HALO_T == 0 && pl.W % HALO_T == 0) {
                 // conv2 weight gradient with the activation halo resident in LDS (halo.cuh)
                 Halo3x3WgradArgs a;
-                a.g = e->GS; a.pl = pl; a.src = bt; a.C = kBottleneck;
+                a.g = GSb; a.pl = pl; a.src = bt; a.C = kBottleneck;
                 a.ssum = fsum(e, e->st_Bt[b][i]); a.ssq = fsq(e, e->st_Bt[b][i]); a.sstride = kBottleneck;
                 a.gamma = P + d.n2.w; a.beta = P + d.n2.b; a.eps = kEps;
                 a.part = e->part; a.tiles_x = pl.W / HALO_T; a.n_tiles = (pl.H / HALO_T) * (pl.W / HALO_T);
@@ -630,40 +658,41 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                     attr_set = true;
                 }
                 {
-                    ProfScope ps(e, st, K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
-                    hipLaunchKernelGGL(conv3x3_halo_wgrad_kernel, dim3(groups, kBottleneck / 32, NS), dim3(256), smem, st, a);
+                    ProfScope ps(e, s2, K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+                    hipLaunchKernelGGL(conv3x3_halo_wgrad_kernel, dim3(groups, kBottleneck / 32, NS), dim3(256), smem, s2, a);
                 }
                 ReduceArgs r;
                 r.part = e->part; r.Z = groups * NS; r.taps = 9; r.rows = kGrowth; r.cols = kBottleneck; r.ldp = kBottleneck;
                 r.z_stride = (int64_t)9 * kGrowth * kBottleneck; r.tap_stride = (int64_t)kGrowth * kBottleneck;
                 r.dw = Gr + d.c2.w; r.ldw_out = kBottleneck * 9; r.cmap = C_3x3;
-                ProfScope ps(e, st, K_W3, 0);
-                hipLaunchKernelGGL(reduce_partials_kernel, dim3((9 * kGrowth * kBottleneck + 255) / 256), dim3(256), 0, st, r);
+                ProfScope ps(e, s2, K_W3, 0);
+                hipLaunchKernelGGL(reduce_partials_kernel, dim3((9 * kGrowth * kBottleneck + 255) / 256), dim3(256), 0, s2, r);
             } else {   // conv2 weight gradient (generic implicit GEMM, one launch slice per tap)
                 const int chunk = 1024, cps = (pl.HWp + chunk - 1) / chunk;   // load-bound: wants many workgroups
                 BwdWeightP<CfgW32x128, W_THREE, C_3x3> p{};
-                p.gbuf = e->GS; p.ldg = kGrowth; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kGrowth;
+                p.gbuf = GSb; p.ldg = kGrowth; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kGrowth;
                 p.bbuf = bt; p.ldb = kBottleneck; p.pb = pl; p.NB = kBottleneck;
                 p.bsum = fsum(e, e->st_Bt[b][i]); p.bsq = fsq(e, e->st_Bt[b][i]); p.bstride = kBottleneck;
                 p.bgamma = P + d.n2.w; p.bbeta = P + d.n2.b; p.eps = kEps;
                 p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
                 p.dw = Gr + d.c2.w; p.ldw_out = kBottleneck * 9;
-                launch_wgrad(e, st, p, dim3(1, 1, 9 * NS * cps), K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth, 9, C_3x3);
+                launch_wgrad(e, s2, p, dim3(1, 1, 9 * NS * cps), K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth, 9, C_3x3);
             }
             {   // norm2 backward applied once, in place: D2 <- gamma2*invstd*(dy - s1/n - xhat*s2/n)
                 BnBwdApplyArgs a;
-                a.g = e->D2; a.ldg = kBottleneck; a.gcoff = 0; a.x = bt; a.ldx = kBottleneck; a.xcoff = 0; a.pl = pl; a.C = kBottleneck;
+                a.g = D2b; a.ldg = kBottleneck; a.gcoff = 0; a.x = bt; a.ldx = kBottleneck; a.xcoff = 0; a.pl = pl; a.C = kBottleneck;
                 a.xsum = fsum(e, e->st_Bt[b][i]); a.xsq = fsq(e, e->st_Bt[b][i]); a.xstride = kBottleneck;
                 a.s1 = b1(e, e->bs_Bt[b][i]); a.s2 = b2(e, e->bs_Bt[b][i]); a.sstride = kBottleneck; a.scoff = 0;
-                a.gamma = P + d.n2.w; a.eps = kEps; a.out = e->D2; a.ldo = kBottleneck;
+                a.gamma = P + d.n2.w; a.eps = kEps; a.out = D2b; a.ldo = kBottleneck;
                 ProfScope ps(e, st, K_OTHER, 0);
                 hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(pl.HWp / 64, NS), dim3(256), 0, st, a);
             }
+            if (fork(e->ev_d2[db])) return -5;
             {   // conv1 (1x1) data gradient -> relu1/norm1 backward accumulated into G'
                 auto run = [&](auto tag) {
                     using Cfg = decltype(tag);
                     BwdDataP<Cfg, false, E_ACCUM> p{};
-                    p.gbuf = e->D2; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kBottleneck;
+                    p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kBottleneck;
                     p.w = P + d.c1.w; p.ldw = d.cin; p.N = d.cin;
                     p.mbuf = e->X[b]; p.ldm = Ct; p.mcoff = 0; p.pm = pl;
                     p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct;
@@ -679,13 +708,14 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 int chunk, cps;
                 pick_chunk(pl, NS, (d.cin + 63) / 64, chunk, cps);
                 BwdWeightP<CfgW128x64, W_ONE, C_IDENT> p{};
-                p.gbuf = e->D2; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck;
+                p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck;
                 p.bbuf = e->X[b]; p.ldb = Ct; p.pb = pl; p.NB = d.cin;
                 p.bsum = fsum(e, e->st_X[b]); p.bsq = fsq(e, e->st_X[b]); p.bstride = Ct;
                 p.bgamma = P + d.n1.w; p.bbeta = P + d.n1.b; p.eps = kEps;
                 p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
                 p.dw = Gr + d.c1.w; p.ldw_out = d.cin;
-                launch_wgrad(e, st, p, dim3(1, (d.cin + 63) / 64, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck, 1, C_IDENT, false);   // measured: atomics beat partials here
+                launch_wgrad(e, s2, p, dim3(1, (d.cin + 63) / 64, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck, 1, C_IDENT, false);   // measured: atomics beat partials here
+                HIP_OK(hipEventRecord(e->ev_side[db], s2));
             }
         }
         if (b > 0) {   // transition b-1: X[b-1] (all channels) -> X[b][:, 0:C0]
@@ -703,7 +733,8 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 p.bgamma = P + T.tnorm[b - 1].w; p.bbeta = P + T.tnorm[b - 1].b; p.eps = kEps;
                 p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
                 p.dw = Gr + T.tconv[b - 1].w; p.ldw_out = Cp;
-                launch_wgrad(e, st, p, dim3(C0 / 128, Cp / 128, NS * cps), K_TW, 2.0 * NS * pl.HW * Cp * C0, 1, C_IDENT);
+                if (fork(e->ev_misc)) return -5;
+                launch_wgrad(e, s2, p, dim3(C0 / 128, Cp / 128, NS * cps), K_TW, 2.0 * NS * pl.HW * Cp * C0, 1, C_IDENT);
             }
             if (pp.H != 2 * pl.H || pp.W != 2 * pl.W) {
                 ProfScope ps(e, st, K_OTHER, 0);
@@ -753,8 +784,11 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
         p.bbuf = e->img4; p.ldb = 4; p.pb = e->p_img; p.NB = 196;
         p.eps = kEps; p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
         p.dw = Gr + T.conv0.w; p.ldw_out = 147;
-        launch_wgrad(e, st, p, dim3(1, 4, NS * cps), K_SW, 2.0 * NS * ps_.HW * 64 * 147, 1, C_STEM);
+        if (fork(e->ev_misc)) return -5;
+        launch_wgrad(e, s2, p, dim3(1, 4, NS * cps), K_SW, 2.0 * NS * ps_.HW * 64 * 147, 1, C_STEM);
     }
+    HIP_OK(hipEventRecord(e->ev_end, s2));          // join: everything after the backward sees every gradient
+    HIP_OK(hipStreamWaitEvent(st, e->ev_end, 0));
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -815,10 +849,14 @@ void smg_engine_destroy(smg_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     void* ptrs[] = {e->img4, e->stem, e->DY0, e->argmax, e->X[0], e->X[1], e->X[2], e->X[3], e->G[0], e->G[1], e->G[2], e->G[3],
-                    e->Bt, e->D2, e->GS, e->part, e->F, e->DF, e->H1, e->DH1, e->fstat, e->bstat, e->packed, e->d_pack, e->d_bnupd,
+                    e->Bt, e->D2[0], e->D2[1], e->GS[0], e->GS[1], e->part, e->F, e->DF, e->H1, e->DH1, e->fstat, e->bstat, e->packed, e->d_pack, e->d_bnupd,
                     e->d_stream_image, e->d_stream_rot, e->d_affine, e->d_pair_a, e->d_pair_b, e->d_seq_t, e->d_seq_h,
                     e->d_user_ptr, e->d_user_pair, e->d_user_slot};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int k = 0; k < 2; ++k) { if (e->ev_gs[k]) (void)hipEventDestroy(e->ev_gs[k]); if (e->ev_d2[k]) (void)hipEventDestroy(e->ev_d2[k]); if (e->ev_side[k]) (void)hipEventDestroy(e->ev_side[k]); }
+    if (e->ev_misc) (void)hipEventDestroy(e->ev_misc);
+    if (e->ev_end) (void)hipEventDestroy(e->ev_end);
+    if (e->side) (void)hipStreamDestroy(e->side);
     for (auto& r : e->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     delete e;
