@@ -668,7 +668,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 ProfScope ps(e, s2, K_W3, 0);
                 hipLaunchKernelGGL(reduce_partials_kernel, dim3((9 * kGrowth * kBottleneck + 255) / 256), dim3(256), 0, s2, r);
             } else {   // conv2 weight gradient (generic implicit GEMM, one launch slice per tap)
-                const int chunk = 1024, cps = (pl.HWp + chunk - 1) / chunk;   // load-bound: wants many workgroups
+                const int chunk = 512, cps = (pl.HWp + chunk - 1) / chunk;   // latency-bound: many short workgroups
                 BwdWeightP<CfgW32x128, W_THREE, C_3x3> p{};
                 p.gbuf = GSb; p.ldg = kGrowth; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kGrowth;
                 p.bbuf = bt; p.ldb = kBottleneck; p.pb = pl; p.NB = kBottleneck;

@@ -56,6 +56,11 @@ struct GemmCfg {
     static constexpr int AB_FLOATS = 2 * A_FLOATS + 2 * B_FLOATS;
 };
 
+// What a fetch leaves in registers: the untouched global loads (NV of them) and whether the
+// element exists at all (conv zero padding / padded pixel rows).  The BN transform is applied later,
+// when the tile is written to LDS, so the loads stay in flight across the MFMA block.
+template <int NV> struct RawT { float4 v[NV]; bool ok; };
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
@@ -165,7 +170,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const P p) {
 
     const int aq = t % C::A_Q, al = t / C::A_Q;
     const int bq = t % C::B_Q, bl = t / C::B_Q;
-    float4 ra[C::A_N], rb[C::B_N];
+    typename P::ARaw ra[C::A_N];
+    typename P::BRaw rb[C::B_N];
     typename P::ARow arow[C::A_N];
     typename P::DRow da[C::A_N], db[C::B_N];
     if constexpr (C::AT) {
@@ -182,46 +188,47 @@ __global__ __launch_bounds__(256) void gemm_kernel(const P p) {
 #pragma unroll
         for (int i = 0; i < C::A_N; ++i) {
             if constexpr (C::AT) {
-                ra[i] = p.a_fetch(ctx, arow[i], kt, aq, sp);
+                ra[i] = p.a_fetch(ctx, arow[i], kt, aq);
             } else {
                 const int kr = al + i * C::A_STEP;
-                ra[i] = (kr < C::BK) ? p.a_fetch_d(ctx, da[i], kt, kr, aq, sp) : zero4();
+                if (kr < C::BK) ra[i] = p.a_fetch_d(ctx, da[i], kt, kr, aq);
                 p.d_next(ctx, da[i]);
             }
         }
 #pragma unroll
         for (int i = 0; i < C::B_N; ++i) {
             const int kr = bl + i * C::B_STEP;
-            rb[i] = (kr < C::BK) ? p.b_fetch(ctx, db[i], kt, kr, bq, sp) : zero4();
+            if (kr < C::BK) rb[i] = p.b_fetch(ctx, db[i], kt, kr, bq);
             p.d_next(ctx, db[i]);
         }
     };
-    auto s_store = [&](int buf) {
+    auto s_store = [&](int buf, int kt) {          // transform (BN / ReLU / BN-backward) + LDS store of k-tile kt
         float* A = As + buf * C::A_FLOATS;
         float* B = Bs + buf * C::B_FLOATS;
 #pragma unroll
         for (int i = 0; i < C::A_N; ++i) {
             if constexpr (C::AT) {
                 const int row = al + i * C::A_STEP;
-                A[(aq * 4 + 0) * C::LDA + row] = ra[i].x;
-                A[(aq * 4 + 1) * C::LDA + row] = ra[i].y;
-                A[(aq * 4 + 2) * C::LDA + row] = ra[i].z;
-                A[(aq * 4 + 3) * C::LDA + row] = ra[i].w;
+                const float4 v = p.a_xform(ctx, ra[i], kt, aq, sp);
+                A[(aq * 4 + 0) * C::LDA + row] = v.x;
+                A[(aq * 4 + 1) * C::LDA + row] = v.y;
+                A[(aq * 4 + 2) * C::LDA + row] = v.z;
+                A[(aq * 4 + 3) * C::LDA + row] = v.w;
             } else {
                 const int kr = al + i * C::A_STEP;
-                if (kr < C::BK) *reinterpret_cast<float4*>(&A[kr * C::LDA + aq * 4]) = ra[i];
+                if (kr < C::BK) *reinterpret_cast<float4*>(&A[kr * C::LDA + aq * 4]) = p.a_xform(ctx, ra[i], kt, aq, sp);
             }
         }
 #pragma unroll
         for (int i = 0; i < C::B_N; ++i) {
             const int kr = bl + i * C::B_STEP;
-            if (kr < C::BK) *reinterpret_cast<float4*>(&B[kr * C::LDB + bq * 4]) = rb[i];
+            if (kr < C::BK) *reinterpret_cast<float4*>(&B[kr * C::LDB + bq * 4]) = p.b_xform(ctx, rb[i], kt, bq, sp);
         }
     };
 
     if (KT > 0) {
         g_load(0);
-        s_store(0);
+        s_store(0, 0);
     }
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const P p) {
                 for (int j = 0; j < C::TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < KT) s_store(buf ^ 1);
+        if (kt + 1 < KT) s_store(buf ^ 1, kt + 1);
         __syncthreads();
     }
     if constexpr (C::WK > 1) {              // in-block split-K: fold the partial tiles into the wk == 0 waves
@@ -344,43 +351,63 @@ struct FwdConvP {
         r.y = p / po.W;
         r.x = p - r.y * po.W;
     }
-    __device__ float4 a_fetch(const Ctx& c, const ARow& r, int kt, int q, const float* sp) const {
+    using ARaw = RawT<(MODE == F_POOL) ? 4 : 1>;
+    using BRaw = RawT<1>;
+    __device__ int a_chan(int kt, int q) const {
+        if constexpr (MODE == F_THREE) { const int kpt = K / Cfg::BK; return (kt % kpt) * Cfg::BK + 4 * q; }
+        else return kt * Cfg::BK + 4 * q;
+    }
+    __device__ ARaw a_fetch(const Ctx& c, const ARow& r, int kt, int q) const {
+        ARaw o;
         if constexpr (MODE == F_ONE) {
-            if (!r.valid) return zero4();
-            const int ch = kt * Cfg::BK + 4 * q;
-            const float4 v = ld4(src + ((int64_t)c.n * ps.HWp + r.y * ps.W + r.x) * lds_ + ch);
-            return bnrelu4(v, sp + ch, K);
+            o.ok = r.valid;
+            o.v[0] = o.ok ? ld4(src + ((int64_t)c.n * ps.HWp + r.y * ps.W + r.x) * lds_ + a_chan(kt, q)) : zero4();
         } else if constexpr (MODE == F_THREE) {
-            const int kpt = K / Cfg::BK;
-            const int tap = kt / kpt;
-            const int ch = (kt - tap * kpt) * Cfg::BK + 4 * q;
+            const int tap = kt / (K / Cfg::BK);
             const int yy = r.y + tap / 3 - 1, xx = r.x + tap % 3 - 1;
-            if (!r.valid || (unsigned)yy >= (unsigned)ps.H || (unsigned)xx >= (unsigned)ps.W) return zero4();
-            const float4 v = ld4(src + ((int64_t)c.n * ps.HWp + yy * ps.W + xx) * lds_ + ch);
-            return bnrelu4(v, sp + ch, K);
+            o.ok = r.valid && (unsigned)yy < (unsigned)ps.H && (unsigned)xx < (unsigned)ps.W;
+            o.v[0] = o.ok ? ld4(src + ((int64_t)c.n * ps.HWp + yy * ps.W + xx) * lds_ + a_chan(kt, q)) : zero4();
         } else if constexpr (MODE == F_POOL) {
-            if (!r.valid) return zero4();
-            const int ch = kt * Cfg::BK + 4 * q;
-            const float* b = src + ((int64_t)c.n * ps.HWp + (2 * r.y) * ps.W + 2 * r.x) * lds_ + ch;
-            const float* pr = sp + ch;
-            float4 s = bnrelu4(ld4(b), pr, K);
-            s = add4(s, bnrelu4(ld4(b + lds_), pr, K));
-            s = add4(s, bnrelu4(ld4(b + (int64_t)ps.W * lds_), pr, K));
-            s = add4(s, bnrelu4(ld4(b + (int64_t)(ps.W + 1) * lds_), pr, K));
-            return make_float4(s.x * 0.25f, s.y * 0.25f, s.z * 0.25f, s.w * 0.25f);
+            o.ok = r.valid;
+            const float* b = src + ((int64_t)c.n * ps.HWp + (2 * r.y) * ps.W + 2 * r.x) * lds_ + a_chan(kt, q);
+            o.v[0] = o.ok ? ld4(b) : zero4();
+            o.v[1] = o.ok ? ld4(b + lds_) : zero4();
+            o.v[2] = o.ok ? ld4(b + (int64_t)ps.W * lds_) : zero4();
+            o.v[3] = o.ok ? ld4(b + (int64_t)(ps.W + 1) * lds_) : zero4();
         } else {
             const int tap = kt * (Cfg::BK / 4) + q;
             const int yy = 2 * r.y + tap / 7 - 3, xx = 2 * r.x + tap % 7 - 3;
-            if (!r.valid || tap >= 49 || (unsigned)yy >= (unsigned)ps.H || (unsigned)xx >= (unsigned)ps.W) return zero4();
-            return ld4(src + ((int64_t)c.n * ps.HWp + yy * ps.W + xx) * 4);
+            o.ok = r.valid && tap < 49 && (unsigned)yy < (unsigned)ps.H && (unsigned)xx < (unsigned)ps.W;
+            o.v[0] = o.ok ? ld4(src + ((int64_t)c.n * ps.HWp + yy * ps.W + xx) * 4) : zero4();
+        }
+        return o;
+    }
+    __device__ float4 a_xform(const Ctx&, const ARaw& o, int kt, int q, const float* sp) const {
+        if constexpr (MODE == F_STEM) {
+            return o.v[0];
+        } else {
+            if (!o.ok) return zero4();                   // zero padding applies AFTER bn + relu
+            const float* pr = sp + a_chan(kt, q);
+            if constexpr (MODE == F_POOL) {
+                float4 s = bnrelu4(o.v[0], pr, K);
+                s = add4(s, bnrelu4(o.v[1], pr, K));
+                s = add4(s, bnrelu4(o.v[2], pr, K));
+                s = add4(s, bnrelu4(o.v[3], pr, K));
+                return make_float4(s.x * 0.25f, s.y * 0.25f, s.z * 0.25f, s.w * 0.25f);
+            } else {
+                return bnrelu4(o.v[0], pr, K);
+            }
         }
     }
-    __device__ float4 a_fetch_d(const Ctx&, const DRow&, int, int, int, const float*) const { return zero4(); }
-    __device__ float4 b_fetch(const Ctx& c, const DRow&, int kt, int kr, int q, const float*) const {
+    __device__ ARaw a_fetch_d(const Ctx&, const DRow&, int, int, int) const { return ARaw{}; }
+    __device__ BRaw b_fetch(const Ctx& c, const DRow&, int kt, int kr, int q) const {
+        BRaw o;
         const int col = c.n0 + 4 * q;
-        if (col >= N) return zero4();
-        return ld4(w + (int64_t)(kt * Cfg::BK + kr) * ldw + col);
+        o.ok = col < N;
+        o.v[0] = o.ok ? ld4(w + (int64_t)(kt * Cfg::BK + kr) * ldw + col) : zero4();
+        return o;
     }
+    __device__ float4 b_xform(const Ctx&, const BRaw& o, int, int, const float*) const { return o.v[0]; }
     __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, float*, bool active) const {
         const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
         const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
@@ -502,31 +529,42 @@ struct BwdDataP {
         r.y = p / pa.W;
         r.x = p - r.y * pa.W;
     }
-    __device__ float4 a_fetch(const Ctx& c, const ARow& r, int kt, int q, const float* sp) const {
-        int ch, yy = r.y, xx = r.x;
+    using ARaw = RawT<2>;       // gradient + (when xbuf is set) the raw activation its BN normalised
+    using BRaw = RawT<1>;
+    __device__ int a_chan(int kt, int q) const {
+        if constexpr (SHIFT3) { const int kpt = KA / Cfg::BK; return (kt % kpt) * Cfg::BK + 4 * q; }
+        else return kt * Cfg::BK + 4 * q;
+    }
+    __device__ ARaw a_fetch(const Ctx& c, const ARow& r, int kt, int q) const {
+        ARaw o;
+        int yy = r.y, xx = r.x;
+        o.ok = r.valid;
         if constexpr (SHIFT3) {
-            const int kpt = KA / Cfg::BK;
-            const int tap = kt / kpt;
-            ch = (kt - tap * kpt) * Cfg::BK + 4 * q;
+            const int tap = kt / (KA / Cfg::BK);
             yy = r.y + 1 - tap / 3;
             xx = r.x + 1 - tap % 3;
-            if (!r.valid || (unsigned)yy >= (unsigned)pa.H || (unsigned)xx >= (unsigned)pa.W) return zero4();
-        } else {
-            ch = kt * Cfg::BK + 4 * q;
-            if (!r.valid) return zero4();
+            o.ok = r.valid && (unsigned)yy < (unsigned)pa.H && (unsigned)xx < (unsigned)pa.W;
         }
+        const int ch = a_chan(kt, q);
         const int64_t pix = (int64_t)c.n * pa.HWp + yy * pa.W + xx;
-        const float4 g = ld4(gbuf + pix * ldg + gcoff + ch);
-        if (!xbuf) return g;               // gradient already BN-corrected (bn_bwd_apply_kernel)
-        const float4 x = ld4(xbuf + pix * ldx + xcoff + ch);
-        return affine2(g, x, sp + ch, KA);
+        o.v[0] = o.ok ? ld4(gbuf + pix * ldg + gcoff + ch) : zero4();
+        o.v[1] = (o.ok && xbuf) ? ld4(xbuf + pix * ldx + xcoff + ch) : zero4();
+        return o;
     }
-    __device__ float4 a_fetch_d(const Ctx&, const DRow&, int, int, int, const float*) const { return zero4(); }
-    __device__ float4 b_fetch(const Ctx& c, const DRow&, int kt, int kr, int q, const float*) const {
+    __device__ float4 a_xform(const Ctx&, const ARaw& o, int kt, int q, const float* sp) const {
+        if (!xbuf) return o.v[0];                      // gradient already BN-corrected (bn_bwd_apply_kernel)
+        if (!o.ok) return zero4();
+        return affine2(o.v[0], o.v[1], sp + a_chan(kt, q), KA);
+    }
+    __device__ ARaw a_fetch_d(const Ctx&, const DRow&, int, int, int) const { return ARaw{}; }
+    __device__ BRaw b_fetch(const Ctx& c, const DRow&, int kt, int kr, int q) const {
+        BRaw o;
         const int col = c.n0 + 4 * q;
-        if (col >= N) return zero4();
-        return ld4(w + (int64_t)(kt * Cfg::BK + kr) * ldw + col);
+        o.ok = col < N;
+        o.v[0] = o.ok ? ld4(w + (int64_t)(kt * Cfg::BK + kr) * ldw + col) : zero4();
+        return o;
     }
+    __device__ float4 b_xform(const Ctx&, const BRaw& o, int, int, const float*) const { return o.v[0]; }
     __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, float* sp, bool active) const {
         const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
         const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
@@ -709,38 +747,62 @@ struct BwdWeightP {
     }
     __device__ int ktiles(const Ctx& c) const { return c.kt; }
     __device__ void a_row_init(const Ctx&, ARow&, int) const {}
-    __device__ float4 a_fetch(const Ctx&, const ARow&, int, int, const float*) const { return zero4(); }
-    __device__ float4 a_fetch_d(const Ctx& c, const DRow& r, int, int, int q, const float* sp) const {
+    using ARaw = RawT<2>;
+    using BRaw = RawT<(BMODE == W_POOL) ? 4 : 1>;
+    __device__ ARaw a_fetch(const Ctx&, const ARow&, int, int) const { return ARaw{}; }
+    __device__ ARaw a_fetch_d(const Ctx& c, const DRow& r, int, int, int q) const {
+        ARaw o;
         const int ch = c.m0 + 4 * q;
-        if (r.p >= pa.HW || ch >= MA) return zero4();
+        o.ok = r.p < pa.HW && ch < MA;
         const int64_t pix = (int64_t)c.n * pa.HWp + r.p;
-        const float4 g = ld4(gbuf + pix * ldg + gcoff + ch);
-        if (!xbuf) return g;
-        const float4 x = ld4(xbuf + pix * ldx + xcoff + ch);
-        return affine2(g, x, sp + 4 * q, Cfg::BM);
+        o.v[0] = o.ok ? ld4(gbuf + pix * ldg + gcoff + ch) : zero4();
+        o.v[1] = (o.ok && xbuf) ? ld4(xbuf + pix * ldx + xcoff + ch) : zero4();
+        return o;
     }
-    __device__ float4 b_fetch(const Ctx& c, const DRow& r, int, int, int q, const float* sp) const {
+    __device__ float4 a_xform(const Ctx&, const ARaw& o, int, int q, const float* sp) const {
+        if (!xbuf) return o.v[0];
+        if (!o.ok) return zero4();
+        return affine2(o.v[0], o.v[1], sp + 4 * q, Cfg::BM);
+    }
+    __device__ BRaw b_fetch(const Ctx& c, const DRow& r, int, int, int q) const {
+        BRaw o;
         const int ch = c.n0 + 4 * q;
-        if (r.p >= pa.HW || ch >= NB) return zero4();
-        const float* pr = sp + 4 * Cfg::BM + 4 * q;
+        o.ok = r.p < pa.HW && ch < NB;
         if constexpr (BMODE == W_ONE) {
-            return bnrelu4(ld4(bbuf + ((int64_t)c.n * pb.HWp + r.p) * ldb + ch), pr, Cfg::BN);
+            o.v[0] = o.ok ? ld4(bbuf + ((int64_t)c.n * pb.HWp + r.p) * ldb + ch) : zero4();
         } else if constexpr (BMODE == W_THREE) {
             const int yy = r.y + c.tap / 3 - 1, xx = r.x + c.tap % 3 - 1;
-            if ((unsigned)yy >= (unsigned)pb.H || (unsigned)xx >= (unsigned)pb.W) return zero4();
-            return bnrelu4(ld4(bbuf + ((int64_t)c.n * pb.HWp + yy * pb.W + xx) * ldb + ch), pr, Cfg::BN);
+            o.ok = o.ok && (unsigned)yy < (unsigned)pb.H && (unsigned)xx < (unsigned)pb.W;
+            o.v[0] = o.ok ? ld4(bbuf + ((int64_t)c.n * pb.HWp + yy * pb.W + xx) * ldb + ch) : zero4();
         } else if constexpr (BMODE == W_POOL) {
             const float* b = bbuf + ((int64_t)c.n * pb.HWp + (2 * r.y) * pb.W + 2 * r.x) * ldb + ch;
-            float4 s = bnrelu4(ld4(b), pr, Cfg::BN);
-            s = add4(s, bnrelu4(ld4(b + ldb), pr, Cfg::BN));
-            s = add4(s, bnrelu4(ld4(b + (int64_t)pb.W * ldb), pr, Cfg::BN));
-            s = add4(s, bnrelu4(ld4(b + (int64_t)(pb.W + 1) * ldb), pr, Cfg::BN));
-            return make_float4(s.x * 0.25f, s.y * 0.25f, s.z * 0.25f, s.w * 0.25f);
+            o.v[0] = o.ok ? ld4(b) : zero4();
+            o.v[1] = o.ok ? ld4(b + ldb) : zero4();
+            o.v[2] = o.ok ? ld4(b + (int64_t)pb.W * ldb) : zero4();
+            o.v[3] = o.ok ? ld4(b + (int64_t)(pb.W + 1) * ldb) : zero4();
         } else {
             const int tap = ch >> 2;
             const int yy = 2 * r.y + tap / 7 - 3, xx = 2 * r.x + tap % 7 - 3;
-            if (tap >= 49 || (unsigned)yy >= (unsigned)pb.H || (unsigned)xx >= (unsigned)pb.W) return zero4();
-            return ld4(bbuf + ((int64_t)c.n * pb.HWp + yy * pb.W + xx) * 4);
+            o.ok = o.ok && tap < 49 && (unsigned)yy < (unsigned)pb.H && (unsigned)xx < (unsigned)pb.W;
+            o.v[0] = o.ok ? ld4(bbuf + ((int64_t)c.n * pb.HWp + yy * pb.W + xx) * 4) : zero4();
+        }
+        return o;
+    }
+    __device__ float4 b_xform(const Ctx&, const BRaw& o, int, int q, const float* sp) const {
+        if constexpr (BMODE == W_STEM) {
+            return o.v[0];
+        } else {
+            if (!o.ok) return zero4();
+            const float* pr = sp + 4 * Cfg::BM + 4 * q;
+            if constexpr (BMODE == W_POOL) {
+                float4 s = bnrelu4(o.v[0], pr, Cfg::BN);
+                s = add4(s, bnrelu4(o.v[1], pr, Cfg::BN));
+                s = add4(s, bnrelu4(o.v[2], pr, Cfg::BN));
+                s = add4(s, bnrelu4(o.v[3], pr, Cfg::BN));
+                return make_float4(s.x * 0.25f, s.y * 0.25f, s.z * 0.25f, s.w * 0.25f);
+            } else {
+                return bnrelu4(o.v[0], pr, Cfg::BN);
+            }
         }
     }
     __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float*, float*, bool active) const {
