@@ -41,8 +41,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_
 
 
 def layout_names():
+    """(name, shape, kind) for synthetic.make_state_dict, from the C library's layout table."""
     import smg_hip
-    kinds = {0: None}
     out = []
     for name, kind, off, shape in smg_hip.layout(1):
         if kind == 3:
@@ -62,7 +62,6 @@ def layout_names():
         else:
             k = "bn_b"
         out.append((name, shape, k))
-    del kinds
     return out
 
 
@@ -95,6 +94,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-samples", type=int, default=4, help="reference-schedule samples timed on the host (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--batched-scenes", type=int, default=4,
+                    help="also time a config-4 style step with this many scenes per engine call (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -179,8 +180,29 @@ def main():
         sweep_ms = (time.perf_counter() - t1) / n_sw * 1e3
         out["sweep_fwd_ms"] = sweep_ms
         out["sweep_fwd_tflops_algorithmic"] = SWEEP_GFLOP / sweep_ms
+        if args.batched_scenes > 1:
+            # SURVEY.md config 4 on one GPU: several scenes per optimizer step in ONE engine call
+            # (more streams -> the late, small stages fill the chip).  Reported beside the headline.
+            nb = args.batched_scenes
+            sc = [synthetic.heightmap_scene(100 + k) for k in range(nb)]
+            d_b = np.stack([c[0] for c in sc])
+            m_b = np.stack([c[0] * c[1][0] for c in sc])
+            lab_b = synthetic.uniform(7, "bench/labels_b", nb * R, 0.0, 1.5)
+            rots_b = [rots] * nb
+            for _ in range(2):
+                tr.train_batch(d_b, m_b, 0, rots_b, lab_b)
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            n_b = max(3, args.steps // 3)
+            for _ in range(n_b):
+                tr.train_batch(d_b, m_b, 0, rots_b, lab_b)
+            torch.cuda.synchronize(dev)
+            ms_b = (time.perf_counter() - t2) / n_b * 1e3
+            out["batched"] = {"scenes_per_step": nb, "samples_per_step": nb * R, "ms_per_step": ms_b,
+                              "passes_per_s": nb / (ms_b * 1e-3), "pass_tflops_algorithmic": PASS_GFLOP * nb / ms_b}
         if not args.no_roofline:
             # per-kernel-class hipEvent timing on the launch stream (separate, untimed passes)
+            eng = models._ENGINES[(local_rank, 640, 1)]        # the batched leg may have regrown the engine
             eng.profile_enable(True)
             n_prof = 3
             for _ in range(n_prof):

@@ -215,35 +215,46 @@ class _AffordanceNet(nn.Module):
 
     def run(self, style, rotations, num_rot, images_nchw=None, heightmaps=None, mean=0.0, std=1.0,
             keep_for_backward=False, update_bn=True):
-        """Evaluate len(rotations) (rotation, mask) samples of one scene: image 0 is the
-        depth image (rotated per sample), image 1 the masked depth image (never rotated,
-        so its trunk pass is computed once - the reference recomputes it per rotation,
-        code/models.py:385).  Returns a cuda tensor [len(rotations), out, OH, OW]."""
+        """Evaluate (rotation, mask) samples.  Inputs hold 2*n_scenes images: image 2k is scene k's
+        depth image (rotated per sample), image 2k+1 its masked depth image (never rotated, so its
+        trunk pass is computed once per scene - the reference recomputes it per rotation,
+        code/models.py:385).  `rotations` is a list of rotation indices (one scene) or a list of such
+        lists (one per scene).  Returns a cuda tensor [n_samples, out, OH, OW], scene-major."""
         self._require_gpu()
         dev = self._flat_params.device
-        R = len(rotations)
         if images_nchw is not None:
             S = int(images_nchw.shape[-1])
-            src = dict(images_nchw=images_nchw.data_ptr(), n_images=2)
+            n_images = int(images_nchw.shape[0])
+            src = dict(images_nchw=images_nchw.data_ptr(), n_images=n_images)
         else:
             hm = int(heightmaps.shape[-1])
+            n_images = int(heightmaps.shape[0])
             diag = np.ceil(float(2 * hm) * np.sqrt(2) / 32) * 32          # code/trainer.py:169-171
             S = 2 * hm + 2 * int((diag - 2 * hm) / 2)
-            src = dict(heightmaps=heightmaps.data_ptr(), hm_size=hm, mean=float(mean), std=float(std), n_images=2)
-        eng = get_engine(dev.index or 0, S, self.HEAD_OUT, R + 1, R)
-        q = torch.empty((R, self.HEAD_OUT, eng.OH, eng.OW), dtype=torch.float32, device=dev)
-        aff = np.concatenate([rotation_theta(r, num_rot) for r in rotations] + [rotation_theta(0, 1)])
-        seq_t = None
-        seq_h = None
-        if update_bn:   # reference order: trunk(rot r), trunk(mask), head(r) for each r
-            seq_t = np.stack([np.arange(R), np.full(R, R)], axis=1).reshape(-1)
-            seq_h = np.arange(R)
+            src = dict(heightmaps=heightmaps.data_ptr(), hm_size=hm, mean=float(mean), std=float(std), n_images=n_images)
+        per_scene = [list(rotations)] if (len(rotations) == 0 or np.isscalar(rotations[0])) else [list(r) for r in rotations]
+        if 2 * len(per_scene) != n_images:
+            raise ValueError("need one (depth, masked depth) image pair per scene")
+        stream_image, stream_rot, thetas, pair_a, pair_b, seq_t, seq_h = [], [], [], [], [], [], []
+        for k, rots in enumerate(per_scene):
+            base = len(stream_image)
+            mask_stream = base + len(rots)
+            for j, r in enumerate(rots):
+                stream_image.append(2 * k); stream_rot.append(1); thetas.append(rotation_theta(r, num_rot))
+                pair_a.append(base + j); pair_b.append(mask_stream)
+                seq_t += [base + j, mask_stream]                         # reference order: trunk(rot r), trunk(mask), head(r)
+                seq_h.append(len(pair_a) - 1)
+            stream_image.append(2 * k + 1); stream_rot.append(0); thetas.append(rotation_theta(0, 1))
+        n_pairs = len(pair_a)
+        eng = get_engine(dev.index or 0, S, self.HEAD_OUT, len(stream_image), n_pairs)
+        q = torch.empty((n_pairs, self.HEAD_OUT, eng.OH, eng.OW), dtype=torch.float32, device=dev)
         trunk_id, head_id = STYLE_TRUNK[style], STYLE_HEAD[style]
         net = self._net_struct(keep_for_backward)
         stream = torch.cuda.current_stream(dev).cuda_stream
         token = eng.forward(net, trunk_id, head_id, q.data_ptr(), stream,
-                            stream_image=[0] * R + [1], stream_affine=aff, stream_rotated=[1] * R + [0],
-                            pair_a=list(range(R)), pair_b=[R] * R, bn_seq_trunk=seq_t, bn_seq_head=seq_h, **src)
+                            stream_image=stream_image, stream_affine=np.concatenate(thetas), stream_rotated=stream_rot,
+                            pair_a=pair_a, pair_b=pair_b, bn_seq_trunk=seq_t if update_bn else None,
+                            bn_seq_head=seq_h if update_bn else None, **src)
         self._saved = (eng, token, trunk_id, head_id) if keep_for_backward else None
         return q
 

@@ -225,27 +225,39 @@ class Trainer(object):
         return loss_value
 
     def train_batch(self, depth_heightmap, m_depth_heightmap, style, rotations, labels, grad_sync=None, return_q=False):
-        """Batched form of backprop for one scene: every rotation in `rotations` is a training
-        sample (forward as branch C, Huber / CE against labels[i]); the gradient of the SUM of
-        the losses is accumulated in one backward pass (the masked stream's trunk is walked once
-        with the summed gradient - exact, the trunk is linear in its output gradient), then ONE
-        Adam step.  Equals len(rotations) reference backprop calls with the optimizer step
-        deferred to the end.  `grad_sync(model, trunk_id, head_id)` is the data-parallel hook
+        """Batched form of backprop: every (scene, rotation) is a training sample (forward as
+        branch C, Huber / CE against its label); the gradient of the SUM of the losses is
+        accumulated in one backward pass (each scene's masked stream is walked once with the summed
+        gradient - exact, the trunk is linear in its output gradient), then ONE Adam step.  Equals
+        that many reference backprop calls with the optimizer step deferred to the end.
+
+        One scene: 2-D heightmaps, `rotations` a list of rotation indices.  Several scenes
+        (SURVEY.md config 4): heightmaps [n_scenes, H, H], `rotations` a list of lists; labels are
+        flat, scene-major.  `grad_sync(model, trunk_id, head_id)` is the data-parallel hook
         (parallel.allreduce_grads) called between backward and Adam.  Returns the loss vector."""
         model = self.model
         self.optimizer.zero_grad()
         model._require_gpu()
-        hm = self._heightmaps_to_device(depth_heightmap, m_depth_heightmap)
+        d = np.asarray(depth_heightmap, dtype=np.float64)
+        m = np.asarray(m_depth_heightmap, dtype=np.float64)
+        if d.ndim == 2:
+            d, m, rotations = d[None], m[None], [list(rotations)]
+        hm = np.empty((2 * d.shape[0],) + d.shape[1:], dtype=np.float64)
+        hm[0::2], hm[1::2] = d, m
+        hm = torch.from_numpy(hm).to(model._flat_params.device)
         num = model.gnum_rotations                     # code/models.py:522,545,568 (gnum for every style)
-        rots = [0 if style == 2 else int(r) for r in rotations]
+        rots = [[0 if style == 2 else int(r) for r in rs] for rs in rotations]
         q = model.run(style, rots, num, heightmaps=hm, mean=self.image_mean, std=self.image_std, keep_for_backward=True)
+        n = q.shape[0]
         dev = q.device
         eng, token, trunk_id, head_id = model._saved
         stream = torch.cuda.current_stream(dev).cuda_stream
-        lab = torch.as_tensor(np.asarray(labels, dtype=np.float32), device=dev)
-        loss = torch.empty(len(rots), dtype=torch.float32, device=dev)
+        lab = torch.as_tensor(np.asarray(labels, dtype=np.float32).reshape(-1), device=dev)
+        if lab.numel() != n:
+            raise ValueError("one label per (scene, rotation) sample")
+        loss = torch.empty(n, dtype=torch.float32, device=dev)
         dq = torch.empty_like(q)
-        eng.loss(0 if self.method == 'reinforcement' else 1, q.data_ptr(), lab.data_ptr(), len(rots), loss.data_ptr(), dq.data_ptr(), stream)
+        eng.loss(0 if self.method == 'reinforcement' else 1, q.data_ptr(), lab.data_ptr(), n, loss.data_ptr(), dq.data_ptr(), stream)
         model._engine_backward(token, dq)
         if grad_sync is not None:
             grad_sync(model, trunk_id, head_id)

@@ -302,3 +302,58 @@ def test_snapshot_roundtrip(gpu, tmp_path):
     assert len(other.state_dict()) == 2217
     # BN buffers changed by the first forward do not enter a training-mode forward
     assert abs(float(other.forward(x, mx, 0, True, 2)) - q0) < 1e-6
+
+
+def test_multi_scene_batch_equals_sum_of_single_scene_gradients(gpu):
+    """Config-4 style batch (several scenes x rotations in ONE engine call): Q values equal the
+    single-scene calls and the gradient equals the sum of the single-scene gradients."""
+    from trainer import Trainer
+    import synthetic
+    tr = Trainer('reinforcement', 0.5, False, None, False)
+    sd = synthetic.make_state_dict(orc.state_layout(1), 3)
+    tr.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    tr.model.gnum_rotations = tr.model.snum_rotations = 16
+    tr.optimizer.lr = 0.0                                   # keep the weights fixed across the calls
+    scenes = [synthetic.heightmap_scene(s) for s in (5, 6)]
+    d = np.stack([sc[0] for sc in scenes])
+    m = np.stack([sc[0] * sc[1][1] for sc in scenes])
+    rots = [[0, 7, 12], [3, 9]]
+    labels = [0.2, 1.4, 0.9, 3.0, 0.1]
+    loss_b, q_b = tr.train_batch(d, m, 0, rots, labels, return_q=True)
+    g_b = tr.model.flat_grads().clone()
+    g_sum = torch.zeros_like(g_b)
+    q_s = []
+    k = 0
+    for i in range(2):
+        _, q = tr.train_batch(d[i], m[i], 0, rots[i], labels[k:k + len(rots[i])], return_q=True)
+        k += len(rots[i])
+        q_s.append(q.reshape(-1).cpu().numpy())
+        g_sum += tr.model.flat_grads()
+    q_s = np.concatenate(q_s)
+    np.testing.assert_allclose(q_b.reshape(-1).cpu().numpy(), q_s, rtol=0, atol=2e-6)      # same kernels, same per-stream work
+    num = float((g_b - g_sum).double().norm())
+    den = float(g_sum.double().norm())
+    assert num <= 2e-3 * den, (num, den)                     # only the fp32 summation order differs (ill-conditioned, see header)
+    assert loss_b.shape == (5,)
+
+
+def test_large_input_dense_qmap(gpu):
+    """Config-5 path: a 640x640 heightmap -> S = 1824: odd plane sizes (57x57), average-pool rows
+    the pooling never reads, and a dense 38x38 Q map per sample."""
+    import synthetic
+    net = product_net(0, R=32)
+    on = oracle_net(0, R=32)
+    depth, masks = synthetic.heightmap_scene(4, size=640, n_boxes=8)
+    x = orc.preprocess(depth, [MEAN] * 3, [STD] * 3)
+    mx = orc.preprocess(depth * masks[0], [MEAN] * 3, [STD] * 3)
+    assert x.shape[-1] == 1824
+    hm = torch.from_numpy(np.stack([depth, depth * masks[0]])).cuda()
+    q = net.run(0, [5], 32, heightmaps=hm, mean=MEAN, std=STD)
+    assert tuple(q.shape) == (1, 1, 38, 38)
+    with torch.no_grad():
+        qo = orc.forward(on, x, mx, 0, True, 5)
+    assert tuple(qo.shape) == (1, 1, 38, 38)
+    a, b = q.cpu().numpy().ravel(), qo.numpy().ravel()
+    ok, worst = q_close(a, b)
+    assert ok, worst
+    assert int(a.argmax()) == int(b.argmax())
