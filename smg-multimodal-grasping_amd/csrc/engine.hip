@@ -48,13 +48,14 @@ using CfgP128x32 = GemmCfg<128, 32, 32, 4, 1, 1, true>;      // 3x3 fwd (N = gro
 using CfgP128x64 = GemmCfg<128, 64, 16, 2, 2, 1, true>;      // stem, head conv0, 1x1 dgrad
 // small stages (late blocks: few pixels per stream -> 64-row tiles, 4x the workgroups)
 using CfgP64x64 = GemmCfg<64, 64, 32, 2, 2, 1, true>;        // 1x1 fwd / dgrad, transitions
-using CfgP64x128 = GemmCfg<64, 128, 16, 2, 2, 1, true>;      // 3x3 dgrad
+using CfgP64x128 = GemmCfg<64, 128, 16, 2, 2, 1, true>;      // 3x3 dgrad, late 1x1 fwd / transitions (A operand read once)
 using CfgP64x32 = GemmCfg<64, 32, 64, 2, 1, 2, true>;        // 3x3 fwd, k-tile split over 2 waves
 // weight gradients (reduction over pixels)
 using CfgW32x128 = GemmCfg<32, 128, 32, 1, 4, 1, false>;     // 3x3 wgrad (32 x 128 per tap)
 using CfgW128x64 = GemmCfg<128, 64, 16, 2, 2, 1, false>;     // 1x1 wgrad (128 x cin)
 using CfgW128x128 = GemmCfg<128, 128, 16, 2, 2, 1, false>;   // transition wgrad
-using CfgW64x64 = GemmCfg<64, 64, 16, 2, 2, 1, false>;       // stem / head conv0 wgrad
+using CfgW64x64 = GemmCfg<64, 64, 16, 2, 2, 1, false>;       // head conv0 wgrad
+using CfgW64x256 = GemmCfg<64, 256, 16, 2, 2, 1, false>;     // stem wgrad: all 196 (tap, channel) columns in one tile
 
 enum Kind {
     K_STEM = 0, K_C1, K_C3, K_TRANS, K_HEAD0, K_D3, K_W3, K_D1, K_W1, K_TW, K_TD, K_SW, K_HW0, K_HD0, K_OTHER, K_COUNT
@@ -441,7 +442,7 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
             p.dsum = fsum(e, e->st_X[b + 1]); p.dsq = fsq(e, e->st_X[b + 1]); p.dstride = kBlockCtot[b + 1];
             launch_gemm(e, st, p, dim3(NS * pn.HWp / Cfg::BM, (Ct / 2) / Cfg::BN), K_TRANS, 2.0 * NS * pn.HW * Ct * (Ct / 2));
             };
-            if (pn.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x64{});
+            if (pn.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
         }
     }
     const Plane p4 = e->p_blk[3];
@@ -776,8 +777,8 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
     {   // conv0 weight gradient (no data gradient: the image needs none)
         const Plane ps_ = e->p_stem;
         int chunk, cps;
-        pick_chunk(ps_, NS, 4, chunk, cps);
-        BwdWeightP<CfgW64x64, W_STEM, C_STEM> p{};
+        pick_chunk(ps_, NS, 1, chunk, cps);
+        BwdWeightP<CfgW64x256, W_STEM, C_STEM> p{};
         p.gbuf = e->DY0; p.ldg = 64; p.gcoff = 0; p.xbuf = e->stem; p.ldx = 64; p.xcoff = 0; p.pa = ps_; p.MA = 64;
         p.xsum = fsum(e, e->st_stem); p.xsq = fsq(e, e->st_stem); p.xstride = 64;
         p.s1 = b1(e, e->bs_stem); p.s2 = b2(e, e->bs_stem); p.sstride = 64; p.scoff = 0; p.agamma = P + T.norm0.w;
@@ -785,7 +786,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
         p.eps = kEps; p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
         p.dw = Gr + T.conv0.w; p.ldw_out = 147;
         if (fork(e->ev_misc)) return -5;
-        launch_wgrad(e, s2, p, dim3(1, 4, NS * cps), K_SW, 2.0 * NS * ps_.HW * 64 * 147, 1, C_STEM);
+        launch_wgrad(e, s2, p, dim3(1, 1, NS * cps), K_SW, 2.0 * NS * ps_.HW * 64 * 147, 1, C_STEM);
     }
     HIP_OK(hipEventRecord(e->ev_end, s2));          // join: everything after the backward sees every gradient
     HIP_OK(hipStreamWaitEvent(st, e->ev_end, 0));
