@@ -146,8 +146,22 @@ struct ProfScope {
 };
 
 template <class P>
-static void launch_gemm(smg_engine* e, hipStream_t st, const P& p, dim3 grid, int kind, double flops) {
+static void launch_gemm(smg_engine* e, hipStream_t st, P p, dim3 grid, int kind, double flops) {
     const size_t smem = (size_t)(P::Cfg::TILE_FLOATS + p.param_floats()) * sizeof(float);
+    p.tm = TileMap{0, 0, 0};
+    if constexpr (P::kSwizzle == 1) {            // x = M tiles, y = N tiles sharing one A operand
+        if (grid.y > 1 && grid.z == 1) {
+            p.tm = TileMap{(int)grid.x, (int)grid.y, 0};
+            grid = dim3(8 * ((grid.x + 7) / 8) * grid.y, 1, 1);
+        }
+    } else {                                     // weight gradient: z = pixel chunks, x*y = tiles sharing them
+        p.gx = grid.x; p.gy = grid.y;
+        const int tiles = grid.x * grid.y;
+        if (tiles > 1) {
+            p.tm = TileMap{(int)grid.z, tiles, (int)grid.x};
+            grid = dim3(8 * ((grid.z + 7) / 8) * tiles, 1, 1);
+        }
+    }
     ProfScope ps(e, st, kind, flops);
     hipLaunchKernelGGL(gemm_kernel<P>, grid, dim3(256), smem, st, p);
 }

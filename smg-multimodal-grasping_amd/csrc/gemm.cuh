@@ -107,6 +107,18 @@ __device__ __forceinline__ float4 affine2(float4 g, float4 x, const float* prm, 
     return r;
 }
 
+// XCD-aware tile order.  Workgroup b is observed to run on XCD b % 8 (MI355X_MICROARCH.md, used for
+// speed only): sibling tiles that re-read the same A operand (the N-tiles of one M-tile, or of one
+// pixel chunk in a weight gradient) are made consecutive on ONE XCD so the re-reads hit its private L2
+// instead of going out to the fabric.  nM == 0 -> plain blockIdx.x / blockIdx.y / blockIdx.z.
+struct TileMap { int nM, nN, gx; };
+__device__ __forceinline__ bool tile_decode(const TileMap& tm, int& major, int& minor) {
+    const int b = blockIdx.x, x = b & 7, slot = b >> 3;
+    major = (slot / tm.nN) * 8 + x;
+    minor = slot % tm.nN;
+    return major < tm.nM;
+}
+
 // Sum per-lane column partials over the rows of the whole workgroup tile.
 // v[q][tn]: this lane's partial for column (wn0 + tn*32 + l31) of quantity q.
 // On return threads t < BN hold the totals of column t in out[q].
@@ -314,6 +326,8 @@ struct FwdConvP {
     const float* w; int ldw; int N;
     float* dst; int ldd; int dcoff;
     double* dsum; double* dsq; int dstride;
+    TileMap tm;
+    static constexpr int kSwizzle = 1;
 
     struct Ctx { int n, m0, n0; };
     struct ARow { int y, x; bool valid; };
@@ -322,8 +336,10 @@ struct FwdConvP {
     __host__ __device__ int param_floats() const { return MODE == F_STEM ? 0 : 3 * K; }
 
     __device__ bool init(Ctx& c, float* sp) const {
-        c.m0 = blockIdx.x * Cfg::BM;
-        c.n0 = blockIdx.y * Cfg::BN;
+        int mt = blockIdx.x, nt = blockIdx.y;
+        if (tm.nM && !tile_decode(tm, mt, nt)) return false;
+        c.m0 = mt * Cfg::BM;
+        c.n0 = nt * Cfg::BN;
         c.n = c.m0 / po.HWp;
         if (c.m0 - c.n * po.HWp >= po.HW) return false;
         if constexpr (MODE != F_STEM) {
@@ -478,6 +494,8 @@ struct BwdDataP {
     double* o1; double* o2; int ostride; int ocoff;
     float* dbeta; float* dgamma;
     float eps;
+    TileMap tm;
+    static constexpr int kSwizzle = 1;
 
     struct Ctx { int n, m0, n0; };
     struct ARow { int y, x; bool valid; };
@@ -488,8 +506,10 @@ struct BwdDataP {
     __device__ void d_init(const Ctx&, DRow&, int) const {}
     __device__ void d_next(const Ctx&, DRow&) const {}
     __device__ bool init(Ctx& c, float* sp) const {
-        c.m0 = blockIdx.x * Cfg::BM;
-        c.n0 = blockIdx.y * Cfg::BN;
+        int mt = blockIdx.x, nt = blockIdx.y;
+        if (tm.nM && !tile_decode(tm, mt, nt)) return false;
+        c.m0 = mt * Cfg::BM;
+        c.n0 = nt * Cfg::BN;
         c.n = c.m0 / pa.HWp;
         if (c.m0 - c.n * pa.HWp >= pa.HW) return false;
         const double inv = 1.0 / (double)pa.HW;
@@ -678,10 +698,13 @@ struct BwdWeightP {
     float eps;
     int chunk, chunks_per_stream, n_chunks;   // blockIdx.z = tap * n_chunks + chunk index
     float* dw; int ldw_out;
-    float* part;                              // if set: partial tiles [z][gridDim.x*BM][gridDim.y*BN] (plain stores,
+    float* part;                              // if set: partial tiles [z][gx*BM][gy*BN] (plain stores,
                                               // summed by reduce_partials_kernel) instead of fp32 atomics into dw
+    int gx, gy;                               // tile grid (M tiles x N tiles) of one pixel chunk
+    TileMap tm;
+    static constexpr int kSwizzle = 2;
 
-    struct Ctx { int n, p0, m0, n0, tap, kt; };
+    struct Ctx { int n, p0, m0, n0, tap, kt, z; };
     struct ARow { int dummy; };
     struct DRow { int p, y, x; };     // the pixel this staging slot reads, advanced BK per k-tile
 
@@ -698,9 +721,11 @@ struct BwdWeightP {
         while (r.x >= pa.W) { r.x -= pa.W; ++r.y; }
     }
     __device__ bool init(Ctx& c, float* sp) const {
-        c.m0 = blockIdx.x * Cfg::BM;
-        c.n0 = blockIdx.y * Cfg::BN;
-        const int z = blockIdx.z;
+        int z = blockIdx.z, tile = blockIdx.y * gx + blockIdx.x;
+        if (tm.nM && !tile_decode(tm, z, tile)) return false;
+        c.z = z;
+        c.m0 = (tile % gx) * Cfg::BM;
+        c.n0 = (tile / gx) * Cfg::BN;
         c.tap = z / n_chunks;
         const int ci = z - c.tap * n_chunks;
         c.n = ci / chunks_per_stream;
@@ -818,7 +843,7 @@ struct BwdWeightP {
                     const int row = c.m0 + SMG_ACC_ROW(wm0, i, r, half);
                     if (active && row < MA && col < NB) {
                         if (part) {
-                            part[((int64_t)blockIdx.z * (gridDim.x * Cfg::BM) + row) * (gridDim.y * Cfg::BN) + col] = acc[i][j][r];
+                            part[((int64_t)c.z * (gx * Cfg::BM) + row) * (gy * Cfg::BN) + col] = acc[i][j][r];
                             continue;
                         }
                         int64_t idx;
