@@ -258,6 +258,36 @@ class _AffordanceNet(nn.Module):
         self._saved = (eng, token, trunk_id, head_id) if keep_for_backward else None
         return q
 
+    def run_pairs(self, style, num_rot, heightmaps, rot_streams, mask_images, pairs, mean=0.0, std=1.0,
+                  bn_seq_trunk=None, bn_seq_head=None):
+        """General form: image 0 is the scene's depth heightmap; `rot_streams` lists the rotation
+        indices evaluated on it (ONE trunk pass each, shared by every pair that uses it);
+        `mask_images` lists image indices (>= 1) fed un-rotated (one trunk pass each);
+        `pairs` = [(i, j)]: head evaluation on rot_streams[i] x mask_images[j].
+        Returns q [len(pairs), out, OH, OW].  Inference only (no saved activations)."""
+        self._require_gpu()
+        dev = self._flat_params.device
+        hm = int(heightmaps.shape[-1])
+        diag = np.ceil(float(2 * hm) * np.sqrt(2) / 32) * 32
+        S = 2 * hm + 2 * int((diag - 2 * hm) / 2)
+        n_rot, n_mask = len(rot_streams), len(mask_images)
+        stream_image = [0] * n_rot + list(mask_images)
+        stream_rot = [1] * n_rot + [0] * n_mask
+        thetas = [rotation_theta(r, num_rot) for r in rot_streams] + [rotation_theta(0, 1)] * n_mask
+        pair_a = [i for i, _ in pairs]
+        pair_b = [n_rot + j for _, j in pairs]
+        eng = get_engine(dev.index or 0, S, self.HEAD_OUT, len(stream_image), len(pairs))
+        q = torch.empty((len(pairs), self.HEAD_OUT, eng.OH, eng.OW), dtype=torch.float32, device=dev)
+        trunk_id, head_id = STYLE_TRUNK[style], STYLE_HEAD[style]
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        eng.forward(self._net_struct(False), trunk_id, head_id, q.data_ptr(), stream,
+                    heightmaps=heightmaps.data_ptr(), hm_size=hm, mean=float(mean), std=float(std),
+                    n_images=int(heightmaps.shape[0]), stream_image=stream_image, stream_affine=np.concatenate(thetas),
+                    stream_rotated=stream_rot, pair_a=pair_a, pair_b=pair_b,
+                    bn_seq_trunk=bn_seq_trunk, bn_seq_head=bn_seq_head)
+        self._saved = None
+        return q
+
     def _engine_backward(self, token, dq):
         if self._saved is None or self._saved[1] != token or self._saved[0].forward_id != token:
             raise RuntimeError("backward: the activations of that forward are gone (another forward ran on the engine)")

@@ -156,6 +156,54 @@ class Trainer(object):
                                           "reference's scalar-per-rotation array (code/trainer.py:205-207)")
             return q.reshape(-1).cpu().numpy().astype(np.float64)
 
+    def forward_objects(self, depth_heightmap, mask_depth, style=0, is_target=False):
+        """All objects of one scene in ONE engine call - the loop of code/main.py:158-166:
+
+            for num in range(objects_number):
+                gra_conf[num] = trainer.forward(depth, depth * mask_depth[num], style, is_volatile=True)
+
+        The rotated full-depth streams are the same for every object, so n objects x R rotations
+        cost R + n trunk passes (the reference runs 2*n*R).  BN running statistics are updated in
+        the reference's order and count.  Returns conf[n_objects, R] float64 (styles 0 / 1)."""
+        if self.method != 'reinforcement' or style not in (0, 1):
+            raise ValueError("forward_objects: reinforcement styles 0 (grasp) and 1 (suction)")
+        model = self.model_target if is_target else self.model
+        d = np.asarray(depth_heightmap, dtype=np.float64)
+        masks = np.asarray(mask_depth, dtype=np.float64)
+        n = masks.shape[0]
+        R = model.gnum_rotations if style == 0 else model.snum_rotations
+        hm = torch.from_numpy(np.concatenate([d[None], d[None] * masks])).to(model._flat_params.device)
+        pairs = [(r, k) for k in range(n) for r in range(R)]
+        seq_t = [v for k in range(n) for r in range(R) for v in (r, R + k)]       # trunk(rot r), trunk(mask k) per sample
+        q = model.run_pairs(style, R, hm, list(range(R)), list(range(1, n + 1)), pairs, self.image_mean, self.image_std,
+                            bn_seq_trunk=seq_t, bn_seq_head=list(range(len(pairs))))
+        if q.shape[2] * q.shape[3] != 1:
+            raise NotImplementedError("dense Q maps")
+        return q.reshape(n, R).cpu().numpy().astype(np.float64)
+
+    def forward_object_pairs(self, depth_heightmap, mask_depth, is_target=False):
+        """The enveloping-then-sucking loop of code/main.py:183-192 in one engine call: for every
+        unordered object pair (g < s) the mask is mask[g] + mask[s], style 2, rotation 0.
+        Returns gs_conf[n, n] with -100 where the reference leaves its fill value (main.py:184)."""
+        model = self.model_target if is_target else self.model
+        d = np.asarray(depth_heightmap, dtype=np.float64)
+        masks = np.asarray(mask_depth, dtype=np.float64)
+        n = masks.shape[0]
+        gs = np.full((n, n), -100.0)
+        idx = [(g, s) for g in range(n) for s in range(g + 1, n)]
+        if not idx:
+            return gs
+        pm = np.stack([d * (masks[g] + masks[s]) for g, s in idx])
+        hm = torch.from_numpy(np.concatenate([d[None], pm])).to(model._flat_params.device)
+        pairs = [(0, k) for k in range(len(idx))]
+        seq_t = [v for k in range(len(idx)) for v in (0, 1 + k)]
+        q = model.run_pairs(2, model.gnum_rotations, hm, [0], list(range(1, len(idx) + 1)), pairs, self.image_mean, self.image_std,
+                            bn_seq_trunk=seq_t, bn_seq_head=list(range(len(idx))))
+        vals = q.reshape(-1).cpu().numpy().astype(np.float64)
+        for (g, s), v in zip(idx, vals):
+            gs[g, s] = v
+        return gs
+
     def get_label_value(self, primitive_action, objects_number,
                         suction_success, grasp_success, gs_success,
                         depth_heightmap, mask_depth, objects_mask,

@@ -357,3 +357,38 @@ def test_large_input_dense_qmap(gpu):
     ok, worst = q_close(a, b)
     assert ok, worst
     assert int(a.argmax()) == int(b.argmax())
+
+
+def test_batched_object_evaluation_equals_per_object_loop(gpu):
+    """main.py:158-192's loops in one engine call per style: same Q values,
+    same argmax, same BN buffers as the per-object Trainer.forward loop."""
+    from trainer import Trainer
+    import synthetic
+    sd = synthetic.make_state_dict(orc.state_layout(1), 1)
+
+    def fresh():
+        tr = Trainer('reinforcement', 0.5, False, None, False)
+        tr.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        tr.model.gnum_rotations = tr.model.snum_rotations = 4
+        return tr
+    depth, masks = synthetic.heightmap_scene(2)
+    masks = masks[:3]
+    a, b = fresh(), fresh()
+    conf_loop = np.stack([a.forward(depth, depth * masks[k], 1, True) for k in range(3)])
+    conf_batch = b.forward_objects(depth, masks, style=1)
+    assert conf_batch.shape == (3, 4)
+    np.testing.assert_allclose(conf_batch, conf_loop, rtol=0, atol=3e-6)
+    assert np.unravel_index(np.argmax(conf_batch), conf_batch.shape) == np.unravel_index(np.argmax(conf_loop), conf_loop.shape)
+    gs_loop = np.full((3, 3), -100.0)
+    for g in range(3):
+        for s_ in range(g + 1, 3):
+            gs_loop[g, s_] = a.forward(depth, depth * (masks[g] + masks[s_]), 2, True)[0]
+    gs_batch = b.forward_object_pairs(depth, masks)
+    np.testing.assert_allclose(gs_batch, gs_loop, rtol=0, atol=3e-6)
+    sa = {k: v.cpu() for k, v in a.model.state_dict().items()}
+    sb = {k: v.cpu() for k, v in b.model.state_dict().items()}
+    for k in ("suction_depth_trunk.features.norm0", "suction_depth_trunk.features.denseblock3.denselayer9.norm1",
+              "suctionnet_val.suction-val-norm1", "gs_depth_trunk.features.norm5"):
+        assert int(sa[k + ".num_batches_tracked"]) == int(sb[k + ".num_batches_tracked"]) > 0
+        np.testing.assert_allclose(sb[k + ".running_mean"].numpy(), sa[k + ".running_mean"].numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(sb[k + ".running_var"].numpy(), sa[k + ".running_var"].numpy(), rtol=1e-5, atol=1e-6)
