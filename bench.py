@@ -101,9 +101,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    distributed = world > 1 or ("RANK" in os.environ and os.environ.get("SMG_FORCE_ALLREDUCE"))
+    if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
@@ -124,14 +127,14 @@ def main():
     depth, masks = synthetic.heightmap_scene(rank)
     mdepth = depth * masks[0]
     labels = synthetic.uniform(rank, "bench/labels", R, 0.0, 1.5)    # both Huber branches occur
-    sync = parallel.allreduce_grads if world > 1 else None
+    sync = parallel.allreduce_grads if distributed else None
     rots = list(range(R))
 
     def step():
         return tr.train_batch(depth, mdepth, 0, rots, labels, grad_sync=sync)
 
     def barrier():
-        if world > 1:
+        if distributed:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -144,7 +147,7 @@ def main():
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         import torch.distributed as dist
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -237,7 +240,7 @@ def main():
             }
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if distributed:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -5,6 +5,8 @@ the backend is "nccl"; gloo in the CPU tests) between backward and Adam.
 The reference has no distributed code at all; this is the
 MI355X-native addition of SURVEY.md 8e.  Samples are independent - BN statistics are
 per sample - so there is no other exchange step on the path."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -32,8 +34,10 @@ def allreduce_flat(flat, segments, average=False):
     """Sum (or average) the given ranges of a flat tensor over all ranks, in place.
     One collective per contiguous range: no bucketing is needed - the ranges ARE the
     buckets (28 MB and 0.6 MB)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return
+    if dist.get_world_size() == 1 and not os.environ.get("SMG_FORCE_ALLREDUCE"):
+        return                      # (the env switch lets a 1-GPU box exercise the RCCL call path)
     for off, n in segments:
         view = flat[off:off + n]
         dist.all_reduce(view, op=dist.ReduceOp.SUM)
