@@ -424,9 +424,18 @@ struct Pool0BwdArgs {
 };
 
 __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArgs a) {
+    // Workgroup = an 8x8 tile of stem pixels x 64 channels.  The <= 5x5 pooled pixels whose windows
+    // cover the tile are finalised (BN-backward-corrected) ONCE into LDS together with their argmax;
+    // every stem pixel then picks its <= 4 windows from LDS.  (The gather straight from global memory
+    // chained argmax load -> compare -> conditional gradient load: one memory round trip per window.)
     __shared__ float prm[8 * 64];
+    __shared__ float gl[25][64];
+    __shared__ unsigned char al[25][64];
     __shared__ float red[2][16][64];
     const int n = blockIdx.y, t = threadIdx.x, cq = t & 15, slot = t >> 4;
+    const int tiles_x = a.ps.W / 8;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * 8, x0 = tx * 8;
     if (t < 64) {
         float mean, invstd;
         bn_moments(a.ssum, a.ssq, (int64_t)n * 64 + t, 1.0 / (double)a.ps.HW, a.eps, mean, invstd);
@@ -438,32 +447,60 @@ __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArgs a) {
         const float q2 = (float)(a.SB[(int64_t)n * a.sstride + t] * inv);
         prm[256 + t] = i1; prm[320 + t] = q1; prm[384 + t] = m1; prm[448 + t] = i1 * q2;
     }
+    // stem values of this thread's 4 pixels: issue early
+    float4 sv[4];
+    int64_t srow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int lp = slot + 16 * i;                       // local pixel 0..63
+        srow[i] = (int64_t)n * a.ps.HWp + (y0 + (lp >> 3)) * a.ps.W + x0 + (lp & 7);
+        sv[i] = ld4(a.stem + srow[i] * 64 + 4 * cq);
+    }
+    // pooled pixels wy in [y0/2, y0/2 + 4], wx likewise
+    const int wy0 = y0 >> 1, wx0 = x0 >> 1;
+    float4 gq[2], xq[2];
+    uchar4 aq[2];
+    bool okq[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int item = t + 256 * k;                       // 25 pooled pixels x 16 quads = 400 items
+        const int pp = item >> 4, q = item & 15;
+        const int wy = wy0 + pp / 5, wx = wx0 + pp % 5;
+        okq[k] = item < 400 && wy < a.p1.H && wx < a.p1.W;
+        const int64_t pr = (int64_t)n * a.p1.HWp + (okq[k] ? wy * a.p1.W + wx : 0);
+        gq[k] = ld4(a.G1 + pr * a.ld1 + 4 * q);
+        xq[k] = ld4(a.X1 + pr * a.ld1 + 4 * q);
+        aq[k] = *reinterpret_cast<const uchar4*>(a.argmax + pr * 64 + 4 * q);
+    }
+    __syncthreads();                                        // prm ready
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int item = t + 256 * k;
+        if (item < 400) {
+            const int pp = item >> 4, q = item & 15;
+            float4 gv = affine2(gq[k], xq[k], prm + 256 + 4 * q, 64);
+            if (!okq[k]) gv = zero4();
+            *reinterpret_cast<float4*>(&gl[pp][4 * q]) = gv;
+            *reinterpret_cast<uchar4*>(&al[pp][4 * q]) = okq[k] ? aq[k] : make_uchar4(255, 255, 255, 255);
+        }
+    }
     __syncthreads();
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int p = blockIdx.x * 64 + slot + 16 * i;
-        if (p >= a.ps.HW) continue;
-        const int y = p / a.ps.W, x = p - y * a.ps.W;
+        const int lp = slot + 16 * i;
+        const int y = y0 + (lp >> 3), x = x0 + (lp & 7);
         float g[4] = {0, 0, 0, 0};
         const int py0 = y >> 1, py1 = (y + 1) >> 1, px0 = x >> 1, px1 = (x + 1) >> 1;
         for (int wy = py0; wy <= py1; ++wy)
             for (int wx = px0; wx <= px1; ++wx) {
-                if (wy >= a.p1.H || wx >= a.p1.W) continue;
                 const int k = (y - (2 * wy - 1)) * 3 + (x - (2 * wx - 1));   // my index inside that window
-                const int64_t pr = (int64_t)n * a.p1.HWp + wy * a.p1.W + wx;
-                const uchar4 am = *reinterpret_cast<const uchar4*>(a.argmax + pr * 64 + 4 * cq);
-                const int amv[4] = {am.x, am.y, am.z, am.w};
-                if (amv[0] != k && amv[1] != k && amv[2] != k && amv[3] != k) continue;
-                const float4 gv = affine2(ld4(a.G1 + pr * a.ld1 + 4 * cq), ld4(a.X1 + pr * a.ld1 + 4 * cq),
-                                          prm + 256 + 4 * cq, 64);
-                const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+                const int pp = (wy - wy0) * 5 + (wx - wx0);
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if (amv[c] == k) g[c] += gg[c];
+                    if (al[pp][4 * cq + c] == k) g[c] += gl[pp][4 * cq + c];
             }
-        const int64_t row = (int64_t)n * a.ps.HWp + p;
-        const float4 sv = ld4(a.stem + row * 64 + 4 * cq);
-        const float st[4] = {sv.x, sv.y, sv.z, sv.w};
+        const float st[4] = {sv[i].x, sv[i].y, sv[i].z, sv[i].w};
         float dy[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -471,7 +508,7 @@ __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArgs a) {
             s1[c] += dy[c];
             s2[c] += dy[c] * ((st[c] - prm[128 + 4 * cq + c]) * prm[192 + 4 * cq + c]);
         }
-        *reinterpret_cast<float4*>(a.DY0 + row * 64 + 4 * cq) = make_float4(dy[0], dy[1], dy[2], dy[3]);
+        *reinterpret_cast<float4*>(a.DY0 + srow[i] * 64 + 4 * cq) = make_float4(dy[0], dy[1], dy[2], dy[3]);
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) { red[0][slot][4 * cq + c] = s1[c]; red[1][slot][4 * cq + c] = s2[c]; }

@@ -786,7 +786,8 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
         a.DY0 = e->DY0; a.o1 = b1(e, e->bs_stem); a.o2 = b2(e, e->bs_stem);
         a.dbeta = Gr + T.norm0.b; a.dgamma = Gr + T.norm0.w;
         ProfScope ps(e, st, K_OTHER, 0);
-        hipLaunchKernelGGL(pool0_bwd_kernel, dim3(e->p_stem.HWp / 64, NS), dim3(256), 0, st, a);
+        if (e->p_stem.H % 8 || e->p_stem.W % 8) return fail(-22, "stem plane must tile by 8 (input_size multiple of 16)");
+        hipLaunchKernelGGL(pool0_bwd_kernel, dim3((e->p_stem.H / 8) * (e->p_stem.W / 8), NS), dim3(256), 0, st, a);
     }
     {   // conv0 weight gradient (no data gradient: the image needs none)
         const Plane ps_ = e->p_stem;
