@@ -392,3 +392,47 @@ def test_batched_object_evaluation_equals_per_object_loop(gpu):
         assert int(sa[k + ".num_batches_tracked"]) == int(sb[k + ".num_batches_tracked"]) > 0
         np.testing.assert_allclose(sb[k + ".running_mean"].numpy(), sa[k + ".running_mean"].numpy(), rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(sb[k + ".running_var"].numpy(), sa[k + ".running_var"].numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_g8_reactive_gradients_and_adam(gpu, golden):
+    """Reactive net train step: weighted-CE gradients reach the same 368 tensors, with norms matching
+    the reference's (same fp32-noise yardstick as the Huber case: 3e-2 per tensor, 1e-2 in the median)."""
+    import synthetic
+    net = product_net(0, out_ch=3, R=1)
+    x, mx = scene_tensors(0, [0])
+    net.zero_grad()
+    q = net.forward(x, mx, 0, False, 0)                       # branch C, rotation 0
+    w = torch.tensor([1.0, 1.0, 0.0], device=q.device)
+    label = torch.ones((1, 1, 1), dtype=torch.long, device=q.device)
+    loss = torch.nn.functional.nll_loss(torch.log_softmax(q[0].view(1, 3, 1, 1), dim=1), label, weight=w).sum()
+    loss.backward()                                            # torch autograd on the 3 logits -> smg_backward
+    assert abs(float(loss.detach()) - float(golden["g8_loss"])) < 2e-3
+    ref = golden["g8_gradnorm"]
+    mine = np.asarray([float(p.grad.double().norm()) if p.grad is not None else 0.0 for p in net.parameters()])
+    assert ((mine > 0) == (ref > 0)).all()
+    big = ref > 1e-3 * ref.max()
+    rel = np.abs(mine[big] - ref[big]) / ref[big]
+    assert rel.max() < 5e-2 and np.median(rel) < 1e-2, (rel.max(), np.median(rel))
+
+
+def test_target_network_sync(gpu):
+    """code/main.py:352-353: model_target.load_state_dict(model.state_dict()) makes the two nets
+    bit-identical (weights AND BN buffers), on the device, without touching the model."""
+    from trainer import Trainer
+    import synthetic
+    tr = Trainer('reinforcement', 0.5, False, None, False)
+    for m in (tr.model, tr.model_target):
+        m.gnum_rotations = m.snum_rotations = 2
+    depth, masks = synthetic.heightmap_scene(3)
+    tr.backprop(depth, 'grasp', (0, 1), (0, 1), (0, 1), (0, 1), 0.7, masks.copy(), None, None, None)
+    a, b = tr.model.state_dict(), tr.model_target.state_dict()
+    assert any(not torch.equal(a[k], b[k]) for k in a)         # they have diverged (weights + BN buffers)
+    before = {k: v.clone() for k, v in a.items()}
+    tr.model_target.load_state_dict(tr.model.state_dict())
+    a, b = tr.model.state_dict(), tr.model_target.state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert all(torch.equal(a[k], before[k]) for k in a)
+    assert b["grasp_depth_trunk.features.norm0.running_mean"].is_cuda
+    q1 = tr.forward(depth, depth * masks[0], 0, True, False, 1)
+    q2 = tr.forward(depth, depth * masks[0], 0, True, True, 1)
+    assert q1[0] == q2[0]
