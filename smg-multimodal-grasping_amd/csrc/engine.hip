@@ -99,9 +99,7 @@ struct smg_engine {
     std::vector<int64_t> pk_c1[4], pk_c2f[4], pk_c2d[4]; int64_t pk_t[3] = {};
     int max_pack = 0;
     // bn update descriptors
-    BnUpdDesc* d_bnupd = nullptr; std::vector<BnUpdDesc> h_bnupd;
-    // small device arrays for the batch description
-    int* d_ints = nullptr; float* d_floats = nullptr; int ints_cap = 0, floats_cap = 0;
+    BnUpdDesc* d_bnupd = nullptr;
     // last forward
     bool have_fwd = false; int f_trunk = 0, f_head = 0, f_streams = 0, f_pairs = 0;
     int* d_stream_image = nullptr; int* d_stream_rot = nullptr; int* d_pair_a = nullptr; int* d_pair_b = nullptr;

@@ -4,10 +4,11 @@
 //
 //   D[i][j] = sum_r A(i, r) * B(r, j)       v_mfma_f32_32x32x2_f32 (exact fp32)
 //
-// Data layout: activations are NHWC fp32, one "plane" of HWp = roundup(H*W, 128)
-// pixel rows per stream, so a 128-row tile never straddles two streams and a dense
-// block is ONE buffer [stream][pixel][Ctot] that every layer appends 32 channels to
-// (torch.cat of code/models.py:386 / torchvision _DenseBlock disappears).
+// Data layout: activations are NHWC fp32, one "plane" of HWp = roundup(H*W, 64)
+// pixel rows per stream, so a 64-row (or, where HWp % 128 == 0, 128-row) tile never
+// straddles two streams and a dense block is ONE buffer [stream][pixel][Ctot] that
+// every layer appends 32 channels to (torch.cat of code/models.py:386 / torchvision
+// _DenseBlock disappears).
 //
 // LDS tiles are k-major: As[k][m], Bs[k][n], so the MFMA operand reads
 // (lane l -> A[i = l&31][k = l>>5]) are 32 consecutive floats per half-wave:
@@ -16,10 +17,16 @@
 // (BM+1); channel-major operands (weights, and both operands of a weight gradient)
 // go in with one ds_write_b128 per float4.
 //
+// Pipeline per k-tile: raw global loads of tile kt+1 are issued first and stay in
+// flight across the MFMA block of tile kt; all operand fragments of the tile are read
+// from LDS before its MFMAs; the BN / ReLU / BN-backward transform is applied when tile
+// kt+1 is written to the other LDS buffer; one barrier per k-tile.
+//
 // BatchNorm (training mode, per stream - SURVEY.md section 7) is never a kernel of
 // its own: the producer's epilogue accumulates per-(stream, channel) sum / sum of
-// squares with fp64 atomics, and every consumer turns them into scale/shift in its
-// prologue (into LDS) and applies BN + ReLU while staging the operand.
+// squares in fp64 (in-lane, then fp64 atomics), and every consumer turns them into
+// (mean, gamma*invstd, beta) in its prologue (into LDS) and applies BN + ReLU in the
+// centered form (x - mean)*scale + beta while staging the operand.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
