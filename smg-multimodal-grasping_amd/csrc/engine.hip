@@ -95,6 +95,7 @@ struct smg_engine {
     // packed weights
     float* packed = nullptr; int64_t packed_floats = 0;
     PackDesc* d_pack = nullptr; std::vector<PackDesc> h_pack[3]; std::vector<PackDesc> h_pack_head[3];
+    int pack_stride = 0, bnupd_stride = 0, n_bnupd = 0;   // d_pack / d_bnupd hold one table per (trunk, head)
     int64_t pk_conv0 = 0, pk_head0 = 0, pk_head1 = 0;
     std::vector<int64_t> pk_c1[4], pk_c2f[4], pk_c2d[4]; int64_t pk_t[3] = {};
     int max_pack = 0;
@@ -105,6 +106,9 @@ struct smg_engine {
     int* d_stream_image = nullptr; int* d_stream_rot = nullptr; int* d_pair_a = nullptr; int* d_pair_b = nullptr;
     int* d_seq_t = nullptr; int* d_seq_h = nullptr; int* d_user_ptr = nullptr; int* d_user_pair = nullptr; int* d_user_slot = nullptr;
     float* d_affine = nullptr;
+    // batch description staging: one pinned ping-pong host block -> one device block per forward
+    int* d_stage = nullptr; int* h_stage[2] = {}; hipEvent_t ev_stage[2] = {}; int stage_ints = 0, stage_turn = 0;
+    int so_image = 0, so_rot = 0, so_pa = 0, so_pb = 0, so_seq_t = 0, so_seq_h = 0, so_uptr = 0, so_upair = 0, so_uslot = 0, so_aff = 0;
     int64_t workspace_bytes = 0;
     // profiling
     bool prof = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> ev_pool;
@@ -279,15 +283,62 @@ static int engine_build(smg_engine* e) {
     e->packed_floats = pk;
     ALLOC(e->packed, pk);
     e->max_pack = (int)(e->h_pack[0].size() + e->h_pack_head[0].size());
-    ALLOC(e->d_pack, e->max_pack);
-    ALLOC(e->d_bnupd, 128);
+    // Descriptor tables are static per (trunk, head): upload all nine once, so a forward
+    // never has to wait on a host->device copy of them.
+    e->pack_stride = e->max_pack;
+    ALLOC(e->d_pack, 9 * e->pack_stride);
+    for (int t = 0; t < 3; ++t)
+        for (int hd = 0; hd < 3; ++hd) {
+            std::vector<PackDesc> v = e->h_pack[t];
+            v.insert(v.end(), e->h_pack_head[hd].begin(), e->h_pack_head[hd].end());
+            HIP_OK(hipMemcpy(e->d_pack + (t * 3 + hd) * e->pack_stride, v.data(), v.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
+        }
+    e->bnupd_stride = 128;
+    ALLOC(e->d_bnupd, 9 * e->bnupd_stride);
+    for (int t = 0; t < 3; ++t)
+        for (int hd = 0; hd < 3; ++hd) {
+            const TrunkRef& T = L.trunk[t];
+            const HeadRef& Hd = L.head[hd];
+            std::vector<BnUpdDesc> v;   // in the reference's module order
+            auto add = [&](const BnRef& r, const StatArr& s, int count, int head) {
+                BnUpdDesc d; d.rm = r.rm; d.rv = r.rv; d.nbt = r.nbt; d.stat_off = s.off; d.stride = s.stride; d.coff = 0;
+                d.C = r.C; d.count = count; d.head = head; v.push_back(d);
+            };
+            add(T.norm0, e->st_stem, e->p_stem.HW, 0);
+            for (int b = 0; b < 4; ++b) {
+                for (size_t i = 0; i < T.layers[b].size(); ++i) {
+                    add(T.layers[b][i].n1, e->st_X[b], e->p_blk[b].HW, 0);
+                    add(T.layers[b][i].n2, e->st_Bt[b][i], e->p_blk[b].HW, 0);
+                }
+                if (b < 3) add(T.tnorm[b], e->st_X[b], e->p_blk[b].HW, 0);
+            }
+            add(T.norm5, e->st_X[3], e->p_blk[3].HW, 0);
+            add(Hd.n0, e->st_F, e->p_blk[3].HW, 1);
+            add(Hd.n1, e->st_H1, e->p_blk[3].HW, 1);
+            if ((int)v.size() > e->bnupd_stride) return fail(-22, "bn descriptor table overflow");
+            e->n_bnupd = (int)v.size();
+            HIP_OK(hipMemcpy(e->d_bnupd + (t * 3 + hd) * e->bnupd_stride, v.data(), v.size() * sizeof(BnUpdDesc), hipMemcpyHostToDevice));
+        }
 
-    // batch description
+    // batch description: one device block, filled by one async copy from pinned memory
     const int R = NS > NP ? NS : NP;
-    ALLOC(e->d_stream_image, NS); ALLOC(e->d_stream_rot, NS); ALLOC(e->d_affine, 6 * NS);
-    ALLOC(e->d_pair_a, NP); ALLOC(e->d_pair_b, NP);
-    ALLOC(e->d_seq_t, 4 * R + 16); ALLOC(e->d_seq_h, 4 * R + 16);
-    ALLOC(e->d_user_ptr, NS + 1); ALLOC(e->d_user_pair, 2 * NP); ALLOC(e->d_user_slot, 2 * NP);
+    int so = 0;
+    auto carve_i = [&](int n) { int at = so; so += (n + 3) / 4 * 4; return at; };
+    e->so_image = carve_i(NS); e->so_rot = carve_i(NS); e->so_pa = carve_i(NP); e->so_pb = carve_i(NP);
+    e->so_seq_t = carve_i(4 * R + 16); e->so_seq_h = carve_i(4 * R + 16);
+    e->so_uptr = carve_i(NS + 1); e->so_upair = carve_i(2 * NP); e->so_uslot = carve_i(2 * NP);
+    e->so_aff = carve_i(6 * NS);
+    e->stage_ints = so;
+    ALLOC(e->d_stage, so);
+    e->d_stream_image = e->d_stage + e->so_image; e->d_stream_rot = e->d_stage + e->so_rot;
+    e->d_pair_a = e->d_stage + e->so_pa; e->d_pair_b = e->d_stage + e->so_pb;
+    e->d_seq_t = e->d_stage + e->so_seq_t; e->d_seq_h = e->d_stage + e->so_seq_h;
+    e->d_user_ptr = e->d_stage + e->so_uptr; e->d_user_pair = e->d_stage + e->so_upair; e->d_user_slot = e->d_stage + e->so_uslot;
+    e->d_affine = (float*)(e->d_stage + e->so_aff);
+    for (int k = 0; k < 2; ++k) {
+        HIP_OK(hipHostMalloc((void**)&e->h_stage[k], (size_t)so * sizeof(int), hipHostMallocDefault));
+        HIP_OK(hipEventCreateWithFlags(&e->ev_stage[k], hipEventDisableTiming));
+    }
     return 0;
 }
 
@@ -322,38 +373,38 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
         if (pad < 0 || 2 * B->hm_size + 2 * pad != e->S) return fail(-22, "heightmap size does not match engine input_size");
     }
 
-    // batch description -> device
-    HIP_OK(hipMemcpyAsync(e->d_stream_image, B->stream_image, NS * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(e->d_stream_rot, B->stream_rotated, NS * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(e->d_affine, B->stream_affine, 6 * NS * sizeof(float), hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(e->d_pair_a, B->pair_a, NP * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(e->d_pair_b, B->pair_b, NP * sizeof(int), hipMemcpyHostToDevice, st));
-    if (n_seq_t) HIP_OK(hipMemcpyAsync(e->d_seq_t, B->bn_seq_trunk, n_seq_t * sizeof(int), hipMemcpyHostToDevice, st));
-    if (n_seq_h) HIP_OK(hipMemcpyAsync(e->d_seq_h, B->bn_seq_head, n_seq_h * sizeof(int), hipMemcpyHostToDevice, st));
-    {   // users of each stream's features (CSR), for the backward
-        std::vector<int> ptr(NS + 1, 0), up, us;
+    {   // batch description -> device: no host synchronisation on the forward path
+        const int turn = e->stage_turn; e->stage_turn ^= 1;
+        HIP_OK(hipEventSynchronize(e->ev_stage[turn]));   // the copy issued two forwards ago (long done)
+        int* h = e->h_stage[turn];
+        memcpy(h + e->so_image, B->stream_image, NS * sizeof(int));
+        memcpy(h + e->so_rot, B->stream_rotated, NS * sizeof(int));
+        memcpy(h + e->so_aff, B->stream_affine, 6 * NS * sizeof(float));
+        memcpy(h + e->so_pa, B->pair_a, NP * sizeof(int));
+        memcpy(h + e->so_pb, B->pair_b, NP * sizeof(int));
+        if (n_seq_t) memcpy(h + e->so_seq_t, B->bn_seq_trunk, n_seq_t * sizeof(int));
+        if (n_seq_h) memcpy(h + e->so_seq_h, B->bn_seq_head, n_seq_h * sizeof(int));
+        // users of each stream's features (CSR), for the backward
+        int* ptr = h + e->so_uptr; int* up = h + e->so_upair; int* us = h + e->so_uslot; int n = 0;
+        ptr[0] = 0;
         for (int s = 0; s < NS; ++s) {
             for (int j = 0; j < NP; ++j) {
-                if (B->pair_a[j] == s) { up.push_back(j); us.push_back(0); }
-                if (B->pair_b[j] == s) { up.push_back(j); us.push_back(1); }
+                if (B->pair_a[j] == s) { up[n] = j; us[n] = 0; ++n; }
+                if (B->pair_b[j] == s) { up[n] = j; us[n] = 1; ++n; }
             }
-            ptr[s + 1] = (int)up.size();
+            ptr[s + 1] = n;
         }
-        HIP_OK(hipMemcpyAsync(e->d_user_ptr, ptr.data(), (NS + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-        HIP_OK(hipMemcpyAsync(e->d_user_pair, up.data(), up.size() * sizeof(int), hipMemcpyHostToDevice, st));
-        HIP_OK(hipMemcpyAsync(e->d_user_slot, us.data(), us.size() * sizeof(int), hipMemcpyHostToDevice, st));
-        HIP_OK(hipStreamSynchronize(st));   // host vectors go out of scope
+        HIP_OK(hipMemcpyAsync(e->d_stage, h, (size_t)e->stage_ints * sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_OK(hipEventRecord(e->ev_stage[turn], st));
     }
     HIP_OK(hipMemsetAsync(e->fstat, 0, 2 * e->fstat_span * sizeof(double), st));
 
     // weights -> K-major packs
     {
-        std::vector<PackDesc> v = e->h_pack[trunk_id];
-        v.insert(v.end(), e->h_pack_head[head_id].begin(), e->h_pack_head[head_id].end());
-        HIP_OK(hipMemcpyAsync(e->d_pack, v.data(), v.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
-        HIP_OK(hipStreamSynchronize(st));
+        const unsigned n_pack = (unsigned)(e->h_pack[trunk_id].size() + e->h_pack_head[head_id].size());
         ProfScope ps(e, st, K_OTHER, 0);
-        hipLaunchKernelGGL(pack_weights_kernel, dim3(64, (unsigned)v.size()), dim3(256), 0, st, e->d_pack, net->params, e->packed);
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(64, n_pack), dim3(256), 0, st,
+                           e->d_pack + (trunk_id * 3 + head_id) * e->pack_stride, net->params, e->packed);
     }
     const float* P = net->params;
 
@@ -490,26 +541,9 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
         hipLaunchKernelGGL(value_conv_kernel, dim3(NP * e->head_out * e->OH * e->OW), dim3(256), 0, st, a);
     }
     if (n_seq_t || n_seq_h) {   // BN running statistics, in the reference's update order
-        std::vector<BnUpdDesc> v;
-        auto add = [&](const BnRef& r, const StatArr& s, int coff, int count, int head) {
-            BnUpdDesc d; d.rm = r.rm; d.rv = r.rv; d.nbt = r.nbt; d.stat_off = s.off; d.stride = s.stride; d.coff = coff;
-            d.C = r.C; d.count = count; d.head = head; v.push_back(d);
-        };
-        add(T.norm0, e->st_stem, 0, e->p_stem.HW, 0);
-        for (int b = 0; b < 4; ++b) {
-            for (size_t i = 0; i < T.layers[b].size(); ++i) {
-                add(T.layers[b][i].n1, e->st_X[b], 0, e->p_blk[b].HW, 0);
-                add(T.layers[b][i].n2, e->st_Bt[b][i], 0, e->p_blk[b].HW, 0);
-            }
-            if (b < 3) add(T.tnorm[b], e->st_X[b], 0, e->p_blk[b].HW, 0);
-        }
-        add(T.norm5, e->st_X[3], 0, p4.HW, 0);
-        add(Hd.n0, e->st_F, 0, p4.HW, 1);
-        add(Hd.n1, e->st_H1, 0, p4.HW, 1);
-        HIP_OK(hipMemcpyAsync(e->d_bnupd, v.data(), v.size() * sizeof(BnUpdDesc), hipMemcpyHostToDevice, st));
-        HIP_OK(hipStreamSynchronize(st));
         ProfScope ps(e, st, K_OTHER, 0);
-        hipLaunchKernelGGL(bn_update_kernel, dim3(8, (unsigned)v.size()), dim3(256), 0, st, e->d_bnupd,
+        hipLaunchKernelGGL(bn_update_kernel, dim3(8, (unsigned)e->n_bnupd), dim3(256), 0, st,
+                           e->d_bnupd + (trunk_id * 3 + head_id) * e->bnupd_stride,
                            e->fstat, e->fstat + e->fstat_span, net->bufs, net->nbt, e->d_seq_t, n_seq_t, e->d_seq_h, n_seq_h);
     }
     HIP_OK(hipGetLastError());
@@ -864,9 +898,9 @@ void smg_engine_destroy(smg_engine* e) {
     (void)hipDeviceSynchronize();
     void* ptrs[] = {e->img4, e->stem, e->DY0, e->argmax, e->X[0], e->X[1], e->X[2], e->X[3], e->G[0], e->G[1], e->G[2], e->G[3],
                     e->Bt, e->D2[0], e->D2[1], e->GS[0], e->GS[1], e->part, e->F, e->DF, e->H1, e->DH1, e->fstat, e->bstat, e->packed, e->d_pack, e->d_bnupd,
-                    e->d_stream_image, e->d_stream_rot, e->d_affine, e->d_pair_a, e->d_pair_b, e->d_seq_t, e->d_seq_h,
-                    e->d_user_ptr, e->d_user_pair, e->d_user_slot};
+                    e->d_stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int k = 0; k < 2; ++k) { if (e->h_stage[k]) (void)hipHostFree(e->h_stage[k]); if (e->ev_stage[k]) (void)hipEventDestroy(e->ev_stage[k]); }
     for (int k = 0; k < 2; ++k) { if (e->ev_gs[k]) (void)hipEventDestroy(e->ev_gs[k]); if (e->ev_d2[k]) (void)hipEventDestroy(e->ev_d2[k]); if (e->ev_side[k]) (void)hipEventDestroy(e->ev_side[k]); }
     if (e->ev_misc) (void)hipEventDestroy(e->ev_misc);
     if (e->ev_end) (void)hipEventDestroy(e->ev_end);
