@@ -212,6 +212,7 @@ def main():
                 step()
             torch.cuda.synchronize(dev)
             prof = eng.profile_read()
+            stages = eng.profile_read_stages()
             eng.profile_enable(False)
             conv = {k: v for k, v in prof.items() if k != "elementwise" and v[1] > 0}
             dom = max(conv, key=lambda k: conv[k][0])
@@ -228,6 +229,9 @@ def main():
                 "elementwise_ms_per_step": prof["elementwise"][0] / n_prof,
                 "per_kernel": {k: {"ms_per_step": v[0] / n_prof, "launches_per_step": v[1] // n_prof,
                                    "tflops": (v[2] / (v[0] * 1e-3) / 1e12) if v[0] > 0 else 0.0} for k, v in prof.items() if v[1] > 0},
+                # [ms per step, TFLOP/s] inside dense block 1..4 (160^2, 80^2, 40^2, 20^2 planes at S=640)
+                "per_stage": {k: [[round(r[0] / n_prof, 4), round(r[2] / (r[0] * 1e-3) / 1e12, 2) if r[0] > 0 else 0.0] for r in rows]
+                              for k, rows in stages.items() if any(r[1] > 0 for r in rows)},
             }
         if args.cpu_samples > 0:
             cores = torch.get_num_threads()

@@ -158,7 +158,8 @@ int smg_engine_geometry(const smg_engine* e, int H[6], int HWp[6]);
  * kind in [0, smg_profile_kinds()): the MFMA convolution classes, last = everything
  * else.  smg_profile_read drains pending events (synchronises) and returns the
  * accumulated milliseconds, launch count and executed FLOPs (2*M*N*K over valid
- * pixels) of one class since smg_profile_enable. */
+ * pixels) of one class since smg_profile_enable.  kind + smg_profile_kinds()*(1+b),
+ * b in 0..3, reads the share of that class issued inside dense block b's layer loops. */
 int smg_profile_enable(smg_engine* e, int on);
 int smg_profile_kinds(void);
 const char* smg_profile_kind_name(int kind);

@@ -536,6 +536,8 @@ struct BnBwdApplyArgs {
     const double* s1; const double* s2; int sstride, scoff;
     const float* gamma; float eps;
     float* out; int ldo;
+    float* dbeta; float* dgamma;                  // if set: the affine gradients, dbeta += sum_n s1[n], dgamma += sum_n s2[n]
+                                                  // (one fp32 atomic per stream and channel instead of one per producer tile)
 };
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs a) {
@@ -550,6 +552,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs 
         prm[a.C + t] = (float)(a.s1[(int64_t)n * a.sstride + a.scoff + t] * inv);
         prm[2 * a.C + t] = mean;
         prm[3 * a.C + t] = invstd * q2;
+        if (a.dbeta && blockIdx.x == 0) {
+            atomicAdd(a.dbeta + t, (float)a.s1[(int64_t)n * a.sstride + a.scoff + t]);
+            atomicAdd(a.dgamma + t, (float)a.s2[(int64_t)n * a.sstride + a.scoff + t]);
+        }
     }
     __syncthreads();
     const int qpr = a.C / 4;                      // float4 per row

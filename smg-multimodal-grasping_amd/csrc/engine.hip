@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -65,7 +66,7 @@ static const char* kKindNames[K_COUNT] = {"stem7x7_fwd", "conv1x1_fwd", "conv3x3
                                           "transition_wgrad", "transition_dgrad", "stem_wgrad", "head_conv0_wgrad",
                                           "head_conv0_dgrad", "elementwise"};
 
-struct ProfRec { hipEvent_t a, b; int kind; double flops; };
+struct ProfRec { hipEvent_t a, b; int kind; double flops; int stage; };
 
 struct StatArr { int64_t off; int stride; };   // into a double arena: sum at off, sumsq at off + span
 
@@ -110,10 +111,15 @@ struct smg_engine {
     int* d_stage = nullptr; int* h_stage[2] = {}; hipEvent_t ev_stage[2] = {}; int stage_ints = 0, stage_turn = 0;
     int so_image = 0, so_rot = 0, so_pa = 0, so_pb = 0, so_seq_t = 0, so_seq_h = 0, so_uptr = 0, so_upair = 0, so_uslot = 0, so_aff = 0;
     int64_t workspace_bytes = 0;
+    bool generic3x3 = false;   // SMG_GENERIC_3X3=1: dense-layer 3x3 convs through the generic implicit GEMM (A/B testing)
     // profiling
     bool prof = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> ev_pool;
-    double prof_ms[K_COUNT] = {}; int64_t prof_n[K_COUNT] = {}; double prof_flops[K_COUNT] = {};
+    // totals per kind in slot 0, and the share of dense block b (kernels issued inside its layer loops) in slot 1 + b
+    double prof_ms[5][K_COUNT] = {}; int64_t prof_n[5][K_COUNT] = {}; double prof_flops[5][K_COUNT] = {}; int prof_stage = -1;
 };
+
+// Tile side of the LDS-halo 3x3 kernels for a plane: 16 where it tiles exactly, else 8 (ragged edges masked).
+static inline int halo_tile(const Plane& p) { return (p.H % 16 == 0 && p.W % 16 == 0) ? 16 : 8; }
 
 static Plane make_plane(int H, int W) {
     Plane p; p.H = H; p.W = W; p.HW = H * W; p.HWp = (p.HW + 63) / 64 * 64; return p;
@@ -143,7 +149,7 @@ struct ProfScope {
         if (e->prof) { a = prof_event(e); b = prof_event(e); (void)hipEventRecord(a, st); }
     }
     ~ProfScope() {
-        if (e->prof) { (void)hipEventRecord(b, st); e->recs.push_back({a, b, kind, flops}); }
+        if (e->prof) { (void)hipEventRecord(b, st); e->recs.push_back({a, b, kind, flops, e->prof_stage}); }
     }
 };
 
@@ -202,6 +208,13 @@ static int engine_build(smg_engine* e) {
     for (int b = 0; b < 4; ++b) { e->p_blk[b] = make_plane(h, h); h /= 2; }
     e->OH = e->OW = e->p_blk[3].H - kHeadKernel + 1;
     if (e->OH < 1) return fail(-22, "input_size too small for the 20x20 value head");
+
+    {   // the 16x16 weight-gradient halo kernel needs more than the default 64 KB of dynamic LDS
+        const int smem = (int)(HaloWgradGeo<16>::smem_floats() * sizeof(float));
+        HIP_OK(hipFuncSetAttribute((const void*)conv3x3_halo_wgrad_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    }
+    const char* g3 = getenv("SMG_GENERIC_3X3");
+    e->generic3x3 = g3 && g3[0] == '1';
 
     ALLOC(e->img4, (int64_t)NS * e->p_img.HWp * 4);
     ALLOC(e->stem, (int64_t)NS * e->p_stem.HWp * 64);
@@ -440,6 +453,7 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
         hipLaunchKernelGGL(pool0_kernel, dim3(e->p_blk[0].HWp / 64, NS), dim3(256), 0, st, a);
     }
     for (int b = 0; b < 4; ++b) {
+        e->prof_stage = b;
         const Plane pl = e->p_blk[b];
         const int Ct = kBlockCtot[b];
         for (size_t i = 0; i < T.layers[b].size(); ++i) {
@@ -459,7 +473,7 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
             };
             if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x64{});
             }
-            if (pl.H % HALO_T == 0 && pl.W % HALO_T == 0) {
+            if (!e->generic3x3) {
                 // norm2 + relu + conv2 (3x3, 128 -> 32) with an LDS-resident input halo (halo.cuh)
                 Halo3x3FwdArgs a;
                 a.src = bt; a.lds_ = kBottleneck; a.pl = pl; a.C = kBottleneck;
@@ -468,15 +482,16 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
                 a.w = e->packed + e->pk_c2f[b][i];
                 a.dst = e->X[b]; a.ldd = Ct; a.dcoff = d.cin;
                 a.dsum = fsum(e, e->st_X[b]); a.dsq = fsq(e, e->st_X[b]); a.dstride = Ct;
-                a.tiles_x = pl.W / HALO_T;
-                const size_t smem = (size_t)(HALO_A_PAD + HALO_B_FLOATS + 3 * kBottleneck) * sizeof(float);
-                static bool attr_set = false;
-                if (!attr_set) {
-                    HIP_OK(hipFuncSetAttribute((const void*)conv3x3_halo_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                    attr_set = true;
-                }
                 ProfScope ps(e, st, K_C3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
-                hipLaunchKernelGGL(conv3x3_halo_fwd_kernel, dim3((pl.H / HALO_T) * (pl.W / HALO_T), NS), dim3(256), smem, st, a);
+                if (halo_tile(pl) == 16) {
+                    a.tiles_x = pl.W / 16;
+                    hipLaunchKernelGGL(conv3x3_halo_fwd_kernel<16>, dim3((pl.H / 16) * a.tiles_x, NS), dim3(256),
+                                       HaloFwdGeo<16>::smem_floats(kBottleneck) * sizeof(float), st, a);
+                } else {
+                    a.tiles_x = (pl.W + 7) / 8;
+                    hipLaunchKernelGGL(conv3x3_halo_fwd_kernel<8>, dim3(((pl.H + 7) / 8) * a.tiles_x, NS), dim3(256),
+                                       HaloFwdGeo<8>::smem_floats(kBottleneck) * sizeof(float), st, a);
+                }
             } else {   // norm2 + relu + conv2 (3x3, 128 -> 32), appended to the block buffer (generic implicit GEMM)
                 auto run = [&](auto tag) {
                     using Cfg = decltype(tag);
@@ -508,6 +523,7 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
             if (pn.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
         }
     }
+    e->prof_stage = -1;
     const Plane p4 = e->p_blk[3];
     {   // norm5 + two-stream concat
         FeatArgs a;
@@ -639,6 +655,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
         hipLaunchKernelGGL(norm5_bwd_kernel, dim3(1, NS, (p4.HW + 15) / 16), dim3(256), 0, st, a);
     }
     for (int b = 3; b >= 0; --b) {
+        e->prof_stage = b;
         const Plane pl = e->p_blk[b];
         const int Ct = kBlockCtot[b];
         for (int i = (int)T.layers[b].size() - 1; i >= 0; --i) {
@@ -650,7 +667,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
             if (layer_no >= 2) HIP_OK(hipStreamWaitEvent(st, e->ev_side[db], 0));   // side stream done with these buffers (2 layers ago)
             ++layer_no;
             {   // finalize this layer's output-slice gradient once: GS = invstd*(G' - SA/n - xhat*SB/n)
-                BnBwdApplyArgs a;
+                BnBwdApplyArgs a{};
                 a.g = e->G[b]; a.ldg = Ct; a.gcoff = d.cin; a.x = e->X[b]; a.ldx = Ct; a.xcoff = d.cin; a.pl = pl; a.C = kGrowth;
                 a.xsum = fsum(e, e->st_X[b]); a.xsq = fsq(e, e->st_X[b]); a.xstride = Ct;
                 a.s1 = b1(e, e->bs_X[b]); a.s2 = b2(e, e->bs_X[b]); a.sstride = Ct; a.scoff = d.cin; a.gamma = nullptr; a.eps = kEps;
@@ -659,17 +676,23 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(pl.HWp / 64, NS), dim3(256), 0, st, a);
             }
             if (fork(e->ev_gs[db])) return -5;
-            if (pl.H % HALO_T == 0 && pl.W % HALO_T == 0) {
+            if (!e->generic3x3) {
                 // conv2 (3x3) data gradient with the gradient halo resident in LDS (halo.cuh)
                 Halo3x3DgradArgs a;
                 a.g = GSb; a.pl = pl; a.w = e->packed + e->pk_c2d[b][i]; a.C = kBottleneck;
                 a.mbuf = bt; a.msum = fsum(e, e->st_Bt[b][i]); a.msq = fsq(e, e->st_Bt[b][i]); a.mstride = kBottleneck;
                 a.gamma = P + d.n2.w; a.beta = P + d.n2.b; a.eps = kEps;
                 a.dst = D2b; a.o1 = b1(e, e->bs_Bt[b][i]); a.o2 = b2(e, e->bs_Bt[b][i]); a.ostride = kBottleneck;
-                a.dbeta = Gr + d.n2.b; a.dgamma = Gr + d.n2.w; a.tiles_x = pl.W / HALO_T;
-                const size_t smem = (size_t)(HD_A_FLOATS + HD_B_FLOATS + 4 * kBottleneck + 256) * sizeof(float);
                 ProfScope ps(e, st, K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
-                hipLaunchKernelGGL(conv3x3_halo_dgrad_kernel, dim3((pl.H / HALO_T) * (pl.W / HALO_T), NS), dim3(256), smem, st, a);
+                if (halo_tile(pl) == 16) {
+                    a.tiles_x = pl.W / 16; a.cg_per_wg = kBottleneck / 32;
+                    hipLaunchKernelGGL(conv3x3_halo_dgrad_kernel<16>, dim3((pl.H / 16) * a.tiles_x, NS), dim3(256),
+                                       HaloDgradGeo<16>::smem_floats(kBottleneck) * sizeof(float), st, a);
+                } else {
+                    a.tiles_x = (pl.W + 7) / 8; a.cg_per_wg = 1;      // small planes: one 64-channel group per workgroup
+                    hipLaunchKernelGGL(conv3x3_halo_dgrad_kernel<8>, dim3(((pl.H + 7) / 8) * a.tiles_x, NS, kBottleneck / 64), dim3(256),
+                                       HaloDgradGeo<8>::smem_floats(kBottleneck) * sizeof(float), st, a);
+                }
             } else {   // conv2 (3x3) data gradient -> dy of relu2/norm2 (D2) + norm2 sums (generic implicit GEMM)
                 auto run = [&](auto tag) {
                     using Cfg = decltype(tag);
@@ -686,27 +709,29 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 };
                 if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
             }
-            if (pl.H % HALO_T == 0 && pl.W % HALO_T == 0) {
+            if (!e->generic3x3) {
                 // conv2 weight gradient with the activation halo resident in LDS (halo.cuh)
+                const int ts = halo_tile(pl);
                 Halo3x3WgradArgs a;
                 a.g = GSb; a.pl = pl; a.src = bt; a.C = kBottleneck;
                 a.ssum = fsum(e, e->st_Bt[b][i]); a.ssq = fsq(e, e->st_Bt[b][i]); a.sstride = kBottleneck;
                 a.gamma = P + d.n2.w; a.beta = P + d.n2.b; a.eps = kEps;
-                a.part = e->part; a.tiles_x = pl.W / HALO_T; a.n_tiles = (pl.H / HALO_T) * (pl.W / HALO_T);
-                int groups = (768 + 4 * NS - 1) / (4 * NS);                 // ~768 workgroups
+                a.part = e->part; a.tiles_x = (pl.W + ts - 1) / ts; a.n_tiles = ((pl.H + ts - 1) / ts) * a.tiles_x;
+                // ~768 workgroups of 16x16 tiles; the 8x8 variant does a quarter of the work per tile, so it
+                // takes longer runs (fewer 36 KB partial blocks to write and re-read)
+                int groups = ((ts == 16 ? 768 : 384) + 4 * NS - 1) / (4 * NS);
                 if (groups > a.n_tiles) groups = a.n_tiles;
                 a.tiles_per_wg = (a.n_tiles + groups - 1) / groups;
                 groups = (a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
                 if ((int64_t)groups * NS * 9 * 32 * kBottleneck > e->part_floats) return fail(-12, "partial-gradient workspace too small");
-                const size_t smem = (size_t)(HW_B_FLOATS + HW_A_FLOATS + 96) * sizeof(float);
-                static bool attr_set = false;
-                if (!attr_set) {
-                    HIP_OK(hipFuncSetAttribute((const void*)conv3x3_halo_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                    attr_set = true;
-                }
                 {
                     ProfScope ps(e, s2, K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
-                    hipLaunchKernelGGL(conv3x3_halo_wgrad_kernel, dim3(groups, kBottleneck / 32, NS), dim3(256), smem, s2, a);
+                    if (ts == 16)
+                        hipLaunchKernelGGL(conv3x3_halo_wgrad_kernel<16>, dim3(groups, kBottleneck / 32, NS), dim3(256),
+                                           HaloWgradGeo<16>::smem_floats() * sizeof(float), s2, a);
+                    else
+                        hipLaunchKernelGGL(conv3x3_halo_wgrad_kernel<8>, dim3(groups, kBottleneck / 32, NS), dim3(256),
+                                           HaloWgradGeo<8>::smem_floats() * sizeof(float), s2, a);
                 }
                 ReduceArgs r;
                 r.part = e->part; r.Z = groups * NS; r.taps = 9; r.rows = kGrowth; r.cols = kBottleneck; r.ldp = kBottleneck;
@@ -726,11 +751,12 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 launch_wgrad(e, s2, p, dim3(1, 1, 9 * NS * cps), K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth, 9, C_3x3);
             }
             {   // norm2 backward applied once, in place: D2 <- gamma2*invstd*(dy - s1/n - xhat*s2/n)
-                BnBwdApplyArgs a;
+                BnBwdApplyArgs a{};
                 a.g = D2b; a.ldg = kBottleneck; a.gcoff = 0; a.x = bt; a.ldx = kBottleneck; a.xcoff = 0; a.pl = pl; a.C = kBottleneck;
                 a.xsum = fsum(e, e->st_Bt[b][i]); a.xsq = fsq(e, e->st_Bt[b][i]); a.xstride = kBottleneck;
                 a.s1 = b1(e, e->bs_Bt[b][i]); a.s2 = b2(e, e->bs_Bt[b][i]); a.sstride = kBottleneck; a.scoff = 0;
                 a.gamma = P + d.n2.w; a.eps = kEps; a.out = D2b; a.ldo = kBottleneck;
+                if (!e->generic3x3) { a.dbeta = Gr + d.n2.b; a.dgamma = Gr + d.n2.w; }   // the halo dgrad leaves these to us
                 ProfScope ps(e, st, K_OTHER, 0);
                 hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(pl.HWp / 64, NS), dim3(256), 0, st, a);
             }
@@ -807,6 +833,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
             }
         }
     }
+    e->prof_stage = -1;
     {   // pool0 / relu0 backward + norm0 sums
         Pool0BwdArgs a;
         a.G1 = e->G[0]; a.X1 = e->X[0]; a.ld1 = kBlockCtot[0]; a.p1 = e->p_blk[0];
@@ -990,7 +1017,8 @@ int smg_profile_enable(smg_engine* e, int on) {
     e->prof = on != 0;
     for (auto& r : e->recs) { e->ev_pool.push_back(r.a); e->ev_pool.push_back(r.b); }
     e->recs.clear();
-    for (int k = 0; k < K_COUNT; ++k) { e->prof_ms[k] = 0; e->prof_n[k] = 0; e->prof_flops[k] = 0; }
+    for (int s = 0; s < 5; ++s)
+        for (int k = 0; k < K_COUNT; ++k) { e->prof_ms[s][k] = 0; e->prof_n[s][k] = 0; e->prof_flops[s][k] = 0; }
     return 0;
 }
 
@@ -999,17 +1027,24 @@ const char* smg_profile_kind_name(int kind) { return (kind >= 0 && kind < K_COUN
 
 // Drains the recorded events (synchronises them) and returns the totals of one kind.
 int smg_profile_read(smg_engine* e, int kind, double* ms, int64_t* launches, double* flops) {
-    if (!e || kind < 0 || kind >= K_COUNT) return fail(-22, "bad profile query");
+    if (!e || kind < 0 || kind >= 5 * K_COUNT) return fail(-22, "bad profile query");
     for (auto& r : e->recs) {
         float t = 0.f;
         (void)hipEventSynchronize(r.b);
-        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { e->prof_ms[r.kind] += t; e->prof_n[r.kind] += 1; e->prof_flops[r.kind] += r.flops; }
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            const int slots[2] = {0, r.stage + 1};
+            for (int q = 0; q < (r.stage >= 0 ? 2 : 1); ++q) {
+                const int s = slots[q];
+                e->prof_ms[s][r.kind] += t; e->prof_n[s][r.kind] += 1; e->prof_flops[s][r.kind] += r.flops;
+            }
+        }
         e->ev_pool.push_back(r.a); e->ev_pool.push_back(r.b);
     }
     e->recs.clear();
-    if (ms) *ms = e->prof_ms[kind];
-    if (launches) *launches = e->prof_n[kind];
-    if (flops) *flops = e->prof_flops[kind];
+    const int slot = kind / K_COUNT; kind %= K_COUNT;
+    if (ms) *ms = e->prof_ms[slot][kind];
+    if (launches) *launches = e->prof_n[slot][kind];
+    if (flops) *flops = e->prof_flops[slot][kind];
     return 0;
 }
 

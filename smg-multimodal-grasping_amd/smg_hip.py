@@ -203,6 +203,21 @@ class Engine(object):
             out[L.smg_profile_kind_name(k).decode()] = (ms.value, n.value, fl.value)
         return out
 
+    def profile_read_stages(self):
+        """{kind_name: [(ms, launches, flops) for dense block 1..4]} -- the share of each dense block
+        (kind ids kinds*(1+block) + kind of smg_profile_read)."""
+        L = lib()
+        out = {}
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        K = L.smg_profile_kinds()
+        for k in range(K):
+            rows = []
+            for b in range(4):
+                check(L.smg_profile_read(self.h, K * (1 + b) + k, C.byref(ms), C.byref(n), C.byref(fl)))
+                rows.append((ms.value, n.value, fl.value))
+            out[L.smg_profile_kind_name(k).decode()] = rows
+        return out
+
 
 def adam_step(params, grads, m, v, offset, count, step, lr, beta1, beta2, eps, stream):
     check(lib().smg_adam_step(params, grads, m, v, offset, count, step, lr, beta1, beta2, eps, stream))
