@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/smg_hip.h"
@@ -572,8 +573,8 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
 // ------------------------------------------------------------------------------------
 // Pixel-chunk size of a weight-gradient launch: enough workgroups to fill the chip
 // (~768) but no more - every workgroup ends with one fp32 atomicAdd per output element.
-static void pick_chunk(const Plane& pl, int n_planes, int tiles_per_chunk, int& chunk, int& cps) {
-    const int want = (768 + tiles_per_chunk - 1) / tiles_per_chunk;
+static void pick_chunk(const Plane& pl, int n_planes, int tiles_per_chunk, int& chunk, int& cps, int target = 768) {
+    const int want = (target + tiles_per_chunk - 1) / tiles_per_chunk;
     cps = (want + n_planes - 1) / n_planes;
     if (cps < 1) cps = 1;
     chunk = ((pl.HWp + cps - 1) / cps + 63) / 64 * 64;
@@ -777,17 +778,20 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 };
                 if (pl.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
             }
-            {   // conv1 weight gradient
+            {   // conv1 weight gradient.  ~384 workgroups: it shares the chip with the data-gradient chain on the other
+                // stream, and every workgroup ends with 128 x 64 fp32 atomics (measured: atomics beat partial tiles here)
+                using Cfg = CfgW128x64;
+                const int nt = (d.cin + Cfg::BN - 1) / Cfg::BN;
                 int chunk, cps;
-                pick_chunk(pl, NS, (d.cin + 63) / 64, chunk, cps);
-                BwdWeightP<CfgW128x64, W_ONE, C_IDENT> p{};
+                pick_chunk(pl, NS, nt, chunk, cps, 384);
+                BwdWeightP<Cfg, W_ONE, C_IDENT> p{};
                 p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck;
                 p.bbuf = e->X[b]; p.ldb = Ct; p.pb = pl; p.NB = d.cin;
                 p.bsum = fsum(e, e->st_X[b]); p.bsq = fsq(e, e->st_X[b]); p.bstride = Ct;
                 p.bgamma = P + d.n1.w; p.bbeta = P + d.n1.b; p.eps = kEps;
                 p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
                 p.dw = Gr + d.c1.w; p.ldw_out = d.cin;
-                launch_wgrad(e, s2, p, dim3(1, (d.cin + 63) / 64, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck, 1, C_IDENT, false);   // measured: atomics beat partials here
+                launch_wgrad(e, s2, p, dim3(1, nt, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck, 1, C_IDENT, false);
                 HIP_OK(hipEventRecord(e->ev_side[db], s2));
             }
         }

@@ -58,6 +58,9 @@ struct GemmCfg {
     static constexpr int B_Q = BN / 4;
     static constexpr int B_STEP = 256 / B_Q;
     static constexpr int B_N = (BK + B_STEP - 1) / B_STEP;
+    // every staging slot of a thread maps inside the tile (no run-time range check, which would also make
+    // hipcc drain vmcnt between the load groups of one k-tile)
+    static constexpr bool A_FULL = A_LINES % A_STEP == 0, B_FULL = BK % B_STEP == 0;
     static constexpr int RED_FLOATS = (WK - 1) * WM * WN * TM * TN * 16 * 64;
     static constexpr int TILE_FLOATS = (2 * A_FLOATS + 2 * B_FLOATS) > RED_FLOATS ? (2 * A_FLOATS + 2 * B_FLOATS) : RED_FLOATS;
     static constexpr int AB_FLOATS = 2 * A_FLOATS + 2 * B_FLOATS;
@@ -189,8 +192,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const P p) {
 
     const int aq = t % C::A_Q, al = t / C::A_Q;
     const int bq = t % C::B_Q, bl = t / C::B_Q;
-    typename P::ARaw ra[C::A_N];
-    typename P::BRaw rb[C::B_N];
+    // Register ring of PD k-tiles in flight (global loads issued PD tiles ahead of their LDS store).
+    constexpr int PD = P::kPrefetch;
+    typename P::ARaw ra[PD][C::A_N];
+    typename P::BRaw rb[PD][C::B_N];
     typename P::ARow arow[C::A_N];
     typename P::DRow da[C::A_N], db[C::B_N];
     if constexpr (C::AT) {
@@ -203,56 +208,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(const P p) {
 #pragma unroll
     for (int i = 0; i < C::B_N; ++i) p.d_init(ctx, db[i], bl + i * C::B_STEP);
 
-    auto g_load = [&](int kt) {
+    auto g_load = [&](int kt, typename P::ARaw (&xa)[C::A_N], typename P::BRaw (&xb)[C::B_N]) {
 #pragma unroll
         for (int i = 0; i < C::A_N; ++i) {
             if constexpr (C::AT) {
-                ra[i] = p.a_fetch(ctx, arow[i], kt, aq);
+                xa[i] = p.a_fetch(ctx, arow[i], kt, aq);
             } else {
                 const int kr = al + i * C::A_STEP;
-                if (kr < C::BK) ra[i] = p.a_fetch_d(ctx, da[i], kt, kr, aq);
+                if (C::A_FULL || kr < C::BK) xa[i] = p.a_fetch_d(ctx, da[i], kt, kr, aq);
                 p.d_next(ctx, da[i]);
             }
         }
 #pragma unroll
         for (int i = 0; i < C::B_N; ++i) {
             const int kr = bl + i * C::B_STEP;
-            if (kr < C::BK) rb[i] = p.b_fetch(ctx, db[i], kt, kr, bq);
+            if (C::B_FULL || kr < C::BK) xb[i] = p.b_fetch(ctx, db[i], kt, kr, bq);
             p.d_next(ctx, db[i]);
         }
     };
-    auto s_store = [&](int buf, int kt) {          // transform (BN / ReLU / BN-backward) + LDS store of k-tile kt
+    // transform (BN / ReLU / BN-backward) + LDS store of k-tile kt
+    auto s_store = [&](int buf, int kt, const typename P::ARaw (&xa)[C::A_N], const typename P::BRaw (&xb)[C::B_N]) {
         float* A = As + buf * C::A_FLOATS;
         float* B = Bs + buf * C::B_FLOATS;
 #pragma unroll
         for (int i = 0; i < C::A_N; ++i) {
             if constexpr (C::AT) {
                 const int row = al + i * C::A_STEP;
-                const float4 v = p.a_xform(ctx, ra[i], kt, aq, sp);
+                const float4 v = p.a_xform(ctx, xa[i], kt, aq, sp);
                 A[(aq * 4 + 0) * C::LDA + row] = v.x;
                 A[(aq * 4 + 1) * C::LDA + row] = v.y;
                 A[(aq * 4 + 2) * C::LDA + row] = v.z;
                 A[(aq * 4 + 3) * C::LDA + row] = v.w;
             } else {
                 const int kr = al + i * C::A_STEP;
-                if (kr < C::BK) *reinterpret_cast<float4*>(&A[kr * C::LDA + aq * 4]) = p.a_xform(ctx, ra[i], kt, aq, sp);
+                if (C::A_FULL || kr < C::BK) *reinterpret_cast<float4*>(&A[kr * C::LDA + aq * 4]) = p.a_xform(ctx, xa[i], kt, aq, sp);
             }
         }
 #pragma unroll
         for (int i = 0; i < C::B_N; ++i) {
             const int kr = bl + i * C::B_STEP;
-            if (kr < C::BK) *reinterpret_cast<float4*>(&B[kr * C::LDB + bq * 4]) = p.b_xform(ctx, rb[i], kt, bq, sp);
+            if (C::B_FULL || kr < C::BK) *reinterpret_cast<float4*>(&B[kr * C::LDB + bq * 4]) = p.b_xform(ctx, xb[i], kt, bq, sp);
         }
     };
-
-    if (KT > 0) {
-        g_load(0);
-        s_store(0, 0);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) g_load(kt + 1);  // global loads in flight across the MFMA block
+    auto compute = [&](int buf) {
         const float* A = As + buf * C::A_FLOATS + (wk * C::KK * 2 + half) * C::LDA + wm0 + l31;
         const float* B = Bs + buf * C::B_FLOATS + (wk * C::KK * 2 + half) * C::LDB + wn0 + l31;
         // All operand fragments of this wave's k-slice first (one LDS round trip per k-tile,
@@ -274,8 +272,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const P p) {
                 for (int j = 0; j < C::TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < KT) s_store(buf ^ 1, kt + 1);
-        __syncthreads();
+    };
+
+#pragma unroll
+    for (int u = 0; u < PD; ++u)
+        if (u < KT) g_load(u, ra[u], rb[u]);
+    if (KT > 0) s_store(0, 0, ra[0], rb[0]);
+    __syncthreads();
+    for (int kt0 = 0; kt0 < KT; kt0 += PD) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            const int kt = kt0 + u;
+            if (kt < KT) {
+                const int buf = kt & 1;
+                if (kt + PD < KT) g_load(kt + PD, ra[u], rb[u]);   // slot u was stored to LDS one iteration ago
+                compute(buf);
+                if (kt + 1 < KT) s_store(buf ^ 1, kt + 1, ra[(u + 1) % PD], rb[(u + 1) % PD]);
+                __syncthreads();
+            }
+        }
     }
     if constexpr (C::WK > 1) {              // in-block split-K: fold the partial tiles into the wk == 0 waves
         constexpr int PER = C::TM * C::TN * 16 * 64;
@@ -335,6 +350,7 @@ struct FwdConvP {
     double* dsum; double* dsq; int dstride;
     TileMap tm;
     static constexpr int kSwizzle = 1;
+    static constexpr int kPrefetch = 1;
 
     struct Ctx { int n, m0, n0; };
     struct ARow { int y, x; bool valid; };
@@ -503,6 +519,7 @@ struct BwdDataP {
     float eps;
     TileMap tm;
     static constexpr int kSwizzle = 1;
+    static constexpr int kPrefetch = 1;
 
     struct Ctx { int n, m0, n0; };
     struct ARow { int y, x; bool valid; };
@@ -690,7 +707,7 @@ struct BwdDataP {
 enum { W_ONE = 0, W_THREE = 1, W_POOL = 2, W_STEM = 3 };
 enum { C_IDENT = 0, C_3x3 = 1, C_STEM = 2 };
 
-template <class Cfg_, int BMODE, int CMAP>
+template <class Cfg_, int BMODE, int CMAP, int PD_ = 1>
 struct BwdWeightP {
     using Cfg = Cfg_;
     const float* gbuf; int ldg; int gcoff;
@@ -710,6 +727,7 @@ struct BwdWeightP {
     int gx, gy;                               // tile grid (M tiles x N tiles) of one pixel chunk
     TileMap tm;
     static constexpr int kSwizzle = 2;
+    static constexpr int kPrefetch = PD_;     // k-tiles of global loads in flight per thread
 
     struct Ctx { int n, p0, m0, n0, tap, kt, z; };
     struct ARow { int dummy; };
@@ -724,8 +742,17 @@ struct BwdWeightP {
     }
     __device__ void d_next(const Ctx&, DRow& r) const {
         r.p += Cfg::BK;
-        r.x += Cfg::BK;
-        while (r.x >= pa.W) { r.x -= pa.W; ++r.y; }
+        if constexpr (BMODE != W_ONE) {      // (y, x) only matter to the spatial modes
+            // Branch-free: a data-dependent loop here makes hipcc drain vmcnt between the load groups of one
+            // k-tile (three serialised memory round trips per tile).  BK <= 32 and W >= 20: two wraps at most.
+            r.x += Cfg::BK;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const bool wrap = r.x >= pa.W;
+                r.x -= wrap ? pa.W : 0;
+                r.y += wrap ? 1 : 0;
+            }
+        }
     }
     __device__ bool init(Ctx& c, float* sp) const {
         int z = blockIdx.z, tile = blockIdx.y * gx + blockIdx.x;

@@ -113,14 +113,16 @@ __global__ __launch_bounds__(256, TS == 16 ? 3 : 4) void conv3x3_halo_fwd_kernel
     auto g_load = [&](int chunk) {
         const int c0 = chunk * HALO_CK;
 #pragma unroll
+        // Unconditional loads from clamped addresses (out-of-image slots read pixel 0 and are zeroed at the
+        // LDS store): a branch around a load makes hipcc drain vmcnt(0) in the middle of the load group.
         for (int i = 0; i < A_N; ++i)
-            ra[i] = (a_off[i] >= 0) ? ld4(src_n + (int64_t)a_off[i] * a.lds_ + c0 + 4 * a_kq[i]) : zero4();
+            ra[i] = ld4(src_n + (int64_t)(a_off[i] < 0 ? 0 : a_off[i]) * a.lds_ + c0 + 4 * a_kq[i]);
 #pragma unroll
         for (int i = 0; i < HALO_B_N; ++i) {
-            const int idx = t + 256 * i;
+            const int idx = min(t + 256 * i, 9 * HALO_CK * 8 - 1);
             const int row = idx >> 3, q = idx & 7;                 // row = tap*16 + cc
             const int tap = row >> 4, cc = row & 15;
-            rb[i] = (idx < 9 * HALO_CK * 8) ? ld4(a.w + ((int64_t)(tap * C + c0 + cc)) * 32 + 4 * q) : zero4();
+            rb[i] = ld4(a.w + ((int64_t)(tap * C + c0 + cc)) * 32 + 4 * q);
         }
     };
     auto s_store = [&](int chunk) {
@@ -325,7 +327,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
             const int hy = hp / G::W, hx = hp - hy * G::W;
             const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
             const bool ok = idx < G::PX * 8 && (unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W;
-            rv[i] = ok ? ld4(g_n + (int64_t)(iy * a.pl.W + ix) * 32 + 4 * q) : zero4();
+            const float4 v = ld4(g_n + (int64_t)(ok ? iy * a.pl.W + ix : 0) * 32 + 4 * q);   // unconditional load, clamped address
+            rv[i] = ok ? v : zero4();
         }
 #pragma unroll
         for (int i = 0; i < A_N; ++i) {
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const Halo3x
                 const int hy = hp / G::W, hx = hp - hy * G::W;
                 const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
                 okv[i] = idx < G::PX * 8 && (unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W;
-                rv[i] = okv[i] ? ld4(src_n + (int64_t)(iy * a.pl.W + ix) * C + 4 * q) : zero4();
+                rv[i] = ld4(src_n + (int64_t)(okv[i] ? iy * a.pl.W + ix : 0) * C + 4 * q);   // unconditional, clamped; zeroed at the store
             }
 #pragma unroll
             for (int i = 0; i < AP; ++i) {
@@ -534,7 +537,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const Halo3x
                 const int px = idx >> 3, q = idx & 7;
                 const int py = y0 + px / TS, pxx = x0 + px % TS;
                 const bool ok = TS == 16 || (py < a.pl.H && pxx < a.pl.W);     // TS == 8 tiles may hang over the edge
-                rg[i] = ok ? ld4(g_n + ((int64_t)py * a.pl.W + pxx) * 32 + 4 * q) : zero4();
+                const float4 v = ld4(g_n + (ok ? (int64_t)py * a.pl.W + pxx : 0) * 32 + 4 * q);
+                rg[i] = ok ? v : zero4();
             }
 #pragma unroll
             for (int i = 0; i < BP; ++i) {
