@@ -7,6 +7,7 @@
 //   torch.optim.Adam.step                              code/trainer.py:383
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -67,6 +68,11 @@ static const char* kKindNames[K_COUNT] = {"stem7x7_fwd", "conv1x1_fwd", "conv3x3
                                           "transition_wgrad", "transition_dgrad", "stem_wgrad", "head_conv0_wgrad",
                                           "head_conv0_dgrad", "elementwise"};
 
+// Backward ring: the finished bottleneck gradients (D2) of one layer group stay alive until the group's joint
+// 1x1 data-gradient kernel has read them, while the side stream may still be two layers behind.
+constexpr int kGroup = GROUP_MAX;          // dense layers per 1x1-dgrad group
+constexpr int kRing = kGroup + 2;
+
 struct ProfRec { hipEvent_t a, b; int kind; double flops; int stage; };
 
 struct StatArr { int64_t off; int stride; };   // into a double arena: sum at off, sumsq at off + span
@@ -86,9 +92,9 @@ struct smg_engine {
     unsigned char* argmax = nullptr;
     float* F = nullptr; float* H1 = nullptr;
     // gradients
-    float* G[4] = {}; float* GS[2] = {}; float* D2[2] = {}; float* part = nullptr; int64_t part_floats = 0;
+    float* G[4] = {}; float* GS[kRing] = {}; float* D2[kRing] = {}; float* part = nullptr; int64_t part_floats = 0;
     // second stream for the weight-gradient kernels (independent of the data-gradient chain)
-    hipStream_t side = nullptr; hipEvent_t ev_gs[2] = {}, ev_d2[2] = {}, ev_side[2] = {}, ev_misc = nullptr, ev_end = nullptr; float* DY0 = nullptr; float* DH1 = nullptr; float* DF = nullptr;
+    hipStream_t side = nullptr; hipEvent_t ev_gs[kRing] = {}, ev_d2[kRing] = {}, ev_side[kRing] = {}, ev_misc = nullptr, ev_end = nullptr; float* DY0 = nullptr; float* DH1 = nullptr; float* DF = nullptr;
     // statistics arenas (doubles). fwd: [sum | sumsq] halves; bwd: [s1 | s2] halves
     double* fstat = nullptr; int64_t fstat_span = 0;
     double* bstat = nullptr; int64_t bstat_span = 0;
@@ -231,7 +237,7 @@ static int engine_build(smg_engine* e) {
         }
     }
     ALLOC(e->Bt, bt_total);
-    for (int k = 0; k < 2; ++k) {   // double-buffered so the main stream never waits for the side stream's previous layer
+    for (int k = 0; k < kRing; ++k) {   // ring: see kRing
         ALLOC(e->D2[k], (int64_t)NS * e->p_blk[0].HWp * kBottleneck);
         ALLOC(e->GS[k], (int64_t)NS * e->p_blk[0].HWp * kGrowth);
         HIP_OK(hipEventCreateWithFlags(&e->ev_gs[k], hipEventDisableTiming));
@@ -662,10 +668,10 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
         for (int i = (int)T.layers[b].size() - 1; i >= 0; --i) {
             const DenseLayerRef& d = T.layers[b][i];
             float* bt = e->Bt + e->bt_off[b][i];
-            const int db = layer_no & 1;
+            const int db = layer_no % kRing;
             float* GSb = e->GS[db];
             float* D2b = e->D2[db];
-            if (layer_no >= 2) HIP_OK(hipStreamWaitEvent(st, e->ev_side[db], 0));   // side stream done with these buffers (2 layers ago)
+            if (layer_no >= kRing) HIP_OK(hipStreamWaitEvent(st, e->ev_side[db], 0));   // side stream done with these buffers (kRing layers ago)
             ++layer_no;
             {   // finalize this layer's output-slice gradient once: GS = invstd*(G' - SA/n - xhat*SB/n)
                 BnBwdApplyArgs a{};
@@ -718,12 +724,21 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 a.ssum = fsum(e, e->st_Bt[b][i]); a.ssq = fsq(e, e->st_Bt[b][i]); a.sstride = kBottleneck;
                 a.gamma = P + d.n2.w; a.beta = P + d.n2.b; a.eps = kEps;
                 a.part = e->part; a.tiles_x = (pl.W + ts - 1) / ts; a.n_tiles = ((pl.H + ts - 1) / ts) * a.tiles_x;
-                // ~768 workgroups of 16x16 tiles; the 8x8 variant does a quarter of the work per tile, so it
-                // takes longer runs (fewer 36 KB partial blocks to write and re-read)
-                int groups = ((ts == 16 ? 768 : 384) + 4 * NS - 1) / (4 * NS);
-                if (groups > a.n_tiles) groups = a.n_tiles;
-                a.tiles_per_wg = (a.n_tiles + groups - 1) / groups;
-                groups = (a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+                // Tiles per workgroup: the launch runs in rounds of 512 resident workgroups (2 per CU), each lasting
+                // tiles_per_wg tile-times plus a fixed prologue + 9-tap flush (~0.6 of a 16x16 tile-time, measured);
+                // take the run length with the shortest total (e.g. 100 tiles x 17 streams -> 7, 25 tiles -> 4).
+                {
+                    const double fix = ts == 16 ? 0.6 : 2.4;
+                    double best = 1e30;
+                    a.tiles_per_wg = 1;
+                    for (int tpw = 1; tpw <= a.n_tiles; ++tpw) {
+                        const int g = (a.n_tiles + tpw - 1) / tpw;
+                        const int rounds = (g * (kBottleneck / 32) * NS + 511) / 512;
+                        const double cost = rounds * (tpw + fix);
+                        if (cost < best - 1e-9) { best = cost; a.tiles_per_wg = tpw; }
+                    }
+                }
+                const int groups = (a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
                 if ((int64_t)groups * NS * 9 * 32 * kBottleneck > e->part_floats) return fail(-12, "partial-gradient workspace too small");
                 {
                     ProfScope ps(e, s2, K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
@@ -762,19 +777,49 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(pl.HWp / 64, NS), dim3(256), 0, st, a);
             }
             if (fork(e->ev_d2[db])) return -5;
-            {   // conv1 (1x1) data gradient -> relu1/norm1 backward accumulated into G'
+            // conv1 (1x1) data gradient -> relu1/norm1 backward accumulated into G'.  Layers are grouped (kGroup,
+            // from the top of the block): inside a group only the channels the group itself produced - needed by
+            // the very next layer - are accumulated per layer; everything below the group's lowest layer is done
+            // once for the whole group by BwdDataGroupP (gemm.cuh), which touches G' and x once instead of once
+            // per layer.
+            const int L = (int)T.layers[b].size();
+            const int g_lo = i - ((L - 1 - i) % kGroup == kGroup - 1 ? 0 : std::min(i, kGroup - 1 - (L - 1 - i) % kGroup));
+            const int cs = T.layers[b][g_lo].cin;                       // channels below the group
+            if (d.cin > cs) {                                           // [cs, cin): per-layer accumulate
                 auto run = [&](auto tag) {
                     using Cfg = decltype(tag);
                     BwdDataP<Cfg, false, E_ACCUM> p{};
                     p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kBottleneck;
-                    p.w = P + d.c1.w; p.ldw = d.cin; p.N = d.cin;
-                    p.mbuf = e->X[b]; p.ldm = Ct; p.mcoff = 0; p.pm = pl;
+                    p.w = P + d.c1.w + cs; p.ldw = d.cin; p.N = d.cin - cs;
+                    p.mbuf = e->X[b]; p.ldm = Ct; p.mcoff = cs; p.pm = pl;
                     p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct;
-                    p.egamma = P + d.n1.w; p.ebeta = P + d.n1.b;
-                    p.dst = e->G[b]; p.ldd = Ct; p.dcoff = 0;
-                    p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.ocoff = 0;
-                    p.dbeta = Gr + d.n1.b; p.dgamma = Gr + d.n1.w; p.eps = kEps;
-                    launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, (d.cin + Cfg::BN - 1) / Cfg::BN), K_D1, 2.0 * NS * pl.HW * d.cin * kBottleneck);
+                    p.egamma = P + d.n1.w + cs; p.ebeta = P + d.n1.b + cs;
+                    p.dst = e->G[b]; p.ldd = Ct; p.dcoff = cs;
+                    p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.ocoff = cs;
+                    p.dbeta = Gr + d.n1.b + cs; p.dgamma = Gr + d.n1.w + cs; p.eps = kEps;
+                    launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, (p.N + Cfg::BN - 1) / Cfg::BN), K_D1, 2.0 * NS * pl.HW * p.N * kBottleneck);
+                };
+                if (pl.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
+            }
+            if (i == g_lo) {                                            // [0, cs): the whole group at once
+                auto run = [&](auto tag) {
+                    using Cfg = decltype(tag);
+                    BwdDataGroupP<Cfg> p{};
+                    const int g_hi = L - 1 - ((L - 1 - g_lo) / kGroup) * kGroup;      // top layer of this group
+                    p.nseg = g_hi - g_lo + 1;
+                    for (int k = 0; k < p.nseg; ++k) {                  // layer g_lo + k ran (k layers) before this one
+                        const DenseLayerRef& dk = T.layers[b][g_lo + k];
+                        const int slot = (layer_no - 1 - k + kRing * 4) % kRing;
+                        p.seg[k].g = e->D2[slot]; p.seg[k].w = P + dk.c1.w; p.seg[k].ldw = dk.cin;
+                        p.seg[k].gamma = P + dk.n1.w; p.seg[k].beta = P + dk.n1.b;
+                        p.seg[k].dbeta = Gr + dk.n1.b; p.seg[k].dgamma = Gr + dk.n1.w;
+                    }
+                    p.ldg = kBottleneck; p.pa = pl; p.KA = kBottleneck; p.N = cs;
+                    p.mbuf = e->X[b]; p.ldm = Ct;
+                    p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct;
+                    p.dst = e->G[b]; p.ldd = Ct;
+                    p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.eps = kEps;
+                    launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, (cs + Cfg::BN - 1) / Cfg::BN), K_D1, 2.0 * NS * pl.HW * cs * kBottleneck * p.nseg);
                 };
                 if (pl.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
             }
@@ -928,11 +973,15 @@ void smg_engine_destroy(smg_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     void* ptrs[] = {e->img4, e->stem, e->DY0, e->argmax, e->X[0], e->X[1], e->X[2], e->X[3], e->G[0], e->G[1], e->G[2], e->G[3],
-                    e->Bt, e->D2[0], e->D2[1], e->GS[0], e->GS[1], e->part, e->F, e->DF, e->H1, e->DH1, e->fstat, e->bstat, e->packed, e->d_pack, e->d_bnupd,
+                    e->Bt, e->part, e->F, e->DF, e->H1, e->DH1, e->fstat, e->bstat, e->packed, e->d_pack, e->d_bnupd,
                     e->d_stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) { if (e->h_stage[k]) (void)hipHostFree(e->h_stage[k]); if (e->ev_stage[k]) (void)hipEventDestroy(e->ev_stage[k]); }
-    for (int k = 0; k < 2; ++k) { if (e->ev_gs[k]) (void)hipEventDestroy(e->ev_gs[k]); if (e->ev_d2[k]) (void)hipEventDestroy(e->ev_d2[k]); if (e->ev_side[k]) (void)hipEventDestroy(e->ev_side[k]); }
+    for (int k = 0; k < kRing; ++k) {
+        if (e->D2[k]) (void)hipFree(e->D2[k]);
+        if (e->GS[k]) (void)hipFree(e->GS[k]);
+        if (e->ev_gs[k]) (void)hipEventDestroy(e->ev_gs[k]); if (e->ev_d2[k]) (void)hipEventDestroy(e->ev_d2[k]); if (e->ev_side[k]) (void)hipEventDestroy(e->ev_side[k]);
+    }
     if (e->ev_misc) (void)hipEventDestroy(e->ev_misc);
     if (e->ev_end) (void)hipEventDestroy(e->ev_end);
     if (e->side) (void)hipStreamDestroy(e->side);

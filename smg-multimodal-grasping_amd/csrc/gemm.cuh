@@ -287,6 +287,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const P p) {
                 const int buf = kt & 1;
                 if (kt + PD < KT) g_load(kt + PD, ra[u], rb[u]);   // slot u was stored to LDS one iteration ago
                 compute(buf);
+                if constexpr (P::kSegmented) p.k_hook(ctx, kt, acc, sp);   // end of a K segment: fold acc away
                 if (kt + 1 < KT) s_store(buf ^ 1, kt + 1, ra[(u + 1) % PD], rb[(u + 1) % PD]);
                 __syncthreads();
             }
@@ -351,6 +352,7 @@ struct FwdConvP {
     TileMap tm;
     static constexpr int kSwizzle = 1;
     static constexpr int kPrefetch = 1;
+    static constexpr bool kSegmented = false;
 
     struct Ctx { int n, m0, n0; };
     struct ARow { int y, x; bool valid; };
@@ -520,6 +522,7 @@ struct BwdDataP {
     TileMap tm;
     static constexpr int kSwizzle = 1;
     static constexpr int kPrefetch = 1;
+    static constexpr bool kSegmented = false;
 
     struct Ctx { int n, m0, n0; };
     struct ARow { int y, x; bool valid; };
@@ -695,6 +698,220 @@ struct BwdDataP {
 };
 
 // ------------------------------------------------------------------------------------
+// Layer-grouped 1x1 data gradient.
+//
+// Inside a dense block every layer i reads ALL earlier channels, so the backward adds
+//   G'[p][c] += gamma_i[c] * relu'_i(x[p][c]) * (D2_i[p][:] . W1_i[:, c])        for c < cin_i
+// once per layer: E_ACCUM above re-reads x and read-modify-writes G' over all cin_i channels for each
+// layer - 26 GB of the 93 GB a training step moves.  The ReLU mask differs per layer (gamma_i, beta_i),
+// so the layers cannot share one K loop, but they can share the OUTPUT TILE: for the channels below the
+// lowest layer of a group (c < N = cin of that layer) this kernel keeps x and a running sum in
+// registers, walks the group's layers as K segments (128 bottleneck channels each), folds the
+// accumulator into the running sum at the end of every segment (mask + gamma of that layer), and
+// touches G' once.  The channels produced inside the group (needed by the very next layer) are still
+// done per layer by E_ACCUM on a narrow column range.
+//   per-segment sums  -> dbeta_i, dgamma_i          (sum dy_i, sum dy_i * xhat)
+//   running-sum sums  -> SA, SB of the block input  (sum_i gamma_i * those, = sums of the running sum)
+// ------------------------------------------------------------------------------------
+constexpr int GROUP_MAX = 4;
+struct GroupSeg {
+    const float* g;                 // finished bottleneck gradient D2_i [n][HWp][KA]
+    const float* w; int ldw;        // conv1 weight [KA][cin_i] (reference layout: K-major already)
+    const float* gamma; const float* beta;
+    float* dbeta; float* dgamma;
+};
+
+template <class Cfg_>
+struct BwdDataGroupP {
+    using Cfg = Cfg_;
+    static_assert(Cfg::WK == 1 && Cfg::AT, "segment hook: no in-block split-K");
+    GroupSeg seg[GROUP_MAX]; int nseg;
+    int ldg; Plane pa; int KA;
+    int N;                                              // output channels [0, N)
+    const float* mbuf; int ldm;                         // block buffer X (mask / xhat source)
+    const double* msum; const double* msq; int mstride;
+    float* dst; int ldd;                                // G'
+    double* o1; double* o2; int ostride;                // SA / SB [n][C]
+    float eps;
+    TileMap tm;
+    static constexpr int kSwizzle = 1;
+    static constexpr int kPrefetch = 1;
+    static constexpr bool kSegmented = true;
+
+    struct Ctx {
+        int n, m0, n0;
+        float x[Cfg::TM][Cfg::TN][16];                  // raw activation of this lane's accumulator elements
+        float run[Cfg::TM][Cfg::TN][16];                // sum_i gamma_i * dy_i
+        float ls[GROUP_MAX][2][Cfg::TN];                // per-segment column partials (sum dy, sum dy*(x-mean))
+    };
+    struct ARow { int p; bool valid; };
+    struct DRow {};
+
+    // LDS parameters: mean | invstd | per segment: gamma*invstd | beta | gamma      (BN floats each)
+    __host__ __device__ int param_floats() const { return (2 + 3 * GROUP_MAX) * Cfg::BN; }
+
+    __device__ void d_init(const Ctx&, DRow&, int) const {}
+    __device__ void d_next(const Ctx&, DRow&) const {}
+    __device__ bool init(Ctx& c, float* sp) const {
+        int mt = blockIdx.x, nt = blockIdx.y;
+        if (tm.nM && !tile_decode(tm, mt, nt)) return false;
+        c.m0 = mt * Cfg::BM;
+        c.n0 = nt * Cfg::BN;
+        c.n = c.m0 / pa.HWp;
+        const int pbase = c.m0 - c.n * pa.HWp;
+        if (pbase >= pa.HW) return false;
+        const double minv = 1.0 / (double)pa.HW;
+        for (int j = threadIdx.x; j < Cfg::BN; j += 256) {
+            const int col = c.n0 + j;
+            float mean = 0.f, invstd = 0.f;
+            if (col < N) bn_moments(msum, msq, (int64_t)c.n * mstride + col, minv, eps, mean, invstd);
+            sp[j] = mean;
+            sp[Cfg::BN + j] = invstd;
+            for (int s = 0; s < nseg; ++s) {
+                const float g = col < N ? seg[s].gamma[col] : 0.f;
+                float* q = sp + (2 + 3 * s) * Cfg::BN;
+                q[j] = g * invstd;
+                q[Cfg::BN + j] = col < N ? seg[s].beta[col] : 0.f;
+                q[2 * Cfg::BN + j] = g;
+            }
+        }
+        // this lane's x elements: in flight under the first K segment
+        const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
+        const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) {
+            const int col = c.n0 + wn0 + j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = SMG_ACC_ROW(wm0, i, r, half);
+                    const bool ok = pbase + row < pa.HW && col < N;
+                    // unconditional load from a clamped address (a branch around it would serialise the loads)
+                    const float v = mbuf[(int64_t)(c.m0 + (ok ? row : 0)) * ldm + (ok ? col : 0)];
+                    c.x[i][j][r] = ok ? v : 0.f;
+                    c.run[i][j][r] = 0.f;
+                }
+        }
+#pragma unroll
+        for (int s = 0; s < GROUP_MAX; ++s)
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) c.ls[s][0][j] = c.ls[s][1][j] = 0.f;
+        return true;
+    }
+    __device__ int kps() const { return KA / Cfg::BK; }                   // k-tiles per segment
+    __device__ int ktiles(const Ctx&) const { return nseg * kps(); }
+    __device__ void a_row_init(const Ctx& c, ARow& r, int line) const {
+        r.p = c.m0 + line;
+        r.valid = r.p - c.n * pa.HWp < pa.HW;
+    }
+    using ARaw = RawT<1>;
+    using BRaw = RawT<1>;
+    __device__ ARaw a_fetch(const Ctx&, const ARow& r, int kt, int q) const {
+        ARaw o;
+        const int s = kt / kps(), ch = (kt - s * kps()) * Cfg::BK + 4 * q;
+        o.ok = r.valid;
+        o.v[0] = ld4(seg[s].g + (int64_t)r.p * ldg + ch);                // rows of the plane padding exist; zeroed below
+        return o;
+    }
+    __device__ float4 a_xform(const Ctx&, const ARaw& o, int, int, const float*) const { return o.ok ? o.v[0] : zero4(); }
+    __device__ ARaw a_fetch_d(const Ctx&, const DRow&, int, int, int) const { return ARaw{}; }
+    __device__ BRaw b_fetch(const Ctx& c, const DRow&, int kt, int kr, int q) const {
+        BRaw o;
+        const int s = kt / kps(), k = (kt - s * kps()) * Cfg::BK + kr;
+        const int col = c.n0 + 4 * q;
+        o.ok = col < N;
+        o.v[0] = ld4(seg[s].w + (int64_t)k * seg[s].ldw + (o.ok ? col : 0));
+        return o;
+    }
+    __device__ float4 b_xform(const Ctx&, const BRaw& o, int, int, const float*) const { return o.ok ? o.v[0] : zero4(); }
+
+    // End of k-tile kt: at a segment boundary fold the accumulator of that layer into the running sum.
+    __device__ void k_hook(Ctx& c, int kt, f32x16 (&acc)[Cfg::TM][Cfg::TN], const float* sp) const {
+        const int per = kps();
+        if ((kt + 1) % per) return;
+        const int s = kt / per;
+        const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31;
+        const int wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
+        const float* q = sp + (2 + 3 * s) * Cfg::BN;
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) {
+            const int cj = wn0 + j * 32 + l31;
+            const float mean = sp[cj], sc = q[cj], be = q[Cfg::BN + cj], gam = q[2 * Cfg::BN + cj];
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float xc = c.x[i][j][r] - mean;
+                    const float dy = fmaf(xc, sc, be) > 0.f ? acc[i][j][r] : 0.f;     // the forward's bn1() > 0
+                    c.run[i][j][r] = fmaf(gam, dy, c.run[i][j][r]);
+                    v0 += dy;
+                    v1 = fmaf(dy, xc, v1);
+                    acc[i][j][r] = 0.f;
+                }
+#pragma unroll
+            for (int z = 0; z < GROUP_MAX; ++z) {          // static register indices: predicated adds, no scratch
+                c.ls[z][0][j] += z == s ? v0 : 0.f;
+                c.ls[z][1][j] += z == s ? v1 : 0.f;
+            }
+        }
+    }
+    __device__ void epilogue(const Ctx& c, f32x16 (&)[Cfg::TM][Cfg::TN], float* smem, float* sp, bool) const {
+        const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
+        const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
+        const int pbase = c.m0 - c.n * pa.HWp;
+        constexpr int NQ = 2 + 2 * GROUP_MAX;
+        float v[NQ][Cfg::TN];
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) {
+            const int cj = wn0 + j * 32 + l31;
+            const int col = c.n0 + cj;
+            const float mean = sp[cj], invstd = sp[Cfg::BN + cj];
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i) {
+                float gold[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {             // every load of the tile first (the stores alias them)
+                    const int row = SMG_ACC_ROW(wm0, i, r, half);
+                    const bool ok = pbase + row < pa.HW && col < N;
+                    const float g = dst[(int64_t)(c.m0 + (ok ? row : 0)) * ldd + (ok ? col : 0)];
+                    gold[r] = ok ? g : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = SMG_ACC_ROW(wm0, i, r, half);
+                    const float run = c.run[i][j][r];
+                    if (pbase + row < pa.HW && col < N) dst[(int64_t)(c.m0 + row) * ldd + col] = gold[r] + run;
+                    a0 += run;                               // run == 0 on masked elements (x, acc are zero there)
+                    a1 = fmaf(run, (c.x[i][j][r] - mean) * invstd, a1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            v[0][j] = a0;
+            v[1][j] = a1;
+#pragma unroll
+            for (int z = 0; z < GROUP_MAX; ++z) { v[2 + 2 * z][j] = c.ls[z][0][j]; v[3 + 2 * z][j] = c.ls[z][1][j] * invstd; }
+        }
+        float tot[NQ];
+        block_col_reduce<Cfg, NQ, float>(v, smem, tot);
+        if (t < Cfg::BN && c.n0 + t < N) {
+            const int col = c.n0 + t;
+            const int64_t oi = (int64_t)c.n * ostride + col;
+            atomicAdd(o1 + oi, (double)tot[0]);
+            atomicAdd(o2 + oi, (double)tot[1]);
+#pragma unroll
+            for (int z = 0; z < GROUP_MAX; ++z)
+                if (z < nseg) {
+                    atomicAdd(seg[z].dbeta + col, tot[2 + 2 * z]);
+                    atomicAdd(seg[z].dgamma + col, tot[3 + 2 * z]);
+                }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------
 // Weight-gradient policy (both operands channel-major; reduction over pixels).
 //   dW[i][j] += sum_p A(p, i) * B(p, j) over the pixels of one z-chunk of one stream.
 //   A(p, i) = g*a[i] + x*b[i] + c[i]        (BN-backward-corrected output gradient)
@@ -728,6 +945,7 @@ struct BwdWeightP {
     TileMap tm;
     static constexpr int kSwizzle = 2;
     static constexpr int kPrefetch = PD_;     // k-tiles of global loads in flight per thread
+    static constexpr bool kSegmented = false;
 
     struct Ctx { int n, p0, m0, n0, tap, kt, z; };
     struct ARow { int dummy; };
