@@ -118,6 +118,7 @@ struct smg_engine {
     int* d_stage = nullptr; int* h_stage[2] = {}; hipEvent_t ev_stage[2] = {}; int stage_ints = 0, stage_turn = 0;
     int so_image = 0, so_rot = 0, so_pa = 0, so_pb = 0, so_seq_t = 0, so_seq_h = 0, so_uptr = 0, so_upair = 0, so_uslot = 0, so_aff = 0;
     int64_t workspace_bytes = 0;
+    int n_cu = 256;            // compute units of the device (persistent-launch sizing)
     bool generic3x3 = false;   // SMG_GENERIC_3X3=1: dense-layer 3x3 convs through the generic implicit GEMM (A/B testing)
     // profiling
     bool prof = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> ev_pool;
@@ -177,8 +178,42 @@ static void launch_gemm(smg_engine* e, hipStream_t st, P p, dim3 grid, int kind,
             grid = dim3(8 * ((grid.z + 7) / 8) * tiles, 1, 1);
         }
     }
-    ProfScope ps(e, st, kind, flops);
-    hipLaunchKernelGGL(gemm_kernel<P>, grid, dim3(256), smem, st, p);
+    static const int tr_kind = getenv("SMG_TRACE_KIND") ? atoi(getenv("SMG_TRACE_KIND")) : -1;   // dev: phase timestamps of one launch
+    static const int tr_skip = getenv("SMG_TRACE_SKIP") ? atoi(getenv("SMG_TRACE_SKIP")) : 0;
+    static int tr_seen = 0;
+    const bool tracing = kind == tr_kind && tr_seen++ == tr_skip;
+    unsigned long long* tbuf = nullptr;
+    const size_t n_wg = (size_t)grid.x * grid.y * grid.z;
+    if (tracing) {
+        (void)hipMalloc((void**)&tbuf, n_wg * 64);
+        (void)hipMemsetAsync(tbuf, 0, n_wg * 64, st);
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_smg_trace), &tbuf, sizeof(tbuf), 0, hipMemcpyHostToDevice, st);
+    }
+    {
+        ProfScope ps(e, st, kind, flops);
+        hipLaunchKernelGGL(gemm_kernel<P>, dim3((unsigned)n_wg), dim3(256), smem, st, p, (int)grid.x, (int)grid.y);
+    }
+    if (tracing) {
+        unsigned long long* nul = nullptr;
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_smg_trace), &nul, sizeof(nul), 0, hipMemcpyHostToDevice, st);
+        std::vector<unsigned long long> h(n_wg * 8);
+        (void)hipMemcpyAsync(h.data(), tbuf, n_wg * 64, hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(tbuf);
+        // phases in shader cycles (s_memtime, per-XCD base); span / residency from the device-wide 100 MHz counter
+        double sum[4] = {0, 0, 0, 0}, life = 0; size_t live = 0; unsigned long long t_min = ~0ull, t_max = 0;
+        for (size_t w = 0; w < n_wg; ++w) {
+            const unsigned long long* r = &h[w * 8];
+            if (!r[4]) continue;
+            ++live;
+            for (int k = 0; k < 4; ++k) sum[k] += (double)(r[k + 1] - r[k]);
+            t_min = std::min(t_min, r[5]); t_max = std::max(t_max, r[6]);
+            life += (double)(r[6] - r[5]);
+        }
+        const double span = (double)(t_max - t_min) * 0.01, resid = life / (double)(t_max - t_min) / 256.0;
+        fprintf(stderr, "[smg trace] kind %d grid %ux%ux%u live %zu: init %.0f | first tile %.0f | k-loop %.0f | epilogue %.0f cycles/WG (mean); span %.1f us, %.2f workgroups resident per CU\n",
+                kind, grid.x, grid.y, grid.z, live, sum[0] / live, sum[1] / live, sum[2] / live, sum[3] / live, span, resid);
+    }
 }
 
 // Weight-gradient launch: partial tiles to the workspace + one reduce kernel (falls back to
@@ -962,6 +997,10 @@ int smg_engine_create(int device, int input_size, int max_streams, int max_pairs
     smg_engine* e = new smg_engine();
     e->device = device; e->S = input_size; e->max_streams = max_streams; e->max_pairs = max_pairs; e->head_out = head_out;
     e->L = &layout_for(head_out);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->n_cu = cus;
+    }
     int r = engine_build(e);
     if (r) { smg_engine_destroy(e); return r; }
     *out = e;

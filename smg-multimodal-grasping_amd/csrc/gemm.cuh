@@ -120,10 +120,10 @@ __device__ __forceinline__ float4 affine2(float4 g, float4 x, const float* prm, 
 // XCD-aware tile order.  Workgroup b is observed to run on XCD b % 8 (MI355X_MICROARCH.md, used for
 // speed only): sibling tiles that re-read the same A operand (the N-tiles of one M-tile, or of one
 // pixel chunk in a weight gradient) are made consecutive on ONE XCD so the re-reads hit its private L2
-// instead of going out to the fabric.  nM == 0 -> plain blockIdx.x / blockIdx.y / blockIdx.z.
+// instead of going out to the fabric.  nM == 0 -> plain (x, y, z) block coordinates.
 struct TileMap { int nM, nN, gx; };
-__device__ __forceinline__ bool tile_decode(const TileMap& tm, int& major, int& minor) {
-    const int b = blockIdx.x, x = b & 7, slot = b >> 3;
+__device__ __forceinline__ bool tile_decode(const TileMap& tm, int b, int& major, int& minor) {
+    const int x = b & 7, slot = b >> 3;
     major = (slot / tm.nN) * 8 + x;
     minor = slot % tm.nN;
     return major < tm.nM;
@@ -161,13 +161,20 @@ __device__ __forceinline__ void block_col_reduce(T (&v)[NQ][C::TN], T* red, T (&
     }
 }
 
+// Dev instrumentation (SMG_TRACE_* in engine.hip): when set, thread 0 of every workgroup of a gemm_kernel launch
+// stores s_memtime at five points: start | parameters ready | first tile staged | k-loop done | epilogue done.
+__device__ unsigned long long* g_smg_trace = nullptr;
+#define SMG_TRACE(slot) do { if (trace) trace[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+
 // ------------------------------------------------------------------------------------
 // The kernel.
 // ------------------------------------------------------------------------------------
+// Virtual block coordinates of one tile (what blockIdx was before the kernel became persistent).
+struct VBlock { int x, y, z, linear; };
+
 template <class P>
-__global__ __launch_bounds__(256) void gemm_kernel(const P p) {
+__device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* smem) {
     using C = typename P::Cfg;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + 2 * C::A_FLOATS;
     float* sp = smem + C::TILE_FLOATS;
@@ -177,9 +184,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const P p) {
     const int wk = wave / (C::WM * C::WN), wmn = wave % (C::WM * C::WN);
     const int wm0 = (wmn / C::WN) * C::TM * 32, wn0 = (wmn % C::WN) * C::TN * 32;
 
+    unsigned long long* trace = (g_smg_trace && t == 0) ? g_smg_trace + 8 * (size_t)vb.linear : nullptr;
+    SMG_TRACE(0);
+    if (trace) trace[5] = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one base for the whole device
     typename P::Ctx ctx;
-    if (!p.init(ctx, sp)) return;          // tile made of padding rows only (block-uniform)
-    __syncthreads();
+    if (!p.init_ctx(ctx, vb)) return;      // tile made of padding rows only (block-uniform)
     const int KT = p.ktiles(ctx);
 
     f32x16 acc[C::TM][C::TN];
@@ -274,11 +283,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const P p) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    // First tile's global loads go out BEFORE the BN-parameter prologue (which waits on its own global loads of
+    // the statistics and does fp64 div / sqrt): one memory round trip per workgroup instead of two.
 #pragma unroll
     for (int u = 0; u < PD; ++u)
         if (u < KT) g_load(u, ra[u], rb[u]);
+    p.init_params(ctx, sp);
+    __syncthreads();
+    SMG_TRACE(1);
     if (KT > 0) s_store(0, 0, ra[0], rb[0]);
     __syncthreads();
+    SMG_TRACE(2);
     for (int kt0 = 0; kt0 < KT; kt0 += PD) {
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
@@ -319,7 +334,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const P p) {
         }
         __syncthreads();
     }
+    SMG_TRACE(3);
     p.epilogue(ctx, acc, smem, sp, wk == 0);
+    SMG_TRACE(4);
+    if (trace) trace[6] = __builtin_amdgcn_s_memrealtime();
+}
+
+// One workgroup per virtual block (x fastest).  A persistent variant (resident workgroups striding over the virtual
+// grid) was measured and rejected: hipcc hoists the per-thread addressing out of the tile loop (+50..70 VGPRs, one
+// workgroup less per CU) and the launch is not dispatch-bound.
+template <class P>
+__global__ __launch_bounds__(256, P::kMinWaves) void gemm_kernel(const P p, const int vgx, const int vgy) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    VBlock vb;
+    vb.linear = blockIdx.x;
+    vb.x = vb.linear % vgx;
+    const int q = vb.linear / vgx;
+    vb.y = q % vgy;
+    vb.z = q / vgy;
+    gemm_tile(p, vb, smem);
 }
 
 // Accumulator element (tm, tn, reg) of this lane sits at tile row / column:
@@ -353,6 +386,8 @@ struct FwdConvP {
     static constexpr int kSwizzle = 1;
     static constexpr int kPrefetch = 1;
     static constexpr bool kSegmented = false;
+    // waves per SIMD the register allocator is held to: the 128x128 tile (64 accumulator registers) must stay at 3
+    static constexpr int kMinWaves = Cfg::TM * Cfg::TN == 4 ? 3 : 1;
 
     struct Ctx { int n, m0, n0; };
     struct ARow { int y, x; bool valid; };
@@ -360,13 +395,15 @@ struct FwdConvP {
 
     __host__ __device__ int param_floats() const { return MODE == F_STEM ? 0 : 3 * K; }
 
-    __device__ bool init(Ctx& c, float* sp) const {
-        int mt = blockIdx.x, nt = blockIdx.y;
-        if (tm.nM && !tile_decode(tm, mt, nt)) return false;
+    __device__ bool init_ctx(Ctx& c, const VBlock& vb) const {
+        int mt = vb.x, nt = vb.y;
+        if (tm.nM && !tile_decode(tm, vb.x, mt, nt)) return false;
         c.m0 = mt * Cfg::BM;
         c.n0 = nt * Cfg::BN;
         c.n = c.m0 / po.HWp;
-        if (c.m0 - c.n * po.HWp >= po.HW) return false;
+        return c.m0 - c.n * po.HWp < po.HW;
+    }
+    __device__ void init_params(const Ctx& c, float* sp) const {
         if constexpr (MODE != F_STEM) {
             const double inv = 1.0 / (double)ps.HW;
             for (int k = threadIdx.x; k < K; k += 256) {
@@ -377,7 +414,6 @@ struct FwdConvP {
                 sp[2 * K + k] = beta[k];
             }
         }
-        return true;
     }
     __device__ void d_init(const Ctx&, DRow&, int) const {}
     __device__ void d_next(const Ctx&, DRow&) const {}
@@ -458,6 +494,39 @@ struct FwdConvP {
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) v[0][j] = v[1][j] = 0.0;
         const int pbase = c.m0 - c.n * po.HWp;
+        if (pbase + Cfg::BM <= po.HW && c.n0 + Cfg::BN <= N) {
+            // Whole tile inside the plane (every tile of the 160^2 / 80^2 / 40^2 stages): straight-line stores, and the
+            // statistics as fp32 sums of (x - s), (x - s)^2 about the lane's first value s of each 16-row strip,
+            // widened to fp64 once per strip: sum x = S1 + 16 s, sum x^2 = S2 + 2 s S1 + 16 s^2.  (Shifted sums
+            // keep the precision the per-element fp64 path has - no cancellation on near-constant channels.)
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < Cfg::TN; ++j) {
+                        // uniform tile base + one running 32-bit lane offset (saddr stores): 16 precomputed 64-bit
+                        // addresses per strip would cost a workgroup of occupancy
+                        float* tb = dst + (int64_t)c.m0 * ldd + dcoff + c.n0;
+                        unsigned o = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + wn0 + j * 32 + l31);
+                        const float s = acc[i][j][0];
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {           // accumulator rows (r & 3) + 8 * (r >> 2)
+                            const float x = acc[i][j][r];
+                            tb[o] = x;
+                            o += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
+                            const float dx = x - s;
+                            s1 += dx;
+                            s2 = fmaf(dx, dx, s2);
+                        }
+                        const double sd = (double)s, s1d = (double)s1;
+                        v[0][j] += s1d + 16.0 * sd;
+                        v[1][j] += (double)s2 + 2.0 * sd * s1d + 16.0 * sd * sd;
+                        __builtin_amdgcn_sched_barrier(0);     // one 32x32 strip at a time: keeps the address math of the
+                                                               // other strips out of the live set (occupancy 3, not 2)
+                    }
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -523,6 +592,7 @@ struct BwdDataP {
     static constexpr int kSwizzle = 1;
     static constexpr int kPrefetch = 1;
     static constexpr bool kSegmented = false;
+    static constexpr int kMinWaves = 1;
 
     struct Ctx { int n, m0, n0; };
     struct ARow { int y, x; bool valid; };
@@ -532,13 +602,15 @@ struct BwdDataP {
 
     __device__ void d_init(const Ctx&, DRow&, int) const {}
     __device__ void d_next(const Ctx&, DRow&) const {}
-    __device__ bool init(Ctx& c, float* sp) const {
-        int mt = blockIdx.x, nt = blockIdx.y;
-        if (tm.nM && !tile_decode(tm, mt, nt)) return false;
+    __device__ bool init_ctx(Ctx& c, const VBlock& vb) const {
+        int mt = vb.x, nt = vb.y;
+        if (tm.nM && !tile_decode(tm, vb.x, mt, nt)) return false;
         c.m0 = mt * Cfg::BM;
         c.n0 = nt * Cfg::BN;
         c.n = c.m0 / pa.HWp;
-        if (c.m0 - c.n * pa.HWp >= pa.HW) return false;
+        return c.m0 - c.n * pa.HWp < pa.HW;
+    }
+    __device__ void init_params(const Ctx& c, float* sp) const {
         const double inv = 1.0 / (double)pa.HW;
         for (int k = threadIdx.x; xbuf && k < KA; k += 256) {
             float mean, invstd;
@@ -567,7 +639,6 @@ struct BwdDataP {
             ep[3 * Cfg::BN + j] = invstd;
             ep[4 * Cfg::BN + j] = g;
         }
-        return true;
     }
     __device__ int ktiles(const Ctx&) const { return (SHIFT3 ? 9 : 1) * (KA / Cfg::BK); }
     __device__ void a_row_init(const Ctx& c, ARow& r, int line) const {
@@ -737,6 +808,7 @@ struct BwdDataGroupP {
     static constexpr int kSwizzle = 1;
     static constexpr int kPrefetch = 1;
     static constexpr bool kSegmented = true;
+    static constexpr int kMinWaves = 1;
 
     struct Ctx {
         int n, m0, n0;
@@ -752,14 +824,7 @@ struct BwdDataGroupP {
 
     __device__ void d_init(const Ctx&, DRow&, int) const {}
     __device__ void d_next(const Ctx&, DRow&) const {}
-    __device__ bool init(Ctx& c, float* sp) const {
-        int mt = blockIdx.x, nt = blockIdx.y;
-        if (tm.nM && !tile_decode(tm, mt, nt)) return false;
-        c.m0 = mt * Cfg::BM;
-        c.n0 = nt * Cfg::BN;
-        c.n = c.m0 / pa.HWp;
-        const int pbase = c.m0 - c.n * pa.HWp;
-        if (pbase >= pa.HW) return false;
+    __device__ void init_params(const Ctx& c, float* sp) const {
         const double minv = 1.0 / (double)pa.HW;
         for (int j = threadIdx.x; j < Cfg::BN; j += 256) {
             const int col = c.n0 + j;
@@ -775,6 +840,15 @@ struct BwdDataGroupP {
                 q[2 * Cfg::BN + j] = g;
             }
         }
+    }
+    __device__ bool init_ctx(Ctx& c, const VBlock& vb) const {
+        int mt = vb.x, nt = vb.y;
+        if (tm.nM && !tile_decode(tm, vb.x, mt, nt)) return false;
+        c.m0 = mt * Cfg::BM;
+        c.n0 = nt * Cfg::BN;
+        c.n = c.m0 / pa.HWp;
+        const int pbase = c.m0 - c.n * pa.HWp;
+        if (pbase >= pa.HW) return false;
         // this lane's x elements: in flight under the first K segment
         const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
         const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
@@ -937,7 +1011,7 @@ struct BwdWeightP {
     const double* bsum; const double* bsq; int bstride;
     const float* bgamma; const float* bbeta;
     float eps;
-    int chunk, chunks_per_stream, n_chunks;   // blockIdx.z = tap * n_chunks + chunk index
+    int chunk, chunks_per_stream, n_chunks;   // virtual block z = tap * n_chunks + chunk index
     float* dw; int ldw_out;
     float* part;                              // if set: partial tiles [z][gx*BM][gy*BN] (plain stores,
                                               // summed by reduce_partials_kernel) instead of fp32 atomics into dw
@@ -946,6 +1020,7 @@ struct BwdWeightP {
     static constexpr int kSwizzle = 2;
     static constexpr int kPrefetch = PD_;     // k-tiles of global loads in flight per thread
     static constexpr bool kSegmented = false;
+    static constexpr int kMinWaves = 1;
 
     struct Ctx { int n, p0, m0, n0, tap, kt, z; };
     struct ARow { int dummy; };
@@ -972,9 +1047,9 @@ struct BwdWeightP {
             }
         }
     }
-    __device__ bool init(Ctx& c, float* sp) const {
-        int z = blockIdx.z, tile = blockIdx.y * gx + blockIdx.x;
-        if (tm.nM && !tile_decode(tm, z, tile)) return false;
+    __device__ bool init_ctx(Ctx& c, const VBlock& vb) const {
+        int z = vb.z, tile = vb.y * gx + vb.x;
+        if (tm.nM && !tile_decode(tm, vb.x, z, tile)) return false;
         c.z = z;
         c.m0 = (tile % gx) * Cfg::BM;
         c.n0 = (tile / gx) * Cfg::BN;
@@ -986,6 +1061,9 @@ struct BwdWeightP {
         int len = pa.HWp - c.p0;
         len = len < chunk ? len : chunk;
         c.kt = len / Cfg::BK;
+        return true;
+    }
+    __device__ void init_params(const Ctx& c, float* sp) const {
         const double inv = 1.0 / (double)pa.HW;
         for (int k = threadIdx.x; xbuf && k < Cfg::BM; k += 256) {
             const int ch = c.m0 + k;
@@ -1020,7 +1098,6 @@ struct BwdWeightP {
                 bp[2 * Cfg::BN + j] = be;
             }
         }
-        return true;
     }
     __device__ int ktiles(const Ctx& c) const { return c.kt; }
     __device__ void a_row_init(const Ctx&, ARow&, int) const {}
