@@ -698,6 +698,36 @@ struct BwdDataP {
             const bool cok = col < N;
             const float sc = ep[cj], sh = ep[Cfg::BN + cj], mean = ep[2 * Cfg::BN + cj], invstd = ep[3 * Cfg::BN + cj];
             const float gam = ep[4 * Cfg::BN + cj];
+            if (EMODE != E_UNPOOL && active && pbase + Cfg::BM <= pa.HW && c.n0 + Cfg::BN <= N) {
+                // Whole tile inside the plane: no per-element predicates, uniform tile bases + running 32-bit lane
+                // offsets (saddr loads / stores) instead of 16 precomputed 64-bit addresses per strip.
+                const float* xb = mbuf + (int64_t)c.m0 * ldm + mcoff + c.n0;
+                float* gb = dst + (int64_t)c.m0 * ldd + dcoff + c.n0;
+#pragma unroll
+                for (int i = 0; i < Cfg::TM; ++i) {
+                    float xv[16], gold[16];
+                    unsigned ox = (unsigned)((wm0 + i * 32 + 4 * half) * ldm + cj);
+                    unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + cj);
+                    const unsigned og0 = og;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {                   // every load of the strip first (the stores alias them)
+                        xv[r] = xb[ox];
+                        if constexpr (EMODE == E_ACCUM) gold[r] = gb[og]; else gold[r] = 0.f;
+                        ox += (r & 3) == 3 ? 5u * (unsigned)ldm : (unsigned)ldm;
+                        og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
+                    }
+                    og = og0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float dy = bn1(xv[r], mean, sc, sh) > 0.f ? acc[i][j][r] : 0.f;
+                        if constexpr (EMODE == E_STORE) gb[og] = dy; else gb[og] = gold[r] + gam * dy;
+                        og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
+                        v[0][j] += dy;
+                        v[1][j] += dy * ((xv[r] - mean) * invstd);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);                // one strip of loads in flight at a time
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i) {
                 // Two passes per 32x32 accumulator tile: every load first (16..64 of them in
@@ -943,6 +973,30 @@ struct BwdDataGroupP {
             const int col = c.n0 + cj;
             const float mean = sp[cj], invstd = sp[Cfg::BN + cj];
             float a0 = 0.f, a1 = 0.f;
+            if (pbase + Cfg::BM <= pa.HW && c.n0 + Cfg::BN <= N) {        // whole tile inside the plane: see E_ACCUM
+                float* gb = dst + (int64_t)c.m0 * ldd + c.n0;
+#pragma unroll
+                for (int i = 0; i < Cfg::TM; ++i) {
+                    float gold[16];
+                    unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + cj);
+                    const unsigned og0 = og;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        gold[r] = gb[og];
+                        og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
+                    }
+                    og = og0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float run = c.run[i][j][r];
+                        gb[og] = gold[r] + run;
+                        og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
+                        a0 += run;
+                        a1 = fmaf(run, (c.x[i][j][r] - mean) * invstd, a1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i) {
                 float gold[16];
