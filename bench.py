@@ -220,9 +220,17 @@ def main():
             conv_ms = sum(v[0] for v in conv.values())
             conv_fl = sum(v[2] for v in conv.values())
             achieved = fl / (ms * 1e-3) / 1e12
+            # HBM bytes per launch of the dominant class, from the committed PMC passes (profiles/; rocprofv3 cannot run
+            # inside this process): FETCH_SIZE x 2 + WRITE_SIZE, see profiles/pmc_r01_hbm_traffic.md.  None if absent.
+            traffic = None
+            try:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_r01_hbm_traffic.json")) as f:
+                    traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                pass
             out["roofline"] = {
                 "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/pmc_r01_hbm_traffic.json)",
                 "avg_launch_ms": ms / n, "launches_per_step": n // n_prof, "flops_per_launch": fl / n,
                 "all_conv_kernels": {"achieved": conv_fl / (conv_ms * 1e-3) / 1e12, "frac": conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                      "ms_per_step": conv_ms / n_prof, "executed_gflop_per_step": conv_fl / n_prof / 1e9},

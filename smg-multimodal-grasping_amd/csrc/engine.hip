@@ -129,6 +129,24 @@ struct smg_engine {
 // Tile side of the LDS-halo 3x3 kernels for a plane: 16 where it tiles exactly, else 8 (ragged edges masked).
 static inline int halo_tile(const Plane& p) { return (p.H % 16 == 0 && p.W % 16 == 0) ? 16 : 8; }
 
+// 3x3 weight-gradient halo kernel: tiles per workgroup.  The launch runs in rounds of 512 resident workgroups (2 per
+// CU), each lasting tiles_per_wg tile-times plus a fixed prologue + 9-tap flush (~0.6 of a 16x16 tile-time, measured);
+// take the run length with the shortest total (e.g. 100 tiles x 17 streams -> 7, 25 tiles -> 4), then lengthen it
+// until the partial tiles fit the workspace.
+static int w3_tiles_per_wg(int n_tiles, int ts, int n_streams, int64_t part_floats) {
+    const double fix = ts == 16 ? 0.6 : 2.4;
+    double best = 1e30;
+    int tpw_best = 1;
+    for (int tpw = 1; tpw <= n_tiles; ++tpw) {
+        const int g = (n_tiles + tpw - 1) / tpw;
+        const int rounds = (g * (kBottleneck / 32) * n_streams + 511) / 512;
+        const double cost = rounds * (tpw + fix);
+        if (cost < best - 1e-9) { best = cost; tpw_best = tpw; }
+    }
+    while (tpw_best < n_tiles && (int64_t)((n_tiles + tpw_best - 1) / tpw_best) * n_streams * 9 * 32 * kBottleneck > part_floats) ++tpw_best;
+    return tpw_best;
+}
+
 static Plane make_plane(int H, int W) {
     Plane p; p.H = H; p.W = W; p.HW = H * W; p.HWp = (p.HW + 63) / 64 * 64; return p;
 }
@@ -282,7 +300,13 @@ static int engine_build(smg_engine* e) {
     HIP_OK(hipEventCreateWithFlags(&e->ev_misc, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&e->ev_end, hipEventDisableTiming));
     HIP_OK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-    e->part_floats = (int64_t)24 << 20;   // 96 MB of partial weight-gradient tiles
+    e->part_floats = (int64_t)24 << 20;   // partial weight-gradient tiles: 96 MB, or what the 3x3 launches of a full batch want
+    for (int b = 0; b < 4; ++b) {
+        const Plane& pl = e->p_blk[b];
+        const int ts = halo_tile(pl), nt = ((pl.H + ts - 1) / ts) * ((pl.W + ts - 1) / ts);
+        const int tpw = w3_tiles_per_wg(nt, ts, NS, INT64_MAX);
+        e->part_floats = std::max<int64_t>(e->part_floats, (int64_t)((nt + tpw - 1) / tpw) * NS * 9 * 32 * kBottleneck);
+    }
     ALLOC(e->part, e->part_floats);
     ALLOC(e->F, (int64_t)NP * e->p_blk[3].HWp * 2 * kFeat);
     ALLOC(e->DF, (int64_t)NP * e->p_blk[3].HWp * 2 * kFeat);
@@ -513,7 +537,7 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
                 p.dsum = fsum(e, e->st_Bt[b][i]); p.dsq = fsq(e, e->st_Bt[b][i]); p.dstride = kBottleneck;
                 launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, kBottleneck / Cfg::BN), K_C1, 2.0 * NS * pl.HW * d.cin * kBottleneck);
             };
-            if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x64{});
+            if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x64{});   // (64x128 here: measured slower)
             }
             if (!e->generic3x3) {
                 // norm2 + relu + conv2 (3x3, 128 -> 32) with an LDS-resident input halo (halo.cuh)
@@ -708,7 +732,16 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
             float* D2b = e->D2[db];
             if (layer_no >= kRing) HIP_OK(hipStreamWaitEvent(st, e->ev_side[db], 0));   // side stream done with these buffers (kRing layers ago)
             ++layer_no;
-            {   // finalize this layer's output-slice gradient once: GS = invstd*(G' - SA/n - xhat*SB/n)
+            // This layer's finished output-slice gradient GS = invstd*(G' - SA/n - xhat*SB/n), materialised once (dense
+            // [px][32]) for the 3x3 data- and weight-gradient kernels.  They can also apply it while loading the G' / X
+            // slices (GradSrc with x set; SMG_GS_FUSED=1): one launch less on the dependency chain, but measured 0.5 ms
+            // per step slower - two strided 128-B-per-pixel reads replace one dense one in both consumers.
+            GradSrc gsrc{};
+            gsrc.g = e->G[b] + d.cin; gsrc.ldg = Ct; gsrc.x = e->X[b] + d.cin; gsrc.ldx = Ct;
+            gsrc.xsum = fsum(e, e->st_X[b]) + d.cin; gsrc.xsq = fsq(e, e->st_X[b]) + d.cin;
+            gsrc.s1 = b1(e, e->bs_X[b]) + d.cin; gsrc.s2 = b2(e, e->bs_X[b]) + d.cin; gsrc.sstride = Ct; gsrc.eps = kEps;
+            static const bool gs_mat = getenv("SMG_GS_FUSED") == nullptr;
+            if (e->generic3x3 || gs_mat) {
                 BnBwdApplyArgs a{};
                 a.g = e->G[b]; a.ldg = Ct; a.gcoff = d.cin; a.x = e->X[b]; a.ldx = Ct; a.xcoff = d.cin; a.pl = pl; a.C = kGrowth;
                 a.xsum = fsum(e, e->st_X[b]); a.xsq = fsq(e, e->st_X[b]); a.xstride = Ct;
@@ -716,12 +749,13 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 a.out = GSb; a.ldo = kGrowth;
                 ProfScope ps(e, st, K_OTHER, 0);
                 hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(pl.HWp / 64, NS), dim3(256), 0, st, a);
+                if (gs_mat) { gsrc = GradSrc{}; gsrc.g = GSb; gsrc.ldg = kGrowth; }
             }
             if (fork(e->ev_gs[db])) return -5;
             if (!e->generic3x3) {
                 // conv2 (3x3) data gradient with the gradient halo resident in LDS (halo.cuh)
                 Halo3x3DgradArgs a;
-                a.g = GSb; a.pl = pl; a.w = e->packed + e->pk_c2d[b][i]; a.C = kBottleneck;
+                a.g = gsrc; a.pl = pl; a.w = e->packed + e->pk_c2d[b][i]; a.C = kBottleneck;
                 a.mbuf = bt; a.msum = fsum(e, e->st_Bt[b][i]); a.msq = fsq(e, e->st_Bt[b][i]); a.mstride = kBottleneck;
                 a.gamma = P + d.n2.w; a.beta = P + d.n2.b; a.eps = kEps;
                 a.dst = D2b; a.o1 = b1(e, e->bs_Bt[b][i]); a.o2 = b2(e, e->bs_Bt[b][i]); a.ostride = kBottleneck;
@@ -755,24 +789,11 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 // conv2 weight gradient with the activation halo resident in LDS (halo.cuh)
                 const int ts = halo_tile(pl);
                 Halo3x3WgradArgs a;
-                a.g = GSb; a.pl = pl; a.src = bt; a.C = kBottleneck;
+                a.g = gsrc; a.pl = pl; a.src = bt; a.C = kBottleneck;
                 a.ssum = fsum(e, e->st_Bt[b][i]); a.ssq = fsq(e, e->st_Bt[b][i]); a.sstride = kBottleneck;
                 a.gamma = P + d.n2.w; a.beta = P + d.n2.b; a.eps = kEps;
                 a.part = e->part; a.tiles_x = (pl.W + ts - 1) / ts; a.n_tiles = ((pl.H + ts - 1) / ts) * a.tiles_x;
-                // Tiles per workgroup: the launch runs in rounds of 512 resident workgroups (2 per CU), each lasting
-                // tiles_per_wg tile-times plus a fixed prologue + 9-tap flush (~0.6 of a 16x16 tile-time, measured);
-                // take the run length with the shortest total (e.g. 100 tiles x 17 streams -> 7, 25 tiles -> 4).
-                {
-                    const double fix = ts == 16 ? 0.6 : 2.4;
-                    double best = 1e30;
-                    a.tiles_per_wg = 1;
-                    for (int tpw = 1; tpw <= a.n_tiles; ++tpw) {
-                        const int g = (a.n_tiles + tpw - 1) / tpw;
-                        const int rounds = (g * (kBottleneck / 32) * NS + 511) / 512;
-                        const double cost = rounds * (tpw + fix);
-                        if (cost < best - 1e-9) { best = cost; a.tiles_per_wg = tpw; }
-                    }
-                }
+                a.tiles_per_wg = w3_tiles_per_wg(a.n_tiles, ts, NS, e->part_floats);
                 const int groups = (a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
                 if ((int64_t)groups * NS * 9 * 32 * kBottleneck > e->part_floats) return fail(-12, "partial-gradient workspace too small");
                 {
@@ -863,7 +884,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 using Cfg = CfgW128x64;
                 const int nt = (d.cin + Cfg::BN - 1) / Cfg::BN;
                 int chunk, cps;
-                pick_chunk(pl, NS, nt, chunk, cps, 384);
+                pick_chunk(pl, NS, nt, chunk, cps, 512);   // 384..768 measure the same; 256 is slower
                 BwdWeightP<Cfg, W_ONE, C_IDENT> p{};
                 p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck;
                 p.bbuf = e->X[b]; p.ldb = Ct; p.pb = pl; p.NB = d.cin;

@@ -1216,6 +1216,25 @@ struct BwdWeightP {
     __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float*, float*, bool active) const {
         const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
         const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
+        if (CMAP == C_IDENT && c.m0 + Cfg::BM <= MA && c.n0 + Cfg::BN <= NB) {
+            // whole tile inside the weight matrix: uniform base + running lane offset, no per-element predicates
+            if (!active) return;
+            float* ob = part ? part + ((int64_t)c.z * (gx * Cfg::BM) + c.m0) * (gy * Cfg::BN) + c.n0
+                             : dw + (int64_t)c.m0 * ldw_out + c.n0;
+            const unsigned ldo = part ? (unsigned)(gy * Cfg::BN) : (unsigned)ldw_out;
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j) {
+                    unsigned o = (unsigned)(wm0 + i * 32 + 4 * half) * ldo + (unsigned)(wn0 + j * 32 + l31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (part) ob[o] = acc[i][j][r]; else atomicAdd(ob + o, acc[i][j][r]);
+                        o += (r & 3) == 3 ? 5u * ldo : ldo;
+                    }
+                }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll

@@ -251,8 +251,33 @@ __global__ __launch_bounds__(256, TS == 16 ? 3 : 4) void conv3x3_halo_fwd_kernel
 // -> 2 workgroups/CU.  TS = 8: the two wave pairs own different output-channel chunks
 // (NCW = 2 chunks per stage, 6 stages), 39 KB.
 // ------------------------------------------------------------------------------------
+// The finished gradient of a layer's 32 output channels, as the 3x3 backward kernels read it: either a dense
+// [n][HWp][32] array (x == nullptr), or the G' and X slices of the block buffers with the deferred BN backward
+// applied on load (what bn_bwd_apply_kernel would have written):
+//   g = invstd * ((G' - SA/n) - (x - mean) * invstd * SB/n)
+// Statistics pointers are already offset to the slice's first channel; sstride = floats per stream.
+struct GradSrc {
+    const float* g; int ldg;
+    const float* x; int ldx;
+    const double* xsum; const double* xsq; const double* s1; const double* s2; int sstride;
+    float eps;
+};
+// parameters a | q1 | mean | k of affine2() for the 32 channels -> gp[4][32]  (threads 0..31)
+__device__ __forceinline__ void grad_src_params(const GradSrc& s, int n, int hw, float* gp) {
+    const int t = threadIdx.x;
+    if (s.x && t < 32) {
+        const double inv = 1.0 / (double)hw;
+        float mean, invstd;
+        bn_moments(s.xsum, s.xsq, (int64_t)n * s.sstride + t, inv, s.eps, mean, invstd);
+        gp[t] = invstd;
+        gp[32 + t] = (float)(s.s1[(int64_t)n * s.sstride + t] * inv);
+        gp[64 + t] = mean;
+        gp[96 + t] = invstd * (float)(s.s2[(int64_t)n * s.sstride + t] * inv);
+    }
+}
+
 struct Halo3x3DgradArgs {
-    const float* g; Plane pl;                        // [n][HWp][32] finalized output gradient
+    GradSrc g; Plane pl;                             // finished output gradient (32 channels)
     const float* w;                                  // packed [(tap*32 + n)][C]
     int C;                                           // bottleneck channels (128)
     const float* mbuf;                               // raw bottleneck [n][HWp][C] (mask + xhat source)
@@ -274,7 +299,7 @@ template <int TS> struct HaloDgradGeo : HaloGeo<TS> {
     static constexpr int NCW = G::WX;                                    // output-channel chunks per stage
     static constexpr int B_FLOATS = NCW * HD_B_CHUNK;
     static constexpr int B_N = B_FLOATS / 4 / 256;                       // 3 / 6
-    __host__ __device__ static constexpr int smem_floats(int C) { return A_FLOATS + B_FLOATS + 4 * C + 256; }
+    __host__ __device__ static constexpr int smem_floats(int C) { return A_FLOATS + B_FLOATS + 4 * C + 256 + 128; }
 };
 
 template <int TS>
@@ -302,6 +327,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
             prm[3 * C + k] = invstd;
         }
     }
+    float* gp = prm + 4 * C + 256;                     // GradSrc parameters [4][32]
+    grad_src_params(a.g, n, a.pl.HW, gp);
     const int cg0 = blockIdx.z * a.cg_per_wg;
     const int NSTAGE = a.cg_per_wg * 3;       // channel-chunk groups x 3 tap rows
     float4 rb[B_N];
@@ -316,10 +343,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
         }
     };
     // (issuing g_load(0) here, under the halo staging, costs registers: spills at 3 waves/SIMD)
-    // gradient halo (plain values, zero outside the image)
-    const float* g_n = a.g + (int64_t)n * a.pl.HWp * 32;
+    // gradient halo (zero outside the image)
+    const float* g_n = a.g.g + (int64_t)n * a.pl.HWp * a.g.ldg;
+    const float* x_n = a.g.x ? a.g.x + (int64_t)n * a.pl.HWp * a.g.ldx : nullptr;
     {
-        float4 rv[A_N];
+        float4 rv[A_N], rx[A_N];
 #pragma unroll
         for (int i = 0; i < A_N; ++i) {            // every load in flight before the first LDS store
             const int idx = t + 256 * i;
@@ -327,15 +355,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
             const int hy = hp / G::W, hx = hp - hy * G::W;
             const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
             const bool ok = idx < G::PX * 8 && (unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W;
-            const float4 v = ld4(g_n + (int64_t)(ok ? iy * a.pl.W + ix : 0) * 32 + 4 * q);   // unconditional load, clamped address
-            rv[i] = ok ? v : zero4();
+            const int64_t pix = ok ? iy * a.pl.W + ix : 0;                 // unconditional loads, clamped address
+            rv[i] = ld4(g_n + pix * a.g.ldg + 4 * q);
+            if (x_n) rx[i] = ld4(x_n + pix * a.g.ldx + 4 * q);
         }
+        __syncthreads();                           // gp (and prm) visible
 #pragma unroll
         for (int i = 0; i < A_N; ++i) {
             const int idx = t + 256 * i;
             if (idx < G::PX * 8) {
-                float* d = As + (idx >> 3) * HD_LDA + 4 * (idx & 7);
-                d[0] = rv[i].x; d[1] = rv[i].y; d[2] = rv[i].z; d[3] = rv[i].w;
+                const int hp = idx >> 3, q = idx & 7;
+                const int hy = hp / G::W, hx = hp - hy * G::W;
+                const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+                const bool ok = (unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W;
+                float4 v = rv[i];
+                if (x_n) v = affine2(rv[i], rx[i], gp + 4 * q, 32);
+                if (!ok) v = zero4();
+                float* d = As + hp * HD_LDA + 4 * q;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
             }
         }
     }
@@ -463,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
 // reduce_partials_kernel sums over workgroups - fp32 atomics here cost ~3 ms/step.
 // ------------------------------------------------------------------------------------
 struct Halo3x3WgradArgs {
-    const float* g; Plane pl;                        // [n][HWp][32] finalized output gradient
+    GradSrc g; Plane pl;                             // finished output gradient (32 channels)
     const float* src; int C;                         // raw bottleneck [n][HWp][C]
     const double* ssum; const double* ssq; int sstride;
     const float* gamma; const float* beta; float eps;
@@ -482,7 +519,7 @@ template <int TS> struct HaloWgradGeo : HaloGeo<TS> {
     static constexpr int NPH = TS == 16 ? 4 : 1;                         // staging phases per tile
     static constexpr int RED_FLOATS = 4 * 16 * 64;                       // flush area
     __host__ __device__ static constexpr int smem_floats() {
-        return (B_FLOATS + A_FLOATS > RED_FLOATS ? B_FLOATS + A_FLOATS : RED_FLOATS) + 96;
+        return (B_FLOATS + A_FLOATS > RED_FLOATS ? B_FLOATS + A_FLOATS : RED_FLOATS) + 96 + 128;
     }
 };
 
@@ -493,7 +530,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const Halo3x
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Bh = smem;                                   // [PX][32] activation halo
     float* Ag = smem + G::B_FLOATS;                     // [TS*TS][32] gradient tile
-    float* prm = smem + G::smem_floats() - 96;          // mean | scale | beta (32 each)
+    float* prm = smem + G::smem_floats() - 96 - 128;    // mean | scale | beta (32 each)
+    float* gp = prm + 96;                               // GradSrc parameters [4][32]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
     const int n = blockIdx.z, cc0 = blockIdx.y * 32;
     const int C = a.C;
@@ -504,13 +542,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const Halo3x
         prm[32 + t] = a.gamma[cc0 + t] * invstd;
         prm[64 + t] = a.beta[cc0 + t];
     }
+    grad_src_params(a.g, n, a.pl.HW, gp);
     f32x16 acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
     const float* src_n = a.src + (int64_t)n * a.pl.HWp * C + cc0;
-    const float* g_n = a.g + (int64_t)n * a.pl.HWp * 32;
+    const float* g_n = a.g.g + (int64_t)n * a.pl.HWp * a.g.ldg;
+    const float* x_n = a.g.x ? a.g.x + (int64_t)n * a.pl.HWp * a.g.ldx : nullptr;
     const int tile0 = blockIdx.x * a.tiles_per_wg;
     const int tile1 = min(tile0 + a.tiles_per_wg, a.n_tiles);
     for (int tile = tile0; tile < tile1; ++tile) {
@@ -537,7 +577,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const Halo3x
                 const int px = idx >> 3, q = idx & 7;
                 const int py = y0 + px / TS, pxx = x0 + px % TS;
                 const bool ok = TS == 16 || (py < a.pl.H && pxx < a.pl.W);     // TS == 8 tiles may hang over the edge
-                const float4 v = ld4(g_n + (ok ? (int64_t)py * a.pl.W + pxx : 0) * 32 + 4 * q);
+                const int64_t pix = ok ? (int64_t)py * a.pl.W + pxx : 0;
+                float4 v = ld4(g_n + pix * a.g.ldg + 4 * q);
+                if (x_n) v = affine2(v, ld4(x_n + pix * a.g.ldx + 4 * q), gp + 4 * q, 32);
                 rg[i] = ok ? v : zero4();
             }
 #pragma unroll

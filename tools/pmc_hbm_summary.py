@@ -1,0 +1,73 @@
+"""Aggregate rocprofv3 FETCH_SIZE / WRITE_SIZE counter_collection CSVs per kernel class (bench.py's class names).
+
+usage: pmc_hbm_summary.py <fetch_dir> <write_dir> <out_prefix>
+FETCH_SIZE is doubled (gfx950: 128-B requests tallied at 64 B, MI355X_MICROARCH.md section HBM); both counters are in KB.
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+TRAIN_STEPS = 3    # bench.py --steps 2 --warmup 1
+FORWARDS = 8       # + 5 forward-only sweeps
+FWD_ONLY = ("prep_rotate", "pack_weights", "pool0_kernel", "feat_kernel", "value_conv", "bn_update", "FwdConvP<", "conv3x3_halo_fwd")
+
+
+def kclass(name):
+    if "conv3x3_halo_fwd" in name: return "conv3x3_fwd"
+    if "conv3x3_halo_dgrad" in name: return "conv3x3_dgrad"
+    if "conv3x3_halo_wgrad" in name or "reduce_partials" in name: return "conv3x3_wgrad"
+    if "FwdConvP<" in name:
+        tail = name.split("FwdConvP<", 1)[1].split(">", 2)[1]
+        return {" 0": "conv1x1_fwd", " 1": "conv3x3_fwd", " 2": "transition_fwd", " 3": "stem7x7_fwd"}.get(tail.replace(",", ""), "conv1x1_fwd")
+    if "BwdDataGroupP" in name: return "conv1x1_dgrad"
+    if "BwdDataP<" in name:
+        args = name.split("BwdDataP<", 1)[1].split(">", 2)[1]
+        if "true" in args: return "conv3x3_dgrad"
+        return {"0": "head_conv0_dgrad", "1": "conv1x1_dgrad", "2": "transition_dgrad"}.get(args.split(",")[-1].strip(), "conv1x1_dgrad")
+    if "BwdWeightP<" in name:
+        args = [a.strip() for a in name.split("BwdWeightP<", 1)[1].split(">", 2)[1].split(",") if a.strip()]
+        return {"0": "conv1x1_wgrad", "1": "conv3x3_wgrad", "2": "transition_wgrad", "3": "stem_wgrad"}.get(args[0], "conv1x1_wgrad")
+    if "smg::" in name: return "elementwise"
+    return None
+
+
+def load(d, counter):
+    tot = collections.defaultdict(float)
+    n = collections.Counter()
+    step = collections.defaultdict(float)          # bytes per training step (1 forward + 1 backward)
+    for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(fn)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = kclass(r["Kernel_Name"])
+            if k is None:
+                continue
+            b = float(r["Counter_Value"]) * 1024.0
+            tot[k] += b
+            n[k] += 1
+            step[k] += b / (FORWARDS if any(f in r["Kernel_Name"] for f in FWD_ONLY) else TRAIN_STEPS)
+    return tot, n, step
+
+
+def main():
+    fetch, nf, fstep = load(sys.argv[1], "FETCH_SIZE")
+    write, _, wstep = load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0))):
+        f = 2.0 * fetch[k] / nf[k]
+        w = write.get(k, 0.0) / nf[k]
+        out[k] = {"launches": nf[k], "fetch_bytes_per_launch": f, "write_bytes_per_launch": w, "hbm_bytes_per_launch": f + w,
+                  "gb_per_train_step": (2.0 * fstep[k] + wstep.get(k, 0.0)) / 1e9}
+    json.dump(out, open(sys.argv[3] + ".json", "w"), indent=1)
+    with open(sys.argv[3] + ".md", "w") as md:
+        md.write("| kernel class | launches (3 train steps + 5 forward sweeps) | FETCH_SIZE x2 (MB / launch) | WRITE_SIZE (MB / launch) | GB per training step |\n|---|---|---|---|---|\n")
+        for k, v in out.items():
+            md.write("| %s | %d | %.1f | %.1f | %.2f |\n" % (k, v["launches"], v["fetch_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6, v["gb_per_train_step"]))
+        md.write("\ntotal %.1f GB per training step (one forward + one backward + Adam)\n" % sum(v["gb_per_train_step"] for v in out.values()))
+    print(open(sys.argv[3] + ".md").read())
+
+
+if __name__ == "__main__":
+    main()
