@@ -1109,6 +1109,7 @@ int64_t smg_debug_read(smg_engine* e, const char* name, float* host_out, int64_t
     else if (s == "feat") { src = e->F; n = (int64_t)NP * e->p_blk[3].HWp * 2 * kFeat; }
     else if (s == "h1") { src = e->H1; n = (int64_t)NP * e->p_blk[3].HWp * kHeadMid; }
     else if (s == "df") { src = e->DF; n = (int64_t)NP * e->p_blk[3].HWp * 2 * kFeat; }
+    else if (s == "dh1") { src = e->DH1; n = (int64_t)NP * e->p_blk[3].HWp * kHeadMid; }
     else if (s.size() == 2 && (s[0] == 'x' || s[0] == 'g') && s[1] >= '1' && s[1] <= '4') {
         const int b = s[1] - '1';
         src = s[0] == 'x' ? e->X[b] : e->G[b]; n = (int64_t)NS * e->p_blk[b].HWp * kBlockCtot[b];

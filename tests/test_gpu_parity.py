@@ -436,3 +436,106 @@ def test_target_network_sync(gpu):
     q1 = tr.forward(depth, depth * masks[0], 0, True, False, 1)
     q2 = tr.forward(depth, depth * masks[0], 0, True, True, 1)
     assert q1[0] == q2[0]
+
+
+def test_backward_other_input_size_ragged_planes(gpu):
+    """A 240^2 heightmap -> S = 704: 176^2 / 88^2 / 44^2 / 22^2 planes.  Block 1 runs the 16x16 halo kernels, block 2
+    the 8x8 ones on an exact tiling, blocks 3-4 the 8x8 ones with masked ragged edges (5.5 / 2.75 tiles per side),
+    the 1x1 kernels their partial-tile epilogues, and the head a dense 3x3 Q map.  Forward and all 368 gradient
+    tensors of a weighted-sum loss against the fp64 oracle.  Yardstick as in test_g5_backward_gradients but with
+    room for ReLU mask flips: on this scene one head activation sits 2e-6 from zero (tests/gpu_diag_head.py), the
+    HIP path and PyTorch-CPU fp32 land on different sides, and that single element moves norm1.bias by 0.8 % and
+    every trunk gradient by ~0.4 %.  A dropped or doubled tile edge would show as >= 4 % (one of 22 rows)."""
+    import synthetic
+    style, rot = 0, 5
+    on = oracle_net(2)
+    depth, masks = synthetic.heightmap_scene(8, size=240, n_boxes=8)
+    x = orc.preprocess(depth, [MEAN] * 3, [STD] * 3)
+    mx = orc.preprocess(depth * masks[0], [MEAN] * 3, [STD] * 3)
+    assert x.shape[-1] == 704
+    wq = torch.from_numpy(synthetic.uniform(3, "ragged/wq", 9, -1.0, 1.0).astype(np.float32)).reshape(1, 1, 3, 3)
+    rx = orc.rotate(x, rot, 16)
+    o64 = copy.deepcopy(on).double()
+    trunk = getattr(o64, orc.STYLE_TRUNK[style]).features
+    head = getattr(o64, orc.STYLE_HEAD[style])
+    q64 = head(torch.cat((trunk(rx.double()), trunk(mx.double())), 1))
+    assert tuple(q64.shape) == (1, 1, 3, 3)
+    (q64 * wq.double()).sum().backward()
+    g64 = {n: p.grad for n, p in o64.named_parameters() if p.grad is not None}
+    on.zero_grad()
+    qo = orc.forward(on, x, mx, style, False, rot)
+    (qo * wq).sum().backward()
+    net = product_net(2)
+    net.zero_grad()
+    qp = net.forward(x, mx, style, False, rot)
+    assert tuple(qp.shape) == (1, 1, 3, 3)
+    (qp * wq.cuda()).sum().backward()
+    ok, worst = q_close(qp.detach().cpu().numpy().ravel(), q64.detach().numpy().ravel())
+    assert ok, worst
+    po = dict(on.named_parameters())
+    gmax = max(float(g.norm()) for g in g64.values())
+    rel_p, rel_o, n_checked = [], [], 0
+    for name, p in net.named_parameters():
+        if name not in g64:
+            assert p.grad is None, "unexpected gradient on " + name
+            continue
+        assert p.grad is not None, "missing gradient on " + name
+        t = g64[name].numpy()
+        e_prod = np.sqrt(((p.grad.cpu().double().numpy() - t) ** 2).sum())
+        e_orc = np.sqrt(((po[name].grad.double().numpy() - t) ** 2).sum())
+        nrm = np.sqrt((t * t).sum())
+        rel_p.append(e_prod / max(nrm, 1e-30))
+        rel_o.append(e_orc / max(nrm, 1e-30))
+        assert e_prod <= 5.0 * e_orc + 2e-2 * nrm + 1e-6 * gmax, \
+            "%s: |err| %.3e vs fp32-oracle |err| %.3e, |g| %.3e" % (name, e_prod, e_orc, nrm)
+        n_checked += 1
+    assert n_checked == 368
+    assert np.median(rel_p) <= 4.0 * np.median(rel_o) + 1e-3, (np.median(rel_p), np.median(rel_o))
+
+
+_VARIANT_SCRIPT = r"""
+import sys, json
+import numpy as np, torch
+sys.path.insert(0, %(tests)r)
+from helpers import product_net, scene_tensors
+net = product_net(4)
+x, mx = scene_tensors(3, [1])
+with torch.no_grad():
+    q = np.concatenate([np.asarray(t.cpu()).ravel() for t in net.forward(x, mx, 0, True, -1)])
+net.zero_grad()
+qp = net.forward(x, mx, 0, False, 11)
+(qp[0, 0, 0, 0] * 1.0).backward()
+g = net.flat_grads().double().cpu().numpy()
+idx = np.linspace(0, g.size - 1, 4096).astype(np.int64)
+print("RESULT " + json.dumps({"q": q.tolist(), "gnorm": float(np.sqrt((g * g).sum())), "gprobe": g[idx].tolist()}))
+"""
+
+
+def test_alternative_kernel_paths_agree(gpu):
+    """The same sweep + one backward through three independent implementations of the 3x3 layers: the LDS-halo kernels
+    (default), the generic implicit GEMM (SMG_GENERIC_3X3=1) and the halo kernels with the BN-backward apply fused
+    into their loads (SMG_GS_FUSED=1).  Separate child processes: the switches are read at engine creation."""
+    import json
+    import os
+    import subprocess
+    import sys
+    tests_dir = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for tag, env in (("halo", {}), ("generic", {"SMG_GENERIC_3X3": "1"}), ("fused", {"SMG_GS_FUSED": "1"})):
+        e = dict(os.environ)
+        e.pop("SMG_GENERIC_3X3", None)
+        e.pop("SMG_GS_FUSED", None)
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", _VARIANT_SCRIPT % {"tests": tests_dir}], env=e, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+        res[tag] = json.loads(line[7:])
+    ref = res["halo"]
+    qs = np.abs(np.asarray(ref["q"])).max()
+    for tag in ("generic", "fused"):
+        r = res[tag]
+        assert np.abs(np.asarray(r["q"]) - np.asarray(ref["q"])).max() <= 2e-5 * max(qs, 1e-2), tag     # fp32 summation order only
+        assert int(np.argmax(r["q"])) == int(np.argmax(ref["q"])), tag
+        gp, g0 = np.asarray(r["gprobe"]), np.asarray(ref["gprobe"])
+        assert np.sqrt(((gp - g0) ** 2).sum()) <= 5e-3 * np.sqrt((g0 * g0).sum()), tag               # ill-conditioned, see header
+        assert abs(r["gnorm"] - ref["gnorm"]) <= 5e-3 * ref["gnorm"], tag
