@@ -487,107 +487,132 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
     }
     const float* P = net->params;
 
-    {   // K1 input preparation
-        PrepArgs a;
-        a.images_nchw = B->images_nchw_dev; a.heightmaps = B->heightmaps_dev; a.hm = B->hm_size; a.pad = pad; a.S = e->S;
-        a.mean = B->image_mean; a.stdv = B->image_std;
-        a.stream_image = e->d_stream_image; a.stream_affine = e->d_affine; a.stream_rotated = e->d_stream_rot;
-        a.img4 = e->img4; a.HWp = e->p_img.HWp;
-        ProfScope ps(e, st, K_OTHER, 0);
-        hipLaunchKernelGGL(prep_rotate_kernel, dim3((e->S * e->S + 255) / 256, NS), dim3(256), 0, st, a);
-    }
-    {   // stem conv0 7x7/2
-        auto run = [&](auto tag) {
-                using Cfg = decltype(tag);
-                FwdConvP<Cfg, F_STEM> p{};
-        p.src = e->img4; p.lds_ = 4; p.ps = e->p_img; p.po = e->p_stem; p.K = 0;
-        p.w = e->packed + e->pk_conv0; p.ldw = 64; p.N = 64;
-        p.dst = e->stem; p.ldd = 64; p.dcoff = 0;
-        p.dsum = fsum(e, e->st_stem); p.dsq = fsq(e, e->st_stem); p.dstride = 64; p.eps = kEps;
-        launch_gemm(e, st, p, dim3(NS * e->p_stem.HWp / Cfg::BM, 1), K_STEM, 2.0 * NS * e->p_stem.HW * 64 * 147);
-            };
-            if (e->p_stem.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
-    }
-    {   // norm0 + relu0 + pool0
-        Pool0Args a;
-        a.stem = e->stem; a.ps = e->p_stem; a.ssum = fsum(e, e->st_stem); a.ssq = fsq(e, e->st_stem);
-        a.gamma = P + T.norm0.w; a.beta = P + T.norm0.b; a.eps = kEps;
-        a.x1 = e->X[0]; a.ldx = kBlockCtot[0]; a.po = e->p_blk[0];
-        a.dsum = fsum(e, e->st_X[0]); a.dsq = fsq(e, e->st_X[0]); a.dstride = kBlockCtot[0];
-        a.argmax = e->argmax;
-        ProfScope ps(e, st, K_OTHER, 0);
-        hipLaunchKernelGGL(pool0_kernel, dim3(e->p_blk[0].HWp / 64, NS), dim3(256), 0, st, a);
-    }
-    for (int b = 0; b < 4; ++b) {
-        e->prof_stage = b;
-        const Plane pl = e->p_blk[b];
-        const int Ct = kBlockCtot[b];
-        for (size_t i = 0; i < T.layers[b].size(); ++i) {
-            const DenseLayerRef& d = T.layers[b][i];
-            float* bt = e->Bt + e->bt_off[b][i];
-            {   // norm1 + relu + conv1 (1x1, cin -> 128)
-                auto run = [&](auto tag) {
-                using Cfg = decltype(tag);
-                FwdConvP<Cfg, F_ONE> p{};
-                p.src = e->X[b]; p.lds_ = Ct; p.ps = pl; p.po = pl; p.K = d.cin;
-                p.ssum = fsum(e, e->st_X[b]); p.ssq = fsq(e, e->st_X[b]); p.sstride = Ct;
-                p.gamma = P + d.n1.w; p.beta = P + d.n1.b; p.eps = kEps;
-                p.w = e->packed + e->pk_c1[b][i]; p.ldw = kBottleneck; p.N = kBottleneck;
-                p.dst = bt; p.ldd = kBottleneck; p.dcoff = 0;
-                p.dsum = fsum(e, e->st_Bt[b][i]); p.dsq = fsq(e, e->st_Bt[b][i]); p.dstride = kBottleneck;
-                launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, kBottleneck / Cfg::BN), K_C1, 2.0 * NS * pl.HW * d.cin * kBottleneck);
-            };
-            if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x64{});   // (64x128 here: measured slower)
-            }
-            if (!e->generic3x3) {
-                // norm2 + relu + conv2 (3x3, 128 -> 32) with an LDS-resident input halo (halo.cuh)
-                Halo3x3FwdArgs a;
-                a.src = bt; a.lds_ = kBottleneck; a.pl = pl; a.C = kBottleneck;
-                a.ssum = fsum(e, e->st_Bt[b][i]); a.ssq = fsq(e, e->st_Bt[b][i]); a.sstride = kBottleneck;
-                a.gamma = P + d.n2.w; a.beta = P + d.n2.b; a.eps = kEps;
-                a.w = e->packed + e->pk_c2f[b][i];
-                a.dst = e->X[b]; a.ldd = Ct; a.dcoff = d.cin;
-                a.dsum = fsum(e, e->st_X[b]); a.dsq = fsq(e, e->st_X[b]); a.dstride = Ct;
-                ProfScope ps(e, st, K_C3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
-                if (halo_tile(pl) == 16) {
-                    a.tiles_x = pl.W / 16;
-                    hipLaunchKernelGGL(conv3x3_halo_fwd_kernel<16>, dim3((pl.H / 16) * a.tiles_x, NS), dim3(256),
-                                       HaloFwdGeo<16>::smem_floats(kBottleneck) * sizeof(float), st, a);
-                } else {
-                    a.tiles_x = (pl.W + 7) / 8;
-                    hipLaunchKernelGGL(conv3x3_halo_fwd_kernel<8>, dim3(((pl.H + 7) / 8) * a.tiles_x, NS), dim3(256),
-                                       HaloFwdGeo<8>::smem_floats(kBottleneck) * sizeof(float), st, a);
-                }
-            } else {   // norm2 + relu + conv2 (3x3, 128 -> 32), appended to the block buffer (generic implicit GEMM)
-                auto run = [&](auto tag) {
-                    using Cfg = decltype(tag);
-                    FwdConvP<Cfg, F_THREE> p{};
-                    p.src = bt; p.lds_ = kBottleneck; p.ps = pl; p.po = pl; p.K = kBottleneck;
-                    p.ssum = fsum(e, e->st_Bt[b][i]); p.ssq = fsq(e, e->st_Bt[b][i]); p.sstride = kBottleneck;
-                    p.gamma = P + d.n2.w; p.beta = P + d.n2.b; p.eps = kEps;
-                    p.w = e->packed + e->pk_c2f[b][i]; p.ldw = kGrowth; p.N = kGrowth;
-                    p.dst = e->X[b]; p.ldd = Ct; p.dcoff = d.cin;
-                    p.dsum = fsum(e, e->st_X[b]); p.dsq = fsq(e, e->st_X[b]); p.dstride = Ct;
-                    launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, 1), K_C3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
-                };
-                if (pl.HWp % 128 == 0) run(CfgP128x32{}); else run(CfgP64x32{});
-            }
+    // The trunk of streams [s0, s0 + ns).  Streams are independent up to the head (BN statistics are per stream), so
+    // the batch is run as TWO chains on two HIP streams: the tail of one chain's kernel overlaps the other chain's
+    // next kernel (two full sweeps side by side take 83 % of their serial time, tests/gpu_concurrency_probe.py).
+    auto trunk_chain = [&](const int s0, const int ns, hipStream_t cs) -> int {
+        auto xs = [&](int b) { return e->X[b] + (int64_t)s0 * e->p_blk[b].HWp * kBlockCtot[b]; };
+        auto st_off = [&](double* base, int stride) { return base + (int64_t)s0 * stride; };
+        float* img4 = e->img4 + (int64_t)s0 * e->p_img.HWp * 4;
+        float* stem = e->stem + (int64_t)s0 * e->p_stem.HWp * 64;
+        {   // K1 input preparation
+            PrepArgs a;
+            a.images_nchw = B->images_nchw_dev; a.heightmaps = B->heightmaps_dev; a.hm = B->hm_size; a.pad = pad; a.S = e->S;
+            a.mean = B->image_mean; a.stdv = B->image_std;
+            a.stream_image = e->d_stream_image + s0; a.stream_affine = e->d_affine + 6 * s0; a.stream_rotated = e->d_stream_rot + s0;
+            a.img4 = img4; a.HWp = e->p_img.HWp;
+            ProfScope ps(e, cs, K_OTHER, 0);
+            hipLaunchKernelGGL(prep_rotate_kernel, dim3((e->S * e->S + 255) / 256, ns), dim3(256), 0, cs, a);
         }
-        if (b < 3) {   // transition: norm + relu + (avgpool2 commuted in front of) conv 1x1
-            const Plane pn = e->p_blk[b + 1];
+        {   // stem conv0 7x7/2
             auto run = [&](auto tag) {
                 using Cfg = decltype(tag);
-                FwdConvP<Cfg, F_POOL> p{};
-            p.src = e->X[b]; p.lds_ = Ct; p.ps = pl; p.po = pn; p.K = Ct;
-            p.ssum = fsum(e, e->st_X[b]); p.ssq = fsq(e, e->st_X[b]); p.sstride = Ct;
-            p.gamma = P + T.tnorm[b].w; p.beta = P + T.tnorm[b].b; p.eps = kEps;
-            p.w = e->packed + e->pk_t[b]; p.ldw = Ct / 2; p.N = Ct / 2;
-            p.dst = e->X[b + 1]; p.ldd = kBlockCtot[b + 1]; p.dcoff = 0;
-            p.dsum = fsum(e, e->st_X[b + 1]); p.dsq = fsq(e, e->st_X[b + 1]); p.dstride = kBlockCtot[b + 1];
-            launch_gemm(e, st, p, dim3(NS * pn.HWp / Cfg::BM, (Ct / 2) / Cfg::BN), K_TRANS, 2.0 * NS * pn.HW * Ct * (Ct / 2));
+                FwdConvP<Cfg, F_STEM> p{};
+                p.src = img4; p.lds_ = 4; p.ps = e->p_img; p.po = e->p_stem; p.K = 0;
+                p.w = e->packed + e->pk_conv0; p.ldw = 64; p.N = 64;
+                p.dst = stem; p.ldd = 64; p.dcoff = 0;
+                p.dsum = st_off(fsum(e, e->st_stem), 64); p.dsq = st_off(fsq(e, e->st_stem), 64); p.dstride = 64; p.eps = kEps;
+                launch_gemm(e, cs, p, dim3(ns * e->p_stem.HWp / Cfg::BM, 1), K_STEM, 2.0 * ns * e->p_stem.HW * 64 * 147);
             };
-            if (pn.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
+            if (e->p_stem.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
         }
+        {   // norm0 + relu0 + pool0
+            Pool0Args a;
+            a.stem = stem; a.ps = e->p_stem; a.ssum = st_off(fsum(e, e->st_stem), 64); a.ssq = st_off(fsq(e, e->st_stem), 64);
+            a.gamma = P + T.norm0.w; a.beta = P + T.norm0.b; a.eps = kEps;
+            a.x1 = xs(0); a.ldx = kBlockCtot[0]; a.po = e->p_blk[0];
+            a.dsum = st_off(fsum(e, e->st_X[0]), kBlockCtot[0]); a.dsq = st_off(fsq(e, e->st_X[0]), kBlockCtot[0]); a.dstride = kBlockCtot[0];
+            a.argmax = e->argmax + (int64_t)s0 * e->p_blk[0].HWp * 64;
+            ProfScope ps(e, cs, K_OTHER, 0);
+            hipLaunchKernelGGL(pool0_kernel, dim3(e->p_blk[0].HWp / 64, ns), dim3(256), 0, cs, a);
+        }
+        for (int b = 0; b < 4; ++b) {
+            e->prof_stage = b;
+            const Plane pl = e->p_blk[b];
+            const int Ct = kBlockCtot[b];
+            double* xsum = st_off(fsum(e, e->st_X[b]), Ct); double* xsq = st_off(fsq(e, e->st_X[b]), Ct);
+            for (size_t i = 0; i < T.layers[b].size(); ++i) {
+                const DenseLayerRef& d = T.layers[b][i];
+                float* bt = e->Bt + e->bt_off[b][i] + (int64_t)s0 * pl.HWp * kBottleneck;
+                double* bsum = st_off(fsum(e, e->st_Bt[b][i]), kBottleneck); double* bsq = st_off(fsq(e, e->st_Bt[b][i]), kBottleneck);
+                {   // norm1 + relu + conv1 (1x1, cin -> 128)
+                    auto run = [&](auto tag) {
+                        using Cfg = decltype(tag);
+                        FwdConvP<Cfg, F_ONE> p{};
+                        p.src = xs(b); p.lds_ = Ct; p.ps = pl; p.po = pl; p.K = d.cin;
+                        p.ssum = xsum; p.ssq = xsq; p.sstride = Ct;
+                        p.gamma = P + d.n1.w; p.beta = P + d.n1.b; p.eps = kEps;
+                        p.w = e->packed + e->pk_c1[b][i]; p.ldw = kBottleneck; p.N = kBottleneck;
+                        p.dst = bt; p.ldd = kBottleneck; p.dcoff = 0;
+                        p.dsum = bsum; p.dsq = bsq; p.dstride = kBottleneck;
+                        launch_gemm(e, cs, p, dim3(ns * pl.HWp / Cfg::BM, kBottleneck / Cfg::BN), K_C1, 2.0 * ns * pl.HW * d.cin * kBottleneck);
+                    };
+                    if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x64{});   // (64x128 here: measured slower)
+                }
+                if (!e->generic3x3) {
+                    // norm2 + relu + conv2 (3x3, 128 -> 32) with an LDS-resident input halo (halo.cuh)
+                    Halo3x3FwdArgs a;
+                    a.src = bt; a.lds_ = kBottleneck; a.pl = pl; a.C = kBottleneck;
+                    a.ssum = bsum; a.ssq = bsq; a.sstride = kBottleneck;
+                    a.gamma = P + d.n2.w; a.beta = P + d.n2.b; a.eps = kEps;
+                    a.w = e->packed + e->pk_c2f[b][i];
+                    a.dst = xs(b); a.ldd = Ct; a.dcoff = d.cin;
+                    a.dsum = xsum; a.dsq = xsq; a.dstride = Ct;
+                    ProfScope ps(e, cs, K_C3, 2.0 * ns * pl.HW * 9 * kBottleneck * kGrowth);
+                    if (halo_tile(pl) == 16) {
+                        a.tiles_x = pl.W / 16;
+                        hipLaunchKernelGGL(conv3x3_halo_fwd_kernel<16>, dim3((pl.H / 16) * a.tiles_x, ns), dim3(256),
+                                           HaloFwdGeo<16>::smem_floats(kBottleneck) * sizeof(float), cs, a);
+                    } else {
+                        a.tiles_x = (pl.W + 7) / 8;
+                        hipLaunchKernelGGL(conv3x3_halo_fwd_kernel<8>, dim3(((pl.H + 7) / 8) * a.tiles_x, ns), dim3(256),
+                                           HaloFwdGeo<8>::smem_floats(kBottleneck) * sizeof(float), cs, a);
+                    }
+                } else {   // norm2 + relu + conv2 (3x3, 128 -> 32), appended to the block buffer (generic implicit GEMM)
+                    auto run = [&](auto tag) {
+                        using Cfg = decltype(tag);
+                        FwdConvP<Cfg, F_THREE> p{};
+                        p.src = bt; p.lds_ = kBottleneck; p.ps = pl; p.po = pl; p.K = kBottleneck;
+                        p.ssum = bsum; p.ssq = bsq; p.sstride = kBottleneck;
+                        p.gamma = P + d.n2.w; p.beta = P + d.n2.b; p.eps = kEps;
+                        p.w = e->packed + e->pk_c2f[b][i]; p.ldw = kGrowth; p.N = kGrowth;
+                        p.dst = xs(b); p.ldd = Ct; p.dcoff = d.cin;
+                        p.dsum = xsum; p.dsq = xsq; p.dstride = Ct;
+                        launch_gemm(e, cs, p, dim3(ns * pl.HWp / Cfg::BM, 1), K_C3, 2.0 * ns * pl.HW * 9 * kBottleneck * kGrowth);
+                    };
+                    if (pl.HWp % 128 == 0) run(CfgP128x32{}); else run(CfgP64x32{});
+                }
+            }
+            if (b < 3) {   // transition: norm + relu + (avgpool2 commuted in front of) conv 1x1
+                const Plane pn = e->p_blk[b + 1];
+                const int Cn = kBlockCtot[b + 1];
+                auto run = [&](auto tag) {
+                    using Cfg = decltype(tag);
+                    FwdConvP<Cfg, F_POOL> p{};
+                    p.src = xs(b); p.lds_ = Ct; p.ps = pl; p.po = pn; p.K = Ct;
+                    p.ssum = xsum; p.ssq = xsq; p.sstride = Ct;
+                    p.gamma = P + T.tnorm[b].w; p.beta = P + T.tnorm[b].b; p.eps = kEps;
+                    p.w = e->packed + e->pk_t[b]; p.ldw = Ct / 2; p.N = Ct / 2;
+                    p.dst = xs(b + 1); p.ldd = Cn; p.dcoff = 0;
+                    p.dsum = st_off(fsum(e, e->st_X[b + 1]), Cn); p.dsq = st_off(fsq(e, e->st_X[b + 1]), Cn); p.dstride = Cn;
+                    launch_gemm(e, cs, p, dim3(ns * pn.HWp / Cfg::BM, (Ct / 2) / Cfg::BN), K_TRANS, 2.0 * ns * pn.HW * Ct * (Ct / 2));
+                };
+                if (pn.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
+            }
+        }
+        return 0;
+    };
+    static const bool one_chain = getenv("SMG_FWD_ONE_CHAIN") != nullptr;      // dev: A/B switch
+    if (NS >= 2 && !e->prof && !one_chain) {
+        const int h = NS / 2;
+        HIP_OK(hipEventRecord(e->ev_misc, st));                 // packed weights + batch description are ready
+        HIP_OK(hipStreamWaitEvent(e->side, e->ev_misc, 0));
+        if (trunk_chain(0, h, st)) return -5;
+        if (trunk_chain(h, NS - h, e->side)) return -5;
+        HIP_OK(hipEventRecord(e->ev_end, e->side));             // join before the head reads every stream's features
+        HIP_OK(hipStreamWaitEvent(st, e->ev_end, 0));
+    } else {
+        if (trunk_chain(0, NS, st)) return -5;                  // profiling: one chain, per-kernel times stay per layer
     }
     e->prof_stage = -1;
     const Plane p4 = e->p_blk[3];
