@@ -51,6 +51,7 @@ using CfgP128x32 = GemmCfg<128, 32, 32, 4, 1, 1, true>;      // 3x3 fwd (N = gro
 using CfgP128x64 = GemmCfg<128, 64, 16, 2, 2, 1, true>;      // stem, head conv0, 1x1 dgrad
 // small stages (late blocks: few pixels per stream -> 64-row tiles, 4x the workgroups)
 using CfgP64x64 = GemmCfg<64, 64, 32, 2, 2, 1, true>;        // 1x1 fwd / dgrad, transitions
+using CfgP64x64k16 = GemmCfg<64, 64, 16, 2, 2, 1, true>;     // 1x1 fwd with many input channels: 29 KB LDS incl. BN parameters
 using CfgP64x128 = GemmCfg<64, 128, 16, 2, 2, 1, true>;      // 3x3 dgrad, late 1x1 fwd / transitions (A operand read once)
 using CfgP64x32 = GemmCfg<64, 32, 64, 2, 1, 2, true>;        // 3x3 fwd, k-tile split over 2 waves
 // weight gradients (reduction over pixels)
@@ -547,7 +548,12 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
                         p.dsum = bsum; p.dsq = bsq; p.dstride = kBottleneck;
                         launch_gemm(e, cs, p, dim3(ns * pl.HWp / Cfg::BM, kBottleneck / Cfg::BN), K_C1, 2.0 * ns * pl.HW * d.cin * kBottleneck);
                     };
-                    if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x64{});   // (64x128 here: measured slower)
+                    // 64-row tiles: the BN parameters of all cin channels sit in LDS (12 B each) next to the 34 KB of
+                    // BK = 32 tiles; past 576 channels only three workgroups fit a CU (768 slots for the 850 tiles of a
+                    // 17-stream 40x40 layer), so those layers take BK = 16 tiles (29 KB, five per CU).  64x128 tiles: slower.
+                    if (pl.HWp % 128 == 0) run(CfgP128x128{});
+                    else if (d.cin > 576) run(CfgP64x64k16{});
+                    else run(CfgP64x64{});
                 }
                 if (!e->generic3x3) {
                     // norm2 + relu + conv2 (3x3, 128 -> 32) with an LDS-resident input halo (halo.cuh)
