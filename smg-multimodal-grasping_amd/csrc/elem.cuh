@@ -421,6 +421,7 @@ struct Pool0BwdArgs {
     float* DY0;                                              // [n][ps.HWp][64]
     double* o1; double* o2;                                  // [n][64]
     float* dbeta; float* dgamma;
+    int tiles_per_wg;                                        // consecutive 8x8 tiles per workgroup (one flush of the sums)
 };
 
 __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArgs a) {
@@ -428,14 +429,14 @@ __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArgs a) {
     // cover the tile are finalised (BN-backward-corrected) ONCE into LDS together with their argmax;
     // every stem pixel then picks its <= 4 windows from LDS.  (The gather straight from global memory
     // chained argmax load -> compare -> conditional gradient load: one memory round trip per window.)
+    // A workgroup walks tiles_per_wg tiles and flushes its BN-backward sums once: one tile per workgroup meant
+    // 27 200 workgroups x 256 atomics on 2 x 64 x (1 + streams) addresses.
     __shared__ float prm[8 * 64];
     __shared__ float gl[25][64];
     __shared__ unsigned char al[25][64];
     __shared__ float red[2][16][64];
     const int n = blockIdx.y, t = threadIdx.x, cq = t & 15, slot = t >> 4;
-    const int tiles_x = a.ps.W / 8;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int y0 = ty * 8, x0 = tx * 8;
+    const int tiles_x = a.ps.W / 8, n_tiles = tiles_x * (a.ps.H / 8);
     if (t < 64) {
         float mean, invstd;
         bn_moments(a.ssum, a.ssq, (int64_t)n * 64 + t, 1.0 / (double)a.ps.HW, a.eps, mean, invstd);
@@ -447,6 +448,11 @@ __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArgs a) {
         const float q2 = (float)(a.SB[(int64_t)n * a.sstride + t] * inv);
         prm[256 + t] = i1; prm[320 + t] = q1; prm[384 + t] = m1; prm[448 + t] = i1 * q2;
     }
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    const int tile0 = blockIdx.x * a.tiles_per_wg, tile1 = min(tile0 + a.tiles_per_wg, n_tiles);
+    for (int tile = tile0; tile < tile1; ++tile) {
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int y0 = ty * 8, x0 = tx * 8;
     // stem values of this thread's 4 pixels: issue early
     float4 sv[4];
     int64_t srow[4];
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArgs a) {
         xq[k] = ld4(a.X1 + pr * a.ld1 + 4 * q);
         aq[k] = *reinterpret_cast<const uchar4*>(a.argmax + pr * 64 + 4 * q);
     }
-    __syncthreads();                                        // prm ready
+    __syncthreads();                                        // prm ready; previous tile's gl / al consumed
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int item = t + 256 * k;
@@ -485,7 +491,6 @@ __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArgs a) {
         }
     }
     __syncthreads();
-    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int lp = slot + 16 * i;
@@ -510,6 +515,7 @@ __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArgs a) {
         }
         *reinterpret_cast<float4*>(a.DY0 + srow[i] * 64 + 4 * cq) = make_float4(dy[0], dy[1], dy[2], dy[3]);
     }
+    }   // tiles
 #pragma unroll
     for (int c = 0; c < 4; ++c) { red[0][slot][4 * cq + c] = s1[c]; red[1][slot][4 * cq + c] = s2[c]; }
     __syncthreads();

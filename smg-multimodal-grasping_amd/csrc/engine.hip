@@ -982,7 +982,10 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
         a.dbeta = Gr + T.norm0.b; a.dgamma = Gr + T.norm0.w;
         ProfScope ps(e, st, K_OTHER, 0);
         if (e->p_stem.H % 8 || e->p_stem.W % 8) return fail(-22, "stem plane must tile by 8 (input_size multiple of 16)");
-        hipLaunchKernelGGL(pool0_bwd_kernel, dim3((e->p_stem.H / 8) * (e->p_stem.W / 8), NS), dim3(256), 0, st, a);
+        static const int exp_tpw = getenv("SMG_POOL0_TPW") ? atoi(getenv("SMG_POOL0_TPW")) : 8;
+        a.tiles_per_wg = exp_tpw;
+        const int n_t = (e->p_stem.H / 8) * (e->p_stem.W / 8);
+        hipLaunchKernelGGL(pool0_bwd_kernel, dim3((n_t + a.tiles_per_wg - 1) / a.tiles_per_wg, NS), dim3(256), 0, st, a);
     }
     {   // conv0 weight gradient (no data gradient: the image needs none)
         const Plane ps_ = e->p_stem;
