@@ -982,8 +982,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
         a.dbeta = Gr + T.norm0.b; a.dgamma = Gr + T.norm0.w;
         ProfScope ps(e, st, K_OTHER, 0);
         if (e->p_stem.H % 8 || e->p_stem.W % 8) return fail(-22, "stem plane must tile by 8 (input_size multiple of 16)");
-        static const int exp_tpw = getenv("SMG_POOL0_TPW") ? atoi(getenv("SMG_POOL0_TPW")) : 8;
-        a.tiles_per_wg = exp_tpw;
+        a.tiles_per_wg = 8;          // 4..20 measure the same; 1 costs 0.7 ms per step in atomics
         const int n_t = (e->p_stem.H / 8) * (e->p_stem.W / 8);
         hipLaunchKernelGGL(pool0_bwd_kernel, dim3((n_t + a.tiles_per_wg - 1) / a.tiles_per_wg, NS), dim3(256), 0, st, a);
     }
