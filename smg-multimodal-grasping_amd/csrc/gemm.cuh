@@ -838,7 +838,7 @@ struct BwdDataGroupP {
     static constexpr int kSwizzle = 1;
     static constexpr int kPrefetch = 1;
     static constexpr bool kSegmented = true;
-    static constexpr int kMinWaves = 1;
+    static constexpr int kMinWaves = 3;       // 160 registers without spilling: 3 workgroups per CU instead of 2 (-0.4 ms per step)
 
     struct Ctx {
         int n, m0, n0;

@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmg_hip.so")
+LIB_PATH = os.environ.get("SMG_HIP_LIB") or os.path.join(_HERE, "libsmg_hip.so")     # SMG_HIP_LIB: dev A/B of two builds
 
 
 class SmgError(RuntimeError):
