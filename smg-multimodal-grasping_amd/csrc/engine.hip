@@ -52,6 +52,7 @@ using CfgP128x64 = GemmCfg<128, 64, 16, 2, 2, 1, true>;      // stem, head conv0
 // small stages (late blocks: few pixels per stream -> 64-row tiles, 4x the workgroups)
 using CfgP64x64 = GemmCfg<64, 64, 32, 2, 2, 1, true>;        // 1x1 fwd / dgrad, transitions
 using CfgP64x64k16 = GemmCfg<64, 64, 16, 2, 2, 1, true>;     // 1x1 fwd with many input channels: 29 KB LDS incl. BN parameters
+using CfgP32x64 = GemmCfg<32, 64, 32, 1, 2, 2, true>;        // 1x1 fwd of a launch too small to fill the chip: 2x the workgroups, half the K chain per wave
 using CfgP64x128 = GemmCfg<64, 128, 16, 2, 2, 1, true>;      // 3x3 dgrad, late 1x1 fwd / transitions (A operand read once)
 using CfgP64x32 = GemmCfg<64, 32, 64, 2, 1, 2, true>;        // 3x3 fwd, k-tile split over 2 waves
 // weight gradients (reduction over pixels)
@@ -127,8 +128,14 @@ struct smg_engine {
     double prof_ms[5][K_COUNT] = {}; int64_t prof_n[5][K_COUNT] = {}; double prof_flops[5][K_COUNT] = {}; int prof_stage = -1;
 };
 
-// Tile side of the LDS-halo 3x3 kernels for a plane: 16 where it tiles exactly, else 8 (ragged edges masked).
-static inline int halo_tile(const Plane& p) { return (p.H % 16 == 0 && p.W % 16 == 0) ? 16 : 8; }
+// Tile side of the LDS-halo 3x3 kernels for a plane: 16 where it tiles exactly, else 8 (ragged edges masked) - and 8
+// as well when the launch would have fewer than 320 16x16 tiles (few streams per call; 80x80 planes of a 9-stream
+// forward chain): four times the workgroups fill the chip (forward sweep 9.05 -> 8.77 ms, single-rotation forward
+// 4.3 -> 3.6 ms).
+static inline int halo_tile(const Plane& p, int n_streams = 1 << 20) {
+    if (p.H % 16 || p.W % 16) return 8;
+    return (int64_t)(p.H / 16) * (p.W / 16) * n_streams >= 320 ? 16 : 8;
+}
 
 // 3x3 weight-gradient halo kernel: tiles per workgroup.  The launch runs in rounds of 512 resident workgroups (2 per
 // CU), each lasting tiles_per_wg tile-times plus a fixed prologue + 9-tap flush (~0.6 of a 16x16 tile-time, measured);
@@ -304,9 +311,11 @@ static int engine_build(smg_engine* e) {
     e->part_floats = (int64_t)24 << 20;   // partial weight-gradient tiles: 96 MB, or what the 3x3 launches of a full batch want
     for (int b = 0; b < 4; ++b) {
         const Plane& pl = e->p_blk[b];
-        const int ts = halo_tile(pl), nt = ((pl.H + ts - 1) / ts) * ((pl.W + ts - 1) / ts);
-        const int tpw = w3_tiles_per_wg(nt, ts, NS, INT64_MAX);
-        e->part_floats = std::max<int64_t>(e->part_floats, (int64_t)((nt + tpw - 1) / tpw) * NS * 9 * 32 * kBottleneck);
+        for (int ts : {halo_tile(pl), 8}) {
+            const int nt = ((pl.H + ts - 1) / ts) * ((pl.W + ts - 1) / ts);
+            const int tpw = w3_tiles_per_wg(nt, ts, NS, INT64_MAX);
+            e->part_floats = std::max<int64_t>(e->part_floats, (int64_t)((nt + tpw - 1) / tpw) * NS * 9 * 32 * kBottleneck);
+        }
     }
     ALLOC(e->part, e->part_floats);
     ALLOC(e->F, (int64_t)NP * e->p_blk[3].HWp * 2 * kFeat);
@@ -551,7 +560,12 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
                     // 64-row tiles: the BN parameters of all cin channels sit in LDS (12 B each) next to the 34 KB of
                     // BK = 32 tiles; past 576 channels only three workgroups fit a CU (768 slots for the 850 tiles of a
                     // 17-stream 40x40 layer), so those layers take BK = 16 tiles (29 KB, five per CU).  64x128 tiles: slower.
-                    if (pl.HWp % 128 == 0) run(CfgP128x128{});
+                    // ... and when even the 64-row tiling leaves most CUs idle (few streams per call, or the 20x20 planes),
+                    // 32x64 tiles with the k-tile split over wave pairs: twice the workgroups, half the serial K chain.
+                    constexpr int small_wgs = 320;                 // 512 / 1024 measured slower on the 17-stream step
+                    const int wg128 = ns * pl.HWp / 128, wg64 = ns * pl.HWp / 64 * 2;
+                    if (pl.HWp % 128 == 0 && wg128 >= small_wgs) run(CfgP128x128{});
+                    else if (wg64 < small_wgs) run(CfgP32x64{});
                     else if (d.cin > 576) run(CfgP64x64k16{});
                     else run(CfgP64x64{});
                 }
@@ -565,7 +579,7 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
                     a.dst = xs(b); a.ldd = Ct; a.dcoff = d.cin;
                     a.dsum = xsum; a.dsq = xsq; a.dstride = Ct;
                     ProfScope ps(e, cs, K_C3, 2.0 * ns * pl.HW * 9 * kBottleneck * kGrowth);
-                    if (halo_tile(pl) == 16) {
+                    if (halo_tile(pl, ns) == 16) {
                         a.tiles_x = pl.W / 16;
                         hipLaunchKernelGGL(conv3x3_halo_fwd_kernel<16>, dim3((pl.H / 16) * a.tiles_x, ns), dim3(256),
                                            HaloFwdGeo<16>::smem_floats(kBottleneck) * sizeof(float), cs, a);
@@ -791,7 +805,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 a.gamma = P + d.n2.w; a.beta = P + d.n2.b; a.eps = kEps;
                 a.dst = D2b; a.o1 = b1(e, e->bs_Bt[b][i]); a.o2 = b2(e, e->bs_Bt[b][i]); a.ostride = kBottleneck;
                 ProfScope ps(e, st, K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
-                if (halo_tile(pl) == 16) {
+                if (halo_tile(pl, NS) == 16) {
                     a.tiles_x = pl.W / 16; a.cg_per_wg = kBottleneck / 32;
                     hipLaunchKernelGGL(conv3x3_halo_dgrad_kernel<16>, dim3((pl.H / 16) * a.tiles_x, NS), dim3(256),
                                        HaloDgradGeo<16>::smem_floats(kBottleneck) * sizeof(float), st, a);
@@ -818,7 +832,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
             }
             if (!e->generic3x3) {
                 // conv2 weight gradient with the activation halo resident in LDS (halo.cuh)
-                const int ts = halo_tile(pl);
+                const int ts = halo_tile(pl, NS);
                 Halo3x3WgradArgs a;
                 a.g = gsrc; a.pl = pl; a.src = bt; a.C = kBottleneck;
                 a.ssum = fsum(e, e->st_Bt[b][i]); a.ssq = fsq(e, e->st_Bt[b][i]); a.sstride = kBottleneck;

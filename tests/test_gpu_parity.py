@@ -330,7 +330,8 @@ def test_multi_scene_batch_equals_sum_of_single_scene_gradients(gpu):
         q_s.append(q.reshape(-1).cpu().numpy())
         g_sum += tr.model.flat_grads()
     q_s = np.concatenate(q_s)
-    np.testing.assert_allclose(q_b.reshape(-1).cpu().numpy(), q_s, rtol=0, atol=2e-6)      # same kernels, same per-stream work
+    # same per-stream work; the tile shapes (hence the fp32 summation order) depend on how many streams a launch holds
+    np.testing.assert_allclose(q_b.reshape(-1).cpu().numpy(), q_s, rtol=0, atol=2e-5)
     num = float((g_b - g_sum).double().norm())
     den = float(g_sum.double().norm())
     assert num <= 2e-3 * den, (num, den)                     # only the fp32 summation order differs (ill-conditioned, see header)
@@ -377,21 +378,22 @@ def test_batched_object_evaluation_equals_per_object_loop(gpu):
     conf_loop = np.stack([a.forward(depth, depth * masks[k], 1, True) for k in range(3)])
     conf_batch = b.forward_objects(depth, masks, style=1)
     assert conf_batch.shape == (3, 4)
-    np.testing.assert_allclose(conf_batch, conf_loop, rtol=0, atol=3e-6)
+    # (tile shapes, hence the fp32 summation order, depend on the number of streams in a launch)
+    np.testing.assert_allclose(conf_batch, conf_loop, rtol=0, atol=3e-5)
     assert np.unravel_index(np.argmax(conf_batch), conf_batch.shape) == np.unravel_index(np.argmax(conf_loop), conf_loop.shape)
     gs_loop = np.full((3, 3), -100.0)
     for g in range(3):
         for s_ in range(g + 1, 3):
             gs_loop[g, s_] = a.forward(depth, depth * (masks[g] + masks[s_]), 2, True)[0]
     gs_batch = b.forward_object_pairs(depth, masks)
-    np.testing.assert_allclose(gs_batch, gs_loop, rtol=0, atol=3e-6)
+    np.testing.assert_allclose(gs_batch, gs_loop, rtol=0, atol=3e-5)
     sa = {k: v.cpu() for k, v in a.model.state_dict().items()}
     sb = {k: v.cpu() for k, v in b.model.state_dict().items()}
     for k in ("suction_depth_trunk.features.norm0", "suction_depth_trunk.features.denseblock3.denselayer9.norm1",
               "suctionnet_val.suction-val-norm1", "gs_depth_trunk.features.norm5"):
         assert int(sa[k + ".num_batches_tracked"]) == int(sb[k + ".num_batches_tracked"]) > 0
-        np.testing.assert_allclose(sb[k + ".running_mean"].numpy(), sa[k + ".running_mean"].numpy(), rtol=1e-5, atol=1e-6)
-        np.testing.assert_allclose(sb[k + ".running_var"].numpy(), sa[k + ".running_var"].numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(sb[k + ".running_mean"].numpy(), sa[k + ".running_mean"].numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(sb[k + ".running_var"].numpy(), sa[k + ".running_var"].numpy(), rtol=1e-4, atol=1e-5)
 
 
 def test_g8_reactive_gradients_and_adam(gpu, golden):
