@@ -304,9 +304,11 @@ def test_snapshot_roundtrip(gpu, tmp_path):
     assert abs(float(other.forward(x, mx, 0, True, 2)) - q0) < 1e-6
 
 
-def test_multi_scene_batch_equals_sum_of_single_scene_gradients(gpu):
+@pytest.mark.parametrize("case", ["two_scenes_few_rotations", "four_scenes_all_rotations"])
+def test_multi_scene_batch_equals_sum_of_single_scene_gradients(gpu, case):
     """Config-4 style batch (several scenes x rotations in ONE engine call): Q values equal the
-    single-scene calls and the gradient equals the sum of the single-scene gradients."""
+    single-scene calls and the gradient equals the sum of the single-scene gradients.  The second case is the
+    bench's batched leg: 4 scenes x 16 rotations = 68 trunk streams, 64 samples (workspace sizing, ring buffers)."""
     from trainer import Trainer
     import synthetic
     tr = Trainer('reinforcement', 0.5, False, None, False)
@@ -314,17 +316,21 @@ def test_multi_scene_batch_equals_sum_of_single_scene_gradients(gpu):
     tr.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     tr.model.gnum_rotations = tr.model.snum_rotations = 16
     tr.optimizer.lr = 0.0                                   # keep the weights fixed across the calls
-    scenes = [synthetic.heightmap_scene(s) for s in (5, 6)]
+    if case == "two_scenes_few_rotations":
+        seeds, rots = (5, 6), [[0, 7, 12], [3, 9]]
+        labels = [0.2, 1.4, 0.9, 3.0, 0.1]
+    else:
+        seeds, rots = (5, 6, 7, 8), [list(range(16))] * 4
+        labels = list(synthetic.uniform(11, "multi/labels", 64, 0.0, 1.5))
+    scenes = [synthetic.heightmap_scene(s) for s in seeds]
     d = np.stack([sc[0] for sc in scenes])
     m = np.stack([sc[0] * sc[1][1] for sc in scenes])
-    rots = [[0, 7, 12], [3, 9]]
-    labels = [0.2, 1.4, 0.9, 3.0, 0.1]
     loss_b, q_b = tr.train_batch(d, m, 0, rots, labels, return_q=True)
     g_b = tr.model.flat_grads().clone()
     g_sum = torch.zeros_like(g_b)
     q_s = []
     k = 0
-    for i in range(2):
+    for i in range(len(seeds)):
         _, q = tr.train_batch(d[i], m[i], 0, rots[i], labels[k:k + len(rots[i])], return_q=True)
         k += len(rots[i])
         q_s.append(q.reshape(-1).cpu().numpy())
@@ -334,8 +340,10 @@ def test_multi_scene_batch_equals_sum_of_single_scene_gradients(gpu):
     np.testing.assert_allclose(q_b.reshape(-1).cpu().numpy(), q_s, rtol=0, atol=2e-5)
     num = float((g_b - g_sum).double().norm())
     den = float(g_sum.double().norm())
-    assert num <= 2e-3 * den, (num, den)                     # only the fp32 summation order differs (ill-conditioned, see header)
-    assert loss_b.shape == (5,)
+    # only the fp32 summation order / ReLU-mask noise differs (ill-conditioned, see header): 0.5e-3 for the small case and
+    # 2.7e-3 for the 64-sample one were measured; one missing sample of 64 would be 1.5e-2
+    assert num <= (2e-3 if len(labels) < 10 else 5e-3) * den, (num, den)
+    assert loss_b.shape == (len(labels),)
 
 
 def test_large_input_dense_qmap(gpu):
