@@ -618,14 +618,21 @@ __global__ void loss_kernel(int mode, const float* q, const float* labels, int n
         if (fabsf(d) < 1.f) { loss[j] = 0.5f * (d * d); dj[0] = d; }
         else { loss[j] = fabsf(d) - 0.5f; dj[0] = d > 0.f ? 1.f : -1.f; }
     } else {
-        const int y = (int)labels[j];
+        // labels outside {0, 1, 2} count as class 2 ("no loss", weight 0); the reference only ever emits 0 / 1
+        // (code/trainer.py:220-234).  A zero class weight gives loss 0 and no gradient - torch's weighted mean
+        // would be 0/0 there and poison every gradient and Adam moment with NaN.
+        const float lf = labels[j];
+        const int y = (lf >= 0.f && lf < 2.5f) ? (int)lf : 2;
         const float m = fmaxf(qj[0], fmaxf(qj[1], qj[2]));
         const float e0 = expf(qj[0] - m), e1 = expf(qj[1] - m), e2 = expf(qj[2] - m);
         const float se = e0 + e1 + e2, lse = logf(se) + m;
-        const float wy = (y == 2) ? 0.f : 1.f;
-        loss[j] = wy * (lse - qj[y]) / wy;          // size_average: weighted mean over 1 element
-        const float sm[3] = {e0 / se, e1 / se, e2 / se};
-        for (int c = 0; c < 3; ++c) dj[c] = wy * (sm[c] - (c == y ? 1.f : 0.f)) / wy;
+        if (y == 2) {
+            loss[j] = 0.f;
+        } else {
+            loss[j] = lse - qj[y];                   // size_average: weighted mean over 1 element of weight 1
+            const float sm[3] = {e0 / se, e1 / se, e2 / se};
+            for (int c = 0; c < 3; ++c) dj[c] = sm[c] - (c == y ? 1.f : 0.f);
+        }
     }
 }
 

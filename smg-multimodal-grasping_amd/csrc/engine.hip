@@ -1118,6 +1118,8 @@ int smg_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, co
 int smg_loss(smg_engine* e, int mode, const float* q_dev, const float* labels_dev, int n_pairs, float* loss_dev, float* dq_dev, void* stream) {
     if (!e || !q_dev || !labels_dev || !loss_dev || !dq_dev) return fail(-22, "NULL argument");
     if (mode == 1 && e->head_out != 3) return fail(-22, "cross-entropy loss needs a 3-class head");
+    if (mode != 0 && mode != 1) return fail(-22, "loss mode must be 0 (Huber) or 1 (cross entropy)");
+    if (n_pairs < 1 || n_pairs > e->max_pairs) return fail(-22, "n_pairs exceeds the engine's max_pairs");
     HIP_OK(hipSetDevice(e->device));
     const int per_pair = e->head_out * e->OH * e->OW;
     hipLaunchKernelGGL(loss_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, (hipStream_t)stream, mode, q_dev, labels_dev, n_pairs, per_pair, loss_dev, dq_dev);
@@ -1138,6 +1140,11 @@ int smg_adam_step(float* params, const float* grads, float* m, float* v, int64_t
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)std::sqrt(bc2);
     if (count == 0) return 0;
+    {   // no engine argument: launch on the device that owns the parameter array
+        hipPointerAttribute_t attr;
+        HIP_OK(hipPointerGetAttributes(&attr, params));
+        HIP_OK(hipSetDevice(attr.device));
+    }
     int blocks = (int)((count + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params + offset, grads + offset, m + offset, v + offset,

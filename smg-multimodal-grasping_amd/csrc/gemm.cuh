@@ -1,8 +1,16 @@
-// gemm.cuh - one fp32-MFMA implicit-GEMM kernel template for gfx950 and the
+// gemm.cuh - one split-precision MFMA implicit-GEMM kernel template for gfx950 and the
 // policies (operand fetchers + epilogues) that turn it into every convolution
 // forward / data-gradient / weight-gradient of the DenseNet-121 affordance path.
 //
-//   D[i][j] = sum_r A(i, r) * B(r, j)       v_mfma_f32_32x32x2_f32 (exact fp32)
+//   D[i][j] = sum_r A(i, r) * B(r, j)
+//
+// Arithmetic: fp32 in, fp32 out, on the bf16 matrix cores.  Every fp32 operand is split into
+// three bf16 pieces  x = hi + mid + lo  (truncating split: 24 significand bits = 3 x 8, so the
+// split is EXACT), and a product is accumulated from six v_mfma_f32_32x32x16_bf16 terms
+//   hi*lo + lo*hi + mid*mid + hi*mid + mid*hi + hi*hi            (fp32 accumulate)
+// - the three dropped terms are <= 2^-22 of the product.  Measured on the MI355X against fp64
+// (tools/split_probe.hip): error / sum|a*b| = 2.9e-8 rms at K = 1024, the same as the exact
+// fp32 FMA chain of v_mfma_f32_32x32x2_f32 (2.7e-8) - at 16/6 = 2.7x its issue rate.
 //
 // Data layout: activations are NHWC fp32, one "plane" of HWp = roundup(H*W, 64)
 // pixel rows per stream, so a 64-row (or, where HWp % 128 == 0, 128-row) tile never
@@ -10,23 +18,29 @@
 // every layer appends 32 channels to (torch.cat of code/models.py:386 / torchvision
 // _DenseBlock disappears).
 //
-// LDS tiles are k-major: As[k][m], Bs[k][n], so the MFMA operand reads
-// (lane l -> A[i = l&31][k = l>>5]) are 32 consecutive floats per half-wave:
-// conflict-free ds_read_b32.  Pixel-major operands (conv forward / data gradient)
-// are transposed on the way in with scalar ds_write_b32 into rows of odd length
-// (BM+1); channel-major operands (weights, and both operands of a weight gradient)
-// go in with one ds_write_b128 per float4.
+// LDS images.  The bf16 MFMA wants, per lane, 8 CONSECUTIVE k of one row: a "unit" = 8 k of one
+// row of one piece = 16 bytes.
+//   * forward / data gradient (Cfg::AT): the A operand arrives pixel-major (a thread holds 4
+//     consecutive channels = k of one pixel row), gets its BN / ReLU / BN-backward transform and
+//     the split at LDS-store time and lands as units [piece][k/8][row] (ds_write_b64); the B operand
+//     (weights) is pre-split by pack_weights_kernel into the SAME unit layout in HBM
+//     [piece][K/8][N], so its staging is a straight 16-byte copy.  Fragments are one ds_read_b128
+//     per (piece, 32-row tile): consecutive lanes read consecutive units, conflict-free.
+//   * weight gradient (!Cfg::AT): the reduction runs over PIXELS while memory is channel-major, so
+//     both operands are stored as they arrive, row-major [pixel][channel] per piece, and the
+//     fragments come out of LDS transposed with ds_read_b64_tr_b16 (two per piece and tile).
 //
 // Pipeline per k-tile: raw global loads of tile kt+1 are issued first and stay in
 // flight across the MFMA block of tile kt; all operand fragments of the tile are read
-// from LDS before its MFMAs; the BN / ReLU / BN-backward transform is applied when tile
-// kt+1 is written to the other LDS buffer; one barrier per k-tile.
+// from LDS before its MFMAs; the transform + split is applied when tile kt+1 is written to
+// the other LDS buffer; one barrier per k-tile.
 //
 // BatchNorm (training mode, per stream - SURVEY.md section 7) is never a kernel of
 // its own: the producer's epilogue accumulates per-(stream, channel) sum / sum of
-// squares in fp64 (in-lane, then fp64 atomics), and every consumer turns them into
-// (mean, gamma*invstd, beta) in its prologue (into LDS) and applies BN + ReLU in the
-// centered form (x - mean)*scale + beta while staging the operand.
+// squares in fp64 (in-lane, then fp64 atomics); bn_prep_kernel (elem.cuh) turns them ONCE per
+// consumer layer into an fp32 table (mean, gamma*invstd, beta, invstd) that the consumer's
+// staging threads read per k-tile (forward: no per-workgroup parameter prologue at all) and
+// applies BN + ReLU in the centered form (x - mean)*scale + beta while staging the operand.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,42 +48,93 @@
 namespace smg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 struct Plane { int H, W, HW, HWp; };
+
+// ------------------------------------------------------------------------------------
+// Split precision.
+// ------------------------------------------------------------------------------------
+constexpr int NPIECE = 3;
+// bf16 pieces of 4 floats (element 0 in the low half of .x): 8 bytes per piece
+struct Split4 { uint2 p[NPIECE]; };
+__device__ __forceinline__ unsigned pack_hi16(float lo_elem, float hi_elem) {      // {bf16(lo_elem), bf16(hi_elem)} truncated
+    return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
+}
+__device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
+__device__ __forceinline__ Split4 split4(float4 v) {
+    Split4 o;
+    o.p[0] = make_uint2(pack_hi16(v.x, v.y), pack_hi16(v.z, v.w));
+    const float r0 = v.x - trunc_bf16(v.x), r1 = v.y - trunc_bf16(v.y), r2 = v.z - trunc_bf16(v.z), r3 = v.w - trunc_bf16(v.w);   // exact
+    o.p[1] = make_uint2(pack_hi16(r0, r1), pack_hi16(r2, r3));
+    const float s0 = r0 - trunc_bf16(r0), s1 = r1 - trunc_bf16(r1), s2 = r2 - trunc_bf16(r2), s3 = r3 - trunc_bf16(r3);           // exact, <= 8 bits left
+    o.p[2] = make_uint2(pack_hi16(s0, s1), pack_hi16(s2, s3));
+    return o;
+}
+// One operand fragment of a 32-row tile for one k16-step: 8 consecutive k per lane, three pieces.
+struct Frag { uint4 p[NPIECE]; };
+__device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// acc[i][j] += A_i * B_j for a TM x TN grid of tiles: six piece products, small terms first, tiles innermost so that
+// consecutive MFMAs never share an accumulator.
+template <int TM, int TN>
+__device__ __forceinline__ void mma_split(f32x16 (&acc)[TM][TN], const Frag (&a)[TM], const Frag (&b)[TN]) {
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].p[PA[t]], b[j].p[PB[t]], acc[i][j]);
+}
 
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int WK_, bool AT_>
 struct GemmCfg {
     static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, WK = WK_;
-    static constexpr bool AT = AT_;  // A tile arrives pixel-major and is transposed into LDS
+    static constexpr bool AT = AT_;  // forward / data-gradient form (A pixel-major, B packed weight units); false: weight gradient
     // 4 waves: WM x WN of them tile the output, WK of them split every k-tile (in-block
     // split-K for the small late stages, reduced through LDS before the epilogue)
     static_assert(WM * WN * WK == 4, "4 waves per workgroup");
     static constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     static_assert(TM >= 1 && TN >= 1 && TM * WM * 32 == BM && TN * WN * 32 == BN, "tile shape");
-    static constexpr int KK = BK / 2 / WK;                   // MFMA k-steps per wave per k-tile
-    static_assert(KK >= 1 && KK * 2 * WK == BK, "k split");
-    static constexpr int LDA = AT ? BM + 1 : BM + 4;
-    static constexpr int LDB = BN + 4;
-    static constexpr int A_FLOATS = BK * LDA, B_FLOATS = BK * LDB;
+    static constexpr int KS = BK / 16 / WK;                  // MFMA k16-steps per wave per k-tile
+    static_assert(KS >= 1 && KS * 16 * WK == BK, "k split");
+    static constexpr int K8 = BK / 8;
+    // ---- AT: unit images [piece][k8][row] of 16-byte units.  The A rows are padded so that the ds_write_b64 of one
+    // 16-lane group (64 / BK rows x BK / 4 quads) spreads over all 32 banks.
+    static constexpr int PADU = 64 / BK > 0 ? 64 / BK : 1;
+    static constexpr int LDUA = BM + PADU, LDUB = BN;
+    // ---- !AT: row-major [k][channel] bf16 images; row stride = 64 (mod 128) bytes keeps the four rows a transposing
+    // read gathers on distinct banks
+    static constexpr int LDTA = BM + ((BM * 2) % 128 == 64 ? 0 : 32), LDTB = BN + ((BN * 2) % 128 == 64 ? 0 : 32);
+    static constexpr int A_BYTES = AT ? NPIECE * K8 * LDUA * 16 : NPIECE * BK * LDTA * 2;
+    static constexpr int B_BYTES = AT ? NPIECE * K8 * LDUB * 16 : NPIECE * BK * LDTB * 2;
+    static_assert(A_BYTES % 16 == 0 && B_BYTES % 16 == 0, "16-byte aligned LDS images");
+    // staging: A (and the weight gradient's B) in float4 slots, (line, quad)
     static constexpr int A_Q = AT ? BK / 4 : BM / 4;       // float4 per tile line
     static constexpr int A_LINES = AT ? BM : BK;
     static constexpr int A_STEP = 256 / A_Q;
     static constexpr int A_N = (A_LINES + A_STEP - 1) / A_STEP;
     static constexpr int B_Q = BN / 4;
     static constexpr int B_STEP = 256 / B_Q;
-    static constexpr int B_N = (BK + B_STEP - 1) / B_STEP;
+    static constexpr int B_N = AT ? (NPIECE * K8 * BN + 255) / 256 : (BK + B_STEP - 1) / B_STEP;    // AT: 16-byte unit copies
     // every staging slot of a thread maps inside the tile (no run-time range check, which would also make
     // hipcc drain vmcnt between the load groups of one k-tile)
-    static constexpr bool A_FULL = A_LINES % A_STEP == 0, B_FULL = BK % B_STEP == 0;
+    static constexpr bool A_FULL = A_LINES % A_STEP == 0, B_FULL = AT ? (NPIECE * K8 * BN) % 256 == 0 : BK % B_STEP == 0;
     static constexpr int RED_FLOATS = (WK - 1) * WM * WN * TM * TN * 16 * 64;
-    static constexpr int TILE_FLOATS = (2 * A_FLOATS + 2 * B_FLOATS) > RED_FLOATS ? (2 * A_FLOATS + 2 * B_FLOATS) : RED_FLOATS;
-    static constexpr int AB_FLOATS = 2 * A_FLOATS + 2 * B_FLOATS;
+    static constexpr int AB_FLOATS = 2 * (A_BYTES + B_BYTES) / 4;
+    static constexpr int TILE_FLOATS = AB_FLOATS > RED_FLOATS ? AB_FLOATS : RED_FLOATS;
 };
 
 // What a fetch leaves in registers: the untouched global loads (NV of them) and whether the
 // element exists at all (conv zero padding / padded pixel rows).  The BN transform is applied later,
 // when the tile is written to LDS, so the loads stay in flight across the MFMA block.
 template <int NV> struct RawT { float4 v[NV]; bool ok; };
+// Per-k-tile BN parameters of a thread's channel quad (forward policies): (mean, scale, beta) x 4 channels
+struct KPrm3 { float4 mean, scale, beta; };
+struct KPrm0 {};
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -83,6 +148,14 @@ __device__ __forceinline__ void bn_moments(const double* sum, const double* sq, 
     invstd = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// The per-layer BN table bn_prep_kernel writes: four fp32 arrays of [rows][C] (rows = streams or pairs), `span` floats apart:
+//   mean | gamma*invstd | beta | invstd
+struct BnTab { const float* base; int64_t span; int C; };
+__device__ __forceinline__ const float* tab_mean(const BnTab& t, int n) { return t.base + (int64_t)n * t.C; }
+__device__ __forceinline__ const float* tab_scale(const BnTab& t, int n) { return t.base + t.span + (int64_t)n * t.C; }
+__device__ __forceinline__ const float* tab_beta(const BnTab& t, int n) { return t.base + 2 * t.span + (int64_t)n * t.C; }
+__device__ __forceinline__ const float* tab_invstd(const BnTab& t, int n) { return t.base + 3 * t.span + (int64_t)n * t.C; }
+
 // BN + ReLU in the centered form (x - mean) * (gamma * invstd) + beta: no cancellation
 // between x*scale and a pre-folded shift on near-constant channels.
 // prm points at {mean[4]...}, scale at prm + stride, beta at prm + 2*stride.
@@ -95,6 +168,14 @@ __device__ __forceinline__ float4 bnrelu4(float4 v, const float* prm, int stride
     r.y = fmaxf(bn1(v.y, prm[1], sc[1], be[1]), 0.f);
     r.z = fmaxf(bn1(v.z, prm[2], sc[2], be[2]), 0.f);
     r.w = fmaxf(bn1(v.w, prm[3], sc[3], be[3]), 0.f);
+    return r;
+}
+__device__ __forceinline__ float4 bnrelu4(float4 v, const KPrm3& k) {
+    float4 r;
+    r.x = fmaxf(bn1(v.x, k.mean.x, k.scale.x, k.beta.x), 0.f);
+    r.y = fmaxf(bn1(v.y, k.mean.y, k.scale.y, k.beta.y), 0.f);
+    r.z = fmaxf(bn1(v.z, k.mean.z, k.scale.z, k.beta.z), 0.f);
+    r.w = fmaxf(bn1(v.w, k.mean.w, k.scale.w, k.beta.w), 0.f);
     return r;
 }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -172,11 +253,13 @@ __device__ unsigned long long* g_smg_trace = nullptr;
 // Virtual block coordinates of one tile (what blockIdx was before the kernel became persistent).
 struct VBlock { int x, y, z, linear; };
 
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
 template <class P>
 __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* smem) {
     using C = typename P::Cfg;
-    float* As = smem;
-    float* Bs = smem + 2 * C::A_FLOATS;
+    char* As = reinterpret_cast<char*>(smem);
+    char* Bs = As + 2 * C::A_BYTES;
     float* sp = smem + C::TILE_FLOATS;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -205,93 +288,147 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
     constexpr int PD = P::kPrefetch;
     typename P::ARaw ra[PD][C::A_N];
     typename P::BRaw rb[PD][C::B_N];
+    typename P::KPrm kp[PD];
     typename P::ARow arow[C::A_N];
-    typename P::DRow da[C::A_N], db[C::B_N];
+    typename P::DRow da[C::A_N], db[C::AT ? 1 : C::B_N];
     if constexpr (C::AT) {
 #pragma unroll
         for (int i = 0; i < C::A_N; ++i) p.a_row_init(ctx, arow[i], al + i * C::A_STEP);
     } else {
 #pragma unroll
         for (int i = 0; i < C::A_N; ++i) p.d_init(ctx, da[i], al + i * C::A_STEP);
+#pragma unroll
+        for (int i = 0; i < C::B_N; ++i) p.d_init(ctx, db[i], bl + i * C::B_STEP);
     }
-#pragma unroll
-    for (int i = 0; i < C::B_N; ++i) p.d_init(ctx, db[i], bl + i * C::B_STEP);
 
-    auto g_load = [&](int kt, typename P::ARaw (&xa)[C::A_N], typename P::BRaw (&xb)[C::B_N]) {
+    auto g_load = [&](int kt, typename P::ARaw (&xa)[C::A_N], typename P::BRaw (&xb)[C::B_N], typename P::KPrm& xk) {
+        if constexpr (C::AT) {
+            xk = p.k_fetch(ctx, kt, aq);
 #pragma unroll
-        for (int i = 0; i < C::A_N; ++i) {
-            if constexpr (C::AT) {
-                xa[i] = p.a_fetch(ctx, arow[i], kt, aq);
-            } else {
+            for (int i = 0; i < C::A_N; ++i) xa[i] = p.a_fetch(ctx, arow[i], kt, aq);
+#pragma unroll
+            for (int i = 0; i < C::B_N; ++i) {           // weight units [piece][k8][row]: consecutive lanes -> consecutive rows
+                const int id = t + 256 * i;
+                const int r = id % C::BN, pk = id / C::BN;                 // pk = piece * K8 + k8
+                if (C::B_FULL || pk < NPIECE * C::K8) xb[i] = p.b_unit(ctx, kt, pk / C::K8, pk % C::K8, r);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < C::A_N; ++i) {
                 const int kr = al + i * C::A_STEP;
                 if (C::A_FULL || kr < C::BK) xa[i] = p.a_fetch_d(ctx, da[i], kt, kr, aq);
                 p.d_next(ctx, da[i]);
             }
-        }
 #pragma unroll
-        for (int i = 0; i < C::B_N; ++i) {
-            const int kr = bl + i * C::B_STEP;
-            if (C::B_FULL || kr < C::BK) xb[i] = p.b_fetch(ctx, db[i], kt, kr, bq);
-            p.d_next(ctx, db[i]);
-        }
-    };
-    // transform (BN / ReLU / BN-backward) + LDS store of k-tile kt
-    auto s_store = [&](int buf, int kt, const typename P::ARaw (&xa)[C::A_N], const typename P::BRaw (&xb)[C::B_N]) {
-        float* A = As + buf * C::A_FLOATS;
-        float* B = Bs + buf * C::B_FLOATS;
-#pragma unroll
-        for (int i = 0; i < C::A_N; ++i) {
-            if constexpr (C::AT) {
-                const int row = al + i * C::A_STEP;
-                const float4 v = p.a_xform(ctx, xa[i], kt, aq, sp);
-                A[(aq * 4 + 0) * C::LDA + row] = v.x;
-                A[(aq * 4 + 1) * C::LDA + row] = v.y;
-                A[(aq * 4 + 2) * C::LDA + row] = v.z;
-                A[(aq * 4 + 3) * C::LDA + row] = v.w;
-            } else {
-                const int kr = al + i * C::A_STEP;
-                if (C::A_FULL || kr < C::BK) *reinterpret_cast<float4*>(&A[kr * C::LDA + aq * 4]) = p.a_xform(ctx, xa[i], kt, aq, sp);
+            for (int i = 0; i < C::B_N; ++i) {
+                const int kr = bl + i * C::B_STEP;
+                if (C::B_FULL || kr < C::BK) xb[i] = p.b_fetch(ctx, db[i], kt, kr, bq);
+                p.d_next(ctx, db[i]);
             }
         }
+    };
+    // transform (BN / ReLU / BN-backward) + split + LDS store of k-tile kt
+    auto s_store = [&](int buf, int kt, const typename P::ARaw (&xa)[C::A_N], const typename P::BRaw (&xb)[C::B_N], const typename P::KPrm& xk) {
+        char* A = As + buf * C::A_BYTES;
+        char* B = Bs + buf * C::B_BYTES;
+        if constexpr (C::AT) {
 #pragma unroll
-        for (int i = 0; i < C::B_N; ++i) {
-            const int kr = bl + i * C::B_STEP;
-            if (C::B_FULL || kr < C::BK) *reinterpret_cast<float4*>(&B[kr * C::LDB + bq * 4]) = p.b_xform(ctx, xb[i], kt, bq, sp);
+            for (int i = 0; i < C::A_N; ++i) {
+                const int row = al + i * C::A_STEP;
+                if (C::A_FULL || row < C::BM) {
+                    const Split4 s = split4(p.a_xform(ctx, xa[i], xk, kt, aq, sp));
+#pragma unroll
+                    for (int pc = 0; pc < NPIECE; ++pc)
+                        *reinterpret_cast<uint2*>(A + ((pc * C::K8 + (aq >> 1)) * C::LDUA + row) * 16 + (aq & 1) * 8) = s.p[pc];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < C::B_N; ++i) {
+                const int id = t + 256 * i;
+                if (C::B_FULL || id < NPIECE * C::K8 * C::BN) *reinterpret_cast<uint4*>(B + id * 16) = p.b_unit_xform(ctx, xb[i], id % C::BN);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < C::A_N; ++i) {
+                const int kr = al + i * C::A_STEP;
+                if (C::A_FULL || kr < C::BK) {
+                    const Split4 s = split4(p.a_xform(ctx, xa[i], xk, kt, aq, sp));
+#pragma unroll
+                    for (int pc = 0; pc < NPIECE; ++pc)
+                        *reinterpret_cast<uint2*>(A + ((pc * C::BK + kr) * C::LDTA + 4 * aq) * 2) = s.p[pc];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < C::B_N; ++i) {
+                const int kr = bl + i * C::B_STEP;
+                if (C::B_FULL || kr < C::BK) {
+                    const Split4 s = split4(p.b_xform(ctx, xb[i], kt, bq, sp));
+#pragma unroll
+                    for (int pc = 0; pc < NPIECE; ++pc)
+                        *reinterpret_cast<uint2*>(B + ((pc * C::BK + kr) * C::LDTB + 4 * bq) * 2) = s.p[pc];
+                }
+            }
         }
     };
+    // transposing-read geometry of this lane (weight gradient): its 16-lane group gathers 4 k-rows x 16 channels; lane i of
+    // the group fetches row i/4, channel quad i%4 and receives channel i of all four rows (ds_read_b64_tr_b16).
+    const int tr_row = (lane & 15) >> 2, tr_col = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
     auto compute = [&](int buf) {
-        const float* A = As + buf * C::A_FLOATS + (wk * C::KK * 2 + half) * C::LDA + wm0 + l31;
-        const float* B = Bs + buf * C::B_FLOATS + (wk * C::KK * 2 + half) * C::LDB + wn0 + l31;
-        // All operand fragments of this wave's k-slice first (one LDS round trip per k-tile,
-        // not one per MFMA k-step), then the MFMAs back to back.
-        float af[C::KK][C::TM], bf[C::KK][C::TN];
+        const char* A = As + buf * C::A_BYTES;
+        const char* B = Bs + buf * C::B_BYTES;
+        // All operand fragments of this wave's k-slice first (one LDS round trip per k16-step, not one per MFMA),
+        // then the MFMAs back to back.
 #pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk) {
+        for (int s = 0; s < C::KS; ++s) {
+            Frag af[C::TM], bf[C::TN];
+            if constexpr (C::AT) {
+                const int k8 = (wk * C::KS + s) * 2 + half;
 #pragma unroll
-            for (int i = 0; i < C::TM; ++i) af[kk][i] = A[2 * kk * C::LDA + i * 32];
+                for (int pc = 0; pc < NPIECE; ++pc) {
 #pragma unroll
-            for (int j = 0; j < C::TN; ++j) bf[kk][j] = B[2 * kk * C::LDB + j * 32];
+                    for (int i = 0; i < C::TM; ++i)
+                        af[i].p[pc] = *reinterpret_cast<const uint4*>(A + ((pc * C::K8 + k8) * C::LDUA + wm0 + i * 32 + l31) * 16);
+#pragma unroll
+                    for (int j = 0; j < C::TN; ++j)
+                        bf[j].p[pc] = *reinterpret_cast<const uint4*>(B + ((pc * C::K8 + k8) * C::LDUB + wn0 + j * 32 + l31) * 16);
+                }
+            } else {
+                const int k0 = (wk * C::KS + s) * 16 + 8 * half + tr_row;
+#pragma unroll
+                for (int pc = 0; pc < NPIECE; ++pc) {
+#pragma unroll
+                    for (int i = 0; i < C::TM; ++i) {
+                        const char* a0 = A + ((pc * C::BK + k0) * C::LDTA + wm0 + i * 32 + tr_col) * 2;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * C::LDTA * 2));
+                        af[i].p[pc] = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y,
+                                                 __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
+                    }
+#pragma unroll
+                    for (int j = 0; j < C::TN; ++j) {
+                        const char* b0 = B + ((pc * C::BK + k0) * C::LDTB + wn0 + j * 32 + tr_col) * 2;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)b0);
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(b0 + 4 * C::LDTB * 2));
+                        bf[j].p[pc] = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y,
+                                                 __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep every ds_read ahead of the MFMA block (hipcc re-interleaves them otherwise)
+            mma_split<C::TM, C::TN>(acc, af, bf);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);   // keep every ds_read ahead of the MFMA block (hipcc re-interleaves them otherwise)
-#pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk)
-#pragma unroll
-            for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-                for (int j = 0; j < C::TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
     };
 
-    // First tile's global loads go out BEFORE the BN-parameter prologue (which waits on its own global loads of
-    // the statistics and does fp64 div / sqrt): one memory round trip per workgroup instead of two.
+    // First tile's global loads go out BEFORE the parameter prologue of the policies that still have one (it waits on its
+    // own global loads): one memory round trip per workgroup instead of two.
 #pragma unroll
     for (int u = 0; u < PD; ++u)
-        if (u < KT) g_load(u, ra[u], rb[u]);
+        if (u < KT) g_load(u, ra[u], rb[u], kp[u]);
     p.init_params(ctx, sp);
-    __syncthreads();
+    if constexpr (P::kHasPrologue) __syncthreads();
     SMG_TRACE(1);
-    if (KT > 0) s_store(0, 0, ra[0], rb[0]);
+    if (KT > 0) s_store(0, 0, ra[0], rb[0], kp[0]);
     __syncthreads();
     SMG_TRACE(2);
     for (int kt0 = 0; kt0 < KT; kt0 += PD) {
@@ -300,10 +437,10 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
             const int kt = kt0 + u;
             if (kt < KT) {
                 const int buf = kt & 1;
-                if (kt + PD < KT) g_load(kt + PD, ra[u], rb[u]);   // slot u was stored to LDS one iteration ago
+                if (kt + PD < KT) g_load(kt + PD, ra[u], rb[u], kp[u]);   // slot u was stored to LDS one iteration ago
                 compute(buf);
                 if constexpr (P::kSegmented) p.k_hook(ctx, kt, acc, sp);   // end of a K segment: fold acc away
-                if (kt + 1 < KT) s_store(buf ^ 1, kt + 1, ra[(u + 1) % PD], rb[(u + 1) % PD]);
+                if (kt + 1 < KT) s_store(buf ^ 1, kt + 1, ra[(u + 1) % PD], rb[(u + 1) % PD], kp[(u + 1) % PD]);
                 __syncthreads();
             }
         }

@@ -39,9 +39,9 @@ def get_engine(device, input_size, head_out, n_streams, n_pairs):
     if eng is None or eng.max_streams < n_streams or eng.max_pairs < n_pairs:
         cap_s = max(n_streams, eng.max_streams if eng else 0, 17)
         cap_p = max(n_pairs, eng.max_pairs if eng else 0, 16)
+        torch.cuda.synchronize(device)      # nothing of the old engine is in flight any more
         if eng is not None:
-            eng.close()
-        torch.cuda.synchronize(device)
+            eng.close()                     # models that saved activations on it get "activations are gone" from backward
         eng = smg_hip.Engine(device, input_size, cap_s, cap_p, head_out)
         _ENGINES[key] = eng
     return eng
@@ -112,12 +112,20 @@ class _AffordanceNet(nn.Module):
                 t = self._flat_nbt[off:off + 1].view(())
                 node.register_buffer(parts[-1], t)
             self._entries.append((node, parts[-1], kind, off, n, shape))
+        # first parameter of every trunk / head gradient range (tells whether the range's .grad views are alive)
+        self._range_probe = {}
+        for kind_, fn in (("t", smg_hip.trunk_range), ("h", smg_hip.head_range)):
+            for i in range(3):
+                off0 = fn(self.HEAD_OUT, i)[0]
+                node, leaf = next((nd, lf) for nd, lf, k, off, n, shp in self._entries if k == 0 and off == off0)
+                self._range_probe[(kind_, i)] = node._parameters[leaf]
         self._init_weights()
         self.gra_prob = []          # code/models.py:356-358
         self.suc_prob = []
         self.gs_prob = []
         self._saved = None
         self._autograd_hook = None
+        self._grads_clean = False
 
     # ---- initialisation ------------------------------------------------------------------
     def _init_weights(self):
@@ -180,11 +188,13 @@ class _AffordanceNet(nn.Module):
     def flat_grads(self):
         if self._flat_grads is None or self._flat_grads.device != self._flat_params.device:
             self._flat_grads = torch.zeros_like(self._flat_params)
+            self._grads_clean = True
         return self._flat_grads
 
     def zero_grad(self, set_to_none=True):
         if self._flat_grads is not None:
             self._flat_grads.zero_()
+        self._grads_clean = True
         for p in self.parameters():
             p.grad = None
 
@@ -289,10 +299,19 @@ class _AffordanceNet(nn.Module):
         return q
 
     def _engine_backward(self, token, dq):
-        if self._saved is None or self._saved[1] != token or self._saved[0].forward_id != token:
+        if self._saved is None or self._saved[1] != token or not self._saved[0].h or self._saved[0].forward_id != token:
             raise RuntimeError("backward: the activations of that forward are gone (another forward ran on the engine)")
         eng, _, trunk_id, head_id = self._saved
         stream = torch.cuda.current_stream(dq.device).cuda_stream
+        # smg_backward ACCUMULATES into the flat gradient buffer (like autograd into p.grad).  A torch optimizer's
+        # zero_grad(set_to_none=True) only drops p.grad and never sees that buffer, so a range whose parameters
+        # have no .grad is started from zero here; a range that still has its .grad keeps accumulating.
+        g = self.flat_grads()
+        for (off, n), probe in ((smg_hip.trunk_range(self.HEAD_OUT, trunk_id), self._range_probe[("t", trunk_id)]),
+                                (smg_hip.head_range(self.HEAD_OUT, head_id), self._range_probe[("h", head_id)])):
+            if probe.grad is None and not self._grads_clean:
+                g[off:off + n].zero_()
+        self._grads_clean = False
         eng.backward(self._net_struct(True), dq.data_ptr(), stream)
         self.expose_grads(trunk_id, head_id)
 

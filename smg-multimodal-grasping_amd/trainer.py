@@ -14,6 +14,7 @@ Differences that are deliberate and documented:
   * no CPU mode: without a GPU (or with force_cpu=True) the first forward raises.
 """
 import copy
+import os
 
 import numpy as np
 import torch
@@ -111,6 +112,41 @@ class Trainer(object):
         self.grasping_type_log = []
         self.episode_success_log = []
         self.training_loss_log = []
+
+    # ---- session resume ---------------------------------------------------------------------
+    # (file stem, attribute, layout): how code/trainer.py:118-160 re-reads each text log of a
+    # previous session.  "rows" keeps the first `iteration` rows of a 2-D log, "col" the first
+    # `iteration` entries of a 1-D log as an [iteration, 1] column, "col_all" every entry.
+    _LOG_FILES = (
+        ("executed-action", "executed_action_log", "rows"),
+        ("label-value", "label_value_log", "col"),
+        ("predicted-value", "predicted_value_log", "col"),
+        ("reward-value", "reward_value_log", "col"),
+        ("use-heuristic", "use_heuristic_log", "col"),
+        ("is-exploit", "is_exploit_log", "col"),
+        ("clearance", "clearance_log", "col_all"),
+        ("grasping_type", "grasping_type_log", "col"),
+        ("episode_success", "episode_success_log", "rows"),
+        ("training_loss", "training_loss_log", "rows"),
+    )
+
+    def preload(self, transitions_directory):
+        """code/trainer.py:118-160 (`--continue_logging`, code/main.py:74): reload the ten
+        `<name>.log.txt` files of a logging session as python lists and resume the
+        iteration counter at (rows of executed-action.log.txt) - 2."""
+        def read(stem):
+            return np.loadtxt(os.path.join(transitions_directory, stem + ".log.txt"), delimiter=" ")
+        self.iteration = read("executed-action").shape[0] - 2
+        n = self.iteration
+        for stem, attr, how in self._LOG_FILES:
+            a = read(stem)
+            if how == "rows":
+                a = a[0:n, :]
+            elif how == "col":
+                a = a[0:n].reshape(n, 1)
+            else:
+                a = a.reshape(a.shape[0], 1)
+            setattr(self, attr, a.tolist())
 
     # ---- network evaluation -----------------------------------------------------------------
     def _heightmaps_to_device(self, depth_heightmap, m_depth_heightmap):
