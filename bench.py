@@ -7,8 +7,9 @@ R = 16 rotations, every rotation a training sample:
     16 Huber losses (code/trainer.py:345-348), backward of their sum,
     gradient all-reduce over RCCL when N > 1, ONE Adam step (code/trainer.py:383).
 Inputs (heightmaps, labels, weights) are resident in HBM when the timed region starts.
-fp32 end to end (v_mfma_f32_32x32x2_f32): the reference runs apex O0 = fp32 and parity
-is gated in fp32.
+fp32 in, fp32 out (the reference runs apex O0 = fp32 and parity is gated in fp32, SURVEY.md
+section 7); the convolutions run on the bf16 matrix cores as 3-way split products with
+fp32-class accuracy (csrc/gemm.cuh).
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -37,7 +38,12 @@ R = 16
 # Algorithmic work of one de-duplicated 16-rotation fwd+bwd pass (SURVEY.md 8d / BASELINE.md 4)
 PASS_GFLOP = 2331.30
 SWEEP_GFLOP = 788.02
-PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz (the fp32 roof the split scheme breaks)
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+SPLIT_TERMS = 6                       # v_mfma_f32_32x32x16_bf16 per fp32 product (gemm.cuh): the convolutions' MFMA roof is 2500 / 6
+PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / SPLIT_TERMS
+PEAK_HBM_GBS = 8000.0                 # HBM3E peak (MI355X_MICROARCH.md; ~6300 achievable)
+PMC_FILE = "pmc_r02_hbm_traffic.json"
 
 
 def layout_names():
@@ -65,10 +71,11 @@ def layout_names():
     return out
 
 
-def cpu_baseline(seed, n_samples, labels):
+def cpu_baseline(seed, n_samples, labels, thread_settings):
     """The oracle (PyTorch-CPU restatement of the reference) running the REFERENCE's
     schedule: batch-1 samples, masked stream recomputed for every sample, one Adam step per
-    sample (code/trainer.py:338-383).  Bounded: n_samples of the 16 samples of a pass."""
+    sample (code/trainer.py:338-383).  Bounded: n_samples of the 16 samples of a pass per thread
+    setting; returns {threads: seconds per 16-sample pass}."""
     from oracle import affordance as orc
     sd = synthetic.make_state_dict(orc.state_layout(1), seed)
     net = orc.OracleNet(1)
@@ -79,12 +86,46 @@ def cpu_baseline(seed, n_samples, labels):
     depth, masks = synthetic.heightmap_scene(seed)
     x = orc.preprocess(depth, [0.01] * 3, [0.03] * 3)
     mx = orc.preprocess(depth * masks[0], [0.01] * 3, [0.03] * 3)
-    orc.train_step(net, opt, x, mx, 0, 0, float(labels[0]))          # warm-up (oneDNN primitives, allocator)
-    t0 = time.perf_counter()
-    for r in range(n_samples):
-        orc.train_step(net, opt, x, mx, 0, r % R, float(labels[r % R]))
-    dt = time.perf_counter() - t0
-    return dt / n_samples * R                                         # seconds per 16-sample pass
+    out = {}
+    for nt in thread_settings:
+        torch.set_num_threads(nt)
+        orc.train_step(net, opt, x, mx, 0, 0, float(labels[0]))          # warm-up (oneDNN primitives, allocator, thread pool)
+        t0 = time.perf_counter()
+        for r in range(n_samples):
+            orc.train_step(net, opt, x, mx, 0, r % R, float(labels[r % R]))
+        out[nt] = (time.perf_counter() - t0) / n_samples * R             # seconds per 16-sample pass
+    return out
+
+
+def physical_cores():
+    """Physical host cores: distinct (package, core id) pairs of /proc/cpuinfo."""
+    try:
+        pairs, phys = set(), "0"
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                pairs.add((phys, line.split(":")[1].strip()))
+        if pairs:
+            return len(pairs)
+    except OSError:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU, RCCL) as a CHILD process before this
+    process has touched the GPU, forward its output and exit with its code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -92,11 +133,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cpu-samples", type=int, default=4, help="reference-schedule samples timed on the host (0 = skip)")
+    ap.add_argument("--cpu-samples", type=int, default=2, help="reference-schedule samples timed on the host per thread setting (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--batched-scenes", type=int, default=4,
                     help="also time a config-4 style step with this many scenes per engine call (0 = skip)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -161,6 +204,7 @@ def main():
         "value": passes_per_s, "unit": "passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "dtype_note": "fp32 storage and results; matrix products on the bf16 MFMA as exact 3-way splits (6 terms, fp32 accumulate)",
         "config": {"workload": "reinforcement_net style 0 (grasp trunk + graspnet_val head): 1 scene x 1 mask x 16 rotations per GPU per "
                                "step, fwd + 16 Huber losses + bwd + Adam, S=640 (224^2 heightmap), masked stream de-duplicated (17 trunk passes)",
                    "rotations": R, "input_size": 640, "scenes_per_step": world, "parallelism": "dp%d" % world},
@@ -214,41 +258,72 @@ def main():
             prof = eng.profile_read()
             stages = eng.profile_read_stages()
             eng.profile_enable(False)
+            # Roofline per kernel class.  MFMA roof: executed FLOPs x 6 bf16 MFMA terms / 2.5 PFLOP/s.  HBM roof: ALGORITHMIC bytes
+            # (every operand read once, every result written once, fp32; the engine's BY() figures) / 8 TB/s.  The larger of the
+            # two times bounds the class; frac = that time / the hipEvent-measured time on the launch stream.
+            def roof(v):
+                ms, n, fl, by = v
+                t_mfma, t_hbm = fl * SPLIT_TERMS / (PEAK_BF16_MFMA_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9)
+                bound = "mfma" if t_mfma >= t_hbm else "hbm"
+                t = ms * 1e-3
+                if bound == "mfma":
+                    r = {"bound": "mfma", "achieved": fl / t / 1e12, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s"}
+                else:
+                    r = {"bound": "hbm", "achieved": by / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s"}
+                r["frac"] = max(t_mfma, t_hbm) / t
+                return r
             conv = {k: v for k, v in prof.items() if k != "elementwise" and v[1] > 0}
             dom = max(conv, key=lambda k: conv[k][0])
-            ms, n, fl = conv[dom]
+            ms, n, fl, by = conv[dom]
             conv_ms = sum(v[0] for v in conv.values())
             conv_fl = sum(v[2] for v in conv.values())
-            achieved = fl / (ms * 1e-3) / 1e12
-            # HBM bytes per launch of the dominant class, from the committed PMC passes (profiles/; rocprofv3 cannot run
-            # inside this process): FETCH_SIZE x 2 + WRITE_SIZE, see profiles/pmc_r01_hbm_traffic.md.  None if absent.
-            traffic = None
+            # HBM bytes per launch of the dominant class from the committed PMC passes of this round (profiles/; rocprofv3
+            # cannot run inside this process): bytes per training step there / launches per step HERE.  None if absent.
+            traffic, traffic_src = None, None
             try:
-                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_r01_hbm_traffic.json")) as f:
-                    traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
-            except (OSError, ValueError):
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_FILE)) as f:
+                    pj = json.load(f)
+                if dom in pj:
+                    traffic = pj[dom]["gb_per_train_step"] * 1e9 / (n / n_prof)
+                    traffic_src = "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x 2)" % PMC_FILE
+            except (OSError, ValueError, KeyError):
                 pass
-            out["roofline"] = {
-                "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/pmc_r01_hbm_traffic.json)",
-                "avg_launch_ms": ms / n, "launches_per_step": n // n_prof, "flops_per_launch": fl / n,
-                "all_conv_kernels": {"achieved": conv_fl / (conv_ms * 1e-3) / 1e12, "frac": conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            rl = roof(conv[dom])
+            rl.update({
+                "kernel": dom, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": by / n, "flops_per_launch": fl / n,
+                "avg_launch_ms": ms / n, "launches_per_step": n // n_prof,
+                "arithmetic": "fp32 in / fp32 out; every product = %d v_mfma_f32_32x32x16_bf16 terms of a 3-piece bf16 split (fp32-class accuracy, "
+                              "tools/split_probe.hip): MFMA roof %.1f TFLOP/s fp32-equivalent" % (SPLIT_TERMS, PEAK_SPLIT_TFLOPS),
+                "all_conv_kernels": {"achieved": conv_fl / (conv_ms * 1e-3) / 1e12, "frac_of_split_mfma_roof": conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_SPLIT_TFLOPS,
+                                     "frac_of_fp32_mfma_peak": conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                      "ms_per_step": conv_ms / n_prof, "executed_gflop_per_step": conv_fl / n_prof / 1e9},
                 "elementwise_ms_per_step": prof["elementwise"][0] / n_prof,
-                "per_kernel": {k: {"ms_per_step": v[0] / n_prof, "launches_per_step": v[1] // n_prof,
-                                   "tflops": (v[2] / (v[0] * 1e-3) / 1e12) if v[0] > 0 else 0.0} for k, v in prof.items() if v[1] > 0},
+                "per_kernel": {k: dict(roof(v), ms_per_step=v[0] / n_prof, launches_per_step=v[1] // n_prof,
+                                       tflops=(v[2] / (v[0] * 1e-3) / 1e12) if v[0] > 0 else 0.0,
+                                       algorithmic_gb_per_step=v[3] / n_prof / 1e9) for k, v in prof.items() if v[1] > 0 and (v[2] > 0 or v[3] > 0)},
                 # [ms per step, TFLOP/s] inside dense block 1..4 (160^2, 80^2, 40^2, 20^2 planes at S=640)
                 "per_stage": {k: [[round(r[0] / n_prof, 4), round(r[2] / (r[0] * 1e-3) / 1e12, 2) if r[0] > 0 else 0.0] for r in rows]
                               for k, rows in stages.items() if any(r[1] > 0 for r in rows)},
-            }
+            })
+            # whole step: the sum of the per-class roofline times against the measured step
+            floor_s = sum(max(v[2] * SPLIT_TERMS / (PEAK_BF16_MFMA_TFLOPS * 1e12), v[3] / (PEAK_HBM_GBS * 1e9)) for v in prof.values()) / n_prof
+            rl["step"] = {"roofline_ms": floor_s * 1e3, "measured_ms": ms_per_step, "frac": floor_s * 1e3 / ms_per_step,
+                          "algorithmic_tflops": PASS_GFLOP / ms_per_step, "frac_of_fp32_mfma_peak": PASS_GFLOP / ms_per_step / PEAK_F32_MFMA_TFLOPS}
+            out["roofline"] = rl
         if args.cpu_samples > 0:
-            cores = torch.get_num_threads()
-            sec = cpu_baseline(0, args.cpu_samples, labels)
+            # threads = physical cores and two smaller settings; the best one is reported
+            pc = physical_cores()
+            settings = sorted({pc, max(1, pc // 2), min(pc, 16)}, reverse=True)
+            secs = cpu_baseline(0, args.cpu_samples, labels, settings)
+            best = min(secs, key=lambda k: secs[k])
             out["cpu_baseline"] = {
-                "value": 1.0 / sec, "unit": "passes/s", "cores": cores, "kind": "port",
-                "sample": "%d of the 16 (rotation, mask) training samples of one pass, reference schedule (batch 1, masked stream "
-                          "recomputed per sample, fwd + Huber + bwd + Adam per sample, PyTorch CPU fp32), extrapolated x%g" % (args.cpu_samples, R / args.cpu_samples),
-                "seconds_per_pass": sec,
+                "value": 1.0 / secs[best], "unit": "passes/s", "cores": best, "kind": "port",
+                "sample": "%d of the 16 (rotation, mask) training samples of one pass per thread setting, reference schedule (batch 1, masked "
+                          "stream recomputed per sample, fwd + Huber + bwd + Adam per sample, PyTorch CPU fp32), extrapolated x%g; best of "
+                          "the thread settings tried" % (args.cpu_samples, R / args.cpu_samples),
+                "seconds_per_pass": secs[best], "physical_cores": pc, "logical_cpus": os.cpu_count(),
+                "seconds_per_pass_by_threads": {str(k): v for k, v in secs.items()},
             }
     if rank == 0:
         print(json.dumps(out))

@@ -112,6 +112,14 @@ typedef struct {
     const int* bn_seq_trunk;       /* host */
     int n_bn_seq_head;
     const int* bn_seq_head;        /* host */
+    /* Object masks applied on the device (heightmap form only), replacing the host products
+     * `depth * mask[k]` / `depth * (mask[g] + mask[s])` of code/main.py:160,187: masks_dev holds n_masks arrays
+     * [hm_size,hm_size] float64; stream s reads heightmap * (mask[stream_mask_a[s]] + mask[stream_mask_b[s]]), an
+     * index of -1 meaning "no such term" (both -1: the plain heightmap).  NULL = no masking. */
+    const double* masks_dev;
+    int n_masks;
+    const int* stream_mask_a;      /* host */
+    const int* stream_mask_b;      /* host */
 } smg_batch;
 
 /* Forward: trunk `trunk_id` (0 suction_depth_trunk, 1 grasp_depth_trunk,
@@ -135,6 +143,10 @@ int smg_loss(smg_engine* e, int mode, const float* q_dev, const float* labels_de
  * net->grads for the trunk and head that forward used.  Replaces loss.backward() at
  * code/trainer.py:350-351. */
 int smg_backward(smg_engine* e, const smg_net* net, const float* dq_dev, void* stream);
+
+/* Index and value of the largest of n float32 values (lowest index on ties, like np.argmax at
+ * code/main.py:172-173,195), on the device: idx_out_dev int32[1], val_out_dev float32[1]. */
+int smg_argmax(const float* values_dev, int n, int* idx_out_dev, float* val_out_dev, void* stream);
 
 /* Adam over [offset, offset+count) of params/grads with moments m, v (same layout),
  * replacing torch.optim.Adam.step (code/trainer.py:99,383): lr 1e-4, betas
@@ -164,6 +176,9 @@ int smg_profile_enable(smg_engine* e, int on);
 int smg_profile_kinds(void);
 const char* smg_profile_kind_name(int kind);
 int smg_profile_read(smg_engine* e, int kind, double* ms, int64_t* launches, double* flops);
+/* Algorithmic HBM bytes of the same class (every operand read once, every result written once, fp32) - the
+ * numerator of bench.py's HBM roofline.  Valid after smg_profile_read of that class. */
+int smg_profile_read_bytes(smg_engine* e, int kind, double* bytes);
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,68 @@ def scene_inputs(seed, mask_ids):
     return depth, masks, x, mx
 
 
+G9_KEYS = ("grasp_depth_trunk.features.norm0", "grasp_depth_trunk.features.denseblock3.denselayer9.norm1",
+           "suction_depth_trunk.features.denseblock2.denselayer5.norm2", "graspnet_val.grasp-val-norm1",
+           "suctionnet_val.suction-val-norm0", "gs_depth_trunk.features.norm5")
+
+
+def g9_object_loops(G, ref_net):
+    """G9: the per-step evaluation loops of code/main.py:158-192 on the reference model - every object x {grasp,
+    suction} as a rotation sweep, every unordered object pair as an ES pass - with 3 objects and 4 rotations.
+    (Trainer.forward divides by image_std = 0 as released, so the loops call model.forward on the finitely
+    normalised tensors, exactly what Trainer.forward would hand it.)  Pins SURVEY.md 8f-1: Trainer.forward_objects /
+    forward_object_pairs must reproduce gra_conf / suc_conf / gs_conf, their argmax and the BN buffers."""
+    n, R = 3, 4
+    net = ref_net(1, 1, R)
+    depth, masks = synthetic.heightmap_scene(2)
+    masks = masks[:n]
+    depth_a = depth * masks.sum(0)                                    # main.py:144-151 valid_depth_heightmap_a
+    x = orc.preprocess(depth_a, [MEAN] * 3, [STD] * 3)
+    gra, suc, gs = np.zeros((n, R)), np.zeros((n, R)), np.full((n, n), -100.0)
+    with torch.no_grad():
+        for num in range(n):
+            mx = orc.preprocess(depth_a * masks[num], [MEAN] * 3, [STD] * 3)
+            gra[num] = [float(t) for t in net.forward(x, mx, 0, True, -1)]
+            suc[num] = [float(t) for t in net.forward(x, mx, 1, True, -1)]
+        for g in range(n):
+            for s_ in range(g + 1, n):
+                mx = orc.preprocess(depth_a * (masks[g] + masks[s_]), [MEAN] * 3, [STD] * 3)
+                gs[g, s_] = float(net.forward(x, mx, 2, True, -1)[0])
+    G["g9_gra_conf"], G["g9_suc_conf"], G["g9_gs_conf"] = gra, suc, gs
+    sd = net.state_dict()
+    for key in G9_KEYS:
+        G["g9_%s_rm" % key] = sd[key + ".running_mean"].numpy().copy()
+        G["g9_%s_rv" % key] = sd[key + ".running_var"].numpy().copy()
+        G["g9_%s_nbt" % key] = np.asarray(int(sd[key + ".num_batches_tracked"]))
+    print("G9", gra, suc, gs)
+
+
+def ref_net_factory(ref_models):
+    lay1, lay3 = orc.state_layout(1), orc.state_layout(3)
+
+    def ref_net(seed, out_ch=1, R=16):
+        net = (ref_models.reinforcement_net if out_ch == 1 else ref_models.reactive_net)(True)
+        sd = synthetic.make_state_dict(lay1 if out_ch == 1 else lay3, seed)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        net.gnum_rotations = R
+        net.snum_rotations = R
+        net.train()
+        return net
+    return ref_net
+
+
+def extend_only():
+    """`python -m oracle.make_golden g9`: add the G9 arrays to the existing file without regenerating the rest."""
+    install_shims()
+    ref_models = importlib.import_module("models")
+    torch.set_num_threads(8)
+    path = os.path.join(OUT, "reference_vectors.npz")
+    G = dict(np.load(path, allow_pickle=False))
+    g9_object_loops(G, ref_net_factory(ref_models))
+    np.savez_compressed(path, **G)
+    print("wrote", path, len(G), "arrays")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_shims()
@@ -308,10 +370,14 @@ def main():
     G["g8_grad_headconv1"] = p.grad.numpy().ravel()[probe_idx(p.numel(), 16, "g8/hc1")].copy()
     print("G8", G["g8_logits"], float(loss))
 
+    g9_object_loops(G, ref_net)
     G["meta_mean_std"] = np.asarray([MEAN, STD])
     np.savez_compressed(os.path.join(OUT, "reference_vectors.npz"), **G)
     print("wrote", os.path.join(OUT, "reference_vectors.npz"), len(G), "arrays")
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "g9":
+        extend_only()
+    else:
+        main()

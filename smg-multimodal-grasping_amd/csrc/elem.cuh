@@ -26,6 +26,9 @@ struct PrepArgs {
     const int* stream_rotated;
     float* img4;                // [streams][HWp][4]
     int HWp;
+    const double* masks;        // [n_masks][hm][hm] or null: object masks applied here (code/main.py:160,187)
+    const int* stream_mask_a;   // per stream: mask index or -1
+    const int* stream_mask_b;   // per stream: second mask index (ES pairs: mask[g] + mask[s]) or -1
 };
 
 __device__ __forceinline__ float lin_coord(int i, int S, float step) {
@@ -63,8 +66,18 @@ __global__ void prep_rotate_kernel(const PrepArgs a) {
         } else {
             const int hy = sy - a.pad, hx = sx - a.pad;
             double v = 0.0;
-            if (hy >= 0 && hx >= 0 && hy < 2 * a.hm && hx < 2 * a.hm)
-                v = a.heightmaps[(int64_t)img * a.hm * a.hm + (hy >> 1) * a.hm + (hx >> 1)];
+            if (hy >= 0 && hx >= 0 && hy < 2 * a.hm && hx < 2 * a.hm) {
+                const int64_t at = (int64_t)(hy >> 1) * a.hm + (hx >> 1);
+                v = a.heightmaps[(int64_t)img * a.hm * a.hm + at];
+                if (a.masks) {
+                    const int ma = a.stream_mask_a[s], mb = a.stream_mask_b[s];
+                    if (ma >= 0) {
+                        double m = a.masks[(int64_t)ma * a.hm * a.hm + at];
+                        if (mb >= 0) m += a.masks[(int64_t)mb * a.hm * a.hm + at];
+                        v *= m;                                  // depth * (mask[g] + mask[s]), float64 like numpy
+                    }
+                }
+            }
             const float f = (float)((v - a.mean) / a.stdv);
             out.x = out.y = out.z = f;
         }
@@ -73,41 +86,100 @@ __global__ void prep_rotate_kernel(const PrepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
-// Weight repack: reference layout [cout][cin][kh][kw] -> the K-major layouts the GEMM
-// B operand streams.  One launch for a whole trunk + head through a descriptor table.
+// Weight repack: reference layout [cout][cin][kh][kw] -> what the kernels stream.  One launch for a
+// whole trunk + head through a descriptor table.
+//   split modes: the B operand of the MFMA GEMMs as 16-byte units [piece][K/8][N] of 8 consecutive k of one
+//   output column n, already split into the three bf16 pieces (gemm.cuh) - staging them is a plain copy;
+//   PK_HF / PK_HD: the per-stage LDS images of the LDS-halo 3x3 kernels; PK_HEAD: the value convolution's fp32 layout.
 // ------------------------------------------------------------------------------------
-enum { PK_T1 = 0, PK_3F = 1, PK_3D = 2, PK_STEM = 3, PK_HEAD = 4 };
-struct PackDesc { int64_t src, dst; int cout, cin, mode, count; };
+enum { PK_T1 = 0, PK_D1 = 1, PK_3F = 2, PK_3D = 3, PK_STEM = 4, PK_HEAD = 5, PK_HF = 6, PK_HD = 7 };
+struct PackDesc { int64_t src, dst; int cout, cin, mode, K8tot, N, count; };   // dst: unit offset (split modes) / float offset (fp32 modes)
 
-__global__ void pack_weights_kernel(const PackDesc* descs, const float* params, float* packed) {
+__global__ void pack_weights_kernel(const PackDesc* descs, const float* params, u32x4* packed_u, float* packed_f) {
     const PackDesc d = descs[blockIdx.y];
     const float* s = params + d.src;
-    float* o = packed + d.dst;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.count; i += gridDim.x * blockDim.x) {
-        float v;
-        if (d.mode == PK_T1) {                 // dst[k][n] = src[n][k]
-            const int k = i / d.cout, n = i - k * d.cout;
-            v = s[(int64_t)n * d.cin + k];
-        } else if (d.mode == PK_3F) {          // dst[(tap*cin + c)][n] = src[n][c][tap]
-            const int r = i / d.cout, n = i - r * d.cout;
-            const int tap = r / d.cin, c = r - tap * d.cin;
-            v = s[((int64_t)n * d.cin + c) * 9 + tap];
-        } else if (d.mode == PK_3D) {          // dst[(tap*cout + n)][c] = src[n][c][tap]
-            const int r = i / d.cin, c = i - r * d.cin;
-            const int tap = r / d.cout, n = r - tap * d.cout;
-            v = s[((int64_t)n * d.cin + c) * 9 + tap];
-        } else if (d.mode == PK_STEM) {        // dst[(tap*4 + c)][n] (K padded to 224) = src[n][c][tap]
-            const int r = i / 64, n = i - r * 64;
-            const int tap = r >> 2, c = r & 3;
-            v = (c < 3 && tap < 49) ? s[((int64_t)n * 3 + c) * 49 + tap] : 0.f;
-        } else {                               // PK_HEAD: dst[o][tap][c] = src[o][c][tap]
-            const int taps = 400;
+    if (d.mode == PK_HEAD) {                       // fp32 dst[o][tap][c] = src[o][c][tap] (value convolution)
+        float* o = packed_f + d.dst;
+        const int taps = 400;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.count; i += gridDim.x * blockDim.x) {
             const int o_ = i / (taps * d.cin), r = i - o_ * taps * d.cin;
             const int tap = r / d.cin, c = r - tap * d.cin;
-            v = s[((int64_t)o_ * d.cin + c) * taps + tap];
+            o[i] = s[((int64_t)o_ * d.cin + c) * taps + tap];
         }
-        o[i] = v;
+        return;
     }
+    const int total = d.K8tot * d.N;               // units per piece
+    u32x4* o = packed_u + d.dst;
+    if (d.mode == PK_HF || d.mode == PK_HD) {
+        // LDS-halo 3x3 kernels: the image of one stage, per stage (halo.cuh)
+        //   PK_HF forward       [chunk = c/16][piece][tap][k8 (2)][n (32)]   unit = 8 input channels c of output channel n
+        //   PK_HD data gradient [cgroup = c/32][tap][piece][k8 (4)][c (32)]  unit = 8 output channels n of input channel c
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+            float v[8];
+            int64_t base, pstride;
+            if (d.mode == PK_HF) {
+                const int n = e & 31, k8 = (e >> 5) & 1, tap = (e >> 6) % 9, chunk = e / 576;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = s[((int64_t)n * d.cin + chunk * 16 + 8 * k8 + j) * 9 + tap];
+                base = ((int64_t)chunk * NPIECE * 9 + tap) * 64 + k8 * 32 + n; pstride = 9 * 64;
+            } else {
+                const int c = e & 31, k8 = (e >> 5) & 3, tap = (e >> 7) % 9, cg = e / 1152;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = s[((int64_t)(8 * k8 + j) * d.cin + cg * 32 + c) * 9 + tap];
+                base = (((int64_t)cg * 9 + tap) * NPIECE) * 128 + k8 * 32 + c; pstride = 128;
+            }
+            const Split4 lo = split4(make_float4(v[0], v[1], v[2], v[3])), hi = split4(make_float4(v[4], v[5], v[6], v[7]));
+#pragma unroll
+            for (int pc = 0; pc < NPIECE; ++pc) o[base + pc * pstride] = u32x4{lo.p[pc].x, lo.p[pc].y, hi.p[pc].x, hi.p[pc].y};
+        }
+        return;
+    }
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int k8 = e / d.N, n = e - k8 * d.N;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * k8 + j;
+            if (d.mode == PK_T1) {                 // B(k = c, n) = src[n][c]
+                v[j] = s[(int64_t)n * d.cin + k];
+            } else if (d.mode == PK_D1) {          // B(k = cout index, n = c) = src[k][c]
+                v[j] = s[(int64_t)k * d.cin + n];
+            } else if (d.mode == PK_3F) {          // B(k = tap*cin + c, n) = src[n][c][tap]
+                const int tap = k / d.cin, c = k - tap * d.cin;
+                v[j] = s[((int64_t)n * d.cin + c) * 9 + tap];
+            } else if (d.mode == PK_3D) {          // B(k = tap*cout + nn, n = c) = src[nn][c][tap]
+                const int tap = k / d.cout, nn = k - tap * d.cout;
+                v[j] = s[((int64_t)nn * d.cin + n) * 9 + tap];
+            } else {                               // PK_STEM: k = tap*4 + c (K padded to 224), src[n][c][tap]
+                const int tap = k >> 2, c = k & 3;
+                v[j] = (c < 3 && tap < 49) ? s[((int64_t)n * 3 + c) * 49 + tap] : 0.f;
+            }
+        }
+        const Split4 lo = split4(make_float4(v[0], v[1], v[2], v[3])), hi = split4(make_float4(v[4], v[5], v[6], v[7]));
+#pragma unroll
+        for (int pc = 0; pc < NPIECE; ++pc) o[(int64_t)pc * total + e] = u32x4{lo.p[pc].x, lo.p[pc].y, hi.p[pc].x, hi.p[pc].y};
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// BN statistics table entries for channels whose producer is not a dense layer (block inputs after pool0 / a
+// transition, the head's concatenated features): fp64 sums -> fp32 mean | invstd, once.  The channels a dense
+// layer appends are finished by their first consumer instead (BnTab, gemm.cuh) - no launch of their own.
+// ------------------------------------------------------------------------------------
+struct BnStatArgs {
+    const double* sum; const double* sq; int sstride;          // [row][sstride] statistics
+    float eps; double inv_count;
+    float* mean; float* invstd; int ld;                        // tables [row][ld]
+    int c0, C, rows;                                           // channels [c0, c0 + C)
+};
+__global__ void bn_stat_kernel(const BnStatArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.rows * a.C) return;
+    const int n = idx / a.C, c = a.c0 + idx - n * a.C;
+    float mean, invstd;
+    bn_moments(a.sum, a.sq, (int64_t)n * a.sstride + c, a.inv_count, a.eps, mean, invstd);
+    a.mean[(int64_t)n * a.ld + c] = mean;
+    a.invstd[(int64_t)n * a.ld + c] = invstd;
 }
 
 // ------------------------------------------------------------------------------------
@@ -634,6 +706,28 @@ __global__ void loss_kernel(int mode, const float* q, const float* labels, int n
             for (int c = 0; c < 3; ++c) dj[c] = sm[c] - (c == y ? 1.f : 0.f);
         }
     }
+}
+
+// Largest value and its index (lowest index on ties, like np.argmax): one workgroup.
+__global__ __launch_bounds__(256) void argmax_kernel(const float* v, int n, int* idx_out, float* val_out) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    const int t = threadIdx.x;
+    float best = -INFINITY; int at = 0x7fffffff;
+    for (int i = t; i < n; i += 256) {
+        const float x = v[i];
+        if (x > best || (x == best && i < at) || at == 0x7fffffff) { if (x > best || at == 0x7fffffff || (x == best && i < at)) { best = x; at = i; } }
+    }
+    bv[t] = best; bi[t] = at;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) {
+            const float x = bv[t + s]; const int j = bi[t + s];
+            if (j != 0x7fffffff && (bi[t] == 0x7fffffff || x > bv[t] || (x == bv[t] && j < bi[t]))) { bv[t] = x; bi[t] = j; }
+        }
+        __syncthreads();
+    }
+    if (t == 0) { *idx_out = bi[0] == 0x7fffffff ? 0 : bi[0]; *val_out = bv[0]; }
 }
 
 // ------------------------------------------------------------------------------------

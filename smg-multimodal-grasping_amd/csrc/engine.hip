@@ -75,7 +75,7 @@ static const char* kKindNames[K_COUNT] = {"stem7x7_fwd", "conv1x1_fwd", "conv3x3
 constexpr int kGroup = GROUP_MAX;          // dense layers per 1x1-dgrad group
 constexpr int kRing = kGroup + 2;
 
-struct ProfRec { hipEvent_t a, b; int kind; double flops; int stage; };
+struct ProfRec { hipEvent_t a, b; int kind; double flops; int stage; double bytes; };
 
 struct StatArr { int64_t off; int stride; };   // into a double arena: sum at off, sumsq at off + span
 
@@ -102,13 +102,19 @@ struct smg_engine {
     double* bstat = nullptr; int64_t bstat_span = 0;
     StatArr st_stem, st_X[4], st_F, st_H1; std::vector<StatArr> st_Bt[4];
     StatArr bs_stem, bs_X[4], bs_F, bs_H1; std::vector<StatArr> bs_Bt[4];
-    // packed weights
-    float* packed = nullptr; int64_t packed_floats = 0;
+    // packed weights: split bf16 units for the MFMA GEMMs (packed_u) and fp32 K-major layouts for the halo 3x3
+    // kernels / the value convolution (packed_f)
+    u32x4* packed_u = nullptr; int64_t packed_units = 0;
+    float* packed_f = nullptr; int64_t packed_floats = 0;
     PackDesc* d_pack = nullptr; std::vector<PackDesc> h_pack[3]; std::vector<PackDesc> h_pack_head[3];
     int pack_stride = 0, bnupd_stride = 0, n_bnupd = 0;   // d_pack / d_bnupd hold one table per (trunk, head)
-    int64_t pk_conv0 = 0, pk_head0 = 0, pk_head1 = 0;
-    std::vector<int64_t> pk_c1[4], pk_c2f[4], pk_c2d[4]; int64_t pk_t[3] = {};
+    int64_t pk_conv0 = 0, pk_head0 = 0, pk_hd0 = 0, pk_head1 = 0;
+    std::vector<int64_t> pk_c1[4], pk_d1[4], pk_g3f[4], pk_g3d[4], pk_hf[4], pk_hd[4]; int64_t pk_t[3] = {}, pk_td[3] = {};
     int max_pack = 0;
+    // BN statistics as fp32 tables (mean | invstd, [rows][C] each): one per dense-block buffer, one per bottleneck, one
+    // for the head's features; written by the first consumer of a channel (BnTab, gemm.cuh), kept until the backward
+    float* stab = nullptr; int64_t stab_floats = 0;
+    int64_t sx_tab[4] = {}, sb_tab[4][24] = {}, sf_tab = 0;
     // bn update descriptors
     BnUpdDesc* d_bnupd = nullptr;
     // last forward
@@ -118,14 +124,15 @@ struct smg_engine {
     float* d_affine = nullptr;
     // batch description staging: one pinned ping-pong host block -> one device block per forward
     int* d_stage = nullptr; int* h_stage[2] = {}; hipEvent_t ev_stage[2] = {}; int stage_ints = 0, stage_turn = 0;
-    int so_image = 0, so_rot = 0, so_pa = 0, so_pb = 0, so_seq_t = 0, so_seq_h = 0, so_uptr = 0, so_upair = 0, so_uslot = 0, so_aff = 0;
+    int so_image = 0, so_rot = 0, so_pa = 0, so_pb = 0, so_seq_t = 0, so_seq_h = 0, so_uptr = 0, so_upair = 0, so_uslot = 0, so_aff = 0, so_ma = 0, so_mb = 0;
     int64_t workspace_bytes = 0;
     int n_cu = 256;            // compute units of the device (persistent-launch sizing)
     bool generic3x3 = false;   // SMG_GENERIC_3X3=1: dense-layer 3x3 convs through the generic implicit GEMM (A/B testing)
     // profiling
     bool prof = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> ev_pool;
     // totals per kind in slot 0, and the share of dense block b (kernels issued inside its layer loops) in slot 1 + b
-    double prof_ms[5][K_COUNT] = {}; int64_t prof_n[5][K_COUNT] = {}; double prof_flops[5][K_COUNT] = {}; int prof_stage = -1;
+    double prof_ms[5][K_COUNT] = {}; int64_t prof_n[5][K_COUNT] = {}; double prof_flops[5][K_COUNT] = {}; double prof_bytes[5][K_COUNT] = {}; int prof_stage = -1;
+    double next_bytes = 0;     // algorithmic HBM bytes of the next profiled launch (set with BY() right before it)
 };
 
 // Tile side of the LDS-halo 3x3 kernels for a plane: 16 where it tiles exactly, else 8 (ragged edges masked) - and 8
@@ -141,8 +148,8 @@ static inline int halo_tile(const Plane& p, int n_streams = 1 << 20) {
 // CU), each lasting tiles_per_wg tile-times plus a fixed prologue + 9-tap flush (~0.6 of a 16x16 tile-time, measured);
 // take the run length with the shortest total (e.g. 100 tiles x 17 streams -> 7, 25 tiles -> 4), then lengthen it
 // until the partial tiles fit the workspace.
-static int w3_tiles_per_wg(int n_tiles, int ts, int n_streams, int64_t part_floats) {
-    const double fix = ts == 16 ? 0.6 : 2.4;
+static int w3_tiles_per_wg(int n_tiles, int ts, int n_streams, int64_t part_floats, double fix_scale = 1.0) {
+    const double fix = (ts == 16 ? 0.6 : 2.4) * fix_scale;
     double best = 1e30;
     int tpw_best = 1;
     for (int tpw = 1; tpw <= n_tiles; ++tpw) {
@@ -177,19 +184,30 @@ static hipEvent_t prof_event(smg_engine* e) {
     if (!e->ev_pool.empty()) { hipEvent_t ev = e->ev_pool.back(); e->ev_pool.pop_back(); return ev; }
     hipEvent_t ev; (void)hipEventCreate(&ev); return ev;
 }
+// Algorithmic HBM bytes of the launch that follows: what the kernel must move once (inputs read once, outputs written
+// once, fp32), the yardstick of bench.py's HBM roofline.
+#define BY(e, x) ((e)->next_bytes = (double)(x))
 struct ProfScope {
-    smg_engine* e; hipStream_t st; int kind; double flops; hipEvent_t a{}, b{};
-    ProfScope(smg_engine* e_, hipStream_t s, int k, double f) : e(e_), st(s), kind(k), flops(f) {
+    smg_engine* e; hipStream_t st; int kind; double flops, bytes; hipEvent_t a{}, b{};
+    ProfScope(smg_engine* e_, hipStream_t s, int k, double f) : e(e_), st(s), kind(k), flops(f), bytes(e_->next_bytes) {
+        e->next_bytes = 0;
         if (e->prof) { a = prof_event(e); b = prof_event(e); (void)hipEventRecord(a, st); }
     }
     ~ProfScope() {
-        if (e->prof) { (void)hipEventRecord(b, st); e->recs.push_back({a, b, kind, flops, e->prof_stage}); }
+        if (e->prof) { (void)hipEventRecord(b, st); e->recs.push_back({a, b, kind, flops, e->prof_stage, bytes}); }
     }
 };
 
 template <class P>
 static void launch_gemm(smg_engine* e, hipStream_t st, P p, dim3 grid, int kind, double flops) {
     const size_t smem = (size_t)(P::Cfg::TILE_FLOATS + p.param_floats()) * sizeof(float);
+    if (smem > 64 * 1024) {      // more dynamic LDS than the default limit: raise it once per (instantiation, device)
+        static bool raised[64] = {};
+        if (!raised[e->device & 63]) {
+            (void)hipFuncSetAttribute((const void*)gemm_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised[e->device & 63] = true;
+        }
+    }
     p.tm = TileMap{0, 0, 0};
     if constexpr (P::kSwizzle == 1) {            // x = M tiles, y = N tiles sharing one A operand
         if (grid.y > 1 && grid.z == 1) {
@@ -277,10 +295,9 @@ static int engine_build(smg_engine* e) {
     e->OH = e->OW = e->p_blk[3].H - kHeadKernel + 1;
     if (e->OH < 1) return fail(-22, "input_size too small for the 20x20 value head");
 
-    {   // the 16x16 weight-gradient halo kernel needs more than the default 64 KB of dynamic LDS
-        const int smem = (int)(HaloWgradGeo<16>::smem_floats() * sizeof(float));
-        HIP_OK(hipFuncSetAttribute((const void*)conv3x3_halo_wgrad_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    }
+    // the 16x16 data-gradient halo kernel needs more than the default 64 KB of dynamic LDS
+    HIP_OK(hipFuncSetAttribute((const void*)conv3x3_halo_dgrad_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               HaloDgradSGeo<16>::smem_bytes(kBottleneck)));
     const char* g3 = getenv("SMG_GENERIC_3X3");
     e->generic3x3 = g3 && g3[0] == '1';
 
@@ -312,8 +329,9 @@ static int engine_build(smg_engine* e) {
     for (int b = 0; b < 4; ++b) {
         const Plane& pl = e->p_blk[b];
         for (int ts : {halo_tile(pl), 8}) {
-            const int nt = ((pl.H + ts - 1) / ts) * ((pl.W + ts - 1) / ts);
-            const int tpw = w3_tiles_per_wg(nt, ts, NS, INT64_MAX);
+            const int th = 8;                                    // weight-gradient tiles are ts x 8 pixels
+            const int nt = ((pl.H + th - 1) / th) * ((pl.W + ts - 1) / ts);
+            const int tpw = w3_tiles_per_wg(nt, ts, NS, INT64_MAX, (double)ts / th);
             e->part_floats = std::max<int64_t>(e->part_floats, (int64_t)((nt + tpw - 1) / tpw) * NS * 9 * 32 * kBottleneck);
         }
     }
@@ -337,40 +355,71 @@ static int engine_build(smg_engine* e) {
     for (int b = 0; b < 4; ++b) { e->bs_X[b] = e->st_X[b]; e->bs_Bt[b] = e->st_Bt[b]; }
     ALLOC(e->fstat, 2 * off);
     ALLOC(e->bstat, 2 * off);
+    {   // BN statistic tables: mean | invstd, [rows][C] each
+        int64_t po = 0;
+        auto carve_t = [&](int rows, int C) { int64_t at = po; po += (int64_t)2 * rows * C; return at; };
+        for (int b = 0; b < 4; ++b) {
+            e->sx_tab[b] = carve_t(NS, kBlockCtot[b]);
+            for (int i = 0; i < kBlockLayers[b]; ++i) e->sb_tab[b][i] = carve_t(NS, kBottleneck);
+        }
+        e->sf_tab = carve_t(NP, 2 * kFeat);
+        e->stab_floats = po;
+        ALLOC(e->stab, po);
+    }
 
     // packed weights + descriptor tables (one table per trunk, one per head)
-    int64_t pk = 0;
-    auto add_pack = [&](std::vector<PackDesc>& v, int64_t src, int cout, int cin, int mode, int64_t count) {
-        PackDesc d; d.src = src; d.dst = pk; d.cout = cout; d.cin = cin; d.mode = mode; d.count = (int)count;
-        v.push_back(d); int64_t at = pk; pk += count; return at;
+    int64_t pku = 0, pkf = 0;
+    auto add_units = [&](std::vector<PackDesc>& v, int64_t src, int cout, int cin, int mode, int K, int N) {
+        PackDesc d{}; d.src = src; d.dst = pku; d.cout = cout; d.cin = cin; d.mode = mode; d.K8tot = K / 8; d.N = N; d.count = 0;
+        v.push_back(d); int64_t at = pku; pku += (int64_t)NPIECE * (K / 8) * N; return at;
+    };
+    auto add_f32 = [&](std::vector<PackDesc>& v, int64_t src, int cout, int cin, int mode, int64_t count) {
+        PackDesc d{}; d.src = src; d.dst = pkf; d.cout = cout; d.cin = cin; d.mode = mode; d.count = (int)count;
+        v.push_back(d); int64_t at = pkf; pkf += count; return at;
     };
     for (int t = 0; t < 3; ++t) {
-        pk = 0;   // every trunk packs into the same region (only one trunk is active per forward)
+        pku = pkf = 0;   // every trunk packs into the same region (only one trunk is active per forward)
         const TrunkRef& T = L.trunk[t];
         std::vector<PackDesc>& v = e->h_pack[t];
-        e->pk_conv0 = add_pack(v, T.conv0.w, 64, 3, PK_STEM, 224 * 64);
+        e->pk_conv0 = add_units(v, T.conv0.w, 64, 3, PK_STEM, 224, 64);
         for (int b = 0; b < 4; ++b) {
-            if (t == 0) { e->pk_c1[b].clear(); e->pk_c2f[b].clear(); e->pk_c2d[b].clear(); }
+            if (t == 0) { e->pk_c1[b].clear(); e->pk_d1[b].clear(); e->pk_g3f[b].clear(); e->pk_g3d[b].clear(); e->pk_hf[b].clear(); e->pk_hd[b].clear(); }
             for (size_t i = 0; i < T.layers[b].size(); ++i) {
                 const DenseLayerRef& d = T.layers[b][i];
-                int64_t a1 = add_pack(v, d.c1.w, kBottleneck, d.cin, PK_T1, d.c1.count());
-                int64_t a2 = add_pack(v, d.c2.w, kGrowth, kBottleneck, PK_3F, d.c2.count());
-                int64_t a3 = add_pack(v, d.c2.w, kGrowth, kBottleneck, PK_3D, d.c2.count());
-                if (t == 0) { e->pk_c1[b].push_back(a1); e->pk_c2f[b].push_back(a2); e->pk_c2d[b].push_back(a3); }
+                int64_t a1 = add_units(v, d.c1.w, kBottleneck, d.cin, PK_T1, d.cin, kBottleneck);
+                int64_t a1d = add_units(v, d.c1.w, kBottleneck, d.cin, PK_D1, kBottleneck, d.cin);
+                int64_t g2 = 0, g3 = 0;
+                const int64_t hf = add_units(v, d.c2.w, kGrowth, kBottleneck, PK_HF, 9 * kBottleneck, kGrowth);
+                const int64_t hd = add_units(v, d.c2.w, kGrowth, kBottleneck, PK_HD, 9 * kGrowth, kBottleneck);
+                if (e->generic3x3) {
+                    g2 = add_units(v, d.c2.w, kGrowth, kBottleneck, PK_3F, 9 * kBottleneck, kGrowth);
+                    g3 = add_units(v, d.c2.w, kGrowth, kBottleneck, PK_3D, 9 * kGrowth, kBottleneck);
+                }
+                if (t == 0) {
+                    e->pk_c1[b].push_back(a1); e->pk_d1[b].push_back(a1d);
+                    e->pk_g3f[b].push_back(g2); e->pk_g3d[b].push_back(g3); e->pk_hf[b].push_back(hf); e->pk_hd[b].push_back(hd);
+                }
             }
-            if (b < 3) e->pk_t[b] = add_pack(v, T.tconv[b].w, T.tconv[b].cout, T.tconv[b].cin, PK_T1, T.tconv[b].count());
+            if (b < 3) {
+                e->pk_t[b] = add_units(v, T.tconv[b].w, T.tconv[b].cout, T.tconv[b].cin, PK_T1, T.tconv[b].cin, T.tconv[b].cout);
+                e->pk_td[b] = add_units(v, T.tconv[b].w, T.tconv[b].cout, T.tconv[b].cin, PK_D1, T.tconv[b].cout, T.tconv[b].cin);
+            }
         }
     }
-    const int64_t trunk_pk = pk;
+    const int64_t trunk_pku = pku, trunk_pkf = pkf;
     for (int hd = 0; hd < 3; ++hd) {
-        pk = trunk_pk;
+        pku = trunk_pku; pkf = trunk_pkf;
         const HeadRef& H = L.head[hd];
         std::vector<PackDesc>& v = e->h_pack_head[hd];
-        e->pk_head0 = add_pack(v, H.c0.w, kHeadMid, 2 * kFeat, PK_T1, H.c0.count());
-        e->pk_head1 = add_pack(v, H.c1.w, e->head_out, kHeadMid, PK_HEAD, H.c1.count());
+        e->pk_head0 = add_units(v, H.c0.w, kHeadMid, 2 * kFeat, PK_T1, 2 * kFeat, kHeadMid);
+        e->pk_hd0 = add_units(v, H.c0.w, kHeadMid, 2 * kFeat, PK_D1, kHeadMid, 2 * kFeat);
+        e->pk_head1 = add_f32(v, H.c1.w, e->head_out, kHeadMid, PK_HEAD, H.c1.count());
     }
-    e->packed_floats = pk;
-    ALLOC(e->packed, pk);
+    e->packed_units = pku + 4096;        // slack: tiles wider than N over-read whole units behind the array (never stored)
+    e->packed_floats = pkf;
+    ALLOC(e->packed_u, e->packed_units);
+    HIP_OK(hipMemset(e->packed_u, 0, (size_t)e->packed_units * sizeof(u32x4)));
+    ALLOC(e->packed_f, pkf + 4);
     e->max_pack = (int)(e->h_pack[0].size() + e->h_pack_head[0].size());
     // Descriptor tables are static per (trunk, head): upload all nine once, so a forward
     // never has to wait on a host->device copy of them.
@@ -416,7 +465,7 @@ static int engine_build(smg_engine* e) {
     e->so_image = carve_i(NS); e->so_rot = carve_i(NS); e->so_pa = carve_i(NP); e->so_pb = carve_i(NP);
     e->so_seq_t = carve_i(4 * R + 16); e->so_seq_h = carve_i(4 * R + 16);
     e->so_uptr = carve_i(NS + 1); e->so_upair = carve_i(2 * NP); e->so_uslot = carve_i(2 * NP);
-    e->so_aff = carve_i(6 * NS);
+    e->so_aff = carve_i(6 * NS); e->so_ma = carve_i(NS); e->so_mb = carve_i(NS);
     e->stage_ints = so;
     ALLOC(e->d_stage, so);
     e->d_stream_image = e->d_stage + e->so_image; e->d_stream_rot = e->d_stage + e->so_rot;
@@ -441,6 +490,14 @@ static inline double* b2(smg_engine* e, const StatArr& s) { return e->bstat + e-
 
 static const float kEps = 1e-5f;
 
+// BN statistics table at float offset `at` of the table arena ([rows_max][C] mean, then invstd), from row r0 on, with the
+// affine parameters of the consuming BatchNorm
+static BnTab bn_table(smg_engine* e, int64_t at, int rows_max, int r0, int C, const float* gamma, const float* beta) {
+    BnTab t;
+    t.mean = e->stab + at + (int64_t)r0 * C; t.invstd = t.mean + (int64_t)rows_max * C; t.ld = C; t.gamma = gamma; t.beta = beta;
+    return t;
+}
+
 static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, const smg_batch* B,
                       float* q_out, hipStream_t st) {
     const Layout& L = *e->L;
@@ -451,6 +508,12 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
     if (!B->images_nchw_dev && !B->heightmaps_dev) return fail(-22, "no input images");
     for (int s = 0; s < NS; ++s)
         if (B->stream_image[s] < 0 || B->stream_image[s] >= B->n_images) return fail(-22, "stream_image out of range");
+    if (B->masks_dev) {
+        if (!B->heightmaps_dev || !B->stream_mask_a || !B->stream_mask_b) return fail(-22, "device masks need the heightmap input form and both index arrays");
+        for (int s = 0; s < NS; ++s)
+            if (B->stream_mask_a[s] >= B->n_masks || B->stream_mask_b[s] >= B->n_masks || (B->stream_mask_a[s] < 0 && B->stream_mask_b[s] >= 0))
+                return fail(-22, "stream mask index out of range");
+    }
     for (int j = 0; j < NP; ++j)
         if (B->pair_a[j] < 0 || B->pair_a[j] >= NS || B->pair_b[j] < 0 || B->pair_b[j] >= NS) return fail(-22, "pair index out of range");
     const int n_seq_t = B->bn_seq_trunk ? B->n_bn_seq_trunk : 0, n_seq_h = B->bn_seq_head ? B->n_bn_seq_head : 0;
@@ -469,6 +532,10 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
         memcpy(h + e->so_image, B->stream_image, NS * sizeof(int));
         memcpy(h + e->so_rot, B->stream_rotated, NS * sizeof(int));
         memcpy(h + e->so_aff, B->stream_affine, 6 * NS * sizeof(float));
+        if (B->masks_dev) {
+            memcpy(h + e->so_ma, B->stream_mask_a, NS * sizeof(int));
+            memcpy(h + e->so_mb, B->stream_mask_b, NS * sizeof(int));
+        }
         memcpy(h + e->so_pa, B->pair_a, NP * sizeof(int));
         memcpy(h + e->so_pb, B->pair_b, NP * sizeof(int));
         if (n_seq_t) memcpy(h + e->so_seq_t, B->bn_seq_trunk, n_seq_t * sizeof(int));
@@ -493,13 +560,22 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
         const unsigned n_pack = (unsigned)(e->h_pack[trunk_id].size() + e->h_pack_head[head_id].size());
         ProfScope ps(e, st, K_OTHER, 0);
         hipLaunchKernelGGL(pack_weights_kernel, dim3(64, n_pack), dim3(256), 0, st,
-                           e->d_pack + (trunk_id * 3 + head_id) * e->pack_stride, net->params, e->packed);
+                           e->d_pack + (trunk_id * 3 + head_id) * e->pack_stride, net->params, e->packed_u, e->packed_f);
     }
     const float* P = net->params;
 
     // The trunk of streams [s0, s0 + ns).  Streams are independent up to the head (BN statistics are per stream), so
     // the batch is run as TWO chains on two HIP streams: the tail of one chain's kernel overlaps the other chain's
     // next kernel (two full sweeps side by side take 83 % of their serial time, tests/gpu_concurrency_probe.py).
+    // BN table of one consumer layer (rows [r0, r0 + rows) of a [max rows][C] table at float offset `at`) + the launch that fills it
+    // table entries of channels [c0, c0 + C) whose producer is not a dense layer (block inputs, head features)
+    auto bn_stat = [&](hipStream_t cs, const BnTab& t, int rows, const double* sum, const double* sq, int sstride, int c0, int C, int count) {
+        BnStatArgs a;
+        a.sum = sum; a.sq = sq; a.sstride = sstride; a.eps = kEps; a.inv_count = 1.0 / (double)count;
+        a.mean = const_cast<float*>(t.mean); a.invstd = const_cast<float*>(t.invstd); a.ld = t.ld; a.c0 = c0; a.C = C; a.rows = rows;
+        ProfScope ps(e, cs, K_OTHER, 0);
+        hipLaunchKernelGGL(bn_stat_kernel, dim3((rows * C + 255) / 256), dim3(256), 0, cs, a);
+    };
     auto trunk_chain = [&](const int s0, const int ns, hipStream_t cs) -> int {
         auto xs = [&](int b) { return e->X[b] + (int64_t)s0 * e->p_blk[b].HWp * kBlockCtot[b]; };
         auto st_off = [&](double* base, int stride) { return base + (int64_t)s0 * stride; };
@@ -511,6 +587,7 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
             a.mean = B->image_mean; a.stdv = B->image_std;
             a.stream_image = e->d_stream_image + s0; a.stream_affine = e->d_affine + 6 * s0; a.stream_rotated = e->d_stream_rot + s0;
             a.img4 = img4; a.HWp = e->p_img.HWp;
+            a.masks = B->masks_dev; a.stream_mask_a = e->d_stage + e->so_ma + s0; a.stream_mask_b = e->d_stage + e->so_mb + s0;
             ProfScope ps(e, cs, K_OTHER, 0);
             hipLaunchKernelGGL(prep_rotate_kernel, dim3((e->S * e->S + 255) / 256, ns), dim3(256), 0, cs, a);
         }
@@ -519,9 +596,10 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
                 using Cfg = decltype(tag);
                 FwdConvP<Cfg, F_STEM> p{};
                 p.src = img4; p.lds_ = 4; p.ps = e->p_img; p.po = e->p_stem; p.K = 0;
-                p.w = e->packed + e->pk_conv0; p.ldw = 64; p.N = 64;
+                p.wp = e->packed_u + e->pk_conv0; p.K8tot = 224 / 8; p.N = 64;
                 p.dst = stem; p.ldd = 64; p.dcoff = 0;
-                p.dsum = st_off(fsum(e, e->st_stem), 64); p.dsq = st_off(fsq(e, e->st_stem), 64); p.dstride = 64; p.eps = kEps;
+                p.dsum = st_off(fsum(e, e->st_stem), 64); p.dsq = st_off(fsq(e, e->st_stem), 64); p.dstride = 64;
+                BY(e, 4.0 * ns * ((double)e->p_img.HW * 4 + (double)e->p_stem.HW * 64));
                 launch_gemm(e, cs, p, dim3(ns * e->p_stem.HWp / Cfg::BM, 1), K_STEM, 2.0 * ns * e->p_stem.HW * 64 * 147);
             };
             if (e->p_stem.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
@@ -546,58 +624,64 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
                 float* bt = e->Bt + e->bt_off[b][i] + (int64_t)s0 * pl.HWp * kBottleneck;
                 double* bsum = st_off(fsum(e, e->st_Bt[b][i]), kBottleneck); double* bsq = st_off(fsq(e, e->st_Bt[b][i]), kBottleneck);
                 {   // norm1 + relu + conv1 (1x1, cin -> 128)
+                    const BnTab t1 = bn_table(e, e->sx_tab[b], e->max_streams, s0, Ct, P + d.n1.w, P + d.n1.b);
+                    if (i == 0) bn_stat(cs, t1, ns, xsum, xsq, Ct, 0, d.cin, pl.HW);     // block input: from pool0 / the transition
                     auto run = [&](auto tag) {
                         using Cfg = decltype(tag);
                         FwdConvP<Cfg, F_ONE> p{};
                         p.src = xs(b); p.lds_ = Ct; p.ps = pl; p.po = pl; p.K = d.cin;
-                        p.ssum = xsum; p.ssq = xsq; p.sstride = Ct;
-                        p.gamma = P + d.n1.w; p.beta = P + d.n1.b; p.eps = kEps;
-                        p.w = e->packed + e->pk_c1[b][i]; p.ldw = kBottleneck; p.N = kBottleneck;
+                        p.bt = t1; p.fresh0 = i == 0 ? d.cin : d.cin - kGrowth; p.fsum = xsum; p.fsq = xsq; p.fstride = Ct; p.eps = kEps;
+                        p.tw_mean = const_cast<float*>(t1.mean); p.tw_invstd = const_cast<float*>(t1.invstd);
+                        p.wp = e->packed_u + e->pk_c1[b][i]; p.K8tot = d.cin / 8; p.N = kBottleneck;
                         p.dst = bt; p.ldd = kBottleneck; p.dcoff = 0;
                         p.dsum = bsum; p.dsq = bsq; p.dstride = kBottleneck;
+                        BY(e, 4.0 * ns * pl.HW * (d.cin + kBottleneck));
                         launch_gemm(e, cs, p, dim3(ns * pl.HWp / Cfg::BM, kBottleneck / Cfg::BN), K_C1, 2.0 * ns * pl.HW * d.cin * kBottleneck);
                     };
-                    // 64-row tiles: the BN parameters of all cin channels sit in LDS (12 B each) next to the 34 KB of
-                    // BK = 32 tiles; past 576 channels only three workgroups fit a CU (768 slots for the 850 tiles of a
-                    // 17-stream 40x40 layer), so those layers take BK = 16 tiles (29 KB, five per CU).  64x128 tiles: slower.
-                    // ... and when even the 64-row tiling leaves most CUs idle (few streams per call, or the 20x20 planes),
-                    // 32x64 tiles with the k-tile split over wave pairs: twice the workgroups, half the serial K chain.
+                    // 128x128 tiles where the plane tiles by 128 rows and the launch still fills the chip; else 64x64 (BK = 32) -
+                    // and when even that leaves most CUs idle (few streams per call, or the 20x20 planes), 32x64 tiles with
+                    // the k-tile split over wave pairs: twice the workgroups, half the serial K chain.
                     constexpr int small_wgs = 320;                 // 512 / 1024 measured slower on the 17-stream step
                     const int wg128 = ns * pl.HWp / 128, wg64 = ns * pl.HWp / 64 * 2;
+                    static const bool k16 = getenv("SMG_C1_K16") != nullptr;      // dev A/B: BK = 16 past 576 channels (round 1's rule)
                     if (pl.HWp % 128 == 0 && wg128 >= small_wgs) run(CfgP128x128{});
                     else if (wg64 < small_wgs) run(CfgP32x64{});
-                    else if (d.cin > 576) run(CfgP64x64k16{});
+                    else if (k16 && d.cin > 576) run(CfgP64x64k16{});
                     else run(CfgP64x64{});
                 }
+                const BnTab t2 = bn_table(e, e->sb_tab[b][i], e->max_streams, s0, kBottleneck, P + d.n2.w, P + d.n2.b);
+                if (e->generic3x3) bn_stat(cs, t2, ns, bsum, bsq, kBottleneck, 0, kBottleneck, pl.HW);
                 if (!e->generic3x3) {
                     // norm2 + relu + conv2 (3x3, 128 -> 32) with an LDS-resident input halo (halo.cuh)
                     Halo3x3FwdArgs a;
                     a.src = bt; a.lds_ = kBottleneck; a.pl = pl; a.C = kBottleneck;
-                    a.ssum = bsum; a.ssq = bsq; a.sstride = kBottleneck;
-                    a.gamma = P + d.n2.w; a.beta = P + d.n2.b; a.eps = kEps;
-                    a.w = e->packed + e->pk_c2f[b][i];
+                    a.ssum = bsum; a.ssq = bsq; a.sstride = kBottleneck; a.gamma = P + d.n2.w; a.beta = P + d.n2.b; a.eps = kEps;
+                    a.tw_mean = const_cast<float*>(t2.mean); a.tw_invstd = const_cast<float*>(t2.invstd);
                     a.dst = xs(b); a.ldd = Ct; a.dcoff = d.cin;
                     a.dsum = xsum; a.dsq = xsq; a.dstride = Ct;
+                    a.wu = e->packed_u + e->pk_hf[b][i];
+                    BY(e, 4.0 * ns * pl.HW * (kBottleneck + kGrowth));
                     ProfScope ps(e, cs, K_C3, 2.0 * ns * pl.HW * 9 * kBottleneck * kGrowth);
                     if (halo_tile(pl, ns) == 16) {
                         a.tiles_x = pl.W / 16;
                         hipLaunchKernelGGL(conv3x3_halo_fwd_kernel<16>, dim3((pl.H / 16) * a.tiles_x, ns), dim3(256),
-                                           HaloFwdGeo<16>::smem_floats(kBottleneck) * sizeof(float), cs, a);
+                                           HaloFwdSGeo<16>::smem_bytes(kBottleneck), cs, a);
                     } else {
                         a.tiles_x = (pl.W + 7) / 8;
                         hipLaunchKernelGGL(conv3x3_halo_fwd_kernel<8>, dim3(((pl.H + 7) / 8) * a.tiles_x, ns), dim3(256),
-                                           HaloFwdGeo<8>::smem_floats(kBottleneck) * sizeof(float), cs, a);
+                                           HaloFwdSGeo<8>::smem_bytes(kBottleneck), cs, a);
                     }
                 } else {   // norm2 + relu + conv2 (3x3, 128 -> 32), appended to the block buffer (generic implicit GEMM)
                     auto run = [&](auto tag) {
                         using Cfg = decltype(tag);
                         FwdConvP<Cfg, F_THREE> p{};
                         p.src = bt; p.lds_ = kBottleneck; p.ps = pl; p.po = pl; p.K = kBottleneck;
-                        p.ssum = bsum; p.ssq = bsq; p.sstride = kBottleneck;
-                        p.gamma = P + d.n2.w; p.beta = P + d.n2.b; p.eps = kEps;
-                        p.w = e->packed + e->pk_c2f[b][i]; p.ldw = kGrowth; p.N = kGrowth;
+                        p.bt = t2; p.fresh0 = kBottleneck; p.fsum = bsum; p.fsq = bsq; p.fstride = kBottleneck; p.eps = kEps;
+                        p.tw_mean = const_cast<float*>(t2.mean); p.tw_invstd = const_cast<float*>(t2.invstd);
+                        p.wp = e->packed_u + e->pk_g3f[b][i]; p.K8tot = 9 * kBottleneck / 8; p.N = kGrowth;
                         p.dst = xs(b); p.ldd = Ct; p.dcoff = d.cin;
                         p.dsum = xsum; p.dsq = xsq; p.dstride = Ct;
+                        BY(e, 4.0 * ns * pl.HW * (kBottleneck + kGrowth));
                         launch_gemm(e, cs, p, dim3(ns * pl.HWp / Cfg::BM, 1), K_C3, 2.0 * ns * pl.HW * 9 * kBottleneck * kGrowth);
                     };
                     if (pl.HWp % 128 == 0) run(CfgP128x32{}); else run(CfgP64x32{});
@@ -606,15 +690,17 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
             if (b < 3) {   // transition: norm + relu + (avgpool2 commuted in front of) conv 1x1
                 const Plane pn = e->p_blk[b + 1];
                 const int Cn = kBlockCtot[b + 1];
+                const BnTab tt = bn_table(e, e->sx_tab[b], e->max_streams, s0, Ct, P + T.tnorm[b].w, P + T.tnorm[b].b);
                 auto run = [&](auto tag) {
                     using Cfg = decltype(tag);
                     FwdConvP<Cfg, F_POOL> p{};
                     p.src = xs(b); p.lds_ = Ct; p.ps = pl; p.po = pn; p.K = Ct;
-                    p.ssum = xsum; p.ssq = xsq; p.sstride = Ct;
-                    p.gamma = P + T.tnorm[b].w; p.beta = P + T.tnorm[b].b; p.eps = kEps;
-                    p.w = e->packed + e->pk_t[b]; p.ldw = Ct / 2; p.N = Ct / 2;
+                    p.bt = tt; p.fresh0 = Ct - kGrowth; p.fsum = xsum; p.fsq = xsq; p.fstride = Ct; p.eps = kEps;     // the block's last layer
+                    p.tw_mean = const_cast<float*>(tt.mean); p.tw_invstd = const_cast<float*>(tt.invstd);
+                    p.wp = e->packed_u + e->pk_t[b]; p.K8tot = Ct / 8; p.N = Ct / 2;
                     p.dst = xs(b + 1); p.ldd = Cn; p.dcoff = 0;
                     p.dsum = st_off(fsum(e, e->st_X[b + 1]), Cn); p.dsq = st_off(fsq(e, e->st_X[b + 1]), Cn); p.dstride = Cn;
+                    BY(e, 4.0 * ns * ((double)pl.HW * Ct + (double)pn.HW * (Ct / 2)));
                     launch_gemm(e, cs, p, dim3(ns * pn.HWp / Cfg::BM, (Ct / 2) / Cfg::BN), K_TRANS, 2.0 * ns * pn.HW * Ct * (Ct / 2));
                 };
                 if (pn.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
@@ -646,15 +732,18 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
         hipLaunchKernelGGL(feat_kernel, dim3(2, NP, (p4.HW + 63) / 64), dim3(256), 0, st, a);
     }
     {   // head norm0 + relu + conv0 (1x1, 2048 -> 64)
+        const BnTab th = bn_table(e, e->sf_tab, e->max_pairs, 0, 2 * kFeat, P + Hd.n0.w, P + Hd.n0.b);
+        bn_stat(st, th, NP, fsum(e, e->st_F), fsq(e, e->st_F), 2 * kFeat, 0, 2 * kFeat, p4.HW);
         auto run = [&](auto tag) {
                 using Cfg = decltype(tag);
                 FwdConvP<Cfg, F_ONE> p{};
         p.src = e->F; p.lds_ = 2 * kFeat; p.ps = p4; p.po = p4; p.K = 2 * kFeat;
-        p.ssum = fsum(e, e->st_F); p.ssq = fsq(e, e->st_F); p.sstride = 2 * kFeat;
-        p.gamma = P + Hd.n0.w; p.beta = P + Hd.n0.b; p.eps = kEps;
-        p.w = e->packed + e->pk_head0; p.ldw = kHeadMid; p.N = kHeadMid;
+        p.bt = th; p.fresh0 = 2 * kFeat; p.fsum = fsum(e, e->st_F); p.fsq = fsq(e, e->st_F); p.fstride = 2 * kFeat; p.eps = kEps;
+        p.tw_mean = const_cast<float*>(th.mean); p.tw_invstd = const_cast<float*>(th.invstd);
+        p.wp = e->packed_u + e->pk_head0; p.K8tot = 2 * kFeat / 8; p.N = kHeadMid;
         p.dst = e->H1; p.ldd = kHeadMid; p.dcoff = 0;
         p.dsum = fsum(e, e->st_H1); p.dsq = fsq(e, e->st_H1); p.dstride = kHeadMid;
+        BY(e, 4.0 * NP * p4.HW * (2 * kFeat + kHeadMid));
         launch_gemm(e, st, p, dim3(NP * p4.HWp / Cfg::BM, 1), K_HEAD0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid);
             };
             if (p4.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
@@ -663,7 +752,7 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
         ValueArgs a;
         a.h1 = e->H1; a.p4 = p4; a.hsum = fsum(e, e->st_H1); a.hsq = fsq(e, e->st_H1);
         a.gamma = P + Hd.n1.w; a.beta = P + Hd.n1.b; a.eps = kEps;
-        a.w2p = e->packed + e->pk_head1; a.q = q_out; a.out_ch = e->head_out; a.OH = e->OH; a.OW = e->OW;
+        a.w2p = e->packed_f + e->pk_head1; a.q = q_out; a.out_ch = e->head_out; a.OH = e->OH; a.OW = e->OW;
         ProfScope ps(e, st, K_OTHER, 0);
         hipLaunchKernelGGL(value_conv_kernel, dim3(NP * e->head_out * e->OH * e->OW), dim3(256), 0, st, a);
     }
@@ -717,7 +806,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
     {   // value conv backward + relu1 + norm1 sums
         ValueBwdArgs a;
         a.h1 = e->H1; a.p4 = p4; a.hsum = fsum(e, e->st_H1); a.hsq = fsq(e, e->st_H1);
-        a.gamma = P + Hd.n1.w; a.beta = P + Hd.n1.b; a.eps = kEps; a.w2p = e->packed + e->pk_head1;
+        a.gamma = P + Hd.n1.w; a.beta = P + Hd.n1.b; a.eps = kEps; a.w2p = e->packed_f + e->pk_head1;
         a.dq = dq; a.out_ch = e->head_out; a.OH = e->OH; a.OW = e->OW; a.dh1 = e->DH1;
         a.o1 = b1(e, e->bs_H1); a.o2 = b2(e, e->bs_H1); a.dbeta = Gr + Hd.n1.b; a.dgamma = Gr + Hd.n1.w; a.dw2 = Gr + Hd.c1.w;
         ProfScope ps(e, st, K_OTHER, 0);
@@ -735,6 +824,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
         p.eps = kEps; p.chunk = chunk4; p.chunks_per_stream = cps4; p.n_chunks = NP * cps4;
         p.dw = Gr + Hd.c0.w; p.ldw_out = 2 * kFeat;
         if (fork(e->ev_misc)) return -5;
+        BY(e, 4.0 * NP * p4.HW * (2 * kHeadMid + 2 * kFeat));
         launch_wgrad(e, s2, p, dim3(1, 2 * kFeat / 64, NP * cps4), K_HW0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid, 1, C_IDENT);
     }
     {   // head conv0 data gradient + relu0 + norm0 sums
@@ -744,12 +834,13 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
         p.gbuf = e->DH1; p.ldg = kHeadMid; p.gcoff = 0; p.xbuf = e->H1; p.ldx = kHeadMid; p.xcoff = 0; p.pa = p4; p.KA = kHeadMid;
         p.xsum = fsum(e, e->st_H1); p.xsq = fsq(e, e->st_H1); p.xstride = kHeadMid;
         p.s1 = b1(e, e->bs_H1); p.s2 = b2(e, e->bs_H1); p.sstride = kHeadMid; p.scoff = 0; p.agamma = P + Hd.n1.w;
-        p.w = P + Hd.c0.w; p.ldw = 2 * kFeat; p.N = 2 * kFeat;
+        p.wp = e->packed_u + e->pk_hd0; p.K8tot = kHeadMid / 8; p.ldn = 2 * kFeat; p.wcol0 = 0; p.N = 2 * kFeat;
         p.mbuf = e->F; p.ldm = 2 * kFeat; p.mcoff = 0; p.pm = p4;
         p.msum = fsum(e, e->st_F); p.msq = fsq(e, e->st_F); p.mstride = 2 * kFeat; p.egamma = P + Hd.n0.w; p.ebeta = P + Hd.n0.b;
         p.dst = e->DF; p.ldd = 2 * kFeat; p.dcoff = 0;
         p.o1 = b1(e, e->bs_F); p.o2 = b2(e, e->bs_F); p.ostride = 2 * kFeat; p.ocoff = 0;
         p.dbeta = Gr + Hd.n0.b; p.dgamma = Gr + Hd.n0.w; p.eps = kEps;
+        BY(e, 4.0 * NP * p4.HW * (2 * kHeadMid + 2 * 2 * kFeat));
         launch_gemm(e, st, p, dim3(NP * p4.HWp / Cfg::BM, 2 * kFeat / Cfg::BN), K_HD0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid);
             };
             if (p4.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
@@ -793,6 +884,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 a.xsum = fsum(e, e->st_X[b]); a.xsq = fsq(e, e->st_X[b]); a.xstride = Ct;
                 a.s1 = b1(e, e->bs_X[b]); a.s2 = b2(e, e->bs_X[b]); a.sstride = Ct; a.scoff = d.cin; a.gamma = nullptr; a.eps = kEps;
                 a.out = GSb; a.ldo = kGrowth;
+                BY(e, 4.0 * NS * pl.HW * 3 * kGrowth);
                 ProfScope ps(e, st, K_OTHER, 0);
                 hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(pl.HWp / 64, NS), dim3(256), 0, st, a);
                 if (gs_mat) { gsrc = GradSrc{}; gsrc.g = GSb; gsrc.ldg = kGrowth; }
@@ -801,32 +893,34 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
             if (!e->generic3x3) {
                 // conv2 (3x3) data gradient with the gradient halo resident in LDS (halo.cuh)
                 Halo3x3DgradArgs a;
-                a.g = gsrc; a.pl = pl; a.w = e->packed + e->pk_c2d[b][i]; a.C = kBottleneck;
-                a.mbuf = bt; a.msum = fsum(e, e->st_Bt[b][i]); a.msq = fsq(e, e->st_Bt[b][i]); a.mstride = kBottleneck;
-                a.gamma = P + d.n2.w; a.beta = P + d.n2.b; a.eps = kEps;
+                a.g = gsrc; a.pl = pl; a.C = kBottleneck;
+                a.mbuf = bt;
                 a.dst = D2b; a.o1 = b1(e, e->bs_Bt[b][i]); a.o2 = b2(e, e->bs_Bt[b][i]); a.ostride = kBottleneck;
+                a.wu = e->packed_u + e->pk_hd[b][i]; a.bt = bn_table(e, e->sb_tab[b][i], e->max_streams, 0, kBottleneck, P + d.n2.w, P + d.n2.b);
+                BY(e, 4.0 * NS * pl.HW * (kGrowth + 2 * kBottleneck));      // gradient in, mask source in, dy out
                 ProfScope ps(e, st, K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
                 if (halo_tile(pl, NS) == 16) {
                     a.tiles_x = pl.W / 16; a.cg_per_wg = kBottleneck / 32;
                     hipLaunchKernelGGL(conv3x3_halo_dgrad_kernel<16>, dim3((pl.H / 16) * a.tiles_x, NS), dim3(256),
-                                       HaloDgradGeo<16>::smem_floats(kBottleneck) * sizeof(float), st, a);
+                                       HaloDgradSGeo<16>::smem_bytes(kBottleneck), st, a);
                 } else {
                     a.tiles_x = (pl.W + 7) / 8; a.cg_per_wg = 1;      // small planes: one 64-channel group per workgroup
                     hipLaunchKernelGGL(conv3x3_halo_dgrad_kernel<8>, dim3(((pl.H + 7) / 8) * a.tiles_x, NS, kBottleneck / 64), dim3(256),
-                                       HaloDgradGeo<8>::smem_floats(kBottleneck) * sizeof(float), st, a);
+                                       HaloDgradSGeo<8>::smem_bytes(kBottleneck), st, a);
                 }
             } else {   // conv2 (3x3) data gradient -> dy of relu2/norm2 (D2) + norm2 sums (generic implicit GEMM)
                 auto run = [&](auto tag) {
                     using Cfg = decltype(tag);
                     BwdDataP<Cfg, true, E_STORE> p{};
                     p.gbuf = GSb; p.ldg = kGrowth; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kGrowth;
-                    p.w = e->packed + e->pk_c2d[b][i]; p.ldw = kBottleneck; p.N = kBottleneck;
+                    p.wp = e->packed_u + e->pk_g3d[b][i]; p.K8tot = 9 * kGrowth / 8; p.ldn = kBottleneck; p.wcol0 = 0; p.N = kBottleneck;
                     p.mbuf = bt; p.ldm = kBottleneck; p.mcoff = 0; p.pm = pl;
                     p.msum = fsum(e, e->st_Bt[b][i]); p.msq = fsq(e, e->st_Bt[b][i]); p.mstride = kBottleneck;
                     p.egamma = P + d.n2.w; p.ebeta = P + d.n2.b;
                     p.dst = D2b; p.ldd = kBottleneck; p.dcoff = 0;
                     p.o1 = b1(e, e->bs_Bt[b][i]); p.o2 = b2(e, e->bs_Bt[b][i]); p.ostride = kBottleneck; p.ocoff = 0;
                     p.dbeta = Gr + d.n2.b; p.dgamma = Gr + d.n2.w; p.eps = kEps;
+                    BY(e, 4.0 * NS * pl.HW * (kGrowth + 2 * kBottleneck));
                     launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, kBottleneck / Cfg::BN), K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
                 };
                 if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
@@ -836,20 +930,21 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 const int ts = halo_tile(pl, NS);
                 Halo3x3WgradArgs a;
                 a.g = gsrc; a.pl = pl; a.src = bt; a.C = kBottleneck;
-                a.ssum = fsum(e, e->st_Bt[b][i]); a.ssq = fsq(e, e->st_Bt[b][i]); a.sstride = kBottleneck;
-                a.gamma = P + d.n2.w; a.beta = P + d.n2.b; a.eps = kEps;
-                a.part = e->part; a.tiles_x = (pl.W + ts - 1) / ts; a.n_tiles = ((pl.H + ts - 1) / ts) * a.tiles_x;
-                a.tiles_per_wg = w3_tiles_per_wg(a.n_tiles, ts, NS, e->part_floats);
+                const int th = 8;                              // tiles are ts x 8 pixels
+                a.bt = bn_table(e, e->sb_tab[b][i], e->max_streams, 0, kBottleneck, P + d.n2.w, P + d.n2.b);
+                a.part = e->part; a.tiles_x = (pl.W + ts - 1) / ts; a.n_tiles = ((pl.H + th - 1) / th) * a.tiles_x;
+                a.tiles_per_wg = w3_tiles_per_wg(a.n_tiles, ts, NS, e->part_floats, (double)ts / th);
                 const int groups = (a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
                 if ((int64_t)groups * NS * 9 * 32 * kBottleneck > e->part_floats) return fail(-12, "partial-gradient workspace too small");
                 {
+                    BY(e, 4.0 * NS * pl.HW * (kGrowth + kBottleneck));
                     ProfScope ps(e, s2, K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
                     if (ts == 16)
                         hipLaunchKernelGGL(conv3x3_halo_wgrad_kernel<16>, dim3(groups, kBottleneck / 32, NS), dim3(256),
-                                           HaloWgradGeo<16>::smem_floats() * sizeof(float), s2, a);
+                                           HaloWgradSGeo<16>::smem_bytes(), s2, a);
                     else
                         hipLaunchKernelGGL(conv3x3_halo_wgrad_kernel<8>, dim3(groups, kBottleneck / 32, NS), dim3(256),
-                                           HaloWgradGeo<8>::smem_floats() * sizeof(float), s2, a);
+                                           HaloWgradSGeo<8>::smem_bytes(), s2, a);
                 }
                 ReduceArgs r;
                 r.part = e->part; r.Z = groups * NS; r.taps = 9; r.rows = kGrowth; r.cols = kBottleneck; r.ldp = kBottleneck;
@@ -866,6 +961,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 p.bgamma = P + d.n2.w; p.bbeta = P + d.n2.b; p.eps = kEps;
                 p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
                 p.dw = Gr + d.c2.w; p.ldw_out = kBottleneck * 9;
+                BY(e, 4.0 * NS * pl.HW * (kGrowth + kBottleneck));
                 launch_wgrad(e, s2, p, dim3(1, 1, 9 * NS * cps), K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth, 9, C_3x3);
             }
             {   // norm2 backward applied once, in place: D2 <- gamma2*invstd*(dy - s1/n - xhat*s2/n)
@@ -875,6 +971,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 a.s1 = b1(e, e->bs_Bt[b][i]); a.s2 = b2(e, e->bs_Bt[b][i]); a.sstride = kBottleneck; a.scoff = 0;
                 a.gamma = P + d.n2.w; a.eps = kEps; a.out = D2b; a.ldo = kBottleneck;
                 if (!e->generic3x3) { a.dbeta = Gr + d.n2.b; a.dgamma = Gr + d.n2.w; }   // the halo dgrad leaves these to us
+                BY(e, 4.0 * NS * pl.HW * 3 * kBottleneck);
                 ProfScope ps(e, st, K_OTHER, 0);
                 hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(pl.HWp / 64, NS), dim3(256), 0, st, a);
             }
@@ -892,13 +989,14 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                     using Cfg = decltype(tag);
                     BwdDataP<Cfg, false, E_ACCUM> p{};
                     p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kBottleneck;
-                    p.w = P + d.c1.w + cs; p.ldw = d.cin; p.N = d.cin - cs;
+                    p.wp = e->packed_u + e->pk_d1[b][i]; p.K8tot = kBottleneck / 8; p.ldn = d.cin; p.wcol0 = cs; p.N = d.cin - cs;
                     p.mbuf = e->X[b]; p.ldm = Ct; p.mcoff = cs; p.pm = pl;
                     p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct;
                     p.egamma = P + d.n1.w + cs; p.ebeta = P + d.n1.b + cs;
                     p.dst = e->G[b]; p.ldd = Ct; p.dcoff = cs;
                     p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.ocoff = cs;
                     p.dbeta = Gr + d.n1.b + cs; p.dgamma = Gr + d.n1.w + cs; p.eps = kEps;
+                    BY(e, 4.0 * NS * pl.HW * (kBottleneck + 3.0 * p.N));          // dy in; x in, G' read + written
                     launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, (p.N + Cfg::BN - 1) / Cfg::BN), K_D1, 2.0 * NS * pl.HW * p.N * kBottleneck);
                 };
                 if (pl.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
@@ -912,7 +1010,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                     for (int k = 0; k < p.nseg; ++k) {                  // layer g_lo + k ran (k layers) before this one
                         const DenseLayerRef& dk = T.layers[b][g_lo + k];
                         const int slot = (layer_no - 1 - k + kRing * 4) % kRing;
-                        p.seg[k].g = e->D2[slot]; p.seg[k].w = P + dk.c1.w; p.seg[k].ldw = dk.cin;
+                        p.seg[k].g = e->D2[slot]; p.seg[k].wp = e->packed_u + e->pk_d1[b][g_lo + k]; p.seg[k].ldn = dk.cin;
                         p.seg[k].gamma = P + dk.n1.w; p.seg[k].beta = P + dk.n1.b;
                         p.seg[k].dbeta = Gr + dk.n1.b; p.seg[k].dgamma = Gr + dk.n1.w;
                     }
@@ -921,6 +1019,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                     p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct;
                     p.dst = e->G[b]; p.ldd = Ct;
                     p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.eps = kEps;
+                    BY(e, 4.0 * NS * pl.HW * ((double)p.nseg * kBottleneck + 3.0 * cs));
                     launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, (cs + Cfg::BN - 1) / Cfg::BN), K_D1, 2.0 * NS * pl.HW * cs * kBottleneck * p.nseg);
                 };
                 if (pl.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
@@ -938,6 +1037,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 p.bgamma = P + d.n1.w; p.bbeta = P + d.n1.b; p.eps = kEps;
                 p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
                 p.dw = Gr + d.c1.w; p.ldw_out = d.cin;
+                BY(e, 4.0 * NS * pl.HW * (kBottleneck + d.cin));
                 launch_wgrad(e, s2, p, dim3(1, nt, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck, 1, C_IDENT, false);
                 HIP_OK(hipEventRecord(e->ev_side[db], s2));
             }
@@ -958,6 +1058,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
                 p.dw = Gr + T.tconv[b - 1].w; p.ldw_out = Cp;
                 if (fork(e->ev_misc)) return -5;
+                BY(e, 4.0 * NS * (2.0 * pl.HW * C0 + (double)pp.HW * Cp));
                 launch_wgrad(e, s2, p, dim3(C0 / 128, Cp / 128, NS * cps), K_TW, 2.0 * NS * pl.HW * Cp * C0, 1, C_IDENT);
             }
             if (pp.H != 2 * pl.H || pp.W != 2 * pl.W) {
@@ -971,13 +1072,14 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 p.gbuf = e->G[b]; p.ldg = Ct; p.gcoff = 0; p.xbuf = e->X[b]; p.ldx = Ct; p.xcoff = 0; p.pa = pl; p.KA = C0;
                 p.xsum = fsum(e, e->st_X[b]); p.xsq = fsq(e, e->st_X[b]); p.xstride = Ct;
                 p.s1 = b1(e, e->bs_X[b]); p.s2 = b2(e, e->bs_X[b]); p.sstride = Ct; p.scoff = 0; p.agamma = nullptr;
-                p.w = P + T.tconv[b - 1].w; p.ldw = Cp; p.N = Cp;
+                p.wp = e->packed_u + e->pk_td[b - 1]; p.K8tot = C0 / 8; p.ldn = Cp; p.wcol0 = 0; p.N = Cp;
                 p.mbuf = e->X[b - 1]; p.ldm = Cp; p.mcoff = 0; p.pm = pp;
                 p.msum = fsum(e, e->st_X[b - 1]); p.msq = fsq(e, e->st_X[b - 1]); p.mstride = Cp;
                 p.egamma = P + T.tnorm[b - 1].w; p.ebeta = P + T.tnorm[b - 1].b;
                 p.dst = e->G[b - 1]; p.ldd = Cp; p.dcoff = 0;
                 p.o1 = b1(e, e->bs_X[b - 1]); p.o2 = b2(e, e->bs_X[b - 1]); p.ostride = Cp; p.ocoff = 0;
                 p.dbeta = Gr + T.tnorm[b - 1].b; p.dgamma = Gr + T.tnorm[b - 1].w; p.eps = kEps;
+                BY(e, 4.0 * NS * (2.0 * pl.HW * C0 + 2.0 * pp.HW * Cp));
                 launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, Cp / Cfg::BN), K_TD, 2.0 * NS * pl.HW * Cp * C0);
             };
             run(CfgP64x128{});   // the 128-row variant of the unpool epilogue spills registers
@@ -1013,6 +1115,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
         p.eps = kEps; p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
         p.dw = Gr + T.conv0.w; p.ldw_out = 147;
         if (fork(e->ev_misc)) return -5;
+        BY(e, 4.0 * NS * (2.0 * ps_.HW * 64 + (double)e->p_img.HW * 4));
         launch_wgrad(e, s2, p, dim3(1, 1, NS * cps), K_SW, 2.0 * NS * ps_.HW * 64 * 147, 1, C_STEM);
     }
     HIP_OK(hipEventRecord(e->ev_end, s2));          // join: everything after the backward sees every gradient
@@ -1081,7 +1184,7 @@ void smg_engine_destroy(smg_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     void* ptrs[] = {e->img4, e->stem, e->DY0, e->argmax, e->X[0], e->X[1], e->X[2], e->X[3], e->G[0], e->G[1], e->G[2], e->G[3],
-                    e->Bt, e->part, e->F, e->DF, e->H1, e->DH1, e->fstat, e->bstat, e->packed, e->d_pack, e->d_bnupd,
+                    e->Bt, e->part, e->F, e->DF, e->H1, e->DH1, e->fstat, e->bstat, e->packed_u, e->packed_f, e->stab, e->d_pack, e->d_bnupd,
                     e->d_stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) { if (e->h_stage[k]) (void)hipHostFree(e->h_stage[k]); if (e->ev_stage[k]) (void)hipEventDestroy(e->ev_stage[k]); }
@@ -1131,6 +1234,16 @@ int smg_backward(smg_engine* e, const smg_net* net, const float* dq_dev, void* s
     if (!e || !net || !dq_dev) return fail(-22, "NULL argument");
     HIP_OK(hipSetDevice(e->device));
     return do_backward(e, net, dq_dev, (hipStream_t)stream);
+}
+
+int smg_argmax(const float* values_dev, int n, int* idx_out_dev, float* val_out_dev, void* stream) {
+    if (!values_dev || !idx_out_dev || !val_out_dev || n < 1) return fail(-22, "bad argmax arguments");
+    hipPointerAttribute_t attr;
+    HIP_OK(hipPointerGetAttributes(&attr, values_dev));
+    HIP_OK(hipSetDevice(attr.device));
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, values_dev, n, idx_out_dev, val_out_dev);
+    HIP_OK(hipGetLastError());
+    return 0;
 }
 
 int smg_adam_step(float* params, const float* grads, float* m, float* v, int64_t offset, int64_t count, int step, float lr,
@@ -1187,7 +1300,7 @@ int smg_profile_enable(smg_engine* e, int on) {
     for (auto& r : e->recs) { e->ev_pool.push_back(r.a); e->ev_pool.push_back(r.b); }
     e->recs.clear();
     for (int s = 0; s < 5; ++s)
-        for (int k = 0; k < K_COUNT; ++k) { e->prof_ms[s][k] = 0; e->prof_n[s][k] = 0; e->prof_flops[s][k] = 0; }
+        for (int k = 0; k < K_COUNT; ++k) { e->prof_ms[s][k] = 0; e->prof_n[s][k] = 0; e->prof_flops[s][k] = 0; e->prof_bytes[s][k] = 0; }
     return 0;
 }
 
@@ -1204,7 +1317,7 @@ int smg_profile_read(smg_engine* e, int kind, double* ms, int64_t* launches, dou
             const int slots[2] = {0, r.stage + 1};
             for (int q = 0; q < (r.stage >= 0 ? 2 : 1); ++q) {
                 const int s = slots[q];
-                e->prof_ms[s][r.kind] += t; e->prof_n[s][r.kind] += 1; e->prof_flops[s][r.kind] += r.flops;
+                e->prof_ms[s][r.kind] += t; e->prof_n[s][r.kind] += 1; e->prof_flops[s][r.kind] += r.flops; e->prof_bytes[s][r.kind] += r.bytes;
             }
         }
         e->ev_pool.push_back(r.a); e->ev_pool.push_back(r.b);
@@ -1214,6 +1327,13 @@ int smg_profile_read(smg_engine* e, int kind, double* ms, int64_t* launches, dou
     if (ms) *ms = e->prof_ms[slot][kind];
     if (launches) *launches = e->prof_n[slot][kind];
     if (flops) *flops = e->prof_flops[slot][kind];
+    return 0;
+}
+
+// Algorithmic HBM bytes (see BY()) accumulated for one class since smg_profile_enable; call after smg_profile_read.
+int smg_profile_read_bytes(smg_engine* e, int kind, double* bytes) {
+    if (!e || kind < 0 || kind >= 5 * K_COUNT || !bytes) return fail(-22, "bad profile query");
+    *bytes = e->prof_bytes[kind / K_COUNT][kind % K_COUNT];
     return 0;
 }
 

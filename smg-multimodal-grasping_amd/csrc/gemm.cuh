@@ -5,10 +5,11 @@
 //   D[i][j] = sum_r A(i, r) * B(r, j)
 //
 // Arithmetic: fp32 in, fp32 out, on the bf16 matrix cores.  Every fp32 operand is split into
-// three bf16 pieces  x = hi + mid + lo  (truncating split: 24 significand bits = 3 x 8, so the
-// split is EXACT), and a product is accumulated from six v_mfma_f32_32x32x16_bf16 terms
+// three bf16 pieces  x = hi + mid + lo  (round-to-nearest pieces, v_cvt_pk_bf16_f32; the residuals
+// are exact, 3 x 8 significand bits cover the 24 of an fp32), and a product is accumulated from six
+// v_mfma_f32_32x32x16_bf16 terms
 //   hi*lo + lo*hi + mid*mid + hi*mid + mid*hi + hi*hi            (fp32 accumulate)
-// - the three dropped terms are <= 2^-22 of the product.  Measured on the MI355X against fp64
+// - the three dropped terms are <= 2^-24 of the product.  Measured on the MI355X against fp64
 // (tools/split_probe.hip): error / sum|a*b| = 2.9e-8 rms at K = 1024, the same as the exact
 // fp32 FMA chain of v_mfma_f32_32x32x2_f32 (2.7e-8) - at 16/6 = 2.7x its issue rate.
 //
@@ -37,19 +38,24 @@
 //
 // BatchNorm (training mode, per stream - SURVEY.md section 7) is never a kernel of
 // its own: the producer's epilogue accumulates per-(stream, channel) sum / sum of
-// squares in fp64 (in-lane, then fp64 atomics); bn_prep_kernel (elem.cuh) turns them ONCE per
-// consumer layer into an fp32 table (mean, gamma*invstd, beta, invstd) that the consumer's
-// staging threads read per k-tile (forward: no per-workgroup parameter prologue at all) and
-// applies BN + ReLU in the centered form (x - mean)*scale + beta while staging the operand.
+// squares in fp64 (in-lane, then fp64 atomics); the first consumer of a channel turns them into
+// fp32 (mean, invstd) table entries - every workgroup for itself, one per stream for the table
+// (BnTab) - and every later consumer's staging threads read the table per k-tile and apply
+// BN + ReLU in the centered form (x - mean)*(gamma*invstd) + beta while staging the operand:
+// a forward workgroup's parameter prologue is 32 channels, whatever K is.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 namespace smg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // one 16-byte unit (HIP's uint4 struct keeps register arrays in scratch)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 struct Plane { int H, W, HW, HWp; };
 
@@ -59,22 +65,35 @@ struct Plane { int H, W, HW, HWp; };
 constexpr int NPIECE = 3;
 // bf16 pieces of 4 floats (element 0 in the low half of .x): 8 bytes per piece
 struct Split4 { uint2 p[NPIECE]; };
-__device__ __forceinline__ unsigned pack_hi16(float lo_elem, float hi_elem) {      // {bf16(lo_elem), bf16(hi_elem)} truncated
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#ifdef SMG_SPLIT_TRUNC      // dev A/B: truncating split (exact, but every residual has the sign of x: biased dropped terms)
+__device__ __forceinline__ unsigned pack_bf16(float lo_elem, float hi_elem) {
     return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
 }
-__device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
+#else                       // round-to-nearest-even pieces: one v_cvt_pk_bf16_f32 per pair
+__device__ __forceinline__ unsigned pack_bf16(float lo_elem, float hi_elem) {
+    const f32x2 v = {lo_elem, hi_elem};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+#endif
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+// x = hi + mid + lo: the residuals x - hi and (x - hi) - mid are exact in fp32, the last one has <= 9 significant bits
 __device__ __forceinline__ Split4 split4(float4 v) {
     Split4 o;
-    o.p[0] = make_uint2(pack_hi16(v.x, v.y), pack_hi16(v.z, v.w));
-    const float r0 = v.x - trunc_bf16(v.x), r1 = v.y - trunc_bf16(v.y), r2 = v.z - trunc_bf16(v.z), r3 = v.w - trunc_bf16(v.w);   // exact
-    o.p[1] = make_uint2(pack_hi16(r0, r1), pack_hi16(r2, r3));
-    const float s0 = r0 - trunc_bf16(r0), s1 = r1 - trunc_bf16(r1), s2 = r2 - trunc_bf16(r2), s3 = r3 - trunc_bf16(r3);           // exact, <= 8 bits left
-    o.p[2] = make_uint2(pack_hi16(s0, s1), pack_hi16(s2, s3));
+    const unsigned h01 = pack_bf16(v.x, v.y), h23 = pack_bf16(v.z, v.w);
+    const float r0 = v.x - bf16_lo(h01), r1 = v.y - bf16_hi(h01), r2 = v.z - bf16_lo(h23), r3 = v.w - bf16_hi(h23);
+    const unsigned m01 = pack_bf16(r0, r1), m23 = pack_bf16(r2, r3);
+    const float s0 = r0 - bf16_lo(m01), s1 = r1 - bf16_hi(m01), s2 = r2 - bf16_lo(m23), s3 = r3 - bf16_hi(m23);
+    o.p[0] = make_uint2(h01, h23);
+    o.p[1] = make_uint2(m01, m23);
+    o.p[2] = make_uint2(pack_bf16(s0, s1), pack_bf16(s2, s3));
     return o;
 }
 // One operand fragment of a 32-row tile for one k16-step: 8 consecutive k per lane, three pieces.
-struct Frag { uint4 p[NPIECE]; };
-__device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, f32x16 c) {
+struct Frag { u32x4 p[NPIECE]; };
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 // acc[i][j] += A_i * B_j for a TM x TN grid of tiles: six piece products, small terms first, tiles innermost so that
@@ -132,12 +151,17 @@ struct GemmCfg {
 // element exists at all (conv zero padding / padded pixel rows).  The BN transform is applied later,
 // when the tile is written to LDS, so the loads stay in flight across the MFMA block.
 template <int NV> struct RawT { float4 v[NV]; bool ok; };
-// Per-k-tile BN parameters of a thread's channel quad (forward policies): (mean, scale, beta) x 4 channels
-struct KPrm3 { float4 mean, scale, beta; };
-struct KPrm0 {};
-
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// Per-k-tile BN parameters of a thread's channel quad (forward policies): as fetched (mean, invstd, gamma, beta) and as
+// applied (mean, gamma*invstd, beta), 4 channels each
+// (native vector types: arrays / structs of HIP's float4 class that cross a branch end up in scratch)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct KPrm4 { f32x4 mean, invstd, gamma, beta; };
+struct KPrm3 { f32x4 mean, scale, beta; };
+struct KPrm0 {};
+__device__ __forceinline__ f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
 
 __device__ __forceinline__ void bn_moments(const double* sum, const double* sq, int64_t idx, double inv_cnt, float eps,
                                            float& mean, float& invstd) {
@@ -148,13 +172,13 @@ __device__ __forceinline__ void bn_moments(const double* sum, const double* sq, 
     invstd = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-// The per-layer BN table bn_prep_kernel writes: four fp32 arrays of [rows][C] (rows = streams or pairs), `span` floats apart:
-//   mean | gamma*invstd | beta | invstd
-struct BnTab { const float* base; int64_t span; int C; };
-__device__ __forceinline__ const float* tab_mean(const BnTab& t, int n) { return t.base + (int64_t)n * t.C; }
-__device__ __forceinline__ const float* tab_scale(const BnTab& t, int n) { return t.base + t.span + (int64_t)n * t.C; }
-__device__ __forceinline__ const float* tab_beta(const BnTab& t, int n) { return t.base + 2 * t.span + (int64_t)n * t.C; }
-__device__ __forceinline__ const float* tab_invstd(const BnTab& t, int n) { return t.base + 3 * t.span + (int64_t)n * t.C; }
+// BatchNorm statistics of one activation buffer as fp32, finished ONCE per (stream, channel): mean | invstd tables of
+// [rows][ld] (rows = streams or pairs), plus the affine parameters of the consuming BN layer.  Who writes them: the first
+// consumer of a channel - every workgroup of that launch derives the (few) channels nobody has finished yet from the
+// fp64 sums itself, and one designated workgroup per stream stores them for all later layers and for the backward.
+struct BnTab { const float* mean; const float* invstd; int ld; const float* gamma; const float* beta; };
+__device__ __forceinline__ const float* tab_mean(const BnTab& t, int n) { return t.mean + (int64_t)n * t.ld; }
+__device__ __forceinline__ const float* tab_invstd(const BnTab& t, int n) { return t.invstd + (int64_t)n * t.ld; }
 
 // BN + ReLU in the centered form (x - mean) * (gamma * invstd) + beta: no cancellation
 // between x*scale and a pre-folded shift on near-constant channels.
@@ -332,11 +356,12 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
         char* A = As + buf * C::A_BYTES;
         char* B = Bs + buf * C::B_BYTES;
         if constexpr (C::AT) {
+            const typename P::KFin kf = p.k_finish(ctx, xk, kt, aq, sp);
 #pragma unroll
             for (int i = 0; i < C::A_N; ++i) {
                 const int row = al + i * C::A_STEP;
                 if (C::A_FULL || row < C::BM) {
-                    const Split4 s = split4(p.a_xform(ctx, xa[i], xk, kt, aq, sp));
+                    const Split4 s = split4(p.a_xform(ctx, xa[i], kf, kt, aq, sp));
 #pragma unroll
                     for (int pc = 0; pc < NPIECE; ++pc)
                         *reinterpret_cast<uint2*>(A + ((pc * C::K8 + (aq >> 1)) * C::LDUA + row) * 16 + (aq & 1) * 8) = s.p[pc];
@@ -345,14 +370,14 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
 #pragma unroll
             for (int i = 0; i < C::B_N; ++i) {
                 const int id = t + 256 * i;
-                if (C::B_FULL || id < NPIECE * C::K8 * C::BN) *reinterpret_cast<uint4*>(B + id * 16) = p.b_unit_xform(ctx, xb[i], id % C::BN);
+                if (C::B_FULL || id < NPIECE * C::K8 * C::BN) *reinterpret_cast<u32x4*>(B + id * 16) = p.b_unit_xform(ctx, xb[i], id % C::BN);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < C::A_N; ++i) {
                 const int kr = al + i * C::A_STEP;
                 if (C::A_FULL || kr < C::BK) {
-                    const Split4 s = split4(p.a_xform(ctx, xa[i], xk, kt, aq, sp));
+                    const Split4 s = split4(p.a_xform(ctx, xa[i], KPrm0{}, kt, aq, sp));
 #pragma unroll
                     for (int pc = 0; pc < NPIECE; ++pc)
                         *reinterpret_cast<uint2*>(A + ((pc * C::BK + kr) * C::LDTA + 4 * aq) * 2) = s.p[pc];
@@ -373,49 +398,59 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
     // transposing-read geometry of this lane (weight gradient): its 16-lane group gathers 4 k-rows x 16 channels; lane i of
     // the group fetches row i/4, channel quad i%4 and receives channel i of all four rows (ds_read_b64_tr_b16).
     const int tr_row = (lane & 15) >> 2, tr_col = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    // One operand fragment piece of a 32-row tile for this wave's k16-step s: ds_read_b128 of a unit (forward / data
+    // gradient) or two transposing reads (weight gradient).
+    auto frag = [&](const char* img, int ldu, int ldt, int r0, int s, int pc) -> u32x4 {
+        if constexpr (C::AT) {
+            const int k8 = (wk * C::KS + s) * 2 + half;
+            return *reinterpret_cast<const u32x4*>(img + ((pc * C::K8 + k8) * ldu + r0 + l31) * 16);
+        } else {
+            const int k0 = (wk * C::KS + s) * 16 + 8 * half + tr_row;
+            const char* a0 = img + ((pc * C::BK + k0) * ldt + r0 + tr_col) * 2;
+            const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0));
+            const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * ldt * 2)));
+            return u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+    };
     auto compute = [&](int buf) {
         const char* A = As + buf * C::A_BYTES;
         const char* B = Bs + buf * C::B_BYTES;
-        // All operand fragments of this wave's k-slice first (one LDS round trip per k16-step, not one per MFMA),
-        // then the MFMAs back to back.
+        // Per k16-step: the hi and lo pieces of every fragment first (one LDS round trip, not one per MFMA), the two
+        // hi x lo product groups, then the mid pieces - fetched under those MFMAs into the registers lo occupied - and the
+        // remaining four groups.  Within a group the tiles are innermost: consecutive MFMAs never share an accumulator.
 #pragma unroll
         for (int s = 0; s < C::KS; ++s) {
-            Frag af[C::TM], bf[C::TN];
-            if constexpr (C::AT) {
-                const int k8 = (wk * C::KS + s) * 2 + half;
+            u32x4 ah[C::TM], bh[C::TN];
+            {
+                u32x4 al_[C::TM], bl_[C::TN];
 #pragma unroll
-                for (int pc = 0; pc < NPIECE; ++pc) {
+                for (int i = 0; i < C::TM; ++i) { ah[i] = frag(A, C::LDUA, C::LDTA, wm0 + i * 32, s, 0); al_[i] = frag(A, C::LDUA, C::LDTA, wm0 + i * 32, s, 2); }
 #pragma unroll
-                    for (int i = 0; i < C::TM; ++i)
-                        af[i].p[pc] = *reinterpret_cast<const uint4*>(A + ((pc * C::K8 + k8) * C::LDUA + wm0 + i * 32 + l31) * 16);
+                for (int j = 0; j < C::TN; ++j) { bh[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 0); bl_[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 2); }
+                __builtin_amdgcn_sched_barrier(0);   // keep every ds_read ahead of the MFMA block (hipcc re-interleaves them otherwise)
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::TN; ++j) acc[i][j] = mfma_bf16(ah[i], bl_[j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::TN; ++j) acc[i][j] = mfma_bf16(al_[i], bh[j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            u32x4 am[C::TM], bm[C::TN];
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i) am[i] = frag(A, C::LDUA, C::LDTA, wm0 + i * 32, s, 1);
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j) bm[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i)
 #pragma unroll
                     for (int j = 0; j < C::TN; ++j)
-                        bf[j].p[pc] = *reinterpret_cast<const uint4*>(B + ((pc * C::K8 + k8) * C::LDUB + wn0 + j * 32 + l31) * 16);
-                }
-            } else {
-                const int k0 = (wk * C::KS + s) * 16 + 8 * half + tr_row;
-#pragma unroll
-                for (int pc = 0; pc < NPIECE; ++pc) {
-#pragma unroll
-                    for (int i = 0; i < C::TM; ++i) {
-                        const char* a0 = A + ((pc * C::BK + k0) * C::LDTA + wm0 + i * 32 + tr_col) * 2;
-                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
-                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * C::LDTA * 2));
-                        af[i].p[pc] = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y,
-                                                 __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
-                    }
-#pragma unroll
-                    for (int j = 0; j < C::TN; ++j) {
-                        const char* b0 = B + ((pc * C::BK + k0) * C::LDTB + wn0 + j * 32 + tr_col) * 2;
-                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)b0);
-                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(b0 + 4 * C::LDTB * 2));
-                        bf[j].p[pc] = make_uint4(__builtin_bit_cast(uint2, lo).x, __builtin_bit_cast(uint2, lo).y,
-                                                 __builtin_bit_cast(uint2, hi).x, __builtin_bit_cast(uint2, hi).y);
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);   // keep every ds_read ahead of the MFMA block (hipcc re-interleaves them otherwise)
-            mma_split<C::TM, C::TN>(acc, af, bf);
+                        acc[i][j] = mfma_bf16((g & 1) ? ah[i] : am[i], g < 2 ? bm[j] : bh[j], acc[i][j]);   // mid*mid, hi*mid, mid*hi, hi*hi
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -510,27 +545,39 @@ enum { F_ONE = 0, F_THREE = 1, F_POOL = 2, F_STEM = 3 };
 template <class Cfg_, int MODE>
 struct FwdConvP {
     using Cfg = Cfg_;
+    static_assert(Cfg::AT, "forward form");
     const float* src; int lds_;
     Plane ps, po;
     int K;
-    const double* ssum; const double* ssq; int sstride;
-    const float* gamma; const float* beta;
-    float eps;
-    const float* w; int ldw; int N;
+    BnTab bt;                       // statistics + affine parameters of the BN in front of this conv
+    // channels [fresh0, K) have no table entry yet (the 32 a dense layer appended last): derived here from the fp64 sums
+    int fresh0; const double* fsum; const double* fsq; int fstride; float eps;
+    float* tw_mean; float* tw_invstd;       // the table again, writable (designated workgroups store the fresh channels)
+    const u32x4* wp; int K8tot;     // packed weight units [piece][K8tot][N] (pack_weights_kernel)
+    int N;
     float* dst; int ldd; int dcoff;
     double* dsum; double* dsq; int dstride;
     TileMap tm;
     static constexpr int kSwizzle = 1;
-    static constexpr int kPrefetch = 1;
+#ifndef SMG_SMALL_PD
+#define SMG_SMALL_PD 1
+#endif
+    // k-tiles of global loads in flight: the one-MFMA-tile-per-wave configurations of the small planes do 0.1 us of MFMAs per
+    // k-tile against ~1 us of memory latency
+    static constexpr int kPrefetch = (Cfg::TM * Cfg::TN == 1) ? SMG_SMALL_PD : 1;
     static constexpr bool kSegmented = false;
+    static constexpr bool kHasPrologue = MODE != F_STEM;
+    static constexpr int kFresh = 32;       // growth rate: at most this many fresh channels
     // waves per SIMD the register allocator is held to: the 128x128 tile (64 accumulator registers) must stay at 3
-    static constexpr int kMinWaves = Cfg::TM * Cfg::TN == 4 ? 3 : 1;
+    static constexpr int kMinWaves = (Cfg::TM * Cfg::TN == 4 && MODE != F_POOL) ? 3 : 1;    // (the pooling fetch holds 4 float4 per row)
 
     struct Ctx { int n, m0, n0; };
     struct ARow { int y, x; bool valid; };
     struct DRow {};
+    using KPrm = typename std::conditional<MODE == F_STEM, KPrm0, KPrm4>::type;
+    using KFin = typename std::conditional<MODE == F_STEM, KPrm0, KPrm3>::type;
 
-    __host__ __device__ int param_floats() const { return MODE == F_STEM ? 0 : 3 * K; }
+    __host__ __device__ int param_floats() const { return MODE == F_STEM ? 0 : 2 * kFresh; }
 
     __device__ bool init_ctx(Ctx& c, const VBlock& vb) const {
         int mt = vb.x, nt = vb.y;
@@ -540,15 +587,19 @@ struct FwdConvP {
         c.n = c.m0 / po.HWp;
         return c.m0 - c.n * po.HWp < po.HW;
     }
+    // mean | invstd of the fresh channels -> LDS; the first tile of every stream also stores them in the table
     __device__ void init_params(const Ctx& c, float* sp) const {
         if constexpr (MODE != F_STEM) {
-            const double inv = 1.0 / (double)ps.HW;
-            for (int k = threadIdx.x; k < K; k += 256) {
+            const int t = threadIdx.x;
+            if (fresh0 < K && t < kFresh) {
                 float mean, invstd;
-                bn_moments(ssum, ssq, (int64_t)c.n * sstride + k, inv, eps, mean, invstd);
-                sp[k] = mean;
-                sp[K + k] = gamma[k] * invstd;
-                sp[2 * K + k] = beta[k];
+                bn_moments(fsum, fsq, (int64_t)c.n * fstride + fresh0 + t, 1.0 / (double)ps.HW, eps, mean, invstd);
+                sp[t] = mean;
+                sp[kFresh + t] = invstd;
+                if (c.n0 == 0 && c.m0 == c.n * po.HWp) {
+                    tw_mean[(int64_t)c.n * bt.ld + fresh0 + t] = mean;
+                    tw_invstd[(int64_t)c.n * bt.ld + fresh0 + t] = invstd;
+                }
             }
         }
     }
@@ -566,10 +617,35 @@ struct FwdConvP {
         r.x = p - r.y * po.W;
     }
     using ARaw = RawT<(MODE == F_POOL) ? 4 : 1>;
-    using BRaw = RawT<1>;
+    using BRaw = u32x4;
     __device__ int a_chan(int kt, int q) const {
         if constexpr (MODE == F_THREE) { const int kpt = K / Cfg::BK; return (kt % kpt) * Cfg::BK + 4 * q; }
         else return kt * Cfg::BK + 4 * q;
+    }
+    // BN parameters of this thread's channel quad for k-tile kt (L1 / L2 resident tables; fetched with the tile's loads)
+    __device__ KPrm k_fetch(const Ctx& c, int kt, int q) const {
+        KPrm k;
+        if constexpr (MODE != F_STEM) {
+            const int ch = a_chan(kt, q);
+            k.mean = ldv4(tab_mean(bt, c.n) + ch);          // (fresh channels: stale table values, replaced in k_finish)
+            k.invstd = ldv4(tab_invstd(bt, c.n) + ch);
+            k.gamma = ldv4(bt.gamma + ch);
+            k.beta = ldv4(bt.beta + ch);
+        }
+        return k;
+    }
+    __device__ KFin k_finish(const Ctx&, const KPrm& k, int kt, int q, const float* sp) const {
+        KFin f;
+        if constexpr (MODE != F_STEM) {
+            const int ch = a_chan(kt, q);
+            const bool fresh = ch >= fresh0;
+            const int fo = fresh ? ch - fresh0 : 0;                 // (LDS reads from a clamped offset: no branch)
+            const f32x4 fm = ldv4(sp + fo), fi = ldv4(sp + kFresh + fo);
+            f.mean = fresh ? fm : k.mean;
+            f.scale = k.gamma * (fresh ? fi : k.invstd);
+            f.beta = k.beta;
+        }
+        return f;
     }
     __device__ ARaw a_fetch(const Ctx& c, const ARow& r, int kt, int q) const {
         ARaw o;
@@ -596,32 +672,29 @@ struct FwdConvP {
         }
         return o;
     }
-    __device__ float4 a_xform(const Ctx&, const ARaw& o, int kt, int q, const float* sp) const {
+    __device__ float4 a_xform(const Ctx&, const ARaw& o, const KFin& k, int, int, const float*) const {
         if constexpr (MODE == F_STEM) {
             return o.v[0];
         } else {
             if (!o.ok) return zero4();                   // zero padding applies AFTER bn + relu
-            const float* pr = sp + a_chan(kt, q);
             if constexpr (MODE == F_POOL) {
-                float4 s = bnrelu4(o.v[0], pr, K);
-                s = add4(s, bnrelu4(o.v[1], pr, K));
-                s = add4(s, bnrelu4(o.v[2], pr, K));
-                s = add4(s, bnrelu4(o.v[3], pr, K));
+                float4 s = bnrelu4(o.v[0], k);
+                s = add4(s, bnrelu4(o.v[1], k));
+                s = add4(s, bnrelu4(o.v[2], k));
+                s = add4(s, bnrelu4(o.v[3], k));
                 return make_float4(s.x * 0.25f, s.y * 0.25f, s.z * 0.25f, s.w * 0.25f);
             } else {
-                return bnrelu4(o.v[0], pr, K);
+                return bnrelu4(o.v[0], k);
             }
         }
     }
     __device__ ARaw a_fetch_d(const Ctx&, const DRow&, int, int, int) const { return ARaw{}; }
-    __device__ BRaw b_fetch(const Ctx& c, const DRow&, int kt, int kr, int q) const {
-        BRaw o;
-        const int col = c.n0 + 4 * q;
-        o.ok = col < N;
-        o.v[0] = o.ok ? ld4(w + (int64_t)(kt * Cfg::BK + kr) * ldw + col) : zero4();
-        return o;
+    // weight unit (piece, k8 of this k-tile, tile row r): rows past N read a neighbouring unit (the packed array has
+    // slack behind it); the columns they feed are never stored
+    __device__ BRaw b_unit(const Ctx& c, int kt, int piece, int k8, int r) const {
+        return wp[((int64_t)piece * K8tot + kt * Cfg::K8 + k8) * N + c.n0 + r];
     }
-    __device__ float4 b_xform(const Ctx&, const BRaw& o, int, int, const float*) const { return o.v[0]; }
+    __device__ u32x4 b_unit_xform(const Ctx&, const BRaw& o, int) const { return o; }
     __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, float*, bool active) const {
         const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
         const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
@@ -710,6 +783,7 @@ enum { E_STORE = 0, E_ACCUM = 1, E_UNPOOL = 2 };
 template <class Cfg_, bool SHIFT3, int EMODE>
 struct BwdDataP {
     using Cfg = Cfg_;
+    static_assert(Cfg::AT, "data-gradient form");
     const float* gbuf; int ldg; int gcoff;
     const float* xbuf; int ldx; int xcoff;
     Plane pa;
@@ -717,7 +791,8 @@ struct BwdDataP {
     const double* xsum; const double* xsq; int xstride;
     const double* s1; const double* s2; int sstride; int scoff;
     const float* agamma;
-    const float* w; int ldw; int N;
+    const u32x4* wp; int K8tot; int ldn; int wcol0;    // packed weight units [piece][K8tot][ldn], first output column wcol0
+    int N;
     const float* mbuf; int ldm; int mcoff; Plane pm;
     const double* msum; const double* msq; int mstride;
     const float* egamma; const float* ebeta;
@@ -729,11 +804,16 @@ struct BwdDataP {
     static constexpr int kSwizzle = 1;
     static constexpr int kPrefetch = 1;
     static constexpr bool kSegmented = false;
+    static constexpr bool kHasPrologue = true;
     static constexpr int kMinWaves = 1;
 
     struct Ctx { int n, m0, n0; };
     struct ARow { int y, x; bool valid; };
     struct DRow {};
+    using KPrm = KPrm0;
+    using KFin = KPrm0;
+    __device__ KPrm k_fetch(const Ctx&, int, int) const { return KPrm{}; }
+    __device__ KFin k_finish(const Ctx&, const KPrm&, int, int, const float*) const { return KFin{}; }
 
     __host__ __device__ int param_floats() const { return 4 * KA + 5 * Cfg::BN; }
 
@@ -785,7 +865,7 @@ struct BwdDataP {
         r.x = p - r.y * pa.W;
     }
     using ARaw = RawT<2>;       // gradient + (when xbuf is set) the raw activation its BN normalised
-    using BRaw = RawT<1>;
+    using BRaw = u32x4;
     __device__ int a_chan(int kt, int q) const {
         if constexpr (SHIFT3) { const int kpt = KA / Cfg::BK; return (kt % kpt) * Cfg::BK + 4 * q; }
         else return kt * Cfg::BK + 4 * q;
@@ -806,20 +886,16 @@ struct BwdDataP {
         o.v[1] = (o.ok && xbuf) ? ld4(xbuf + pix * ldx + xcoff + ch) : zero4();
         return o;
     }
-    __device__ float4 a_xform(const Ctx&, const ARaw& o, int kt, int q, const float* sp) const {
+    __device__ float4 a_xform(const Ctx&, const ARaw& o, const KPrm&, int kt, int q, const float* sp) const {
         if (!xbuf) return o.v[0];                      // gradient already BN-corrected (bn_bwd_apply_kernel)
         if (!o.ok) return zero4();
         return affine2(o.v[0], o.v[1], sp + a_chan(kt, q), KA);
     }
     __device__ ARaw a_fetch_d(const Ctx&, const DRow&, int, int, int) const { return ARaw{}; }
-    __device__ BRaw b_fetch(const Ctx& c, const DRow&, int kt, int kr, int q) const {
-        BRaw o;
-        const int col = c.n0 + 4 * q;
-        o.ok = col < N;
-        o.v[0] = o.ok ? ld4(w + (int64_t)(kt * Cfg::BK + kr) * ldw + col) : zero4();
-        return o;
+    __device__ BRaw b_unit(const Ctx& c, int kt, int piece, int k8, int r) const {
+        return wp[((int64_t)piece * K8tot + kt * Cfg::K8 + k8) * ldn + wcol0 + c.n0 + r];
     }
-    __device__ float4 b_xform(const Ctx&, const BRaw& o, int, int, const float*) const { return o.v[0]; }
+    __device__ u32x4 b_unit_xform(const Ctx&, const BRaw& o, int) const { return o; }
     __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, float* sp, bool active) const {
         const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
         const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
@@ -954,7 +1030,7 @@ struct BwdDataP {
 constexpr int GROUP_MAX = 4;
 struct GroupSeg {
     const float* g;                 // finished bottleneck gradient D2_i [n][HWp][KA]
-    const float* w; int ldw;        // conv1 weight [KA][cin_i] (reference layout: K-major already)
+    const u32x4* wp; int ldn;       // conv1 weight, packed data-gradient units [piece][KA/8][cin_i]
     const float* gamma; const float* beta;
     float* dbeta; float* dgamma;
 };
@@ -975,6 +1051,7 @@ struct BwdDataGroupP {
     static constexpr int kSwizzle = 1;
     static constexpr int kPrefetch = 1;
     static constexpr bool kSegmented = true;
+    static constexpr bool kHasPrologue = true;
     static constexpr int kMinWaves = 3;       // 160 registers without spilling: 3 workgroups per CU instead of 2 (-0.4 ms per step)
 
     struct Ctx {
@@ -985,6 +1062,10 @@ struct BwdDataGroupP {
     };
     struct ARow { int p; bool valid; };
     struct DRow {};
+    using KPrm = KPrm0;
+    using KFin = KPrm0;
+    __device__ KPrm k_fetch(const Ctx&, int, int) const { return KPrm{}; }
+    __device__ KFin k_finish(const Ctx&, const KPrm&, int, int, const float*) const { return KFin{}; }
 
     // LDS parameters: mean | invstd | per segment: gamma*invstd | beta | gamma      (BN floats each)
     __host__ __device__ int param_floats() const { return (2 + 3 * GROUP_MAX) * Cfg::BN; }
@@ -1047,7 +1128,7 @@ struct BwdDataGroupP {
         r.valid = r.p - c.n * pa.HWp < pa.HW;
     }
     using ARaw = RawT<1>;
-    using BRaw = RawT<1>;
+    using BRaw = u32x4;
     __device__ ARaw a_fetch(const Ctx&, const ARow& r, int kt, int q) const {
         ARaw o;
         const int s = kt / kps(), ch = (kt - s * kps()) * Cfg::BK + 4 * q;
@@ -1055,17 +1136,13 @@ struct BwdDataGroupP {
         o.v[0] = ld4(seg[s].g + (int64_t)r.p * ldg + ch);                // rows of the plane padding exist; zeroed below
         return o;
     }
-    __device__ float4 a_xform(const Ctx&, const ARaw& o, int, int, const float*) const { return o.ok ? o.v[0] : zero4(); }
+    __device__ float4 a_xform(const Ctx&, const ARaw& o, const KPrm&, int, int, const float*) const { return o.ok ? o.v[0] : zero4(); }
     __device__ ARaw a_fetch_d(const Ctx&, const DRow&, int, int, int) const { return ARaw{}; }
-    __device__ BRaw b_fetch(const Ctx& c, const DRow&, int kt, int kr, int q) const {
-        BRaw o;
-        const int s = kt / kps(), k = (kt - s * kps()) * Cfg::BK + kr;
-        const int col = c.n0 + 4 * q;
-        o.ok = col < N;
-        o.v[0] = ld4(seg[s].w + (int64_t)k * seg[s].ldw + (o.ok ? col : 0));
-        return o;
+    __device__ BRaw b_unit(const Ctx& c, int kt, int piece, int k8, int r) const {
+        const int s = kt / kps(), k8g = (kt - s * kps()) * Cfg::K8 + k8;
+        return seg[s].wp[((int64_t)piece * (KA / 8) + k8g) * seg[s].ldn + c.n0 + r];       // rows past N: never stored
     }
-    __device__ float4 b_xform(const Ctx&, const BRaw& o, int, int, const float*) const { return o.ok ? o.v[0] : zero4(); }
+    __device__ u32x4 b_unit_xform(const Ctx&, const BRaw& o, int) const { return o; }
 
     // End of k-tile kt: at a segment boundary fold the accumulator of that layer into the running sum.
     __device__ void k_hook(Ctx& c, int kt, f32x16 (&acc)[Cfg::TM][Cfg::TN], const float* sp) const {
@@ -1192,6 +1269,7 @@ enum { C_IDENT = 0, C_3x3 = 1, C_STEM = 2 };
 template <class Cfg_, int BMODE, int CMAP, int PD_ = 1>
 struct BwdWeightP {
     using Cfg = Cfg_;
+    static_assert(!Cfg::AT, "weight-gradient form");
     const float* gbuf; int ldg; int gcoff;
     const float* xbuf; int ldx; int xcoff;
     Plane pa; int MA;
@@ -1211,9 +1289,14 @@ struct BwdWeightP {
     static constexpr int kSwizzle = 2;
     static constexpr int kPrefetch = PD_;     // k-tiles of global loads in flight per thread
     static constexpr bool kSegmented = false;
+    static constexpr bool kHasPrologue = true;
     static constexpr int kMinWaves = 1;
 
     struct Ctx { int n, p0, m0, n0, tap, kt, z; };
+    using KPrm = KPrm0;
+    using KFin = KPrm0;
+    __device__ KPrm k_fetch(const Ctx&, int, int) const { return KPrm{}; }
+    __device__ KFin k_finish(const Ctx&, const KPrm&, int, int, const float*) const { return KFin{}; }
     struct ARow { int dummy; };
     struct DRow { int p, y, x; };     // the pixel this staging slot reads, advanced BK per k-tile
 
@@ -1304,7 +1387,7 @@ struct BwdWeightP {
         o.v[1] = (o.ok && xbuf) ? ld4(xbuf + pix * ldx + xcoff + ch) : zero4();
         return o;
     }
-    __device__ float4 a_xform(const Ctx&, const ARaw& o, int, int q, const float* sp) const {
+    __device__ float4 a_xform(const Ctx&, const ARaw& o, const KPrm&, int, int q, const float* sp) const {
         if (!xbuf) return o.v[0];
         if (!o.ok) return zero4();
         return affine2(o.v[0], o.v[1], sp + 4 * q, Cfg::BM);

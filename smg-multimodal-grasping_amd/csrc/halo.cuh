@@ -10,20 +10,17 @@
 //
 //   out[p][n] = sum_{tap, c} relu(bn(in[p + d(tap)][c])) * W[n][c][tap]
 //
+// Arithmetic and LDS images: the split-precision scheme of gemm.cuh (three bf16 pieces per fp32 operand, six
+// v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; 16-byte units of 8 consecutive k).
+//
 // Two tile sizes:
 //   TS = 16  planes that tile by 16 (160^2, 80^2 at S = 640).  4 waves, wave w owns pixel
 //            rows 4w..4w+3 (two 32x32 MFMA tiles: 2 rows x 16 cols each).
 //   TS = 8   everything else (40^2, 20^2, ragged edges masked): 64 pixels per workgroup so
 //            that a 17-stream launch still has hundreds of workgroups.  Two waves split
 //            the pixels (4 rows x 8 cols each, one MFMA tile); the other factor of two
-//            splits the reduction (forward: halves of every channel chunk, folded through
-//            LDS at the end), the output channels (data gradient) or the pixels again
-//            (weight gradient).
-// Forward LDS: A[(TS+2)^2 px][17] (pixel-major, odd stride -> conflict-free fragment
-// reads), B[9*16][32]: 42 KB / 27 KB, so several workgroups share a CU and one's
-// staging / epilogue hides under another's MFMAs.  The next chunk is prefetched into
-// registers during the MFMAs; operand fragments of tap t+1 are fetched while the MFMAs
-// of tap t run.
+//            splits the taps (forward, folded through LDS at the end), the output channels
+//            (data gradient) or the pixels again (weight gradient, 16 x 8 / 8 x 8 tiles).
 #pragma once
 #include "gemm.cuh"
 
@@ -45,103 +42,98 @@ struct HaloGeo {
 struct Halo3x3FwdArgs {
     const float* src; int lds_; Plane pl;           // [n][HWp][C] raw bottleneck output
     int C;                                          // input channels (128)
-    const double* ssum; const double* ssq; int sstride;
+    const double* ssum; const double* ssq; int sstride;     // fp64 statistics of src (norm2 input)
     const float* gamma; const float* beta; float eps;
-    const float* w;                                 // packed [(tap*C + c)][32]
+    float* tw_mean; float* tw_invstd;               // [n][C]: the first tile of every stream stores mean / invstd for the backward
+    const u32x4* wu;                                // weight units [chunk][piece][tap][k8][n] (PK_HF)
     float* dst; int ldd, dcoff;
     double* dsum; double* dsq; int dstride;
     int tiles_x;
 };
 
-constexpr int HALO_T = 16;                 // tile side of the big-plane variant
-constexpr int HALO_CK = 16;                // channels per chunk
-constexpr int HALO_LDA = HALO_CK + 1;      // 17
-constexpr int HALO_B_FLOATS = 9 * HALO_CK * 32;            // 4608
-constexpr int HALO_B_N = (9 * HALO_CK * 8 + 255) / 256;    // 5
+constexpr int HALO_CK = 16;                // channels per chunk (one k16-step per tap)
 
-template <int TS> struct HaloFwdGeo : HaloGeo<TS> {
+// ------------------------------------------------------------------------------------
+// Split-precision forward (the arithmetic of gemm.cuh: three bf16 pieces per fp32 operand, six
+// v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate).
+//
+// Per 16-channel chunk (one k16-step per tap) the halo lands in LDS as units [piece][k8 (2)][halo pixel] of 16 bytes
+// (BN + ReLU + split applied once, at the store), the chunk's weights as units [piece][tap][k8][n] - pack_weights_kernel
+// writes exactly that image per chunk (PK_HF), so their staging is a copy.  A fragment is one ds_read_b128 per piece:
+// lanes 0..15 / 16..31 read two runs of 16 consecutive halo pixels.  The 128 BN parameters of the stream are derived
+// from the fp64 sums in the prologue (one channel per thread) and stored once per stream for the backward kernels.
+//   TS = 16: 4 waves x 2 pixel tiles, 60 KB LDS (2 workgroups per CU).
+//   TS = 8 : 2 waves split the pixels, the other factor of two splits the TAPS (5 + 4; a chunk is a single k16-step).
+// ------------------------------------------------------------------------------------
+constexpr int HS_BU = NPIECE * 9 * 2 * 32;                  // weight units per chunk: 1728
+template <int TS> struct HaloFwdSGeo : HaloGeo<TS> {
     using G = HaloGeo<TS>;
-    static constexpr int A_FLOATS = (G::PX * HALO_LDA + 7) / 8 * 8;      // keeps B 32-byte aligned
-    static constexpr int A_N = (G::PX * (HALO_CK / 4) + 255) / 256;      // float4 per thread: 6 / 2
-    static constexpr int KS = G::WX;                                     // waves splitting each chunk's channels
-    static constexpr int KK = 8 / KS;                                    // MFMA k-steps per wave per (chunk, tap)
-    __host__ __device__ static constexpr int smem_floats(int C) { return A_FLOATS + HALO_B_FLOATS + 3 * C; }
+    static constexpr int LDH = G::PX;
+    static constexpr int A_UNITS = NPIECE * 2 * LDH;
+    static constexpr int A_N = (G::PX * 4 + 255) / 256;                  // float4 slots per thread: 6 / 2
+    static constexpr int B_N = (HS_BU + 255) / 256;                      // 7 (the last 64 copies of a round read / write padding)
+    __host__ __device__ static constexpr int smem_bytes(int C) { return (A_UNITS + B_N * 256) * 16 + 3 * C * 4; }
 };
 
 template <int TS>
-__global__ __launch_bounds__(256, TS == 16 ? 3 : 4) void conv3x3_halo_fwd_kernel(const Halo3x3FwdArgs a) {
-    using G = HaloFwdGeo<TS>;
-    constexpr int MT = G::MT, KK = G::KK, A_N = G::A_N;
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const Halo3x3FwdArgs a) {
+    using G = HaloFwdSGeo<TS>;
+    constexpr int MT = G::MT, A_N = G::A_N, B_N = G::B_N, LDH = G::LDH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                   // [PX][17] (+pad to 16 B)
-    float* Bs = smem + G::A_FLOATS;                     // [HALO_B_FLOATS]
-    float* prm = Bs + HALO_B_FLOATS;                    // mean | scale | beta, C each
+    char* As = reinterpret_cast<char*>(smem);                // [piece][k8][LDH] units
+    char* Bs = As + G::A_UNITS * 16;                         // [piece][tap][k8][32] units
+    float* prm = reinterpret_cast<float*>(Bs + B_N * 256 * 16);      // mean | scale | beta, C each
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
-    const int wq = wave % G::WQ, wk = wave / G::WQ;     // pixel slice, channel-split slice
+    const int wq = wave % G::WQ, wk = wave / G::WQ;          // pixel slice, tap slice
+    const int tap0 = (G::WX > 1 && wk) ? 5 : 0, tap1 = (G::WX > 1 && !wk) ? 5 : 9;
     const int n = blockIdx.y;
     const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
     const int y0 = ty * TS, x0 = tx * TS;
-    const int C = a.C;
-
-    {   // BN parameters of this stream
-        const double inv = 1.0 / (double)a.pl.HW;
-        for (int k = t; k < C; k += 256) {
-            float mean, invstd;
-            bn_moments(a.ssum, a.ssq, (int64_t)n * a.sstride + k, inv, a.eps, mean, invstd);
-            prm[k] = mean;
-            prm[C + k] = a.gamma[k] * invstd;
-            prm[2 * C + k] = a.beta[k];
-        }
+    const int C = a.C, kq = t & 3;                           // this thread's channel quad inside every chunk
+    for (int k = t; k < C; k += 256) {                       // BN parameters of this stream
+        float mean, invstd;
+        bn_moments(a.ssum, a.ssq, (int64_t)n * a.sstride + k, 1.0 / (double)a.pl.HW, a.eps, mean, invstd);
+        prm[k] = mean;
+        prm[C + k] = a.gamma[k] * invstd;
+        prm[2 * C + k] = a.beta[k];
+        if (blockIdx.x == 0) { a.tw_mean[(int64_t)n * C + k] = mean; a.tw_invstd[(int64_t)n * C + k] = invstd; }
     }
-    // staging slots of this thread (fixed across chunks)
-    int a_off[A_N];       // global float offset of the pixel (without channel), -1 = outside the image / unused
-    int a_lds[A_N];       // LDS float offset hp*17 + 4*kq
-    int a_kq[A_N];
+
+    int a_off[A_N];       // global pixel index, -1 = outside the image / unused slot
+    int a_hp[A_N];        // halo pixel of the slot, -1 = unused
 #pragma unroll
     for (int i = 0; i < A_N; ++i) {
         const int idx = t + 256 * i;
-        const int hp = idx >> 2, kq = idx & 3;
+        const int hp = idx >> 2;
         const int hy = hp / G::W, hx = hp - hy * G::W;
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
         const bool ok = idx < G::PX * 4 && (unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W;
         a_off[i] = ok ? (iy * a.pl.W + ix) : -1;
-        a_lds[i] = (idx < G::PX * 4) ? hp * HALO_LDA + 4 * kq : -1;
-        a_kq[i] = kq;
+        a_hp[i] = (idx < G::PX * 4) ? hp : -1;
     }
     const float* src_n = a.src + (int64_t)n * a.pl.HWp * a.lds_;
-    float4 ra[A_N], rb[HALO_B_N];
+    const u32x4* wu = a.wu;
+    float4 ra[A_N]; u32x4 rb[B_N];
     auto g_load = [&](int chunk) {
-        const int c0 = chunk * HALO_CK;
+        const int c0 = chunk * HALO_CK + 4 * kq;
 #pragma unroll
-        // Unconditional loads from clamped addresses (out-of-image slots read pixel 0 and are zeroed at the
-        // LDS store): a branch around a load makes hipcc drain vmcnt(0) in the middle of the load group.
-        for (int i = 0; i < A_N; ++i)
-            ra[i] = ld4(src_n + (int64_t)(a_off[i] < 0 ? 0 : a_off[i]) * a.lds_ + c0 + 4 * a_kq[i]);
+        for (int i = 0; i < A_N; ++i)                               // unconditional loads from clamped addresses
+            ra[i] = ld4(src_n + (int64_t)(a_off[i] < 0 ? 0 : a_off[i]) * a.lds_ + c0);
 #pragma unroll
-        for (int i = 0; i < HALO_B_N; ++i) {
-            const int idx = min(t + 256 * i, 9 * HALO_CK * 8 - 1);
-            const int row = idx >> 3, q = idx & 7;                 // row = tap*16 + cc
-            const int tap = row >> 4, cc = row & 15;
-            rb[i] = ld4(a.w + ((int64_t)(tap * C + c0 + cc)) * 32 + 4 * q);
-        }
+        for (int i = 0; i < B_N; ++i) rb[i] = wu[(int64_t)chunk * HS_BU + t + 256 * i];      // (slack behind the packed array)
     };
     auto s_store = [&](int chunk) {
-        float* A = As;
-        float* B = Bs;
-        const int c0 = chunk * HALO_CK;
+        const float* pq = prm + chunk * HALO_CK + 4 * kq;
 #pragma unroll
         for (int i = 0; i < A_N; ++i) {
-            if (a_lds[i] < 0) continue;
-            float4 v = zero4();                                     // conv zero padding applies AFTER bn+relu
-            if (a_off[i] >= 0) v = bnrelu4(ra[i], prm + c0 + 4 * a_kq[i], C);
-            float* d = A + a_lds[i];
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            if (a_hp[i] < 0) continue;
+            const Split4 s = split4(a_off[i] >= 0 ? bnrelu4(ra[i], pq, C) : zero4());   // conv zero padding applies AFTER bn+relu
+#pragma unroll
+            for (int pc = 0; pc < NPIECE; ++pc)
+                *reinterpret_cast<uint2*>(As + ((pc * 2 + (kq >> 1)) * LDH + a_hp[i]) * 16 + (kq & 1) * 8) = s.p[pc];
         }
 #pragma unroll
-        for (int i = 0; i < HALO_B_N; ++i) {
-            const int idx = t + 256 * i;
-            if (idx < 9 * HALO_CK * 8) *reinterpret_cast<float4*>(B + idx * 4) = rb[i];
-        }
+        for (int i = 0; i < B_N; ++i) *reinterpret_cast<u32x4*>(Bs + (t + 256 * i) * 16) = rb[i];
     };
 
     f32x16 acc[MT];
@@ -149,53 +141,91 @@ __global__ __launch_bounds__(256, TS == 16 ? 3 : 4) void conv3x3_halo_fwd_kernel
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-
-    // fragment base addresses: MFMA tile m, tile row l31 -> pixel (G::row, G::col); this wave's
-    // share of every chunk starts at channel 2*KK*wk
-    int abase[MT];
+    int abase[MT];        // halo pixel of this lane's tile row at tap (0, 0)
 #pragma unroll
-    for (int m = 0; m < MT; ++m) abase[m] = (G::row(wq, m, l31) * G::W + G::col(l31)) * HALO_LDA + half + 2 * KK * wk;
-    const int bbase = (half + 2 * KK * wk) * 32 + l31;
+    for (int m = 0; m < MT; ++m) abase[m] = G::row(wq, m, l31) * G::W + G::col(l31);
+    auto fa = [&](int m, int tap, int pc) -> u32x4 {
+        return *reinterpret_cast<const u32x4*>(As + ((pc * 2 + half) * LDH + abase[m] + (tap / 3) * G::W + tap % 3) * 16);
+    };
+    auto fb = [&](int tap, int pc) -> u32x4 {
+        return *reinterpret_cast<const u32x4*>(Bs + (((pc * 9 + tap) * 2 + half) * 32 + l31) * 16);
+    };
 
     const int NCH = C / HALO_CK;
-    __syncthreads();                 // prm visible
     g_load(0);
+    __syncthreads();                 // prm visible
     s_store(0);
     __syncthreads();
     for (int ch = 0; ch < NCH; ++ch) {
         if (ch + 1 < NCH) g_load(ch + 1);
-        const float* A = As;
-        const float* B = Bs;
-        float fa[2][KK][MT], fb[2][KK];
-        auto frag = [&](int set, int tap) {
-            const int toff = ((tap / 3) * G::W + (tap % 3)) * HALO_LDA;
+        // per tap: hi and lo pieces, the two hi x lo groups, then the mid pieces (fetched under those MFMAs) and the rest;
+        // the next tap's hi / lo pieces are requested before the last four groups of this one
+        u32x4 ah[2][MT], al[2][MT], bh[2], bl[2];
+        auto load_hl = [&](int set, int tap) {
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) fa[set][kk][m] = A[abase[m] + toff + 2 * kk];
-                fb[set][kk] = B[(tap * HALO_CK + 2 * kk) * 32 + bbase];
-            }
+            for (int m = 0; m < MT; ++m) { ah[set][m] = fa(m, tap, 0); al[set][m] = fa(m, tap, 2); }
+            bh[set] = fb(tap, 0); bl[set] = fb(tap, 2);
         };
-        frag(0, 0);
+        load_hl(0, tap0);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int set = tap & 1;
-            if (tap + 1 < 9) frag(set ^ 1, tap + 1);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int tp = 0; tp < 5; ++tp) {
+            const int tap = tap0 + tp;
+            if (tap < tap1) {
+                const int set = tp & 1;
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][m], bl[set], acc[m]);
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][kk][m], fb[set][kk], acc[m], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(al[set][m], bh[set], acc[m]);
+                u32x4 am[MT], bm;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) am[m] = fa(m, tap, 1);
+                bm = fb(tap, 1);
+                if (tap + 1 < tap1) load_hl(set ^ 1, tap + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(am[m], bm, acc[m]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][m], bm, acc[m]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(am[m], bh[set], acc[m]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][m], bh[set], acc[m]);
+            }
         }
+        if constexpr (TS == 16) {      // taps 5..8 of the single tap slice
+#pragma unroll
+            for (int tp = 5; tp < 9; ++tp) {
+                const int tap = tp, set = tp & 1;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][m], bl[set], acc[m]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(al[set][m], bh[set], acc[m]);
+                u32x4 am[MT], bm;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) am[m] = fa(m, tap, 1);
+                bm = fb(tap, 1);
+                if (tap + 1 < 9) load_hl(set ^ 1, tap + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(am[m], bm, acc[m]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][m], bm, acc[m]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(am[m], bh[set], acc[m]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][m], bh[set], acc[m]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                          // every wave is done reading this chunk
         if (ch + 1 < NCH) {
             s_store(ch + 1);
             __syncthreads();
         }
     }
-    if constexpr (G::KS > 1) {                    // fold the channel-split partial tiles into the wk == 0 waves
+    if constexpr (G::WX > 1) {                    // fold the tap-split partial tiles into the wk == 0 waves
         float* r = smem + (wq * 16) * 64 + lane;  // [WQ][16][64], MT == 1
         if (wk > 0) {
 #pragma unroll
@@ -241,16 +271,6 @@ __global__ __launch_bounds__(256, TS == 16 ? 3 : 4) void conv3x3_halo_fwd_kernel
 }
 
 
-// ------------------------------------------------------------------------------------
-// 3x3 data gradient (transposed convolution) with the gradient halo resident in LDS:
-//   dc[p][c] = sum_{tap, n} g[p - d(tap)][n] * W[n][c][tap]          (g: [pixel][32])
-// followed by the ReLU mask and BN(norm2) backward sums of the bottleneck (the same
-// epilogue as BwdDataP/E_STORE).  The (TS+2)^2 x 32 halo of g is staged once per
-// workgroup; the weights of one (32-channel output chunk, tap row) - 12 KB - are streamed
-// through LDS, prefetched into registers under the MFMAs.  TS = 16: 12 stages, 57 KB LDS
-// -> 2 workgroups/CU.  TS = 8: the two wave pairs own different output-channel chunks
-// (NCW = 2 chunks per stage, 6 stages), 39 KB.
-// ------------------------------------------------------------------------------------
 // The finished gradient of a layer's 32 output channels, as the 3x3 backward kernels read it: either a dense
 // [n][HWp][32] array (x == nullptr), or the G' and X slices of the block buffers with the deferred BN backward
 // applied on load (what bn_bwd_apply_kernel would have written):
@@ -278,72 +298,72 @@ __device__ __forceinline__ void grad_src_params(const GradSrc& s, int n, int hw,
 
 struct Halo3x3DgradArgs {
     GradSrc g; Plane pl;                             // finished output gradient (32 channels)
-    const float* w;                                  // packed [(tap*32 + n)][C]
+    const u32x4* wu;                                 // weight units [c/32][tap][piece][k8][c%32] (PK_HD)
+    BnTab bt;                                        // norm2 statistics of this layer (stored by the forward) + gamma / beta
     int C;                                           // bottleneck channels (128)
     const float* mbuf;                               // raw bottleneck [n][HWp][C] (mask + xhat source)
-    const double* msum; const double* msq; int mstride;
-    const float* gamma; const float* beta; float eps;
     float* dst;                                      // dy [n][HWp][C]
     double* o1; double* o2; int ostride;             // per-stream sums [n][C]
     int tiles_x;
     int cg_per_wg;                                   // output-channel groups (NCW chunks of 32) per workgroup; blockIdx.z picks the run
 };
 
-constexpr int HD_LDA = 33;
-constexpr int HD_B_CHUNK = 3 * 32 * 32;                     // one tap row x 32 n x 32 c
-
-template <int TS> struct HaloDgradGeo : HaloGeo<TS> {
+// ------------------------------------------------------------------------------------
+// Split-precision data gradient.  The (TS+2)^2 x 32 gradient halo is split ONCE per workgroup into units
+// [piece][k8 (4)][halo pixel] (62 KB at TS = 16: two workgroups per CU); the weights of one stage = one tap x NCW
+// 32-channel output chunks ([piece][k8][c] units, 6 KB per chunk; pack mode PK_HD) stream through a double buffer, one
+// barrier per stage, prefetched into registers under the stage's MFMAs.  A stage is two k16-steps (32 gradient channels)
+// per pixel tile; after the ninth tap of a chunk the epilogue applies the ReLU mask and collects the norm2 sums.
+// ------------------------------------------------------------------------------------
+constexpr int HDS_BU = NPIECE * 4 * 32;                      // weight units per (tap, 32-channel chunk): 384
+template <int TS> struct HaloDgradSGeo : HaloGeo<TS> {
     using G = HaloGeo<TS>;
-    static constexpr int A_FLOATS = (G::PX * HD_LDA + 3) / 4 * 4;
-    static constexpr int A_N = (G::PX * 8 + 255) / 256;                  // float4 per thread: 11 / 4
+    static constexpr int LDH = G::PX;
+    static constexpr int A_UNITS = NPIECE * 4 * LDH;
+    static constexpr int A_N = (G::PX * 8 + 255) / 256;                  // float4 slots per thread: 11 / 4
     static constexpr int NCW = G::WX;                                    // output-channel chunks per stage
-    static constexpr int B_FLOATS = NCW * HD_B_CHUNK;
-    static constexpr int B_N = B_FLOATS / 4 / 256;                       // 3 / 6
-    __host__ __device__ static constexpr int smem_floats(int C) { return A_FLOATS + B_FLOATS + 4 * C + 256 + 128; }
+    static constexpr int B_UNITS = NCW * HDS_BU;                         // per buffer
+    static constexpr int B_N = (B_UNITS + 255) / 256;                    // 2 / 3
+    static constexpr int B_PAD = B_N * 256;                              // units per buffer incl. the padding the last copy round touches
+    __host__ __device__ static constexpr int smem_bytes(int C) { return (A_UNITS + 2 * B_PAD) * 16 + (4 * C + 256 + 128) * 4; }
 };
 
 template <int TS>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x3DgradArgs a) {
-    using G = HaloDgradGeo<TS>;
-    constexpr int MT = G::MT, NCW = G::NCW, A_N = G::A_N, B_N = G::B_N;
+    using G = HaloDgradSGeo<TS>;
+    constexpr int MT = G::MT, NCW = G::NCW, A_N = G::A_N, B_N = G::B_N, LDH = G::LDH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                   // [PX][33]
-    float* Bs = smem + G::A_FLOATS;                     // [NCW][96][32]
-    float* prm = Bs + G::B_FLOATS;                      // scale | beta | mean | invstd, C each
+    char* As = reinterpret_cast<char*>(smem);                            // [piece][k8][LDH] units
+    char* Bs = As + G::A_UNITS * 16;                                     // [2][NCW][piece][k8][32] units
+    float* prm = reinterpret_cast<float*>(Bs + 2 * G::B_PAD * 16);       // scale | beta | mean | invstd, C each
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
     const int wq = wave % G::WQ, wc = wave / G::WQ;     // pixel slice, output-channel chunk of the stage
     const int n = blockIdx.y;
     const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
     const int y0 = ty * TS, x0 = tx * TS;
     const int C = a.C;
-    {
-        const double inv = 1.0 / (double)a.pl.HW;
-        for (int k = t; k < C; k += 256) {
-            float mean, invstd;
-            bn_moments(a.msum, a.msq, (int64_t)n * a.mstride + k, inv, a.eps, mean, invstd);
-            prm[k] = a.gamma[k] * invstd;
-            prm[C + k] = a.beta[k];
-            prm[2 * C + k] = mean;
-            prm[3 * C + k] = invstd;
-        }
+    for (int k = t; k < C; k += 256) {                  // norm2 parameters of this stream (layer table of the forward)
+        const float invstd = tab_invstd(a.bt, n)[k];
+        prm[k] = a.bt.gamma[k] * invstd;
+        prm[C + k] = a.bt.beta[k];
+        prm[2 * C + k] = tab_mean(a.bt, n)[k];
+        prm[3 * C + k] = invstd;
     }
     float* gp = prm + 4 * C + 256;                     // GradSrc parameters [4][32]
     grad_src_params(a.g, n, a.pl.HW, gp);
     const int cg0 = blockIdx.z * a.cg_per_wg;
-    const int NSTAGE = a.cg_per_wg * 3;       // channel-chunk groups x 3 tap rows
-    float4 rb[B_N];
-    auto g_load = [&](int stage) {            // stage = cgroup*3 + tap row
-        const int cg = cg0 + stage / 3, dy = stage % 3;
+    const int NSTAGE = a.cg_per_wg * 9;                // channel-chunk groups x 9 taps
+    u32x4 rb[B_N];
+    auto g_load = [&](int stage) {                     // stage = cgroup * 9 + tap; cgroup holds NCW chunks
+        const int cg = cg0 + stage / 9, tap = stage % 9;
 #pragma unroll
         for (int i = 0; i < B_N; ++i) {
-            const int idx = t + 256 * i;      // NCW x 768 float4: j = chunk of the stage, row = dx*32 + nn, q
-            const int j = idx / 768, rem = idx - j * 768;
-            const int row = rem >> 3, q = rem & 7;
-            rb[i] = ld4(a.w + (int64_t)((dy * 3) * 32 + row) * C + (cg * NCW + j) * 32 + 4 * q);
+            const int idx = t + 256 * i;                                   // past B_UNITS: padding (slack behind the packed array)
+            const int j = min(idx / HDS_BU, NCW - 1), rem = idx - j * HDS_BU;
+            rb[i] = a.wu[((int64_t)(cg * NCW + j) * 9 + tap) * HDS_BU + rem];
         }
     };
-    // (issuing g_load(0) here, under the halo staging, costs registers: spills at 3 waves/SIMD)
-    // gradient halo (zero outside the image)
+    // gradient halo (zero outside the image), split at the store
     const float* g_n = a.g.g + (int64_t)n * a.pl.HWp * a.g.ldg;
     const float* x_n = a.g.x ? a.g.x + (int64_t)n * a.pl.HWp * a.g.ldx : nullptr;
     {
@@ -371,22 +391,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
                 float4 v = rv[i];
                 if (x_n) v = affine2(rv[i], rx[i], gp + 4 * q, 32);
                 if (!ok) v = zero4();
-                float* d = As + hp * HD_LDA + 4 * q;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                const Split4 sp = split4(v);
+#pragma unroll
+                for (int pc = 0; pc < NPIECE; ++pc)
+                    *reinterpret_cast<uint2*>(As + ((pc * 4 + (q >> 1)) * LDH + hp) * 16 + (q & 1) * 8) = sp.p[pc];
             }
         }
     }
-    auto s_store = [&]() {
+    auto s_store = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < B_N; ++i) *reinterpret_cast<float4*>(Bs + (t + 256 * i) * 4) = rb[i];
+        for (int i = 0; i < B_N; ++i) *reinterpret_cast<u32x4*>(Bs + (buf * G::B_PAD + t + 256 * i) * 16) = rb[i];
     };
     int abase[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) abase[m] = (G::row(wq, m, l31) * G::W + G::col(l31)) * HD_LDA + half;
-    const int bbase = wc * HD_B_CHUNK + half * 32 + l31;
+    for (int m = 0; m < MT; ++m) abase[m] = G::row(wq, m, l31) * G::W + G::col(l31);
 
     g_load(0);
-    s_store();
+    s_store(0);
     __syncthreads();
     f32x16 acc[MT];
     float xvp[MT][16];                        // TS == 8: prefetched one stage ahead
@@ -402,8 +423,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
             }
     };
     for (int stage = 0; stage < NSTAGE; ++stage) {
-        const int dy = stage % 3;
-        if (dy == 0) {
+        const int tap = stage % 9, buf = stage & 1;
+        const int dy = tap / 3, dx = tap - 3 * dy;
+        if (tap == 0) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -411,38 +433,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
         }
         if (stage + 1 < NSTAGE) g_load(stage + 1);
         if constexpr (TS == 8) {
-            if (dy == 2) load_mask(((cg0 + stage / 3) * NCW + wc) * 32 + l31, xvp);   // in flight under the last MFMA block
+            if (tap == 8) load_mask(((cg0 + stage / 9) * NCW + wc) * 32 + l31, xvp);   // in flight under the last MFMA block
         }
-        float fa[2][8][MT], fb[2][8];
         // output pixel (ry, rx), tap (dy, dx) reads g at halo (ry + 2 - dy, rx + 2 - dx)
-        auto frag = [&](int set, int step) {          // step = dx*2 + (n half): 16 n per step
-            const int dx = step >> 1, nh = step & 1;
-            const int toff = ((2 - dy) * G::W + (2 - dx)) * HD_LDA + nh * 16;
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) fa[set][kk][m] = As[abase[m] + toff + 2 * kk];
-                fb[set][kk] = Bs[(dx * 32 + nh * 16 + 2 * kk) * 32 + bbase];
-            }
+        const int toff = (2 - dy) * G::W + (2 - dx);
+        const char* Bw = Bs + (buf * G::B_PAD + wc * HDS_BU) * 16;
+        auto fa = [&](int m, int ks, int pc) -> u32x4 {
+            return *reinterpret_cast<const u32x4*>(As + ((pc * 4 + 2 * ks + half) * LDH + abase[m] + toff) * 16);
         };
-        frag(0, 0);
+        auto fb = [&](int ks, int pc) -> u32x4 {
+            return *reinterpret_cast<const u32x4*>(Bw + ((pc * 4 + 2 * ks + half) * 32 + l31) * 16);
+        };
 #pragma unroll
-        for (int step = 0; step < 6; ++step) {
-            const int set = step & 1;
-            if (step + 1 < 6) frag(set ^ 1, step + 1);
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 ah[MT], al[MT], bh, bl;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { ah[m] = fa(m, ks, 0); al[m] = fa(m, ks, 2); }
+            bh = fb(ks, 0); bl = fb(ks, 2);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
+            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[m], bl, acc[m]);
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][kk][m], fb[set][kk], acc[m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(al[m], bh, acc[m]);
+            u32x4 am[MT], bm;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) am[m] = fa(m, ks, 1);
+            bm = fb(ks, 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(am[m], bm, acc[m]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[m], bm, acc[m]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(am[m], bh, acc[m]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[m], bh, acc[m]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();                          // B of this stage fully consumed
-        if (stage + 1 < NSTAGE) s_store();
-        if (dy == 2) {
+        if (stage + 1 < NSTAGE) s_store(buf ^ 1);       // the other buffer: last read one stage ago, behind a barrier
+        if (tap == 8) {
             // epilogue of this wave's output-channel chunk: ReLU mask, store dy, BN(norm2) backward sums
-            const int c = ((cg0 + stage / 3) * NCW + wc) * 32 + l31;
+            const int c = ((cg0 + stage / 9) * NCW + wc) * 32 + l31;
             const float sc = prm[c], be = prm[C + c], mean = prm[2 * C + c], invstd = prm[3 * C + c];
             float s1 = 0.f, s2 = 0.f;
             auto finish = [&](float (&xv)[MT][16]) {
@@ -476,10 +507,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
                 float tot = 0.f;
 #pragma unroll
                 for (int w = 0; w < G::WQ; ++w) tot += red[q * 128 + (j * G::WQ + w) * 32 + cc];
-                const int ch = ((cg0 + stage / 3) * NCW + j) * 32 + cc;
+                const int ch = ((cg0 + stage / 9) * NCW + j) * 32 + cc;
                 atomicAdd((q ? a.o2 : a.o1) + (int64_t)n * a.ostride + ch, (double)tot);
-                // dgamma / dbeta = the same sums over streams: bn_bwd_apply_kernel adds them from o1 / o2 (one
-                // atomic per stream and channel; here every tile of every stream would hit the same 2*C addresses)
             }
         }
         __syncthreads();
@@ -487,60 +516,52 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
 }
 
 
-// ------------------------------------------------------------------------------------
-// 3x3 weight gradient with the activation halo resident in LDS:
-//   dW[n][c][tap] += sum_p g[p][n] * relu(bn(in[p + d(tap)][c]))
-// A workgroup owns (a run of TSxTS pixel tiles of one stream) x (a 32-channel chunk of
-// c).  Per tile it stages the (TS+2)^2 x 32 activation halo (BN+ReLU applied once) and
-// the TS^2 x 32 gradient tile; every wave then walks its own quarter of the pixels as the
-// MFMA reduction dimension and accumulates ALL nine taps (9 accumulator tiles) by shifting
-// the halo read address - the operands are fetched once for 9 taps instead of once per tap.
-// The accumulators persist across the run of tiles; at the end the four waves' tiles
-// are folded through LDS and written (plain stores) to a partial buffer that
-// reduce_partials_kernel sums over workgroups - fp32 atomics here cost ~3 ms/step.
-// ------------------------------------------------------------------------------------
 struct Halo3x3WgradArgs {
     GradSrc g; Plane pl;                             // finished output gradient (32 channels)
     const float* src; int C;                         // raw bottleneck [n][HWp][C]
-    const double* ssum; const double* ssq; int sstride;
-    const float* gamma; const float* beta; float eps;
+    BnTab bt;                                        // norm2 statistics of this layer (stored by the forward) + gamma / beta
     float* part;                                     // partial sums [gridDim.x*gridDim.z][9][32][C]
     int tiles_x, n_tiles, tiles_per_wg;
 };
 
-template <int TS> struct HaloWgradGeo : HaloGeo<TS> {
-    using G = HaloGeo<TS>;
-    static constexpr int B_FLOATS = G::PX * 32;                          // activation halo
-    static constexpr int A_FLOATS = G::NPIX * 32;                        // gradient tile
-    static constexpr int B_N = (G::PX * 8 + 255) / 256;                  // 11 / 4
-    static constexpr int A_N = G::NPIX * 8 / 256;                        // 8 / 2
-    static constexpr int KSTEPS = G::NPIX / 4 / 2;                       // MFMA k-steps per wave per tile: 32 / 8
-    static constexpr int WROWS = TS / 4;                                 // pixel rows per wave: 4 / 2
-    static constexpr int NPH = TS == 16 ? 4 : 1;                         // staging phases per tile
-    static constexpr int RED_FLOATS = 4 * 16 * 64;                       // flush area
-    __host__ __device__ static constexpr int smem_floats() {
-        return (B_FLOATS + A_FLOATS > RED_FLOATS ? B_FLOATS + A_FLOATS : RED_FLOATS) + 96 + 128;
+// ------------------------------------------------------------------------------------
+// Split-precision weight gradient.  The reduction runs over pixels, so both operands stay row-major
+// [pixel][32 channels] in LDS (bf16 pieces, split at the store) and the MFMA fragments are gathered with
+// ds_read_b64_tr_b16: a 16-lane group fetches 4 consecutive pixels x 16 channels and every lane receives its channel
+// of all four (gemm.cuh, weight-gradient form).  The activation halo serves all nine taps by shifting the pixel a lane
+// points at; the gradient fragment is read once per k16-step.
+//   TW = 16: tile 16 x 8 pixels, a k16-step is one tile row; each wave reduces two rows.   59 KB LDS, 2 workgroups / CU
+//   TW = 8 : tile  8 x 8 pixels, a k16-step is two tile rows; each wave reduces one step.
+// Three taps (one kernel row) are in flight at a time: 18 MFMAs on three independent accumulators per group.
+// ------------------------------------------------------------------------------------
+template <int TW> struct HaloWgradSGeo {
+    static_assert(TW == 16 || TW == 8, "tile width");
+    static constexpr int TH = 8, HW_ = TW + 2, HH = TH + 2, PX = HW_ * HH, NPIX = TW * TH;
+    static constexpr int KSTEPS = NPIX / 16 / 4;                          // k16-steps per wave per tile: 2 / 1
+    static constexpr int B_BYTES = NPIECE * PX * 64, A_BYTES = NPIECE * NPIX * 64;
+    static constexpr int B_N = (PX * 8 + 255) / 256, A_N = NPIX * 8 / 256;   // float4 slots per thread: 6 / 4 halo, 4 / 2 gradient
+    static constexpr int RED_BYTES = 4 * 16 * 64 * 4;
+    __host__ __device__ static constexpr int smem_bytes() {
+        return (B_BYTES + A_BYTES > RED_BYTES ? B_BYTES + A_BYTES : RED_BYTES) + (96 + 128) * 4;
     }
 };
 
-template <int TS>
+template <int TW>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const Halo3x3WgradArgs a) {
-    using G = HaloWgradGeo<TS>;
+    using G = HaloWgradSGeo<TW>;
     constexpr int B_N = G::B_N, A_N = G::A_N;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Bh = smem;                                   // [PX][32] activation halo
-    float* Ag = smem + G::B_FLOATS;                     // [TS*TS][32] gradient tile
-    float* prm = smem + G::smem_floats() - 96 - 128;    // mean | scale | beta (32 each)
+    char* Bh = reinterpret_cast<char*>(smem);           // [piece][PX][32] bf16: activation halo
+    char* Ag = Bh + G::B_BYTES;                         // [piece][NPIX][32] bf16: gradient tile
+    float* prm = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + G::smem_bytes()) - 96 - 128;    // mean | scale | beta (32 each)
     float* gp = prm + 96;                               // GradSrc parameters [4][32]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, half = lane >> 5;
     const int n = blockIdx.z, cc0 = blockIdx.y * 32;
     const int C = a.C;
     if (t < 32) {
-        float mean, invstd;
-        bn_moments(a.ssum, a.ssq, (int64_t)n * a.sstride + cc0 + t, 1.0 / (double)a.pl.HW, a.eps, mean, invstd);
-        prm[t] = mean;
-        prm[32 + t] = a.gamma[cc0 + t] * invstd;
-        prm[64 + t] = a.beta[cc0 + t];
+        prm[t] = tab_mean(a.bt, n)[cc0 + t];
+        prm[32 + t] = a.bt.gamma[cc0 + t] * tab_invstd(a.bt, n)[cc0 + t];
+        prm[64 + t] = a.bt.beta[cc0 + t];
     }
     grad_src_params(a.g, n, a.pl.HW, gp);
     f32x16 acc[9];
@@ -551,73 +572,91 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const Halo3x
     const float* src_n = a.src + (int64_t)n * a.pl.HWp * C + cc0;
     const float* g_n = a.g.g + (int64_t)n * a.pl.HWp * a.g.ldg;
     const float* x_n = a.g.x ? a.g.x + (int64_t)n * a.pl.HWp * a.g.ldx : nullptr;
+    // transposing-read geometry: lane i of a 16-lane group fetches pixel-row (k) i/4, channel quad i%4 and receives channel i
+    const int tr_row = (lane & 15) >> 2, tr_col = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
     const int tile0 = blockIdx.x * a.tiles_per_wg;
     const int tile1 = min(tile0 + a.tiles_per_wg, a.n_tiles);
     for (int tile = tile0; tile < tile1; ++tile) {
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-        const int y0 = ty * TS, x0 = tx * TS;
+        const int y0 = ty * G::TH, x0 = tx * TW;
         __syncthreads();                              // previous tile fully consumed (and prm visible)
+        {
+            float4 rv[B_N], rg[A_N];
+            bool okv[B_N];
 #pragma unroll
-        for (int ph = 0; ph < G::NPH; ++ph) {         // staging in NPH phases: fewer registers live -> 2 workgroups / CU
-            constexpr int BP = (B_N + G::NPH - 1) / G::NPH, AP = A_N / G::NPH;
-            float4 rv[BP], rg[AP];
-            bool okv[BP];
-#pragma unroll
-            for (int i = 0; i < BP; ++i) {            // all loads of the phase in flight, then transform + store
-                const int idx = t + 256 * (ph * BP + i);
+            for (int i = 0; i < B_N; ++i) {           // all loads in flight, then transform + split + store
+                const int idx = t + 256 * i;
                 const int hp = idx >> 3, q = idx & 7;
-                const int hy = hp / G::W, hx = hp - hy * G::W;
+                const int hy = hp / G::HW_, hx = hp - hy * G::HW_;
                 const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
                 okv[i] = idx < G::PX * 8 && (unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W;
                 rv[i] = ld4(src_n + (int64_t)(okv[i] ? iy * a.pl.W + ix : 0) * C + 4 * q);   // unconditional, clamped; zeroed at the store
             }
 #pragma unroll
-            for (int i = 0; i < AP; ++i) {
-                const int idx = t + 256 * (ph * AP + i);
+            for (int i = 0; i < A_N; ++i) {
+                const int idx = t + 256 * i;
                 const int px = idx >> 3, q = idx & 7;
-                const int py = y0 + px / TS, pxx = x0 + px % TS;
-                const bool ok = TS == 16 || (py < a.pl.H && pxx < a.pl.W);     // TS == 8 tiles may hang over the edge
+                const int py = y0 + px / TW, pxx = x0 + px % TW;
+                const bool ok = py < a.pl.H && pxx < a.pl.W;                  // tiles may hang over the edge
                 const int64_t pix = ok ? (int64_t)py * a.pl.W + pxx : 0;
                 float4 v = ld4(g_n + pix * a.g.ldg + 4 * q);
                 if (x_n) v = affine2(v, ld4(x_n + pix * a.g.ldx + 4 * q), gp + 4 * q, 32);
                 rg[i] = ok ? v : zero4();
             }
 #pragma unroll
-            for (int i = 0; i < BP; ++i) {
-                const int idx = t + 256 * (ph * BP + i);
+            for (int i = 0; i < B_N; ++i) {
+                const int idx = t + 256 * i;
                 if (idx < G::PX * 8) {
                     const int q = idx & 7;
-                    const float4 v = okv[i] ? bnrelu4(rv[i], prm + 4 * q, 32) : zero4();   // zero padding AFTER bn+relu
-                    *reinterpret_cast<float4*>(Bh + (idx >> 3) * 32 + 4 * q) = v;
+                    const Split4 sp = split4(okv[i] ? bnrelu4(rv[i], prm + 4 * q, 32) : zero4());   // zero padding AFTER bn+relu
+#pragma unroll
+                    for (int pc = 0; pc < NPIECE; ++pc)
+                        *reinterpret_cast<uint2*>(Bh + ((pc * G::PX + (idx >> 3)) * 32 + 4 * q) * 2) = sp.p[pc];
                 }
             }
 #pragma unroll
-            for (int i = 0; i < AP; ++i) {
-                const int idx = t + 256 * (ph * AP + i);
-                *reinterpret_cast<float4*>(Ag + (idx >> 3) * 32 + 4 * (idx & 7)) = rg[i];
+            for (int i = 0; i < A_N; ++i) {
+                const int idx = t + 256 * i;
+                const Split4 sp = split4(rg[i]);
+#pragma unroll
+                for (int pc = 0; pc < NPIECE; ++pc)
+                    *reinterpret_cast<uint2*>(Ag + ((pc * G::NPIX + (idx >> 3)) * 32 + 4 * (idx & 7)) * 2) = sp.p[pc];
             }
         }
         __syncthreads();
-        // wave w reduces over its quarter of the pixels (rows WROWS*w ..); lane half selects the pixel parity
-        float fa[2], fb[2][9];
-        auto frag = [&](int set, int kk) {
-            const int pw = 2 * kk + half;
-            const int ry = G::WROWS * wave + pw / TS, rx = pw % TS;
-            fa[set] = Ag[(ry * TS + rx) * 32 + l31];
-            const float* b = Bh + (ry * G::W + rx) * 32 + l31;
+        // wave w reduces over its k16-steps; this lane's 4-pixel run of the step starts at k = 8*half + tr_row (+4 for the second read)
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) fb[set][tap] = b[((tap / 3) * G::W + (tap % 3)) * 32];
-        };
-        frag(0, 0);
-#pragma unroll 2
-        for (int kk = 0; kk < G::KSTEPS; ++kk) {
-            const int set = kk & 1;
-            if (kk + 1 < G::KSTEPS) frag(set ^ 1, kk + 1);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int ks = 0; ks < G::KSTEPS; ++ks) {
+            const int k = 8 * half + tr_row;                     // pixel inside the step (second read: + 4)
+            int ry, rx;
+            if constexpr (TW == 16) { ry = wave * 2 + ks; rx = k; }
+            else { ry = wave * 2 + (k >> 3); rx = k & 7; }
+            auto tr2 = [&](const char* p0, int stride) -> u32x4 {        // 8 consecutive k of this lane's channel
+                const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0));
+                const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + stride)));
+                return u32x4{lo.x, lo.y, hi.x, hi.y};
+            };
+            // second read = pixels k + 4: the same tile row for TW == 16 and TW == 8 (k + 4 < 8 within a row of 8)
+            const char* ga = Ag + ((ry * TW + rx) * 32 + tr_col) * 2;
+            const char* hb = Bh + ((ry * G::HW_ + rx) * 32 + tr_col) * 2;
+            u32x4 af[NPIECE];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set], fb[set][tap], acc[tap], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int pc = 0; pc < NPIECE; ++pc) af[pc] = tr2(ga + pc * G::NPIX * 64, 4 * 64);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                u32x4 bf[3][NPIECE];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int pc = 0; pc < NPIECE; ++pc) bf[dx][pc] = tr2(hb + pc * G::PX * 64 + (dy * G::HW_ + dx) * 64, 4 * 64);
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+                for (int g = 0; g < 6; ++g)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) acc[dy * 3 + dx] = mfma_bf16(af[PA[g]], bf[dx][PB[g]], acc[dy * 3 + dx]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     // flush: per tap, fold the four waves' tiles through LDS and add into the gradient

@@ -269,11 +269,13 @@ class _AffordanceNet(nn.Module):
         return q
 
     def run_pairs(self, style, num_rot, heightmaps, rot_streams, mask_images, pairs, mean=0.0, std=1.0,
-                  bn_seq_trunk=None, bn_seq_head=None):
+                  bn_seq_trunk=None, bn_seq_head=None, masks=None, mask_a=None, mask_b=None):
         """General form: image 0 is the scene's depth heightmap; `rot_streams` lists the rotation
         indices evaluated on it (ONE trunk pass each, shared by every pair that uses it);
         `mask_images` lists image indices (>= 1) fed un-rotated (one trunk pass each);
         `pairs` = [(i, j)]: head evaluation on rot_streams[i] x mask_images[j].
+        `masks` (device tensor [n_masks, H, H] float64) with `mask_a` / `mask_b` (one index per entry of
+        mask_images, -1 = none): those streams read image * (masks[a] + masks[b]), formed on the device.
         Returns q [len(pairs), out, OH, OW].  Inference only (no saved activations)."""
         self._require_gpu()
         dev = self._flat_params.device
@@ -290,11 +292,15 @@ class _AffordanceNet(nn.Module):
         q = torch.empty((len(pairs), self.HEAD_OUT, eng.OH, eng.OW), dtype=torch.float32, device=dev)
         trunk_id, head_id = STYLE_TRUNK[style], STYLE_HEAD[style]
         stream = torch.cuda.current_stream(dev).cuda_stream
+        mk = {}
+        if masks is not None:
+            mk = dict(masks=masks.data_ptr(), n_masks=int(masks.shape[0]),
+                      stream_mask_a=[-1] * n_rot + list(mask_a), stream_mask_b=[-1] * n_rot + list(mask_b))
         eng.forward(self._net_struct(False), trunk_id, head_id, q.data_ptr(), stream,
                     heightmaps=heightmaps.data_ptr(), hm_size=hm, mean=float(mean), std=float(std),
                     n_images=int(heightmaps.shape[0]), stream_image=stream_image, stream_affine=np.concatenate(thetas),
                     stream_rotated=stream_rot, pair_a=pair_a, pair_b=pair_b,
-                    bn_seq_trunk=bn_seq_trunk, bn_seq_head=bn_seq_head)
+                    bn_seq_trunk=bn_seq_trunk, bn_seq_head=bn_seq_head, **mk)
         self._saved = None
         return q
 

@@ -27,6 +27,7 @@ class SmgBatch(C.Structure):
         ("n_pairs", C.c_int), ("pair_a", C.POINTER(C.c_int)), ("pair_b", C.POINTER(C.c_int)),
         ("n_bn_seq_trunk", C.c_int), ("bn_seq_trunk", C.POINTER(C.c_int)),
         ("n_bn_seq_head", C.c_int), ("bn_seq_head", C.POINTER(C.c_int)),
+        ("masks_dev", C.c_void_p), ("n_masks", C.c_int), ("stream_mask_a", C.POINTER(C.c_int)), ("stream_mask_b", C.POINTER(C.c_int)),
     ]
 
 
@@ -63,6 +64,7 @@ def lib():
     L.smg_forward.argtypes = [C.c_void_p, C.POINTER(SmgNet), C.c_int, C.c_int, C.POINTER(SmgBatch), C.c_void_p, C.c_void_p]
     L.smg_loss.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.smg_backward.argtypes = [C.c_void_p, C.POINTER(SmgNet), C.c_void_p, C.c_void_p]
+    L.smg_argmax.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.smg_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
     L.smg_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]
@@ -72,6 +74,7 @@ def lib():
     L.smg_profile_kind_name.argtypes = [C.c_int]
     L.smg_profile_kind_name.restype = C.c_char_p
     L.smg_profile_read.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    L.smg_profile_read_bytes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -80,8 +83,8 @@ EXPORTS = (
     "smg_last_error", "smg_version", "smg_layout_count", "smg_layout_param_floats", "smg_layout_buffer_floats",
     "smg_layout_nbt_count", "smg_layout_entry", "smg_layout_trunk_range", "smg_layout_head_range",
     "smg_engine_create", "smg_engine_destroy", "smg_engine_workspace_bytes", "smg_engine_geometry",
-    "smg_forward", "smg_loss", "smg_backward", "smg_adam_step", "smg_debug_read",
-    "smg_profile_enable", "smg_profile_kinds", "smg_profile_kind_name", "smg_profile_read",
+    "smg_forward", "smg_loss", "smg_backward", "smg_adam_step", "smg_argmax", "smg_debug_read",
+    "smg_profile_enable", "smg_profile_kinds", "smg_profile_kind_name", "smg_profile_read", "smg_profile_read_bytes",
 )
 
 
@@ -151,7 +154,8 @@ class Engine(object):
 
     def forward(self, net, trunk_id, head_id, q_out, stream, images_nchw=None, heightmaps=None, hm_size=0,
                 mean=0.0, std=1.0, n_images=0, stream_image=(), stream_affine=(), stream_rotated=(),
-                pair_a=(), pair_b=(), bn_seq_trunk=None, bn_seq_head=None):
+                pair_a=(), pair_b=(), bn_seq_trunk=None, bn_seq_head=None, masks=None, n_masks=0, stream_mask_a=None,
+                stream_mask_b=None):
         b = SmgBatch()
         b.n_images = n_images
         b.images_nchw_dev = images_nchw
@@ -170,6 +174,11 @@ class Engine(object):
             a, p = _iarr(bn_seq_trunk); keep.append(a); b.bn_seq_trunk = p; b.n_bn_seq_trunk = len(a)
         if bn_seq_head is not None and len(bn_seq_head):
             a, p = _iarr(bn_seq_head); keep.append(a); b.bn_seq_head = p; b.n_bn_seq_head = len(a)
+        if masks is not None:
+            b.masks_dev, b.n_masks = masks, n_masks
+            a, p = _iarr(stream_mask_a); keep.append(a); b.stream_mask_a = p
+            a, p = _iarr(stream_mask_b); keep.append(a); b.stream_mask_b = p
+            assert len(stream_mask_a) == b.n_streams == len(stream_mask_b)
         check(lib().smg_forward(self.h, C.byref(net), trunk_id, head_id, C.byref(b), q_out, stream))
         self.forward_id += 1
         return self.forward_id
@@ -194,13 +203,14 @@ class Engine(object):
         check(lib().smg_profile_enable(self.h, 1 if on else 0))
 
     def profile_read(self):
-        """{kind_name: (ms, launches, flops)}"""
+        """{kind_name: (ms, launches, flops, algorithmic HBM bytes)}"""
         L = lib()
         out = {}
-        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
         for k in range(L.smg_profile_kinds()):
             check(L.smg_profile_read(self.h, k, C.byref(ms), C.byref(n), C.byref(fl)))
-            out[L.smg_profile_kind_name(k).decode()] = (ms.value, n.value, fl.value)
+            check(L.smg_profile_read_bytes(self.h, k, C.byref(by)))
+            out[L.smg_profile_kind_name(k).decode()] = (ms.value, n.value, fl.value, by.value)
         return out
 
     def profile_read_stages(self):
@@ -217,6 +227,10 @@ class Engine(object):
                 rows.append((ms.value, n.value, fl.value))
             out[L.smg_profile_kind_name(k).decode()] = rows
         return out
+
+
+def argmax(values, n, idx_out, val_out, stream):
+    check(lib().smg_argmax(values, n, idx_out, val_out, stream))
 
 
 def adam_step(params, grads, m, v, offset, count, step, lr, beta1, beta2, eps, stream):

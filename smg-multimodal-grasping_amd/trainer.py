@@ -192,53 +192,93 @@ class Trainer(object):
                                           "reference's scalar-per-rotation array (code/trainer.py:205-207)")
             return q.reshape(-1).cpu().numpy().astype(np.float64)
 
-    def forward_objects(self, depth_heightmap, mask_depth, style=0, is_target=False):
+    def _objects_on_device(self, model, depth_heightmap, mask_depth):
+        dev = model._flat_params.device
+        d = torch.from_numpy(np.ascontiguousarray(np.asarray(depth_heightmap, dtype=np.float64))[None]).to(dev)
+        m = torch.from_numpy(np.ascontiguousarray(np.asarray(mask_depth, dtype=np.float64))).to(dev)
+        if m.ndim != 3 or m.shape[1:] != d.shape[1:]:
+            raise ValueError("mask_depth must be [n_objects, H, H] like the heightmap")
+        return d, m
+
+    def forward_objects(self, depth_heightmap, mask_depth, style=0, is_target=False, return_device=False):
         """All objects of one scene in ONE engine call - the loop of code/main.py:158-166:
 
             for num in range(objects_number):
                 gra_conf[num] = trainer.forward(depth, depth * mask_depth[num], style, is_volatile=True)
 
         The rotated full-depth streams are the same for every object, so n objects x R rotations
-        cost R + n trunk passes (the reference runs 2*n*R).  BN running statistics are updated in
-        the reference's order and count.  Returns conf[n_objects, R] float64 (styles 0 / 1)."""
+        cost R + n trunk passes (the reference runs 2*n*R).  The products depth * mask[k] are formed
+        on the device by the input kernel (the host ships the heightmap and the masks once).  BN
+        running statistics are updated in the reference's order and count.
+        Returns conf[n_objects, R] float64 (styles 0 / 1), or the device tensor [n*R] if asked."""
         if self.method != 'reinforcement' or style not in (0, 1):
             raise ValueError("forward_objects: reinforcement styles 0 (grasp) and 1 (suction)")
         model = self.model_target if is_target else self.model
-        d = np.asarray(depth_heightmap, dtype=np.float64)
-        masks = np.asarray(mask_depth, dtype=np.float64)
-        n = masks.shape[0]
+        d, m = self._objects_on_device(model, depth_heightmap, mask_depth)
+        n = int(m.shape[0])
         R = model.gnum_rotations if style == 0 else model.snum_rotations
-        hm = torch.from_numpy(np.concatenate([d[None], d[None] * masks])).to(model._flat_params.device)
         pairs = [(r, k) for k in range(n) for r in range(R)]
         seq_t = [v for k in range(n) for r in range(R) for v in (r, R + k)]       # trunk(rot r), trunk(mask k) per sample
-        q = model.run_pairs(style, R, hm, list(range(R)), list(range(1, n + 1)), pairs, self.image_mean, self.image_std,
-                            bn_seq_trunk=seq_t, bn_seq_head=list(range(len(pairs))))
+        q = model.run_pairs(style, R, d, list(range(R)), [0] * n, pairs, self.image_mean, self.image_std,
+                            bn_seq_trunk=seq_t, bn_seq_head=list(range(len(pairs))),
+                            masks=m, mask_a=list(range(n)), mask_b=[-1] * n)
         if q.shape[2] * q.shape[3] != 1:
             raise NotImplementedError("dense Q maps")
+        if return_device:
+            return q.reshape(-1)
         return q.reshape(n, R).cpu().numpy().astype(np.float64)
 
-    def forward_object_pairs(self, depth_heightmap, mask_depth, is_target=False):
+    def forward_object_pairs(self, depth_heightmap, mask_depth, is_target=False, return_device=False):
         """The enveloping-then-sucking loop of code/main.py:183-192 in one engine call: for every
-        unordered object pair (g < s) the mask is mask[g] + mask[s], style 2, rotation 0.
-        Returns gs_conf[n, n] with -100 where the reference leaves its fill value (main.py:184)."""
+        unordered object pair (g < s) the mask is mask[g] + mask[s] (summed and applied on the device),
+        style 2, rotation 0.  Returns gs_conf[n, n] with -100 where the reference leaves its fill value
+        (main.py:184), or (device tensor of the pair values, [(g, s)]) if asked."""
         model = self.model_target if is_target else self.model
-        d = np.asarray(depth_heightmap, dtype=np.float64)
-        masks = np.asarray(mask_depth, dtype=np.float64)
-        n = masks.shape[0]
+        n = int(np.asarray(mask_depth).shape[0])
         gs = np.full((n, n), -100.0)
         idx = [(g, s) for g in range(n) for s in range(g + 1, n)]
         if not idx:
-            return gs
-        pm = np.stack([d * (masks[g] + masks[s]) for g, s in idx])
-        hm = torch.from_numpy(np.concatenate([d[None], pm])).to(model._flat_params.device)
+            return (None, idx) if return_device else gs
+        d, m = self._objects_on_device(model, depth_heightmap, mask_depth)
         pairs = [(0, k) for k in range(len(idx))]
         seq_t = [v for k in range(len(idx)) for v in (0, 1 + k)]
-        q = model.run_pairs(2, model.gnum_rotations, hm, [0], list(range(1, len(idx) + 1)), pairs, self.image_mean, self.image_std,
-                            bn_seq_trunk=seq_t, bn_seq_head=list(range(len(idx))))
+        q = model.run_pairs(2, model.gnum_rotations, d, [0], [0] * len(idx), pairs, self.image_mean, self.image_std,
+                            bn_seq_trunk=seq_t, bn_seq_head=list(range(len(idx))),
+                            masks=m, mask_a=[g for g, _ in idx], mask_b=[s_ for _, s_ in idx])
+        if return_device:
+            return q.reshape(-1), idx
         vals = q.reshape(-1).cpu().numpy().astype(np.float64)
         for (g, s), v in zip(idx, vals):
             gs[g, s] = v
         return gs
+
+    def best_actions(self, depth_heightmap, mask_depth, is_ets=True):
+        """The whole per-step evaluation of code/main.py:158-195 - grasp and suction sweeps over every object, the ES
+        pass over every object pair, and the three np.argmax selections - in three engine calls whose maxima are
+        found on the device (smg_argmax: lowest index on ties, like np.argmax); the host reads back three
+        (index, value) pairs instead of 2*n*R + n(n-1)/2 scalars.
+        Returns bestg_id / bests_id = (object, rotation), bestg_conf / bests_conf, and for ES bestgs_num = (g, s),
+        bestgs_conf (None / 0 with fewer than two objects, main.py:180-183)."""
+        model = self.model
+        dev = model._flat_params.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        idx = torch.empty(3, dtype=torch.int32, device=dev)
+        val = torch.zeros(3, dtype=torch.float32, device=dev)
+        R = (model.gnum_rotations, model.snum_rotations)
+        for style in (0, 1):
+            q = self.forward_objects(depth_heightmap, mask_depth, style, return_device=True)
+            smg_hip.argmax(q.data_ptr(), q.numel(), idx[style:].data_ptr(), val[style:].data_ptr(), stream)
+        pair_list = []
+        if is_ets and np.asarray(mask_depth).shape[0] > 1:
+            q, pair_list = self.forward_object_pairs(depth_heightmap, mask_depth, return_device=True)
+            smg_hip.argmax(q.data_ptr(), q.numel(), idx[2:].data_ptr(), val[2:].data_ptr(), stream)
+        i, v = idx.cpu().numpy(), val.cpu().numpy().astype(np.float64)
+        out = {"bestg_id": (int(i[0]) // R[0], int(i[0]) % R[0]), "bestg_conf": v[0],
+               "bests_id": (int(i[1]) // R[1], int(i[1]) % R[1]), "bests_conf": v[1],
+               "bestgs_num": None, "bestgs_conf": 0}
+        if pair_list:
+            out["bestgs_num"], out["bestgs_conf"] = pair_list[int(i[2])], v[2]
+        return out
 
     def get_label_value(self, primitive_action, objects_number,
                         suction_success, grasp_success, gs_success,

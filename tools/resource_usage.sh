@@ -1,0 +1,18 @@
+#!/bin/bash
+# dev helper: VGPR / scratch / occupancy / LDS of every kernel in engine.hip (hipcc -Rpass-analysis=kernel-resource-usage)
+cd "$(dirname "$0")/../smg-multimodal-grasping_amd/csrc"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Rpass-analysis=kernel-resource-usage -c engine.hip -o /dev/null 2>&1 | python3 -c "
+import sys,re,subprocess
+cur=None;rows=[]
+for l in sys.stdin:
+    m=re.search(r'Function Name: (\S+)',l)
+    if m: cur={'name':m.group(1)}; rows.append(cur)
+    for key,pat in [('V',r' VGPRs: (\d+)'),('A',r'AGPRs: (\d+)'),('scr',r'ScratchSize \[bytes/lane\]: (\d+)'),('occ',r'Occupancy \[waves/SIMD\]: (\d+)'),('lds',r'LDS Size \[bytes/block\]: (\d+)'),('S',r' SGPRs: (\d+)')]:
+        m=re.search(pat,l)
+        if m and cur is not None: cur[key]=m.group(1)
+names=subprocess.run(['c++filt']+[r['name'] for r in rows],capture_output=True,text=True).stdout.split('\n')
+for r,n in zip(rows,names):
+    n=n.replace('smg::','').replace('GemmCfg','Cfg')
+    n=re.sub(r'\(.*','',n)
+    print(n[:100].ljust(100),'V',r.get('V'),'A',r.get('A'),'S',r.get('S'),'scr',r.get('scr'),'occ',r.get('occ'),'lds',r.get('lds'))
+"
