@@ -144,6 +144,13 @@ int smg_loss(smg_engine* e, int mode, const float* q_dev, const float* labels_de
  * code/trainer.py:350-351. */
 int smg_backward(smg_engine* e, const smg_net* net, const float* dq_dev, void* stream);
 
+/* Operand precision of every matrix product of the engine:
+ *   0  fp32-class (default): each fp32 operand as three bf16 pieces, six MFMA terms per product - what the reference's
+ *      apex O0 arithmetic (code/trainer.py:101) is gated against;
+ *   1  bf16 operands, 2  fp16 operands: one MFMA term per product (BASELINE.json configs 3 and 5).
+ * Activations, gradients, BN statistics and every accumulation stay fp32.  Takes effect with the next smg_forward. */
+int smg_engine_set_precision(smg_engine* e, int precision);
+
 /* Index and value of the largest of n float32 values (lowest index on ties, like np.argmax at
  * code/main.py:172-173,195), on the device: idx_out_dev int32[1], val_out_dev float32[1]. */
 int smg_argmax(const float* values_dev, int n, int* idx_out_dev, float* val_out_dev, void* stream);

@@ -95,7 +95,7 @@ __global__ void prep_rotate_kernel(const PrepArgs a) {
 enum { PK_T1 = 0, PK_D1 = 1, PK_3F = 2, PK_3D = 3, PK_STEM = 4, PK_HEAD = 5, PK_HF = 6, PK_HD = 7 };
 struct PackDesc { int64_t src, dst; int cout, cin, mode, K8tot, N, count; };   // dst: unit offset (split modes) / float offset (fp32 modes)
 
-__global__ void pack_weights_kernel(const PackDesc* descs, const float* params, u32x4* packed_u, float* packed_f) {
+__global__ void pack_weights_kernel(const PackDesc* descs, const float* params, u32x4* packed_u, float* packed_f, const int prec) {
     const PackDesc d = descs[blockIdx.y];
     const float* s = params + d.src;
     if (d.mode == PK_HEAD) {                       // fp32 dst[o][tap][c] = src[o][c][tap] (value convolution)
@@ -128,7 +128,9 @@ __global__ void pack_weights_kernel(const PackDesc* descs, const float* params, 
                 for (int j = 0; j < 8; ++j) v[j] = s[((int64_t)(8 * k8 + j) * d.cin + cg * 32 + c) * 9 + tap];
                 base = (((int64_t)cg * 9 + tap) * NPIECE) * 128 + k8 * 32 + c; pstride = 128;
             }
-            const Split4 lo = split4(make_float4(v[0], v[1], v[2], v[3])), hi = split4(make_float4(v[4], v[5], v[6], v[7]));
+            const float4 v0 = make_float4(v[0], v[1], v[2], v[3]), v1 = make_float4(v[4], v[5], v[6], v[7]);
+            const Split4 lo = prec == 0 ? split4<0>(v0) : prec == 1 ? split4<1>(v0) : split4<2>(v0);
+            const Split4 hi = prec == 0 ? split4<0>(v1) : prec == 1 ? split4<1>(v1) : split4<2>(v1);
 #pragma unroll
             for (int pc = 0; pc < NPIECE; ++pc) o[base + pc * pstride] = u32x4{lo.p[pc].x, lo.p[pc].y, hi.p[pc].x, hi.p[pc].y};
         }
@@ -155,7 +157,9 @@ __global__ void pack_weights_kernel(const PackDesc* descs, const float* params, 
                 v[j] = (c < 3 && tap < 49) ? s[((int64_t)n * 3 + c) * 49 + tap] : 0.f;
             }
         }
-        const Split4 lo = split4(make_float4(v[0], v[1], v[2], v[3])), hi = split4(make_float4(v[4], v[5], v[6], v[7]));
+        const float4 v0 = make_float4(v[0], v[1], v[2], v[3]), v1 = make_float4(v[4], v[5], v[6], v[7]);
+            const Split4 lo = prec == 0 ? split4<0>(v0) : prec == 1 ? split4<1>(v0) : split4<2>(v0);
+            const Split4 hi = prec == 0 ? split4<0>(v1) : prec == 1 ? split4<1>(v1) : split4<2>(v1);
 #pragma unroll
         for (int pc = 0; pc < NPIECE; ++pc) o[(int64_t)pc * total + e] = u32x4{lo.p[pc].x, lo.p[pc].y, hi.p[pc].x, hi.p[pc].y};
     }

@@ -127,6 +127,7 @@ struct smg_engine {
     int so_image = 0, so_rot = 0, so_pa = 0, so_pb = 0, so_seq_t = 0, so_seq_h = 0, so_uptr = 0, so_upair = 0, so_uslot = 0, so_aff = 0, so_ma = 0, so_mb = 0;
     int64_t workspace_bytes = 0;
     int n_cu = 256;            // compute units of the device (persistent-launch sizing)
+    int prec = 0;              // operand precision of the matrix products: 0 fp32-class split, 1 bf16, 2 fp16 (smg_engine_set_precision)
     bool generic3x3 = false;   // SMG_GENERIC_3X3=1: dense-layer 3x3 convs through the generic implicit GEMM (A/B testing)
     // profiling
     bool prof = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> ev_pool;
@@ -198,14 +199,22 @@ struct ProfScope {
     }
 };
 
+// Runs CALL with a compile-time PREC equal to the engine's run-time precision setting.
+#define PREC_DISPATCH(e, CALL)                                            \
+    switch ((e)->prec) {                                                  \
+        case 1: { constexpr int PREC = 1; CALL; } break;                  \
+        case 2: { constexpr int PREC = 2; CALL; } break;                  \
+        default: { constexpr int PREC = 0; CALL; } break;                 \
+    }
+
 template <class P>
 static void launch_gemm(smg_engine* e, hipStream_t st, P p, dim3 grid, int kind, double flops) {
     const size_t smem = (size_t)(P::Cfg::TILE_FLOATS + p.param_floats()) * sizeof(float);
     if (smem > 64 * 1024) {      // more dynamic LDS than the default limit: raise it once per (instantiation, device)
-        static bool raised[64] = {};
-        if (!raised[e->device & 63]) {
-            (void)hipFuncSetAttribute((const void*)gemm_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            raised[e->device & 63] = true;
+        static bool raised[64][3] = {};
+        if (!raised[e->device & 63][e->prec]) {
+            PREC_DISPATCH(e, (void)hipFuncSetAttribute((const void*)gemm_kernel<P, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised[e->device & 63][e->prec] = true;
         }
     }
     p.tm = TileMap{0, 0, 0};
@@ -235,7 +244,7 @@ static void launch_gemm(smg_engine* e, hipStream_t st, P p, dim3 grid, int kind,
     }
     {
         ProfScope ps(e, st, kind, flops);
-        hipLaunchKernelGGL(gemm_kernel<P>, dim3((unsigned)n_wg), dim3(256), smem, st, p, (int)grid.x, (int)grid.y);
+        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_kernel<P, PREC>), dim3((unsigned)n_wg), dim3(256), smem, st, p, (int)grid.x, (int)grid.y));
     }
     if (tracing) {
         unsigned long long* nul = nullptr;
@@ -296,8 +305,9 @@ static int engine_build(smg_engine* e) {
     if (e->OH < 1) return fail(-22, "input_size too small for the 20x20 value head");
 
     // the 16x16 data-gradient halo kernel needs more than the default 64 KB of dynamic LDS
-    HIP_OK(hipFuncSetAttribute((const void*)conv3x3_halo_dgrad_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               HaloDgradSGeo<16>::smem_bytes(kBottleneck)));
+    HIP_OK(hipFuncSetAttribute((const void*)conv3x3_halo_dgrad_kernel<16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloDgradSGeo<16>::smem_bytes(kBottleneck)));
+    HIP_OK(hipFuncSetAttribute((const void*)conv3x3_halo_dgrad_kernel<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloDgradSGeo<16>::smem_bytes(kBottleneck)));
+    HIP_OK(hipFuncSetAttribute((const void*)conv3x3_halo_dgrad_kernel<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloDgradSGeo<16>::smem_bytes(kBottleneck)));
     const char* g3 = getenv("SMG_GENERIC_3X3");
     e->generic3x3 = g3 && g3[0] == '1';
 
@@ -560,7 +570,7 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
         const unsigned n_pack = (unsigned)(e->h_pack[trunk_id].size() + e->h_pack_head[head_id].size());
         ProfScope ps(e, st, K_OTHER, 0);
         hipLaunchKernelGGL(pack_weights_kernel, dim3(64, n_pack), dim3(256), 0, st,
-                           e->d_pack + (trunk_id * 3 + head_id) * e->pack_stride, net->params, e->packed_u, e->packed_f);
+                           e->d_pack + (trunk_id * 3 + head_id) * e->pack_stride, net->params, e->packed_u, e->packed_f, e->prec);
     }
     const float* P = net->params;
 
@@ -664,12 +674,12 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
                     ProfScope ps(e, cs, K_C3, 2.0 * ns * pl.HW * 9 * kBottleneck * kGrowth);
                     if (halo_tile(pl, ns) == 16) {
                         a.tiles_x = pl.W / 16;
-                        hipLaunchKernelGGL(conv3x3_halo_fwd_kernel<16>, dim3((pl.H / 16) * a.tiles_x, ns), dim3(256),
-                                           HaloFwdSGeo<16>::smem_bytes(kBottleneck), cs, a);
+                        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_fwd_kernel<16, PREC>), dim3((pl.H / 16) * a.tiles_x, ns), dim3(256),
+                                           HaloFwdSGeo<16>::smem_bytes(kBottleneck), cs, a));
                     } else {
                         a.tiles_x = (pl.W + 7) / 8;
-                        hipLaunchKernelGGL(conv3x3_halo_fwd_kernel<8>, dim3(((pl.H + 7) / 8) * a.tiles_x, ns), dim3(256),
-                                           HaloFwdSGeo<8>::smem_bytes(kBottleneck), cs, a);
+                        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_fwd_kernel<8, PREC>), dim3(((pl.H + 7) / 8) * a.tiles_x, ns), dim3(256),
+                                           HaloFwdSGeo<8>::smem_bytes(kBottleneck), cs, a));
                     }
                 } else {   // norm2 + relu + conv2 (3x3, 128 -> 32), appended to the block buffer (generic implicit GEMM)
                     auto run = [&](auto tag) {
@@ -901,12 +911,12 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 ProfScope ps(e, st, K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
                 if (halo_tile(pl, NS) == 16) {
                     a.tiles_x = pl.W / 16; a.cg_per_wg = kBottleneck / 32;
-                    hipLaunchKernelGGL(conv3x3_halo_dgrad_kernel<16>, dim3((pl.H / 16) * a.tiles_x, NS), dim3(256),
-                                       HaloDgradSGeo<16>::smem_bytes(kBottleneck), st, a);
+                    PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_dgrad_kernel<16, PREC>), dim3((pl.H / 16) * a.tiles_x, NS), dim3(256),
+                                       HaloDgradSGeo<16>::smem_bytes(kBottleneck), st, a));
                 } else {
                     a.tiles_x = (pl.W + 7) / 8; a.cg_per_wg = 1;      // small planes: one 64-channel group per workgroup
-                    hipLaunchKernelGGL(conv3x3_halo_dgrad_kernel<8>, dim3(((pl.H + 7) / 8) * a.tiles_x, NS, kBottleneck / 64), dim3(256),
-                                       HaloDgradSGeo<8>::smem_bytes(kBottleneck), st, a);
+                    PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_dgrad_kernel<8, PREC>), dim3(((pl.H + 7) / 8) * a.tiles_x, NS, kBottleneck / 64), dim3(256),
+                                       HaloDgradSGeo<8>::smem_bytes(kBottleneck), st, a));
                 }
             } else {   // conv2 (3x3) data gradient -> dy of relu2/norm2 (D2) + norm2 sums (generic implicit GEMM)
                 auto run = [&](auto tag) {
@@ -939,12 +949,13 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 {
                     BY(e, 4.0 * NS * pl.HW * (kGrowth + kBottleneck));
                     ProfScope ps(e, s2, K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
-                    if (ts == 16)
-                        hipLaunchKernelGGL(conv3x3_halo_wgrad_kernel<16>, dim3(groups, kBottleneck / 32, NS), dim3(256),
-                                           HaloWgradSGeo<16>::smem_bytes(), s2, a);
-                    else
-                        hipLaunchKernelGGL(conv3x3_halo_wgrad_kernel<8>, dim3(groups, kBottleneck / 32, NS), dim3(256),
-                                           HaloWgradSGeo<8>::smem_bytes(), s2, a);
+                    if (ts == 16) {
+                        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_wgrad_kernel<16, PREC>), dim3(groups, kBottleneck / 32, NS), dim3(256),
+                                                            HaloWgradSGeo<16>::smem_bytes(), s2, a));
+                    } else {
+                        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_wgrad_kernel<8, PREC>), dim3(groups, kBottleneck / 32, NS), dim3(256),
+                                                            HaloWgradSGeo<8>::smem_bytes(), s2, a));
+                    }
                 }
                 ReduceArgs r;
                 r.part = e->part; r.Z = groups * NS; r.taps = 9; r.rows = kGrowth; r.cols = kBottleneck; r.ldp = kBottleneck;
@@ -1234,6 +1245,14 @@ int smg_backward(smg_engine* e, const smg_net* net, const float* dq_dev, void* s
     if (!e || !net || !dq_dev) return fail(-22, "NULL argument");
     HIP_OK(hipSetDevice(e->device));
     return do_backward(e, net, dq_dev, (hipStream_t)stream);
+}
+
+int smg_engine_set_precision(smg_engine* e, int precision) {
+    if (!e) return fail(-22, "engine is NULL");
+    if (precision < 0 || precision > 2) return fail(-22, "precision must be 0 (fp32-class split), 1 (bf16 operands) or 2 (fp16 operands)");
+    e->prec = precision;
+    e->have_fwd = false;        // activations saved by a forward of another precision are not backward-compatible
+    return 0;
 }
 
 int smg_argmax(const float* values_dev, int n, int* idx_out_dev, float* val_out_dev, void* stream) {

@@ -49,6 +49,20 @@
 
 #include <type_traits>
 
+// dev knobs: k-tiles of global loads in flight per policy family (register ring depth of the staging pipeline)
+#ifndef SMG_PD_FWD_SMALL
+#define SMG_PD_FWD_SMALL 1
+#endif
+#ifndef SMG_PD_FWD_BIG
+#define SMG_PD_FWD_BIG 1
+#endif
+#ifndef SMG_PD_DGRAD
+#define SMG_PD_DGRAD 1
+#endif
+#ifndef SMG_PD_WGRAD
+#define SMG_PD_WGRAD 1
+#endif
+
 namespace smg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -63,6 +77,14 @@ struct Plane { int H, W, HW, HWp; };
 // Split precision.
 // ------------------------------------------------------------------------------------
 constexpr int NPIECE = 3;
+// Operand precision of the matrix products (compile-time PREC of every MFMA kernel; smg_engine_set_precision picks the
+// instantiation):
+//   0  fp32-class: 3-piece bf16 split, six MFMA terms (default; what the parity suite gates)
+//   1  bf16 operands: the hi piece only, ONE v_mfma_f32_32x32x16_bf16 per product   (BASELINE.json config 3)
+//   2  fp16 operands: round-to-nearest fp16, ONE v_mfma_f32_32x32x16_f16 per product (config 5)
+// Activations, gradients, BN statistics and the accumulation stay fp32 in every mode.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // bf16 pieces of 4 floats (element 0 in the low half of .x): 8 bytes per piece
 struct Split4 { uint2 p[NPIECE]; };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -77,11 +99,21 @@ __device__ __forceinline__ unsigned pack_bf16(float lo_elem, float hi_elem) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 #endif
+__device__ __forceinline__ unsigned pack_f16(float lo_elem, float hi_elem) {
+    const f32x2 v = {lo_elem, hi_elem};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
 // x = hi + mid + lo: the residuals x - hi and (x - hi) - mid are exact in fp32, the last one has <= 9 significant bits
+template <int PREC = 0>
 __device__ __forceinline__ Split4 split4(float4 v) {
     Split4 o;
+    if constexpr (PREC != 0) {                           // single-piece modes
+        o.p[0] = PREC == 1 ? make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)) : make_uint2(pack_f16(v.x, v.y), pack_f16(v.z, v.w));
+        o.p[1] = o.p[2] = make_uint2(0u, 0u);
+        return o;
+    }
     const unsigned h01 = pack_bf16(v.x, v.y), h23 = pack_bf16(v.z, v.w);
     const float r0 = v.x - bf16_lo(h01), r1 = v.y - bf16_hi(h01), r2 = v.z - bf16_lo(h23), r3 = v.w - bf16_hi(h23);
     const unsigned m01 = pack_bf16(r0, r1), m23 = pack_bf16(r2, r3);
@@ -95,6 +127,14 @@ __device__ __forceinline__ Split4 split4(float4 v) {
 struct Frag { u32x4 p[NPIECE]; };
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_f16(const u32x4& a, const u32x4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// one term of a single-piece mode
+template <int PREC>
+__device__ __forceinline__ f32x16 mfma_1p(const u32x4& a, const u32x4& b, f32x16 c) {
+    if constexpr (PREC == 2) return mfma_f16(a, b, c); else return mfma_bf16(a, b, c);
 }
 // acc[i][j] += A_i * B_j for a TM x TN grid of tiles: six piece products, small terms first, tiles innermost so that
 // consecutive MFMAs never share an accumulator.
@@ -279,7 +319,7 @@ struct VBlock { int x, y, z, linear; };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-template <class P>
+template <class P, int PREC>
 __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* smem) {
     using C = typename P::Cfg;
     char* As = reinterpret_cast<char*>(smem);
@@ -361,9 +401,9 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
             for (int i = 0; i < C::A_N; ++i) {
                 const int row = al + i * C::A_STEP;
                 if (C::A_FULL || row < C::BM) {
-                    const Split4 s = split4(p.a_xform(ctx, xa[i], kf, kt, aq, sp));
+                    const Split4 s = split4<PREC>(p.a_xform(ctx, xa[i], kf, kt, aq, sp));
 #pragma unroll
-                    for (int pc = 0; pc < NPIECE; ++pc)
+                    for (int pc = 0; pc < (PREC ? 1 : NPIECE); ++pc)
                         *reinterpret_cast<uint2*>(A + ((pc * C::K8 + (aq >> 1)) * C::LDUA + row) * 16 + (aq & 1) * 8) = s.p[pc];
                 }
             }
@@ -377,9 +417,9 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
             for (int i = 0; i < C::A_N; ++i) {
                 const int kr = al + i * C::A_STEP;
                 if (C::A_FULL || kr < C::BK) {
-                    const Split4 s = split4(p.a_xform(ctx, xa[i], KPrm0{}, kt, aq, sp));
+                    const Split4 s = split4<PREC>(p.a_xform(ctx, xa[i], KPrm0{}, kt, aq, sp));
 #pragma unroll
-                    for (int pc = 0; pc < NPIECE; ++pc)
+                    for (int pc = 0; pc < (PREC ? 1 : NPIECE); ++pc)
                         *reinterpret_cast<uint2*>(A + ((pc * C::BK + kr) * C::LDTA + 4 * aq) * 2) = s.p[pc];
                 }
             }
@@ -387,9 +427,9 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
             for (int i = 0; i < C::B_N; ++i) {
                 const int kr = bl + i * C::B_STEP;
                 if (C::B_FULL || kr < C::BK) {
-                    const Split4 s = split4(p.b_xform(ctx, xb[i], kt, bq, sp));
+                    const Split4 s = split4<PREC>(p.b_xform(ctx, xb[i], kt, bq, sp));
 #pragma unroll
-                    for (int pc = 0; pc < NPIECE; ++pc)
+                    for (int pc = 0; pc < (PREC ? 1 : NPIECE); ++pc)
                         *reinterpret_cast<uint2*>(B + ((pc * C::BK + kr) * C::LDTB + 4 * bq) * 2) = s.p[pc];
                 }
             }
@@ -421,37 +461,50 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
 #pragma unroll
         for (int s = 0; s < C::KS; ++s) {
             u32x4 ah[C::TM], bh[C::TN];
-            {
-                u32x4 al_[C::TM], bl_[C::TN];
 #pragma unroll
-                for (int i = 0; i < C::TM; ++i) { ah[i] = frag(A, C::LDUA, C::LDTA, wm0 + i * 32, s, 0); al_[i] = frag(A, C::LDUA, C::LDTA, wm0 + i * 32, s, 2); }
+            for (int i = 0; i < C::TM; ++i) ah[i] = frag(A, C::LDUA, C::LDTA, wm0 + i * 32, s, 0);
 #pragma unroll
-                for (int j = 0; j < C::TN; ++j) { bh[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 0); bl_[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 2); }
-                __builtin_amdgcn_sched_barrier(0);   // keep every ds_read ahead of the MFMA block (hipcc re-interleaves them otherwise)
-#pragma unroll
-                for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < C::TN; ++j) acc[i][j] = mfma_bf16(ah[i], bl_[j], acc[i][j]);
+            for (int j = 0; j < C::TN; ++j) bh[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 0);
+            if constexpr (PREC != 0) {       // single-piece modes: one term per tile
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < C::TN; ++j) acc[i][j] = mfma_bf16(al_[i], bh[j], acc[i][j]);
+                    for (int j = 0; j < C::TN; ++j) acc[i][j] = mfma_1p<PREC>(ah[i], bh[j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                {
+                    u32x4 al_[C::TM], bl_[C::TN];
+#pragma unroll
+                    for (int i = 0; i < C::TM; ++i) al_[i] = frag(A, C::LDUA, C::LDTA, wm0 + i * 32, s, 2);
+#pragma unroll
+                    for (int j = 0; j < C::TN; ++j) bl_[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 2);
+                    __builtin_amdgcn_sched_barrier(0);   // keep every ds_read ahead of the MFMA block (hipcc re-interleaves them otherwise)
+#pragma unroll
+                    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::TN; ++j) acc[i][j] = mfma_bf16(ah[i], bl_[j], acc[i][j]);
+#pragma unroll
+                    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::TN; ++j) acc[i][j] = mfma_bf16(al_[i], bh[j], acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                u32x4 am[C::TM], bm[C::TN];
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i) am[i] = frag(A, C::LDUA, C::LDTA, wm0 + i * 32, s, 1);
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j) bm[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::TN; ++j)
+                            acc[i][j] = mfma_bf16((g & 1) ? ah[i] : am[i], g < 2 ? bm[j] : bh[j], acc[i][j]);   // mid*mid, hi*mid, mid*hi, hi*hi
                 __builtin_amdgcn_sched_barrier(0);
             }
-            u32x4 am[C::TM], bm[C::TN];
-#pragma unroll
-            for (int i = 0; i < C::TM; ++i) am[i] = frag(A, C::LDUA, C::LDTA, wm0 + i * 32, s, 1);
-#pragma unroll
-            for (int j = 0; j < C::TN; ++j) bm[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < C::TN; ++j)
-                        acc[i][j] = mfma_bf16((g & 1) ? ah[i] : am[i], g < 2 ? bm[j] : bh[j], acc[i][j]);   // mid*mid, hi*mid, mid*hi, hi*hi
-            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -515,7 +568,7 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
 // One workgroup per virtual block (x fastest).  A persistent variant (resident workgroups striding over the virtual
 // grid) was measured and rejected: hipcc hoists the per-thread addressing out of the tile loop (+50..70 VGPRs, one
 // workgroup less per CU) and the launch is not dispatch-bound.
-template <class P>
+template <class P, int PREC = 0>
 __global__ __launch_bounds__(256, P::kMinWaves) void gemm_kernel(const P p, const int vgx, const int vgy) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     VBlock vb;
@@ -524,7 +577,7 @@ __global__ __launch_bounds__(256, P::kMinWaves) void gemm_kernel(const P p, cons
     const int q = vb.linear / vgx;
     vb.y = q % vgy;
     vb.z = q / vgy;
-    gemm_tile(p, vb, smem);
+    gemm_tile<P, PREC>(p, vb, smem);
 }
 
 // Accumulator element (tm, tn, reg) of this lane sits at tile row / column:
@@ -559,12 +612,9 @@ struct FwdConvP {
     double* dsum; double* dsq; int dstride;
     TileMap tm;
     static constexpr int kSwizzle = 1;
-#ifndef SMG_SMALL_PD
-#define SMG_SMALL_PD 1
-#endif
     // k-tiles of global loads in flight: the one-MFMA-tile-per-wave configurations of the small planes do 0.1 us of MFMAs per
     // k-tile against ~1 us of memory latency
-    static constexpr int kPrefetch = (Cfg::TM * Cfg::TN == 1) ? SMG_SMALL_PD : 1;
+    static constexpr int kPrefetch = (Cfg::TM * Cfg::TN == 1) ? SMG_PD_FWD_SMALL : SMG_PD_FWD_BIG;
     static constexpr bool kSegmented = false;
     static constexpr bool kHasPrologue = MODE != F_STEM;
     static constexpr int kFresh = 32;       // growth rate: at most this many fresh channels
@@ -647,34 +697,36 @@ struct FwdConvP {
         }
         return f;
     }
+    // Unconditional loads from clamped addresses (rows of the plane padding / taps outside the image read pixel 0 and are
+    // zeroed at the LDS store): a branch around a staged load makes hipcc drain vmcnt(0) before the next load group.
     __device__ ARaw a_fetch(const Ctx& c, const ARow& r, int kt, int q) const {
         ARaw o;
         if constexpr (MODE == F_ONE) {
             o.ok = r.valid;
-            o.v[0] = o.ok ? ld4(src + ((int64_t)c.n * ps.HWp + r.y * ps.W + r.x) * lds_ + a_chan(kt, q)) : zero4();
+            o.v[0] = ld4(src + ((int64_t)c.n * ps.HWp + (o.ok ? r.y * ps.W + r.x : 0)) * lds_ + a_chan(kt, q));
         } else if constexpr (MODE == F_THREE) {
             const int tap = kt / (K / Cfg::BK);
             const int yy = r.y + tap / 3 - 1, xx = r.x + tap % 3 - 1;
             o.ok = r.valid && (unsigned)yy < (unsigned)ps.H && (unsigned)xx < (unsigned)ps.W;
-            o.v[0] = o.ok ? ld4(src + ((int64_t)c.n * ps.HWp + yy * ps.W + xx) * lds_ + a_chan(kt, q)) : zero4();
+            o.v[0] = ld4(src + ((int64_t)c.n * ps.HWp + (o.ok ? yy * ps.W + xx : 0)) * lds_ + a_chan(kt, q));
         } else if constexpr (MODE == F_POOL) {
             o.ok = r.valid;
-            const float* b = src + ((int64_t)c.n * ps.HWp + (2 * r.y) * ps.W + 2 * r.x) * lds_ + a_chan(kt, q);
-            o.v[0] = o.ok ? ld4(b) : zero4();
-            o.v[1] = o.ok ? ld4(b + lds_) : zero4();
-            o.v[2] = o.ok ? ld4(b + (int64_t)ps.W * lds_) : zero4();
-            o.v[3] = o.ok ? ld4(b + (int64_t)(ps.W + 1) * lds_) : zero4();
+            const float* b = src + ((int64_t)c.n * ps.HWp + (o.ok ? (2 * r.y) * ps.W + 2 * r.x : 0)) * lds_ + a_chan(kt, q);
+            o.v[0] = ld4(b);
+            o.v[1] = ld4(b + lds_);
+            o.v[2] = ld4(b + (int64_t)ps.W * lds_);
+            o.v[3] = ld4(b + (int64_t)(ps.W + 1) * lds_);
         } else {
             const int tap = kt * (Cfg::BK / 4) + q;
             const int yy = 2 * r.y + tap / 7 - 3, xx = 2 * r.x + tap % 7 - 3;
             o.ok = r.valid && tap < 49 && (unsigned)yy < (unsigned)ps.H && (unsigned)xx < (unsigned)ps.W;
-            o.v[0] = o.ok ? ld4(src + ((int64_t)c.n * ps.HWp + yy * ps.W + xx) * 4) : zero4();
+            o.v[0] = ld4(src + ((int64_t)c.n * ps.HWp + (o.ok ? yy * ps.W + xx : 0)) * 4);
         }
         return o;
     }
     __device__ float4 a_xform(const Ctx&, const ARaw& o, const KFin& k, int, int, const float*) const {
         if constexpr (MODE == F_STEM) {
-            return o.v[0];
+            return o.ok ? o.v[0] : zero4();
         } else {
             if (!o.ok) return zero4();                   // zero padding applies AFTER bn + relu
             if constexpr (MODE == F_POOL) {
@@ -802,7 +854,7 @@ struct BwdDataP {
     float eps;
     TileMap tm;
     static constexpr int kSwizzle = 1;
-    static constexpr int kPrefetch = 1;
+    static constexpr int kPrefetch = (Cfg::TM * Cfg::TN <= 2) ? SMG_PD_DGRAD : 1;
     static constexpr bool kSegmented = false;
     static constexpr bool kHasPrologue = true;
     static constexpr int kMinWaves = 1;
@@ -881,14 +933,14 @@ struct BwdDataP {
             o.ok = r.valid && (unsigned)yy < (unsigned)pa.H && (unsigned)xx < (unsigned)pa.W;
         }
         const int ch = a_chan(kt, q);
-        const int64_t pix = (int64_t)c.n * pa.HWp + yy * pa.W + xx;
-        o.v[0] = o.ok ? ld4(gbuf + pix * ldg + gcoff + ch) : zero4();
-        o.v[1] = (o.ok && xbuf) ? ld4(xbuf + pix * ldx + xcoff + ch) : zero4();
+        const int64_t pix = (int64_t)c.n * pa.HWp + (o.ok ? yy * pa.W + xx : 0);      // unconditional loads, clamped address
+        o.v[0] = ld4(gbuf + pix * ldg + gcoff + ch);
+        if (xbuf) o.v[1] = ld4(xbuf + pix * ldx + xcoff + ch);                       // (launch-uniform)
         return o;
     }
     __device__ float4 a_xform(const Ctx&, const ARaw& o, const KPrm&, int kt, int q, const float* sp) const {
-        if (!xbuf) return o.v[0];                      // gradient already BN-corrected (bn_bwd_apply_kernel)
         if (!o.ok) return zero4();
+        if (!xbuf) return o.v[0];                      // gradient already BN-corrected (bn_bwd_apply_kernel)
         return affine2(o.v[0], o.v[1], sp + a_chan(kt, q), KA);
     }
     __device__ ARaw a_fetch_d(const Ctx&, const DRow&, int, int, int) const { return ARaw{}; }
@@ -1049,7 +1101,7 @@ struct BwdDataGroupP {
     float eps;
     TileMap tm;
     static constexpr int kSwizzle = 1;
-    static constexpr int kPrefetch = 1;
+    static constexpr int kPrefetch = (Cfg::TM * Cfg::TN <= 1) ? SMG_PD_DGRAD : 1;
     static constexpr bool kSegmented = true;
     static constexpr bool kHasPrologue = true;
     static constexpr int kMinWaves = 3;       // 160 registers without spilling: 3 workgroups per CU instead of 2 (-0.4 ms per step)
@@ -1266,7 +1318,7 @@ struct BwdDataGroupP {
 enum { W_ONE = 0, W_THREE = 1, W_POOL = 2, W_STEM = 3 };
 enum { C_IDENT = 0, C_3x3 = 1, C_STEM = 2 };
 
-template <class Cfg_, int BMODE, int CMAP, int PD_ = 1>
+template <class Cfg_, int BMODE, int CMAP, int PD_ = SMG_PD_WGRAD>
 struct BwdWeightP {
     using Cfg = Cfg_;
     static_assert(!Cfg::AT, "weight-gradient form");
@@ -1378,18 +1430,21 @@ struct BwdWeightP {
     using ARaw = RawT<2>;
     using BRaw = RawT<(BMODE == W_POOL) ? 4 : 1>;
     __device__ ARaw a_fetch(const Ctx&, const ARow&, int, int) const { return ARaw{}; }
+    // Unconditional loads from clamped addresses (pixel 0 / channel 0 of the stream where the slot lies outside the plane or
+    // the matrix; zeroed at the LDS store): a branch around a staged load makes hipcc drain vmcnt(0) between load groups.
     __device__ ARaw a_fetch_d(const Ctx& c, const DRow& r, int, int, int q) const {
         ARaw o;
         const int ch = c.m0 + 4 * q;
         o.ok = r.p < pa.HW && ch < MA;
-        const int64_t pix = (int64_t)c.n * pa.HWp + r.p;
-        o.v[0] = o.ok ? ld4(gbuf + pix * ldg + gcoff + ch) : zero4();
-        o.v[1] = (o.ok && xbuf) ? ld4(xbuf + pix * ldx + xcoff + ch) : zero4();
+        const int64_t pix = (int64_t)c.n * pa.HWp + (o.ok ? r.p : 0);
+        const int chc = o.ok ? ch : 0;
+        o.v[0] = ld4(gbuf + pix * ldg + gcoff + chc);
+        if (xbuf) o.v[1] = ld4(xbuf + pix * ldx + xcoff + chc);          // (launch-uniform)
         return o;
     }
     __device__ float4 a_xform(const Ctx&, const ARaw& o, const KPrm&, int, int q, const float* sp) const {
-        if (!xbuf) return o.v[0];
         if (!o.ok) return zero4();
+        if (!xbuf) return o.v[0];
         return affine2(o.v[0], o.v[1], sp + 4 * q, Cfg::BM);
     }
     __device__ BRaw b_fetch(const Ctx& c, const DRow& r, int, int, int q) const {
@@ -1397,28 +1452,28 @@ struct BwdWeightP {
         const int ch = c.n0 + 4 * q;
         o.ok = r.p < pa.HW && ch < NB;
         if constexpr (BMODE == W_ONE) {
-            o.v[0] = o.ok ? ld4(bbuf + ((int64_t)c.n * pb.HWp + r.p) * ldb + ch) : zero4();
+            o.v[0] = ld4(bbuf + ((int64_t)c.n * pb.HWp + (o.ok ? r.p : 0)) * ldb + (o.ok ? ch : 0));
         } else if constexpr (BMODE == W_THREE) {
             const int yy = r.y + c.tap / 3 - 1, xx = r.x + c.tap % 3 - 1;
             o.ok = o.ok && (unsigned)yy < (unsigned)pb.H && (unsigned)xx < (unsigned)pb.W;
-            o.v[0] = o.ok ? ld4(bbuf + ((int64_t)c.n * pb.HWp + yy * pb.W + xx) * ldb + ch) : zero4();
+            o.v[0] = ld4(bbuf + ((int64_t)c.n * pb.HWp + (o.ok ? yy * pb.W + xx : 0)) * ldb + (o.ok ? ch : 0));
         } else if constexpr (BMODE == W_POOL) {
-            const float* b = bbuf + ((int64_t)c.n * pb.HWp + (2 * r.y) * pb.W + 2 * r.x) * ldb + ch;
-            o.v[0] = o.ok ? ld4(b) : zero4();
-            o.v[1] = o.ok ? ld4(b + ldb) : zero4();
-            o.v[2] = o.ok ? ld4(b + (int64_t)pb.W * ldb) : zero4();
-            o.v[3] = o.ok ? ld4(b + (int64_t)(pb.W + 1) * ldb) : zero4();
+            const float* b = bbuf + ((int64_t)c.n * pb.HWp + (o.ok ? (2 * r.y) * pb.W + 2 * r.x : 0)) * ldb + (o.ok ? ch : 0);
+            o.v[0] = ld4(b);
+            o.v[1] = ld4(b + ldb);
+            o.v[2] = ld4(b + (int64_t)pb.W * ldb);
+            o.v[3] = ld4(b + (int64_t)(pb.W + 1) * ldb);
         } else {
             const int tap = ch >> 2;
             const int yy = 2 * r.y + tap / 7 - 3, xx = 2 * r.x + tap % 7 - 3;
             o.ok = o.ok && tap < 49 && (unsigned)yy < (unsigned)pb.H && (unsigned)xx < (unsigned)pb.W;
-            o.v[0] = o.ok ? ld4(bbuf + ((int64_t)c.n * pb.HWp + yy * pb.W + xx) * 4) : zero4();
+            o.v[0] = ld4(bbuf + ((int64_t)c.n * pb.HWp + (o.ok ? yy * pb.W + xx : 0)) * 4);
         }
         return o;
     }
     __device__ float4 b_xform(const Ctx&, const BRaw& o, int, int q, const float* sp) const {
         if constexpr (BMODE == W_STEM) {
-            return o.v[0];
+            return o.ok ? o.v[0] : zero4();
         } else {
             if (!o.ok) return zero4();
             const float* pr = sp + 4 * Cfg::BM + 4 * q;

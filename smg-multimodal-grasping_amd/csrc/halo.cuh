@@ -75,7 +75,7 @@ template <int TS> struct HaloFwdSGeo : HaloGeo<TS> {
     __host__ __device__ static constexpr int smem_bytes(int C) { return (A_UNITS + B_N * 256) * 16 + 3 * C * 4; }
 };
 
-template <int TS>
+template <int TS, int PREC = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const Halo3x3FwdArgs a) {
     using G = HaloFwdSGeo<TS>;
     constexpr int MT = G::MT, A_N = G::A_N, B_N = G::B_N, LDH = G::LDH;
@@ -127,9 +127,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const Halo3x3F
 #pragma unroll
         for (int i = 0; i < A_N; ++i) {
             if (a_hp[i] < 0) continue;
-            const Split4 s = split4(a_off[i] >= 0 ? bnrelu4(ra[i], pq, C) : zero4());   // conv zero padding applies AFTER bn+relu
+            const Split4 s = split4<PREC>(a_off[i] >= 0 ? bnrelu4(ra[i], pq, C) : zero4());   // conv zero padding applies AFTER bn+relu
 #pragma unroll
-            for (int pc = 0; pc < NPIECE; ++pc)
+            for (int pc = 0; pc < (PREC ? 1 : NPIECE); ++pc)
                 *reinterpret_cast<uint2*>(As + ((pc * 2 + (kq >> 1)) * LDH + a_hp[i]) * 16 + (kq & 1) * 8) = s.p[pc];
         }
 #pragma unroll
@@ -163,60 +163,44 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const Halo3x3F
         u32x4 ah[2][MT], al[2][MT], bh[2], bl[2];
         auto load_hl = [&](int set, int tap) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) { ah[set][m] = fa(m, tap, 0); al[set][m] = fa(m, tap, 2); }
-            bh[set] = fb(tap, 0); bl[set] = fb(tap, 2);
+            for (int m = 0; m < MT; ++m) { ah[set][m] = fa(m, tap, 0); if constexpr (PREC == 0) al[set][m] = fa(m, tap, 2); }
+            bh[set] = fb(tap, 0); if constexpr (PREC == 0) bl[set] = fb(tap, 2);
+        };
+        auto tap_body = [&](int set, int tap, bool more) {
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PREC != 0) {                      // single-piece modes: one term
+                if (more) load_hl(set ^ 1, tap + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_1p<PREC>(ah[set][m], bh[set], acc[m]);
+                return;
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][m], bl[set], acc[m]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(al[set][m], bh[set], acc[m]);
+            u32x4 am[MT], bm;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) am[m] = fa(m, tap, 1);
+            bm = fb(tap, 1);
+            if (more) load_hl(set ^ 1, tap + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(am[m], bm, acc[m]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][m], bm, acc[m]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(am[m], bh[set], acc[m]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][m], bh[set], acc[m]);
         };
         load_hl(0, tap0);
 #pragma unroll
-        for (int tp = 0; tp < 5; ++tp) {
-            const int tap = tap0 + tp;
-            if (tap < tap1) {
-                const int set = tp & 1;
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][m], bl[set], acc[m]);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(al[set][m], bh[set], acc[m]);
-                u32x4 am[MT], bm;
-#pragma unroll
-                for (int m = 0; m < MT; ++m) am[m] = fa(m, tap, 1);
-                bm = fb(tap, 1);
-                if (tap + 1 < tap1) load_hl(set ^ 1, tap + 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(am[m], bm, acc[m]);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][m], bm, acc[m]);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(am[m], bh[set], acc[m]);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][m], bh[set], acc[m]);
-            }
-        }
+        for (int tp = 0; tp < 5; ++tp)
+            if (tap0 + tp < tap1) tap_body(tp & 1, tap0 + tp, tap0 + tp + 1 < tap1);
         if constexpr (TS == 16) {      // taps 5..8 of the single tap slice
 #pragma unroll
-            for (int tp = 5; tp < 9; ++tp) {
-                const int tap = tp, set = tp & 1;
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][m], bl[set], acc[m]);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(al[set][m], bh[set], acc[m]);
-                u32x4 am[MT], bm;
-#pragma unroll
-                for (int m = 0; m < MT; ++m) am[m] = fa(m, tap, 1);
-                bm = fb(tap, 1);
-                if (tap + 1 < 9) load_hl(set ^ 1, tap + 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(am[m], bm, acc[m]);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][m], bm, acc[m]);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(am[m], bh[set], acc[m]);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][m], bh[set], acc[m]);
-            }
+            for (int tp = 5; tp < 9; ++tp) tap_body(tp & 1, tp, tp + 1 < 9);
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                          // every wave is done reading this chunk
@@ -328,7 +312,7 @@ template <int TS> struct HaloDgradSGeo : HaloGeo<TS> {
     __host__ __device__ static constexpr int smem_bytes(int C) { return (A_UNITS + 2 * B_PAD) * 16 + (4 * C + 256 + 128) * 4; }
 };
 
-template <int TS>
+template <int TS, int PREC = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x3DgradArgs a) {
     using G = HaloDgradSGeo<TS>;
     constexpr int MT = G::MT, NCW = G::NCW, A_N = G::A_N, B_N = G::B_N, LDH = G::LDH;
@@ -391,9 +375,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
                 float4 v = rv[i];
                 if (x_n) v = affine2(rv[i], rx[i], gp + 4 * q, 32);
                 if (!ok) v = zero4();
-                const Split4 sp = split4(v);
+                const Split4 sp = split4<PREC>(v);
 #pragma unroll
-                for (int pc = 0; pc < NPIECE; ++pc)
+                for (int pc = 0; pc < (PREC ? 1 : NPIECE); ++pc)
                     *reinterpret_cast<uint2*>(As + ((pc * 4 + (q >> 1)) * LDH + hp) * 16 + (q & 1) * 8) = sp.p[pc];
             }
         }
@@ -448,9 +432,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
         for (int ks = 0; ks < 2; ++ks) {
             u32x4 ah[MT], al[MT], bh, bl;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) { ah[m] = fa(m, ks, 0); al[m] = fa(m, ks, 2); }
-            bh = fb(ks, 0); bl = fb(ks, 2);
+            for (int m = 0; m < MT; ++m) { ah[m] = fa(m, ks, 0); if constexpr (PREC == 0) al[m] = fa(m, ks, 2); }
+            bh = fb(ks, 0); if constexpr (PREC == 0) bl = fb(ks, 2);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PREC != 0) {                      // single-piece modes: one term
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_1p<PREC>(ah[m], bh, acc[m]);
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[m], bl, acc[m]);
 #pragma unroll
@@ -546,7 +536,7 @@ template <int TW> struct HaloWgradSGeo {
     }
 };
 
-template <int TW>
+template <int TW, int PREC = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const Halo3x3WgradArgs a) {
     using G = HaloWgradSGeo<TW>;
     constexpr int B_N = G::B_N, A_N = G::A_N;
@@ -608,18 +598,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const Halo3x
                 const int idx = t + 256 * i;
                 if (idx < G::PX * 8) {
                     const int q = idx & 7;
-                    const Split4 sp = split4(okv[i] ? bnrelu4(rv[i], prm + 4 * q, 32) : zero4());   // zero padding AFTER bn+relu
+                    const Split4 sp = split4<PREC>(okv[i] ? bnrelu4(rv[i], prm + 4 * q, 32) : zero4());   // zero padding AFTER bn+relu
 #pragma unroll
-                    for (int pc = 0; pc < NPIECE; ++pc)
+                    for (int pc = 0; pc < (PREC ? 1 : NPIECE); ++pc)
                         *reinterpret_cast<uint2*>(Bh + ((pc * G::PX + (idx >> 3)) * 32 + 4 * q) * 2) = sp.p[pc];
                 }
             }
 #pragma unroll
             for (int i = 0; i < A_N; ++i) {
                 const int idx = t + 256 * i;
-                const Split4 sp = split4(rg[i]);
+                const Split4 sp = split4<PREC>(rg[i]);
 #pragma unroll
-                for (int pc = 0; pc < NPIECE; ++pc)
+                for (int pc = 0; pc < (PREC ? 1 : NPIECE); ++pc)
                     *reinterpret_cast<uint2*>(Ag + ((pc * G::NPIX + (idx >> 3)) * 32 + 4 * (idx & 7)) * 2) = sp.p[pc];
             }
         }
@@ -641,20 +631,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const Halo3x
             const char* hb = Bh + ((ry * G::HW_ + rx) * 32 + tr_col) * 2;
             u32x4 af[NPIECE];
 #pragma unroll
-            for (int pc = 0; pc < NPIECE; ++pc) af[pc] = tr2(ga + pc * G::NPIX * 64, 4 * 64);
+            for (int pc = 0; pc < NPIECE; ++pc)
+                if (pc == 0 || PREC == 0) af[pc] = tr2(ga + pc * G::NPIX * 64, 4 * 64);
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 u32x4 bf[3][NPIECE];
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-                    for (int pc = 0; pc < NPIECE; ++pc) bf[dx][pc] = tr2(hb + pc * G::PX * 64 + (dy * G::HW_ + dx) * 64, 4 * 64);
+                    for (int pc = 0; pc < NPIECE; ++pc)
+                        if (pc == 0 || PREC == 0) bf[dx][pc] = tr2(hb + pc * G::PX * 64 + (dy * G::HW_ + dx) * 64, 4 * 64);
                 __builtin_amdgcn_sched_barrier(0);
-                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+                if constexpr (PREC != 0) {                  // single-piece modes: one term per tap
 #pragma unroll
-                for (int g = 0; g < 6; ++g)
+                    for (int dx = 0; dx < 3; ++dx) acc[dy * 3 + dx] = mfma_1p<PREC>(af[0], bf[dx][0], acc[dy * 3 + dx]);
+                } else {
+                    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) acc[dy * 3 + dx] = mfma_bf16(af[PA[g]], bf[dx][PB[g]], acc[dy * 3 + dx]);
+                    for (int g = 0; g < 6; ++g)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) acc[dy * 3 + dx] = mfma_bf16(af[PA[g]], bf[dx][PB[g]], acc[dy * 3 + dx]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

@@ -126,6 +126,7 @@ class _AffordanceNet(nn.Module):
         self._saved = None
         self._autograd_hook = None
         self._grads_clean = False
+        self.precision = "fp32"     # operand precision of the matrix products (set_precision)
 
     # ---- initialisation ------------------------------------------------------------------
     def _init_weights(self):
@@ -159,13 +160,32 @@ class _AffordanceNet(nn.Module):
             else:
                 node._buffers[leaf] = self._flat_nbt[off:off + 1].view(())
 
+    def set_precision(self, name):
+        """Operand precision of the matrix products: 'fp32' (default - every fp32 operand as three bf16 pieces, six MFMA
+        terms per product: the accuracy of the reference's apex O0 arithmetic, code/trainer.py:101), 'bf16' or 'fp16'
+        (one MFMA term per product; BASELINE.json configs 3 and 5).  Parameters, activations, gradients, BN statistics
+        and Adam stay fp32 in every mode."""
+        name = str(name).replace("torch.", "")
+        if name not in smg_hip.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(smg_hip.PRECISIONS))
+        self.precision = {0: "fp32", 1: "bf16", 2: "fp16"}[smg_hip.PRECISIONS[name]]
+        self._saved = None
+        return self
+
     def _apply(self, fn, recurse=True):
+        probe = fn(torch.zeros(1, dtype=torch.float32, device=self._flat_params.device))
+        if probe.dtype in (torch.bfloat16, torch.float16):
+            # model.half() / .bfloat16(): the master copy stays fp32 (like apex O1/O2 keep fp32 weights); only the
+            # matrix products change their operand precision
+            self.set_precision("bf16" if probe.dtype == torch.bfloat16 else "fp16")
+            dev = probe.device
+            fn = lambda t: t.to(dev)                                     # noqa: E731
+        elif probe.dtype != torch.float32:
+            raise TypeError("the affordance engine stores fp32 and computes in fp32 / bf16 / fp16 operands; got %s" % probe.dtype)
         self._flat_params = fn(self._flat_params)
         self._flat_bufs = fn(self._flat_bufs)
         nbt = fn(self._flat_nbt)
         self._flat_nbt = nbt if nbt.dtype == torch.int64 else nbt.to(torch.int64)
-        if self._flat_params.dtype != torch.float32:
-            raise TypeError("the affordance engine computes in fp32 (reference: apex O0, code/trainer.py:101)")
         self._flat_grads = None
         self._rebind()
         return self
@@ -177,6 +197,7 @@ class _AffordanceNet(nn.Module):
         new._flat_nbt = self._flat_nbt.clone()
         new._rebind()
         new.gnum_rotations, new.snum_rotations = self.gnum_rotations, self.snum_rotations
+        new.precision = self.precision
         return new
 
     def train(self, mode=True):
@@ -257,6 +278,8 @@ class _AffordanceNet(nn.Module):
             stream_image.append(2 * k + 1); stream_rot.append(0); thetas.append(rotation_theta(0, 1))
         n_pairs = len(pair_a)
         eng = get_engine(dev.index or 0, S, self.HEAD_OUT, len(stream_image), n_pairs)
+        if eng.precision != self.precision:
+            eng.set_precision(self.precision)
         q = torch.empty((n_pairs, self.HEAD_OUT, eng.OH, eng.OW), dtype=torch.float32, device=dev)
         trunk_id, head_id = STYLE_TRUNK[style], STYLE_HEAD[style]
         net = self._net_struct(keep_for_backward)
@@ -289,6 +312,8 @@ class _AffordanceNet(nn.Module):
         pair_a = [i for i, _ in pairs]
         pair_b = [n_rot + j for _, j in pairs]
         eng = get_engine(dev.index or 0, S, self.HEAD_OUT, len(stream_image), len(pairs))
+        if eng.precision != self.precision:
+            eng.set_precision(self.precision)
         q = torch.empty((len(pairs), self.HEAD_OUT, eng.OH, eng.OW), dtype=torch.float32, device=dev)
         trunk_id, head_id = STYLE_TRUNK[style], STYLE_HEAD[style]
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -308,6 +333,8 @@ class _AffordanceNet(nn.Module):
         if self._saved is None or self._saved[1] != token or not self._saved[0].h or self._saved[0].forward_id != token:
             raise RuntimeError("backward: the activations of that forward are gone (another forward ran on the engine)")
         eng, _, trunk_id, head_id = self._saved
+        if eng.precision != self.precision:
+            raise RuntimeError("backward: the engine's precision changed since the forward")
         stream = torch.cuda.current_stream(dq.device).cuda_stream
         # smg_backward ACCUMULATES into the flat gradient buffer (like autograd into p.grad).  A torch optimizer's
         # zero_grad(set_to_none=True) only drops p.grad and never sees that buffer, so a range whose parameters

@@ -38,9 +38,15 @@ def allreduce_flat(flat, segments, average=False):
         return
     if dist.get_world_size() == 1 and not os.environ.get("SMG_FORCE_ALLREDUCE"):
         return                      # (the env switch lets a 1-GPU box exercise the RCCL call path)
+    via_host = flat.is_cuda and dist.get_backend() == "gloo"      # (tests: two ranks sharing one GPU cannot use RCCL)
     for off, n in segments:
         view = flat[off:off + n]
-        dist.all_reduce(view, op=dist.ReduceOp.SUM)
+        if via_host:
+            tmp = view.cpu()
+            dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+            view.copy_(tmp)
+        else:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM)
         if average:
             view.div_(dist.get_world_size())
 
@@ -48,3 +54,32 @@ def allreduce_flat(flat, segments, average=False):
 def allreduce_grads(model, trunk_id, head_id, average=False):
     """grad_sync hook for Trainer.train_batch."""
     allreduce_flat(model.flat_grads(), grad_segments(model.HEAD_OUT, trunk_id, head_id), average)
+
+
+def sweep_sharded(trainer, depth_heightmap, m_depth_heightmap, style=0, is_target=False):
+    """The R-rotation Q sweep of code/main.py:165-173 with the rotations sharded over the ranks: rank r
+    evaluates a contiguous block of rotations (each rank recomputes the masked stream: one extra trunk pass), the R
+    scalars are all-gathered (64 bytes - no other exchange on the forward path) and every rank takes the argmax on the
+    host, lowest index on ties like np.argmax (main.py:172).  Returns (q[R] float64, best rotation).
+    BN running statistics: every rank applies its own rotations' updates (replicas diverge in the buffers the training-mode
+    forward never reads); call it on the target network or re-sync the buffers if they matter."""
+    model = trainer.model_target if is_target else trainer.model
+    R = model.gnum_rotations if style == 0 else (model.snum_rotations if style == 1 else 1)
+    rots = list(range(R))
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    mine = shard(rots) if world > 1 else rots
+    q_mine = []
+    if mine:
+        hm = trainer._heightmaps_to_device(depth_heightmap, m_depth_heightmap)
+        num = model.gnum_rotations if style == 0 else (model.snum_rotations if style == 1 else model.gnum_rotations)
+        q = model.run(style, [0 if style == 2 else r for r in mine], num, heightmaps=hm, mean=trainer.image_mean, std=trainer.image_std)
+        q_mine = [float(v) for v in q.reshape(-1).cpu().numpy().astype("float64")]
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, q_mine)
+        q_all = [v for p in parts for v in p]
+    else:
+        q_all = q_mine
+    import numpy as np
+    q_all = np.asarray(q_all, dtype=np.float64)
+    return q_all, int(np.argmax(q_all))

@@ -64,6 +64,7 @@ def lib():
     L.smg_forward.argtypes = [C.c_void_p, C.POINTER(SmgNet), C.c_int, C.c_int, C.POINTER(SmgBatch), C.c_void_p, C.c_void_p]
     L.smg_loss.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.smg_backward.argtypes = [C.c_void_p, C.POINTER(SmgNet), C.c_void_p, C.c_void_p]
+    L.smg_engine_set_precision.argtypes = [C.c_void_p, C.c_int]
     L.smg_argmax.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.smg_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
@@ -83,7 +84,7 @@ EXPORTS = (
     "smg_last_error", "smg_version", "smg_layout_count", "smg_layout_param_floats", "smg_layout_buffer_floats",
     "smg_layout_nbt_count", "smg_layout_entry", "smg_layout_trunk_range", "smg_layout_head_range",
     "smg_engine_create", "smg_engine_destroy", "smg_engine_workspace_bytes", "smg_engine_geometry",
-    "smg_forward", "smg_loss", "smg_backward", "smg_adam_step", "smg_argmax", "smg_debug_read",
+    "smg_forward", "smg_loss", "smg_backward", "smg_adam_step", "smg_argmax", "smg_engine_set_precision", "smg_debug_read",
     "smg_profile_enable", "smg_profile_kinds", "smg_profile_kind_name", "smg_profile_read", "smg_profile_read_bytes",
 )
 
@@ -136,6 +137,7 @@ class Engine(object):
         self.H, self.HWp = list(H), list(HWp)
         self.OH = self.OW = self.H[5] - 20 + 1
         self.forward_id = 0
+        self.precision = "fp32"
 
     def close(self):
         if self.h:
@@ -147,6 +149,12 @@ class Engine(object):
             self.close()
         except Exception:
             pass
+
+    def set_precision(self, name):
+        """Operand precision of the matrix products: 'fp32' (3-piece bf16 split, fp32-class; default), 'bf16' or
+        'fp16' (single-piece operands; fp32 storage and accumulation)."""
+        check(lib().smg_engine_set_precision(self.h, PRECISIONS[str(name).replace("torch.", "")]))
+        self.precision = str(name).replace("torch.", "")
 
     @property
     def workspace_bytes(self):
@@ -227,6 +235,9 @@ class Engine(object):
                 rows.append((ms.value, n.value, fl.value))
             out[L.smg_profile_kind_name(k).decode()] = rows
         return out
+
+
+PRECISIONS = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "fp16": 2, "float16": 2, "half": 2}
 
 
 def argmax(values, n, idx_out, val_out, stream):

@@ -140,3 +140,29 @@ def test_input_kernel_formula_restated_in_numpy(golden):
         idx = (fy.astype(np.int64) * S + fx.astype(np.int64)).astype(np.int32)
         idx[~ok] = -1
         assert np.uint32(zlib.crc32(idx.tobytes()) & 0xFFFFFFFF) == golden["g1_crc_640"][r], r
+
+
+def test_trainer_preload_resumes_logs(tmp_path):
+    """Trainer.preload (code/trainer.py:118-160, used by `--continue_logging`, code/main.py:74): the ten text logs of a
+    session come back as lists, truncated to iteration = rows(executed-action) - 2; clearance is kept whole."""
+    import trainer as tr_mod
+    rows = 7
+    rng = np.random.RandomState(0)
+    logs = {"executed-action": rng.rand(rows, 4), "label-value": rng.rand(rows), "predicted-value": rng.rand(rows),
+            "reward-value": rng.rand(rows), "use-heuristic": rng.rand(rows), "is-exploit": rng.rand(rows),
+            "clearance": rng.rand(3), "grasping_type": rng.rand(rows), "episode_success": rng.rand(rows, 3),
+            "training_loss": rng.rand(rows, 2)}             # column counts as code/main.py:125,342 writes them
+    for k, v in logs.items():
+        np.savetxt(str(tmp_path / (k + ".log.txt")), v, delimiter=" ")
+    t = tr_mod.Trainer.__new__(tr_mod.Trainer)            # no network needed for the log plumbing
+    t.preload(str(tmp_path))
+    n = rows - 2
+    assert t.iteration == n
+    assert np.allclose(t.executed_action_log, logs["executed-action"][:n]) and isinstance(t.executed_action_log, list)
+    for attr, key in (("label_value_log", "label-value"), ("predicted_value_log", "predicted-value"), ("reward_value_log", "reward-value"),
+                      ("use_heuristic_log", "use-heuristic"), ("is_exploit_log", "is-exploit"), ("grasping_type_log", "grasping_type")):
+        got = np.asarray(getattr(t, attr))
+        assert got.shape == (n, 1) and np.allclose(got[:, 0], logs[key][:n]), attr
+    assert np.asarray(t.clearance_log).shape == (3, 1)
+    assert np.allclose(t.episode_success_log, logs["episode_success"][:n])
+    assert np.asarray(t.training_loss_log).shape == (n, 2)

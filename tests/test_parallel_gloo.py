@@ -42,8 +42,25 @@ def _worker(rank, world, port, out):
         parallel.allreduce_flat(flat, segs)
         inside = sum(float(flat[o:o + c].sum()) for o, c in segs)
         total = float(flat.sum())
+        # rotation-sharded forward sweep (stub model: Q(r) = a known table), 16 scalars gathered, argmax on every rank
+        table = torch.tensor([0.1, -0.3, 0.7, 0.2, 0.7, 0.0, -1.0, 0.5, 0.3, 0.6, -0.2, 0.1, 0.4, 0.69, 0.2, -0.5])
+
+        class _Model(object):
+            gnum_rotations = snum_rotations = 16
+
+            def run(self, style, rots, num, heightmaps=None, mean=0.0, std=1.0):
+                assert num == 16 and len(rots) == 8
+                return table[rots].reshape(-1, 1, 1, 1)
+
+        class _Trainer(object):
+            model = model_target = _Model()
+            image_mean, image_std = 0.01, 0.03
+
+            def _heightmaps_to_device(self, a, b):
+                return None
+        q, best = parallel.sweep_sharded(_Trainer(), None, None, style=0)
         if rank == 0:
-            out.put((gathered, segs, inside, total, n))
+            out.put((gathered, segs, inside, total, n, q, best))
     finally:
         dist.destroy_process_group()
 
@@ -56,7 +73,7 @@ def test_shard_and_allreduce_world2():
     procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
     for p in procs:
         p.start()
-    gathered, segs, inside, total, n = out.get(timeout=120)
+    gathered, segs, inside, total, n, q, best = out.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -66,6 +83,8 @@ def test_shard_and_allreduce_world2():
     assert seg_elems == 6953856 + 160896                                            # 28.5 MB per style
     assert inside == pytest.approx(3.0 * seg_elems)                                 # 1 + 2 summed inside the segments
     assert total == pytest.approx(3.0 * seg_elems + 1.0 * (n - seg_elems))          # untouched elsewhere (rank 0 holds 1.0)
+    assert q.shape == (16,) and q.dtype == np.float64 and abs(q[13] - 0.69) < 1e-6    # rank order = rotation order
+    assert best == 2                                                                  # tie 0.7 / 0.7: lowest index, like np.argmax
 
 
 def test_shard_uneven():
