@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--batched-scenes", type=int, default=4,
                     help="also time a config-4 style step with this many scenes per engine call (0 = skip)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE.json config 3 / 4 / 5 legs")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -212,6 +213,12 @@ def main():
     }
 
     if rank == 0 and world == 1:
+        # host time to ENQUEUE one step (no synchronisation inside): how far the launch path is from being host-bound
+        torch.cuda.synchronize(dev)
+        t_h = time.perf_counter()
+        step()
+        out["host_enqueue_ms_per_step"] = (time.perf_counter() - t_h) * 1e3
+        torch.cuda.synchronize(dev)
         import models
         eng = models._ENGINES[(local_rank, 640, 1)]
         # forward-only sweep (BASELINE.json configs[1]), reported beside the headline number
@@ -247,6 +254,71 @@ def main():
             ms_b = (time.perf_counter() - t2) / n_b * 1e3
             out["batched"] = {"scenes_per_step": nb, "samples_per_step": nb * R, "ms_per_step": ms_b,
                               "passes_per_s": nb / (ms_b * 1e-3), "pass_tflops_algorithmic": PASS_GFLOP * nb / ms_b}
+        if not args.no_configs:
+            def timed(fn, reps):
+                fn(); torch.cuda.synchronize(dev)
+                t = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize(dev)
+                return (time.perf_counter() - t) / reps * 1e3
+            cfg = {}
+            # ---- config 3: E + S + ES heads, forward + Huber backward, 16 rotations, bf16 MFMA operands ----------------
+            md2 = depth * (masks[1] + masks[2])
+            lab1 = synthetic.uniform(5, "bench/labels_c3", 1, 0.0, 1.5)
+
+            def three_heads():
+                tr.train_batch(depth, mdepth, 0, rots, labels)
+                tr.train_batch(depth, mdepth, 1, rots, labels)
+                tr.train_batch(depth, md2, 2, [0], lab1)              # ES: rotation 0 only (code/models.py:418)
+
+            def q_sweeps():
+                return np.concatenate([tr.model.run(st_, rots, R, heightmaps=x_d, mean=tr.image_mean, std=tr.image_std,
+                                                    update_bn=False).reshape(-1).cpu().numpy() for st_ in (0, 1)])
+            lr0, tr.optimizer.lr = tr.optimizer.lr, 0.0              # weights stay put: the error figures compare like with like
+            q_ref = q_sweeps()
+            ms32 = timed(three_heads, 3)
+            tr.model.set_precision("bf16")
+            ms16 = timed(three_heads, 3)
+            q16 = q_sweeps()
+            tr.model.set_precision("fp32")
+            cfg["config3_three_heads_bf16"] = {
+                "workload": "styles 0 and 1: 16 rotations each, style 2: rotation 0; fwd + Huber + bwd + Adam per head (33 samples, 35 + 35 trunk streams)",
+                "dtype": "bf16 MFMA operands (one term per product), fp32 activations / statistics / accumulation",
+                "ms": ms16, "ms_fp32_class": ms32, "samples_per_s": 33.0 / (ms16 * 1e-3),
+                "q_max_abs_err_vs_fp32_class": float(np.abs(q16 - q_ref).max()), "q_max_abs": float(np.abs(q_ref).max()),
+                "argmax_agrees": [bool(int(q16[:R].argmax()) == int(q_ref[:R].argmax())), bool(int(q16[R:].argmax()) == int(q_ref[R:].argmax()))]}
+            # ---- config 4: per-GPU share of 64 scenes x 16 rotations on 8 GPUs = 8 scenes (136 streams, 128 samples) --------
+            nb = 8
+            sc = [synthetic.heightmap_scene(200 + k) for k in range(nb)]
+            d8 = np.stack([c[0] for c in sc]); m8 = np.stack([c[0] * c[1][0] for c in sc])
+            lab8 = synthetic.uniform(8, "bench/labels_c4", nb * R, 0.0, 1.5)
+            ms8 = timed(lambda: tr.train_batch(d8, m8, 0, [rots] * nb, lab8), 2)
+            cfg["config4_share_8_scenes"] = {"scenes_per_step": nb, "samples_per_step": nb * R, "streams": nb * (R + 1), "ms_per_step": ms8,
+                                             "passes_per_s": nb / (ms8 * 1e-3), "pass_tflops_algorithmic": PASS_GFLOP * nb / ms8,
+                                             "engine_workspace_gb": models._ENGINES[(local_rank, 640, 1)].workspace_bytes / 1e9}
+            # ---- config 5: 640^2 heightmap -> S = 1824, 32 rotations over 8 GPUs = 4 rotations per GPU, fp16 operands ---------
+            dbig, mbig = synthetic.heightmap_scene(4, size=640, n_boxes=8)
+            mdb = dbig * mbig[0]
+            tr.model.gnum_rotations = tr.model.snum_rotations = 32
+            r5, l5 = [5, 6, 7, 8], [0.3, 1.9, 0.1, 0.7]
+            _, qb32 = tr.train_batch(dbig, mdb, 0, r5, l5, return_q=True)
+            ms5_32 = timed(lambda: tr.train_batch(dbig, mdb, 0, r5, l5), 2)
+            tr.model.set_precision("fp16")
+            _, qb16 = tr.train_batch(dbig, mdb, 0, r5, l5, return_q=True)
+            ms5_16 = timed(lambda: tr.train_batch(dbig, mdb, 0, r5, l5), 2)
+            tr.model.set_precision("fp32")
+            tr.model.gnum_rotations = tr.model.snum_rotations = R
+            a32, a16 = qb32.reshape(4, -1).cpu().numpy(), qb16.reshape(4, -1).cpu().numpy()
+            cfg["config5_share_1824_fp16"] = {
+                "workload": "640x640 heightmap -> 1824x1824 input, 4 of 32 rotations as training samples (5 trunk streams), dense 38x38 Q maps, Huber on [0,0,0,0]",
+                "dtype": "fp16 MFMA operands (one term per product), fp32 activations / statistics / accumulation",
+                "ms_per_step": ms5_16, "ms_fp32_class": ms5_32, "algorithmic_tflops": 4 * 2225.73 / ms5_16 * (5.0 / 8.0),
+                "q_max_abs_err_vs_fp32_class": float(np.abs(a16 - a32).max()), "q_max_abs": float(np.abs(a32).max()),
+                "argmax_agrees": [bool(int(a16[k].argmax()) == int(a32[k].argmax())) for k in range(4)],
+                "engine_workspace_gb": models._ENGINES[(local_rank, 1824, 1)].workspace_bytes / 1e9}
+            tr.optimizer.lr = lr0
+            out["configs"] = cfg
         if not args.no_roofline:
             # per-kernel-class hipEvent timing on the launch stream (separate, untimed passes)
             eng = models._ENGINES[(local_rank, 640, 1)]        # the batched leg may have regrown the engine

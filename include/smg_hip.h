@@ -151,6 +151,13 @@ int smg_backward(smg_engine* e, const smg_net* net, const float* dq_dev, void* s
  * Activations, gradients, BN statistics and every accumulation stay fp32.  Takes effect with the next smg_forward. */
 int smg_engine_set_precision(smg_engine* e, int precision);
 
+/* Heightmap generation in front of the path (utils.get_heightmap, code/utils.py:38-68): the robot-frame height of every
+ * camera pixel (get_pointcloud + cam_pose, :12-47) warped onto the table plane (cv2.warpPerspective, INTER_LINEAR,
+ * constant 0 border, :62-66).  depth_img_dev float64 [h][w]; intrinsics row-major 3x3, cam_pose row-major 4x4 and the
+ * INVERSE of cv2.getPerspectiveTransform(src, dst) row-major 3x3 in host memory; out_dev float64 [out_h][out_w]. */
+int smg_heightmap(const double* depth_img_dev, int h, int w, const double* intrinsics3x3, const double* cam_pose4x4,
+                  const double* inv_homography3x3, int out_w, int out_h, double* out_dev, void* stream);
+
 /* Index and value of the largest of n float32 values (lowest index on ties, like np.argmax at
  * code/main.py:172-173,195), on the device: idx_out_dev int32[1], val_out_dev float32[1]. */
 int smg_argmax(const float* values_dev, int n, int* idx_out_dev, float* val_out_dev, void* stream);

@@ -712,6 +712,43 @@ __global__ void loss_kernel(int mode, const float* q, const float* labels, int n
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Heightmap generation, the step in front of Trainer.forward (utils.get_heightmap, code/utils.py:38-68): camera depth
+// image -> robot-frame z of every pixel (get_pointcloud + cam_pose, :12-47) -> perspective warp onto the table
+// (cv2.warpPerspective with an INTER_LINEAR / BORDER_CONSTANT inverse map, :62-66), fused: one thread per heightmap
+// pixel gathers its four taps and converts them on the fly.  Arithmetic restated in oracle/heightmap.py: coordinates in
+// double, rounded to 1/32 pixel, float32 table weights.
+// ------------------------------------------------------------------------------------
+struct HeightmapArgs {
+    const double* depth; int h, w;          // camera depth image [h][w]
+    double fx, fy, cx, cy;                  // intrinsics
+    double r20, r21, r22, t2;               // third row of the camera pose (robot-frame z)
+    double mi[9];                           // INVERSE of the source -> heightmap homography
+    double* out; int ow, oh;
+};
+__global__ void heightmap_warp_kernel(const HeightmapArgs a) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= a.ow) return;
+    const double xd = (double)x, yd = (double)y;
+    const double den = a.mi[6] * xd + a.mi[7] * yd + a.mi[8];
+    const double scale = den != 0.0 ? 32.0 / den : 0.0;
+    double fxs = (a.mi[0] * xd + a.mi[1] * yd + a.mi[2]) * scale, fys = (a.mi[3] * xd + a.mi[4] * yd + a.mi[5]) * scale;
+    fxs = fmin(fmax(fxs, -2147483648.0), 2147483647.0);
+    fys = fmin(fmax(fys, -2147483648.0), 2147483647.0);
+    const long long ix = (long long)rint(fxs), iy = (long long)rint(fys);      // saturate_cast<int>: round half to even
+    const long long x0 = ix >> 5, y0 = iy >> 5;
+    const float ax = (float)(ix & 31) * (1.0f / 32.0f), ay = (float)(iy & 31) * (1.0f / 32.0f);
+    const float w00 = (1.0f - ay) * (1.0f - ax), w01 = (1.0f - ay) * ax, w10 = ay * (1.0f - ax), w11 = ay * ax;
+    auto tap = [&](long long yy, long long xx) -> double {
+        if (yy < 0 || yy >= a.h || xx < 0 || xx >= a.w) return 0.0;
+        const double d = a.depth[yy * a.w + xx];
+        const double px = ((double)xx - a.cx) * (d / a.fx), py = ((double)yy - a.cy) * (d / a.fy);
+        return a.r20 * px + a.r21 * py + a.r22 * d + a.t2;
+    };
+    a.out[(int64_t)y * a.ow + x] = tap(y0, x0) * (double)w00 + tap(y0, x0 + 1) * (double)w01 + tap(y0 + 1, x0) * (double)w10 +
+                                   tap(y0 + 1, x0 + 1) * (double)w11;
+}
+
 // Largest value and its index (lowest index on ties, like np.argmax): one workgroup.
 __global__ __launch_bounds__(256) void argmax_kernel(const float* v, int n, int* idx_out, float* val_out) {
     __shared__ float bv[256];

@@ -887,7 +887,8 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
             gsrc.xsum = fsum(e, e->st_X[b]) + d.cin; gsrc.xsq = fsq(e, e->st_X[b]) + d.cin;
             gsrc.s1 = b1(e, e->bs_X[b]) + d.cin; gsrc.s2 = b2(e, e->bs_X[b]) + d.cin; gsrc.sstride = Ct; gsrc.eps = kEps;
             static const bool gs_env_fused = getenv("SMG_GS_FUSED") != nullptr;
-            const bool gs_mat = !gs_env_fused && NS > 4;      // few streams: launch-bound, the fused form wins (8.78 -> 8.56 ms per sample)
+            static const int gs_fused_hw = getenv("SMG_GS_FUSED_HW") ? atoi(getenv("SMG_GS_FUSED_HW")) : 0;   // dev A/B: fuse on planes up to this many pixels
+            const bool gs_mat = !gs_env_fused && NS > 4 && pl.HW > gs_fused_hw;      // few streams: launch-bound, the fused form wins (8.78 -> 8.56 ms per sample)
             if (e->generic3x3 || gs_mat) {
                 BnBwdApplyArgs a{};
                 a.g = e->G[b]; a.ldg = Ct; a.gcoff = d.cin; a.x = e->X[b]; a.ldx = Ct; a.xcoff = d.cin; a.pl = pl; a.C = kGrowth;
@@ -1252,6 +1253,24 @@ int smg_engine_set_precision(smg_engine* e, int precision) {
     if (precision < 0 || precision > 2) return fail(-22, "precision must be 0 (fp32-class split), 1 (bf16 operands) or 2 (fp16 operands)");
     e->prec = precision;
     e->have_fwd = false;        // activations saved by a forward of another precision are not backward-compatible
+    return 0;
+}
+
+int smg_heightmap(const double* depth_img_dev, int h, int w, const double* intrinsics3x3, const double* cam_pose4x4,
+                  const double* inv_homography3x3, int out_w, int out_h, double* out_dev, void* stream) {
+    if (!depth_img_dev || !intrinsics3x3 || !cam_pose4x4 || !inv_homography3x3 || !out_dev || h < 1 || w < 1 || out_w < 1 || out_h < 1)
+        return fail(-22, "bad heightmap arguments");
+    hipPointerAttribute_t attr;
+    HIP_OK(hipPointerGetAttributes(&attr, depth_img_dev));
+    HIP_OK(hipSetDevice(attr.device));
+    HeightmapArgs a;
+    a.depth = depth_img_dev; a.h = h; a.w = w;
+    a.fx = intrinsics3x3[0]; a.fy = intrinsics3x3[4]; a.cx = intrinsics3x3[2]; a.cy = intrinsics3x3[5];
+    a.r20 = cam_pose4x4[8]; a.r21 = cam_pose4x4[9]; a.r22 = cam_pose4x4[10]; a.t2 = cam_pose4x4[11];
+    for (int i = 0; i < 9; ++i) a.mi[i] = inv_homography3x3[i];
+    a.out = out_dev; a.ow = out_w; a.oh = out_h;
+    hipLaunchKernelGGL(heightmap_warp_kernel, dim3((out_w + 255) / 256, out_h), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_OK(hipGetLastError());
     return 0;
 }
 

@@ -65,6 +65,8 @@ def lib():
     L.smg_loss.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.smg_backward.argtypes = [C.c_void_p, C.POINTER(SmgNet), C.c_void_p, C.c_void_p]
     L.smg_engine_set_precision.argtypes = [C.c_void_p, C.c_int]
+    L.smg_heightmap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.smg_argmax.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.smg_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
@@ -84,7 +86,7 @@ EXPORTS = (
     "smg_last_error", "smg_version", "smg_layout_count", "smg_layout_param_floats", "smg_layout_buffer_floats",
     "smg_layout_nbt_count", "smg_layout_entry", "smg_layout_trunk_range", "smg_layout_head_range",
     "smg_engine_create", "smg_engine_destroy", "smg_engine_workspace_bytes", "smg_engine_geometry",
-    "smg_forward", "smg_loss", "smg_backward", "smg_adam_step", "smg_argmax", "smg_engine_set_precision", "smg_debug_read",
+    "smg_forward", "smg_loss", "smg_backward", "smg_adam_step", "smg_argmax", "smg_heightmap", "smg_engine_set_precision", "smg_debug_read",
     "smg_profile_enable", "smg_profile_kinds", "smg_profile_kind_name", "smg_profile_read", "smg_profile_read_bytes",
 )
 
@@ -238,6 +240,17 @@ class Engine(object):
 
 
 PRECISIONS = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "fp16": 2, "float16": 2, "half": 2}
+
+
+def heightmap(depth_img, h, w, intrinsics, cam_pose, inv_homography, out_w, out_h, out, stream):
+    def d(a, n):
+        a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+        assert a.size == n
+        return a, a.ctypes.data_as(C.POINTER(C.c_double))
+    k, kp = d(intrinsics, 9)
+    t, tp = d(cam_pose, 16)
+    m, mp = d(inv_homography, 9)
+    check(lib().smg_heightmap(depth_img, h, w, kp, tp, mp, out_w, out_h, out, stream))
 
 
 def argmax(values, n, idx_out, val_out, stream):

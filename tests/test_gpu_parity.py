@@ -381,6 +381,30 @@ def test_reduced_precision_operand_modes(gpu):
     assert (sweep() == ref).all() or np.abs(sweep() - ref).max() <= 1e-6
 
 
+def test_heightmap_generation_matches_restatement(gpu):
+    """utils.get_heightmap (code/utils.py:38-68) on the device against oracle/heightmap.py (whose
+    cv2 semantics are restated, not pinned): the fused point-cloud / rigid-transform / perspective-warp kernel must agree
+    to double rounding (only the summation order of the 3-term dot product may differ from BLAS)."""
+    import synthetic
+    import utils as smg_utils
+    from oracle import heightmap as hm
+    depth = 0.45 + 0.2 * synthetic.uniform(3, "hm/depth", 480 * 640).reshape(480, 640)
+    depth[100:140, 200:260] = 0.0                                       # invalid-depth patch, as the simulator emits
+    color = (synthetic.uniform(3, "hm/color", 480 * 640 * 3) * 255).astype(np.uint8).reshape(480, 640, 3)
+    k = np.asarray([[618.62, 0, 320], [0, 618.62, 240], [0, 0, 1]])
+    pose = np.eye(4)
+    th = 0.05
+    pose[:3, :3] = np.array([[1, 0, 0], [0, -np.cos(th), np.sin(th)], [0, -np.sin(th), -np.cos(th)]])
+    pose[:3, 3] = [-0.5, 0.02, 0.62]
+    ch, dh, cm, dm, a_htor = smg_utils.get_heightmap(color, depth, k, pose, None, 0.002)
+    oh, om, oa = hm.get_depth_heightmaps(depth, k, pose)
+    assert dh.shape == (224, 224) and dm.shape == (448, 448) and dh.dtype == np.float64
+    np.testing.assert_allclose(dh, oh, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(dm, om, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(a_htor, oa, rtol=0, atol=1e-12)
+    assert ch.shape == (224, 224, 3) and cm.shape == (448, 448, 3) and ch.dtype == np.uint8
+
+
 def test_model_api_errors(gpu):
     import models
     net = models.reinforcement_net(True)      # not moved to the GPU
@@ -413,7 +437,7 @@ def test_snapshot_roundtrip(gpu, tmp_path):
     assert abs(float(other.forward(x, mx, 0, True, 2)) - q0) < 1e-6
 
 
-@pytest.mark.parametrize("case", ["two_scenes_few_rotations", "four_scenes_all_rotations"])
+@pytest.mark.parametrize("case", ["two_scenes_few_rotations", "four_scenes_all_rotations", "eight_scenes_all_rotations"])
 def test_multi_scene_batch_equals_sum_of_single_scene_gradients(gpu, case):
     """Config-4 style batch (several scenes x rotations in ONE engine call): Q values equal the
     single-scene calls and the gradient equals the sum of the single-scene gradients.  The second case is the
@@ -428,9 +452,12 @@ def test_multi_scene_batch_equals_sum_of_single_scene_gradients(gpu, case):
     if case == "two_scenes_few_rotations":
         seeds, rots = (5, 6), [[0, 7, 12], [3, 9]]
         labels = [0.2, 1.4, 0.9, 3.0, 0.1]
-    else:
+    elif case == "four_scenes_all_rotations":
         seeds, rots = (5, 6, 7, 8), [list(range(16))] * 4
         labels = list(synthetic.uniform(11, "multi/labels", 64, 0.0, 1.5))
+    else:       # BASELINE.json config 4's per-GPU share: 8 scenes x 16 rotations = 136 trunk streams, 128 samples
+        seeds, rots = tuple(range(5, 13)), [list(range(16))] * 8
+        labels = list(synthetic.uniform(12, "multi/labels8", 128, 0.0, 1.5))
     scenes = [synthetic.heightmap_scene(s) for s in seeds]
     d = np.stack([sc[0] for sc in scenes])
     m = np.stack([sc[0] * sc[1][1] for sc in scenes])
@@ -453,6 +480,11 @@ def test_multi_scene_batch_equals_sum_of_single_scene_gradients(gpu, case):
     # 2.7e-3 for the 64-sample one were measured; one missing sample of 64 would be 1.5e-2
     assert num <= (2e-3 if len(labels) < 10 else 5e-3) * den, (num, den)
     assert loss_b.shape == (len(labels),)
+    if len(seeds) == 8:
+        import models
+        ws = models._ENGINES[(0, 640, 1)].workspace_bytes
+        print("config-4 share: 136 streams / 128 samples per call, engine workspace %.1f GB" % (ws / 1e9))
+        assert ws < 120e9
 
 
 def test_large_input_dense_qmap(gpu):
@@ -475,6 +507,69 @@ def test_large_input_dense_qmap(gpu):
     ok, worst = q_close(a, b)
     assert ok, worst
     assert int(a.argmax()) == int(b.argmax())
+
+
+def test_large_input_backward_config5_share(gpu):
+    """Config 5's per-GPU share: a 640x640 heightmap (S = 1824), 4 of the 32 rotations as training samples in ONE call
+    (5 trunk streams, dense 38x38 Q maps, Huber on element [0,0,0,0] like code/trainer.py:345).  (a) every sample's Q map
+    and the gradient of ONE sample against the PyTorch-CPU oracle evaluated in fp64; (b) the 4-sample batch gradient
+    against the sum of the four single-sample gradients."""
+    import psutil
+    import synthetic
+    from trainer import Trainer
+    tr = Trainer('reinforcement', 0.5, False, None, False)
+    sd = synthetic.make_state_dict(orc.state_layout(1), 0)
+    tr.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    tr.model.gnum_rotations = tr.model.snum_rotations = 32
+    tr.optimizer.lr = 0.0
+    depth, masks = synthetic.heightmap_scene(4, size=640, n_boxes=8)
+    md = depth * masks[0]
+    rots, labels = [5, 6, 7, 8], [0.3, 1.9, 0.1, 0.7]
+    loss_b, q_b = tr.train_batch(depth, md, 0, rots, labels, return_q=True)
+    assert tuple(q_b.shape) == (4, 1, 38, 38)
+    g_b = tr.model.flat_grads().clone()
+    g_sum = torch.zeros_like(g_b)
+    for r, lab in zip(rots, labels):
+        _, q1 = tr.train_batch(depth, md, 0, [r], [lab], return_q=True)
+        g_sum += tr.model.flat_grads()
+        np.testing.assert_allclose(q1.reshape(-1).cpu().numpy(), q_b[rots.index(r)].reshape(-1).cpu().numpy(), rtol=0, atol=5e-5)
+        if r == 5:
+            g_one = tr.model.flat_grads().double().cpu().numpy().copy()
+            q_one = q1.reshape(38, 38).cpu().numpy().copy()
+    num, den = float((g_b - g_sum).double().norm()), float(g_sum.double().norm())
+    assert num <= 5e-3 * den, (num, den)
+    import models
+    print("config-5 share: S=1824, 5 streams, engine workspace %.1f GB" % (models._ENGINES[(0, 1824, 1)].workspace_bytes / 1e9))
+    # oracle (fp64 where the host has the memory for its autograd graph at S = 1824: ~40 GB; else fp32)
+    big = psutil.virtual_memory().available > 160e9
+    on = oracle_net(0, R=32)
+    if big:
+        on = on.double()
+    x = orc.preprocess(depth, [MEAN] * 3, [STD] * 3)
+    mx = orc.preprocess(md, [MEAN] * 3, [STD] * 3)
+    rx = orc.rotate(x, 5, 32)
+    if big:
+        rx, mx = rx.double(), mx.double()
+    trunk = getattr(on, orc.STYLE_TRUNK[0]).features
+    head = getattr(on, orc.STYLE_HEAD[0])
+    q = head(torch.cat((trunk(rx), trunk(mx)), 1))
+    orc.huber(q[0, 0, 0, 0], labels[0]).sum().backward()
+    ok, worst = q_close(q_one.ravel(), q.detach().double().numpy().ravel())
+    assert ok, worst
+    assert int(q_one.argmax()) == int(q.detach().numpy().argmax())
+    off = {name: (o, n) for name, kind, o, shape in __import__("smg_hip").layout(1) if kind == 0 for n in [int(np.prod(shape))]}
+    rels = []
+    for name, p in on.named_parameters():
+        if p.grad is None:
+            continue
+        o, n = off[name]
+        t = p.grad.double().numpy().ravel()
+        nrm = np.sqrt((t * t).sum())
+        if nrm > 0 and "norm5" not in name:
+            rels.append(np.sqrt(((g_one[o:o + n] - t) ** 2).sum()) / nrm)
+    rels = np.asarray(rels)
+    print("config-5 share: gradient vs %s oracle: median rel %.3e, max %.3e over %d tensors" % ("fp64" if big else "fp32", np.median(rels), rels.max(), rels.size))
+    assert rels.size >= 360 and np.median(rels) < 2e-2 and rels.max() < 1e-1
 
 
 def test_batched_object_evaluation_equals_per_object_loop(gpu):

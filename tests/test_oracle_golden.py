@@ -176,3 +176,33 @@ def test_label_value_known_answers():
     assert orc.label_value("reinforcement", "grasp_then_suction", 3, 0, 0, 0.5, 0.8, 0.5) == (0.5 + 0.4, 0.5)
     assert orc.label_value("reactive", "grasp", 3, 0, 0, 0, 0, 0.5) == (1, 0)
     assert orc.label_value("reactive", "grasp_then_suction", 3, 0, 0, 2.5, 0, 0.5) == (0, 2.5)
+
+
+def test_heightmap_restatement_known_answers():
+    """oracle/heightmap.py (utils.get_heightmap, code/utils.py:38-68; parity unpinned - OpenCV is not installed): the
+    homography maps the four corners exactly, an axis-aligned crop + scale warp of a linear ramp is the ramp sampled on
+    the 1/32-pixel grid, taps outside the image count as zero."""
+    from oracle import heightmap as hm
+    dst = np.array([[0, 0], [0, 224], [224, 224], [224, 0]], np.float32)
+    m = hm.perspective_transform(hm.SRC_SIM, dst)
+    for (x, y), (u, v) in zip(hm.SRC_SIM, dst):
+        p = m @ np.array([x, y, 1.0])
+        assert np.allclose(p[:2] / p[2], [u, v], atol=1e-9)
+    assert np.allclose(hm.perspective_transform(dst, hm.SRC_SIM) @ m, np.eye(3) * (hm.perspective_transform(dst, hm.SRC_SIM) @ m)[2, 2], atol=1e-9)
+    yy, xx = np.meshgrid(np.arange(480.0), np.arange(640.0), indexing="ij")
+    ramp = 0.25 * xx + 2.0 * yy + 1.0
+    out = hm.warp_perspective(ramp, m, (224, 224))
+    # destination (x, y) samples the source at (110 + x*400/224, y*400/224), rounded to 1/32 pixel
+    sx = np.rint((110 + np.arange(224) * 400.0 / 224) * 32) / 32
+    sy = np.rint((np.arange(224) * 400.0 / 224) * 32) / 32
+    want = 0.25 * sx[None, :] + 2.0 * sy[:, None] + 1.0
+    assert np.allclose(out, want, rtol=0, atol=1e-4)          # float32 table weights: ~1e-7 relative
+    shifted = hm.perspective_transform(np.array([[-10, 0], [-10, 400], [390, 400], [390, 0]], np.float32), dst)
+    edge = hm.warp_perspective(np.ones((480, 640)), shifted, (224, 224))
+    assert edge[100, 0] == 0.0 and edge[100, 5] == 0.0 and abs(edge[100, 6] - 1.0) < 1e-6      # x_src = -10 + x*400/224 < 0 for x <= 5
+    k = np.asarray([[618.62, 0, 320], [0, 618.62, 240], [0, 0, 1]])
+    pose = np.eye(4)
+    pose[:3, :3] = [[1, 0, 0], [0, -1, 0], [0, 0, -1]]
+    pose[:3, 3] = [-0.5, 0.0, 0.6]
+    z = hm.world_z(np.full((480, 640), 0.55), k, pose)       # a plane 0.55 m in front of a downward camera 0.6 m up
+    assert np.allclose(z, 0.05)
