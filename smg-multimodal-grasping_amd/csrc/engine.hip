@@ -142,7 +142,8 @@ struct smg_engine {
 // 4.3 -> 3.6 ms).
 static inline int halo_tile(const Plane& p, int n_streams = 1 << 20) {
     if (p.H % 16 || p.W % 16) return 8;
-    return (int64_t)(p.H / 16) * (p.W / 16) * n_streams >= 320 ? 16 : 8;
+    static const int min16 = getenv("SMG_HALO16_MIN") ? atoi(getenv("SMG_HALO16_MIN")) : 320;      // dev A/B
+    return (int64_t)(p.H / 16) * (p.W / 16) * n_streams >= min16 ? 16 : 8;
 }
 
 // 3x3 weight-gradient halo kernel: tiles per workgroup.  The launch runs in rounds of 512 resident workgroups (2 per
@@ -651,7 +652,7 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
                     // 128x128 tiles where the plane tiles by 128 rows and the launch still fills the chip; else 64x64 (BK = 32) -
                     // and when even that leaves most CUs idle (few streams per call, or the 20x20 planes), 32x64 tiles with
                     // the k-tile split over wave pairs: twice the workgroups, half the serial K chain.
-                    constexpr int small_wgs = 320;                 // 512 / 1024 measured slower on the 17-stream step
+                    static const int small_wgs = getenv("SMG_C1_SMALL") ? atoi(getenv("SMG_C1_SMALL")) : 320;   // 512 / 1024 measured slower on the 17-stream step
                     const int wg128 = ns * pl.HWp / 128, wg64 = ns * pl.HWp / 64 * 2;
                     static const bool k16 = getenv("SMG_C1_K16") != nullptr;      // dev A/B: BK = 16 past 576 channels (round 1's rule)
                     if (pl.HWp % 128 == 0 && wg128 >= small_wgs) run(CfgP128x128{});
@@ -1041,7 +1042,8 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 using Cfg = CfgW128x64;
                 const int nt = (d.cin + Cfg::BN - 1) / Cfg::BN;
                 int chunk, cps;
-                pick_chunk(pl, NS, nt, chunk, cps, 512);   // 384..768 measure the same; 256 is slower
+                static const int w1_target = getenv("SMG_W1_WGS") ? atoi(getenv("SMG_W1_WGS")) : 512;            // dev A/B
+                pick_chunk(pl, NS, nt, chunk, cps, w1_target);   // 384..768 measure the same; 256 is slower
                 BwdWeightP<Cfg, W_ONE, C_IDENT> p{};
                 p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck;
                 p.bbuf = e->X[b]; p.ldb = Ct; p.pb = pl; p.NB = d.cin;

@@ -9,9 +9,9 @@ import glob
 import json
 import sys
 
-TRAIN_STEPS = 3    # bench.py --steps 2 --warmup 1
-FORWARDS = 8       # + 5 forward-only sweeps
-FWD_ONLY = ("prep_rotate", "pack_weights", "pool0_kernel", "feat_kernel", "value_conv", "bn_update", "FwdConvP<", "conv3x3_halo_fwd")
+TRAIN_STEPS = 4    # bench.py --steps 2 --warmup 1 + the host-enqueue probe step
+FORWARDS = 9       # + 5 forward-only sweeps
+FWD_ONLY = ("prep_rotate", "pack_weights", "pool0_kernel", "feat_kernel", "value_conv", "bn_update", "bn_stat", "FwdConvP<", "conv3x3_halo_fwd")
 
 
 def kclass(name):
@@ -62,7 +62,7 @@ def main():
                   "gb_per_train_step": (2.0 * fstep[k] + wstep.get(k, 0.0)) / 1e9}
     json.dump(out, open(sys.argv[3] + ".json", "w"), indent=1)
     with open(sys.argv[3] + ".md", "w") as md:
-        md.write("| kernel class | launches (3 train steps + 5 forward sweeps) | FETCH_SIZE x2 (MB / launch) | WRITE_SIZE (MB / launch) | GB per training step |\n|---|---|---|---|---|\n")
+        md.write("| kernel class | launches (4 train steps + 5 forward sweeps) | FETCH_SIZE x2 (MB / launch) | WRITE_SIZE (MB / launch) | GB per training step |\n|---|---|---|---|---|\n")
         for k, v in out.items():
             md.write("| %s | %d | %.1f | %.1f | %.2f |\n" % (k, v["launches"], v["fetch_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6, v["gb_per_train_step"]))
         md.write("\ntotal %.1f GB per training step (one forward + one backward + Adam)\n" % sum(v["gb_per_train_step"] for v in out.values()))

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/rocprof_stats
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/rocprof_stats -- python3 bench.py --steps 5 --warmup 2 --cpu-samples 0 --batched-scenes 0 --no-roofline > gpurun_out/rocprof_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/rocprof_stats -- python3 bench.py --steps 5 --warmup 2 --cpu-samples 0 --batched-scenes 0 --no-roofline --no-configs > gpurun_out/rocprof_stats.log 2>&1
 f=$(find gpurun_out/rocprof_stats -name "*kernel_stats.csv" | head -1)
 echo "stats file: $f"
 python3 - "$f" <<'PY'
