@@ -59,6 +59,9 @@
 #ifndef SMG_PD_DGRAD
 #define SMG_PD_DGRAD 1
 #endif
+#ifndef SMG_PD_DGRAD_BIG
+#define SMG_PD_DGRAD_BIG 1
+#endif
 #ifndef SMG_PD_WGRAD
 #define SMG_PD_WGRAD 1
 #endif
@@ -192,6 +195,22 @@ struct GemmCfg {
 // when the tile is written to LDS, so the loads stay in flight across the MFMA block.
 template <int NV> struct RawT { float4 v[NV]; bool ok; };
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// Staged operand loads go through buffer descriptors: workgroup-uniform base (SGPRs) + a loop-invariant 32-bit byte offset per
+// lane (VGPR) + a per-k-tile scalar byte offset (SGPR) - no address arithmetic on the VALU inside the k-loop (a flat
+// global_load needs a 64-bit add per load per k-tile; hipcc widens the lane offset outside the loop and cannot pick the
+// scalar-base form).  Bytes at or past `bytes` read as zero: lanes whose element does not exist carry kOOB as offset.
+constexpr unsigned kOOB = 0xC0000000u;          // + any scalar offset (< 1 GiB) stays past every descriptor's extent
+constexpr unsigned kWholeBuf = 0xBFFFFFFFu;     // extent of descriptors without a tight bound
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ubase, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ubase), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 bload_u4(const void* ubase, unsigned bytes, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(ubase, bytes), (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ float4 bload4(const void* ubase, unsigned bytes, unsigned voff, unsigned soff) {
+    const u32x4 v = bload_u4(ubase, bytes, voff, soff);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 // Per-k-tile BN parameters of a thread's channel quad (forward policies): as fetched (mean, invstd, gamma, beta) and as
 // applied (mean, gamma*invstd, beta), 4 channels each
@@ -201,6 +220,9 @@ struct KPrm4 { f32x4 mean, invstd, gamma, beta; };
 struct KPrm3 { f32x4 mean, scale, beta; };
 struct KPrm0 {};
 __device__ __forceinline__ f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 bloadv4(const void* ubase, unsigned bytes, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, bload_u4(ubase, bytes, voff, soff));
+}
 
 
 __device__ __forceinline__ void bn_moments(const double* sum, const double* sq, int64_t idx, double inv_cnt, float eps,
@@ -235,11 +257,18 @@ __device__ __forceinline__ float4 bnrelu4(float4 v, const float* prm, int stride
     return r;
 }
 __device__ __forceinline__ float4 bnrelu4(float4 v, const KPrm3& k) {
+    // two channels per instruction (v_pk_add_f32 / v_pk_fma_f32); the relu has no packed form
+    const f32x2 a = __builtin_elementwise_fma(f32x2{v.x, v.y} - k.mean.xy, k.scale.xy, k.beta.xy);
+    const f32x2 b = __builtin_elementwise_fma(f32x2{v.z, v.w} - k.mean.zw, k.scale.zw, k.beta.zw);
+    return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(b.x, 0.f), fmaxf(b.y, 0.f));
+}
+// the same with an upper clamp: cap = +inf -> relu; cap = 0 -> 0 (rows of the plane padding)
+__device__ __forceinline__ float4 bnrelu4(float4 v, const KPrm3& k, float cap) {
     float4 r;
-    r.x = fmaxf(bn1(v.x, k.mean.x, k.scale.x, k.beta.x), 0.f);
-    r.y = fmaxf(bn1(v.y, k.mean.y, k.scale.y, k.beta.y), 0.f);
-    r.z = fmaxf(bn1(v.z, k.mean.z, k.scale.z, k.beta.z), 0.f);
-    r.w = fmaxf(bn1(v.w, k.mean.w, k.scale.w, k.beta.w), 0.f);
+    r.x = __builtin_amdgcn_fmed3f(bn1(v.x, k.mean.x, k.scale.x, k.beta.x), 0.f, cap);
+    r.y = __builtin_amdgcn_fmed3f(bn1(v.y, k.mean.y, k.scale.y, k.beta.y), 0.f, cap);
+    r.z = __builtin_amdgcn_fmed3f(bn1(v.z, k.mean.z, k.scale.z, k.beta.z), 0.f, cap);
+    r.w = __builtin_amdgcn_fmed3f(bn1(v.w, k.mean.w, k.scale.w, k.beta.w), 0.f, cap);
     return r;
 }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -511,24 +540,55 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
     // First tile's global loads go out BEFORE the parameter prologue of the policies that still have one (it waits on its
     // own global loads): one memory round trip per workgroup instead of two.
 #pragma unroll
-    for (int u = 0; u < PD; ++u)
-        if (u < KT) g_load(u, ra[u], rb[u], kp[u]);
+    for (int u = 0; u < PD; ++u) {
+        if constexpr (PD > 1) g_load(u < KT ? u : KT - 1, ra[u], rb[u], kp[u]);   // same load count on every path: exact vmcnt
+        else if (u < KT) g_load(u, ra[u], rb[u], kp[u]);
+    }
     p.init_params(ctx, sp);
     if constexpr (P::kHasPrologue) __syncthreads();
     SMG_TRACE(1);
     if (KT > 0) s_store(0, 0, ra[0], rb[0], kp[0]);
     __syncthreads();
     SMG_TRACE(2);
-    for (int kt0 = 0; kt0 < KT; kt0 += PD) {
+    if constexpr (PD == 1) {
+        // two k-tiles per trip: the LDS buffer of every access is a compile-time constant (immediate offsets, no address VALU)
+        auto step = [&](int kt, auto BUF, bool more) {
+            constexpr int buf = decltype(BUF)::value;
+            if (more) g_load(kt + 1, ra[0], rb[0], kp[0]);
+            compute(buf);
+            if constexpr (P::kSegmented) p.k_hook(ctx, kt, acc, sp);   // end of a K segment: fold acc away
+            if (more) s_store(buf ^ 1, kt + 1, ra[0], rb[0], kp[0]);
+            __syncthreads();
+        };
+        int kt = 0;
+        for (; kt + 2 <= KT; kt += 2) {
+            step(kt, std::integral_constant<int, 0>{}, true);
+            step(kt + 1, std::integral_constant<int, 1>{}, kt + 2 < KT);
+        }
+        if (kt < KT) step(kt, std::integral_constant<int, 0>{}, false);
+    } else {
+        // PD tiles in flight.  Whole groups of PD tiles run branch-free with unconditional (tail-clamped) loads: with the same
+        // number of loads issued on every path hipcc counts vmcnt exactly instead of draining to 0 at the loop header; the last
+        // KT % PD tiles are peeled (tile kt0 + u sits in ring slot u because kt0 is a multiple of PD).
+        int kt0 = 0;
+        for (; kt0 + PD <= KT; kt0 += PD) {
 #pragma unroll
-        for (int u = 0; u < PD; ++u) {
-            const int kt = kt0 + u;
-            if (kt < KT) {
-                const int buf = kt & 1;
-                if (kt + PD < KT) g_load(kt + PD, ra[u], rb[u], kp[u]);   // slot u was stored to LDS one iteration ago
+            for (int u = 0; u < PD; ++u) {
+                const int kt = kt0 + u, buf = kt & 1;
+                g_load(kt + PD < KT ? kt + PD : KT - 1, ra[u], rb[u], kp[u]);   // slot u went to LDS one step ago
                 compute(buf);
-                if constexpr (P::kSegmented) p.k_hook(ctx, kt, acc, sp);   // end of a K segment: fold acc away
-                if (kt + 1 < KT) s_store(buf ^ 1, kt + 1, ra[(u + 1) % PD], rb[(u + 1) % PD], kp[(u + 1) % PD]);
+                if constexpr (P::kSegmented) p.k_hook(ctx, kt, acc, sp);
+                s_store(buf ^ 1, kt + 1 < KT ? kt + 1 : KT - 1, ra[(u + 1) % PD], rb[(u + 1) % PD], kp[(u + 1) % PD]);   // at kt + 1 == KT: a dead store of the clamped re-load
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int u = 0; u + 1 < PD; ++u) {
+            const int kt = kt0 + u, buf = kt & 1;
+            if (kt < KT) {
+                compute(buf);
+                if constexpr (P::kSegmented) p.k_hook(ctx, kt, acc, sp);
+                if (kt + 1 < KT) s_store(buf ^ 1, kt + 1, ra[u + 1], rb[u + 1], kp[u + 1]);
                 __syncthreads();
             }
         }
@@ -622,7 +682,7 @@ struct FwdConvP {
     static constexpr int kMinWaves = (Cfg::TM * Cfg::TN == 4 && MODE != F_POOL) ? 3 : 1;    // (the pooling fetch holds 4 float4 per row)
 
     struct Ctx { int n, m0, n0; };
-    struct ARow { int y, x; bool valid; };
+    struct ARow { int y, x; bool valid; unsigned off; };     // off: element offset of the row inside its stream (F_ONE)
     struct DRow {};
     using KPrm = typename std::conditional<MODE == F_STEM, KPrm0, KPrm4>::type;
     using KFin = typename std::conditional<MODE == F_STEM, KPrm0, KPrm3>::type;
@@ -637,19 +697,20 @@ struct FwdConvP {
         c.n = c.m0 / po.HWp;
         return c.m0 - c.n * po.HWp < po.HW;
     }
-    // mean | invstd of the fresh channels -> LDS; the first tile of every stream also stores them in the table
-    __device__ void init_params(const Ctx& c, float* sp) const {
+    // mean | invstd of the fresh channels: EVERY workgroup derives them from the fp64 sums and stores them in the table
+    // (all workgroups of a stream store the same bits), then reads them back like any other channel when the k-loop reaches
+    // them.  Its own stores are visible to its later loads (same CU, same L1, issued after the prologue barrier); the
+    // fresh channels are the LAST kFresh of K, i.e. never in k-tile 0, whose loads go out before this prologue
+    // (the launch site checks fresh0 >= BK).
+    __device__ void init_params(const Ctx& c, float*) const {
         if constexpr (MODE != F_STEM) {
+            static_assert(kPrefetch == 1, "the fresh tile must be fetched after the prologue");
             const int t = threadIdx.x;
             if (fresh0 < K && t < kFresh) {
                 float mean, invstd;
                 bn_moments(fsum, fsq, (int64_t)c.n * fstride + fresh0 + t, 1.0 / (double)ps.HW, eps, mean, invstd);
-                sp[t] = mean;
-                sp[kFresh + t] = invstd;
-                if (c.n0 == 0 && c.m0 == c.n * po.HWp) {
-                    tw_mean[(int64_t)c.n * bt.ld + fresh0 + t] = mean;
-                    tw_invstd[(int64_t)c.n * bt.ld + fresh0 + t] = invstd;
-                }
+                tw_mean[(int64_t)c.n * bt.ld + fresh0 + t] = mean;
+                tw_invstd[(int64_t)c.n * bt.ld + fresh0 + t] = invstd;
             }
         }
     }
@@ -665,34 +726,35 @@ struct FwdConvP {
         r.valid = p < po.HW;
         r.y = p / po.W;
         r.x = p - r.y * po.W;
+        r.off = 4u * (unsigned)(p * lds_);               // byte offset of the row inside its stream
     }
     using ARaw = RawT<(MODE == F_POOL) ? 4 : 1>;
     using BRaw = u32x4;
-    __device__ int a_chan(int kt, int q) const {
-        if constexpr (MODE == F_THREE) { const int kpt = K / Cfg::BK; return (kt % kpt) * Cfg::BK + 4 * q; }
-        else return kt * Cfg::BK + 4 * q;
+    // first channel of k-tile kt (workgroup-uniform: the per-thread part of every address below is loop-invariant, so the
+    // loads are scalar base + 32-bit lane offset with no address arithmetic per k-tile)
+    __device__ int a_chan0(int kt) const {
+        if constexpr (MODE == F_THREE) { const int kpt = K / Cfg::BK; return (kt % kpt) * Cfg::BK; }
+        else return kt * Cfg::BK;
     }
+    __device__ int a_chan(int kt, int q) const { return a_chan0(kt) + 4 * q; }
     // BN parameters of this thread's channel quad for k-tile kt (L1 / L2 resident tables; fetched with the tile's loads)
     __device__ KPrm k_fetch(const Ctx& c, int kt, int q) const {
         KPrm k;
         if constexpr (MODE != F_STEM) {
-            const int ch = a_chan(kt, q);
-            k.mean = ldv4(tab_mean(bt, c.n) + ch);          // (fresh channels: stale table values, replaced in k_finish)
-            k.invstd = ldv4(tab_invstd(bt, c.n) + ch);
-            k.gamma = ldv4(bt.gamma + ch);
-            k.beta = ldv4(bt.beta + ch);
+            const int ch0 = a_chan0(kt);
+            const unsigned qo = 16u * (unsigned)q, so = 4u * (unsigned)ch0;
+            k.mean = bloadv4(tab_mean(bt, c.n), kWholeBuf, qo, so);    // (fresh channels: stale table values, replaced in k_finish)
+            k.invstd = bloadv4(tab_invstd(bt, c.n), kWholeBuf, qo, so);
+            k.gamma = bloadv4(bt.gamma, kWholeBuf, qo, so);
+            k.beta = bloadv4(bt.beta, kWholeBuf, qo, so);
         }
         return k;
     }
-    __device__ KFin k_finish(const Ctx&, const KPrm& k, int kt, int q, const float* sp) const {
+    __device__ KFin k_finish(const Ctx&, const KPrm& k, int, int, const float*) const {
         KFin f;
         if constexpr (MODE != F_STEM) {
-            const int ch = a_chan(kt, q);
-            const bool fresh = ch >= fresh0;
-            const int fo = fresh ? ch - fresh0 : 0;                 // (LDS reads from a clamped offset: no branch)
-            const f32x4 fm = ldv4(sp + fo), fi = ldv4(sp + kFresh + fo);
-            f.mean = fresh ? fm : k.mean;
-            f.scale = k.gamma * (fresh ? fi : k.invstd);
+            f.mean = k.mean;
+            f.scale = k.gamma * k.invstd;
             f.beta = k.beta;
         }
         return f;
@@ -702,8 +764,9 @@ struct FwdConvP {
     __device__ ARaw a_fetch(const Ctx& c, const ARow& r, int kt, int q) const {
         ARaw o;
         if constexpr (MODE == F_ONE) {
-            o.ok = r.valid;
-            o.v[0] = ld4(src + ((int64_t)c.n * ps.HWp + (o.ok ? r.y * ps.W + r.x : 0)) * lds_ + a_chan(kt, q));
+            // rows of the plane padding are read as they are (they exist) and produce output rows nobody stores or sums
+            o.ok = true;
+            o.v[0] = bload4(src + (int64_t)c.n * ps.HWp * lds_, kWholeBuf, r.off + 16u * (unsigned)q, 4u * (unsigned)(kt * Cfg::BK));
         } else if constexpr (MODE == F_THREE) {
             const int tap = kt / (K / Cfg::BK);
             const int yy = r.y + tap / 3 - 1, xx = r.x + tap % 3 - 1;
@@ -728,6 +791,7 @@ struct FwdConvP {
         if constexpr (MODE == F_STEM) {
             return o.ok ? o.v[0] : zero4();
         } else {
+            if constexpr (MODE == F_ONE) return bnrelu4(o.v[0], k);
             if (!o.ok) return zero4();                   // zero padding applies AFTER bn + relu
             if constexpr (MODE == F_POOL) {
                 float4 s = bnrelu4(o.v[0], k);
@@ -744,7 +808,7 @@ struct FwdConvP {
     // weight unit (piece, k8 of this k-tile, tile row r): rows past N read a neighbouring unit (the packed array has
     // slack behind it); the columns they feed are never stored
     __device__ BRaw b_unit(const Ctx& c, int kt, int piece, int k8, int r) const {
-        return wp[((int64_t)piece * K8tot + kt * Cfg::K8 + k8) * N + c.n0 + r];
+        return bload_u4(wp, kWholeBuf, 16u * (unsigned)((piece * K8tot + k8) * N + r), 16u * (unsigned)(kt * Cfg::K8 * N + c.n0));
     }
     __device__ u32x4 b_unit_xform(const Ctx&, const BRaw& o, int) const { return o; }
     __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, float*, bool active) const {
@@ -854,7 +918,7 @@ struct BwdDataP {
     float eps;
     TileMap tm;
     static constexpr int kSwizzle = 1;
-    static constexpr int kPrefetch = (Cfg::TM * Cfg::TN <= 2) ? SMG_PD_DGRAD : 1;
+    static constexpr int kPrefetch = (Cfg::TM * Cfg::TN <= 2) ? SMG_PD_DGRAD : SMG_PD_DGRAD_BIG;
     static constexpr bool kSegmented = false;
     static constexpr bool kHasPrologue = true;
     static constexpr int kMinWaves = 1;
@@ -1101,7 +1165,7 @@ struct BwdDataGroupP {
     float eps;
     TileMap tm;
     static constexpr int kSwizzle = 1;
-    static constexpr int kPrefetch = (Cfg::TM * Cfg::TN <= 1) ? SMG_PD_DGRAD : 1;
+    static constexpr int kPrefetch = (Cfg::TM * Cfg::TN <= 1) ? SMG_PD_DGRAD : SMG_PD_DGRAD_BIG;
     static constexpr bool kSegmented = true;
     static constexpr bool kHasPrologue = true;
     static constexpr int kMinWaves = 3;       // 160 registers without spilling: 3 workgroups per CU instead of 2 (-0.4 ms per step)
