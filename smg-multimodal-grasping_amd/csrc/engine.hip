@@ -53,6 +53,9 @@ using CfgP128x64 = GemmCfg<128, 64, 16, 2, 2, 1, true>;      // stem, head conv0
 using CfgP64x64 = GemmCfg<64, 64, 32, 2, 2, 1, true>;        // 1x1 fwd / dgrad, transitions
 using CfgP64x64k16 = GemmCfg<64, 64, 16, 2, 2, 1, true>;     // 1x1 fwd with many input channels: 29 KB LDS incl. BN parameters
 using CfgP32x64 = GemmCfg<32, 64, 32, 1, 2, 2, true>;        // 1x1 fwd of a launch too small to fill the chip: 2x the workgroups, half the K chain per wave
+using CfgP128x128d = GemmCfg<128, 128, 32, 2, 2, 1, true>;   // 1x1 fwd of launches with fewer 128-row tiles than CUs: one workgroup per CU, deep register prefetch
+using CfgP64x128d = GemmCfg<64, 128, 32, 2, 2, 1, true>;     // the same for planes that tile by 64 rows only (40^2)
+using CfgP64x64w = GemmCfg<64, 64, 32, 1, 2, 2, true>;       // 64x64 with 64x32 wave tiles over half the k-steps each: 25% fewer fragment reads per MFMA
 using CfgP64x128 = GemmCfg<64, 128, 16, 2, 2, 1, true>;      // 3x3 dgrad, late 1x1 fwd / transitions (A operand read once)
 using CfgP64x32 = GemmCfg<64, 32, 64, 2, 1, 2, true>;        // 3x3 fwd, k-tile split over 2 waves
 // weight gradients (reduction over pixels)
@@ -654,10 +657,16 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
                     // the k-tile split over wave pairs: twice the workgroups, half the serial K chain.
                     static const int small_wgs = getenv("SMG_C1_SMALL") ? atoi(getenv("SMG_C1_SMALL")) : 320;   // 512 / 1024 measured slower on the 17-stream step
                     const int wg128 = ns * pl.HWp / 128, wg64 = ns * pl.HWp / 64 * 2;
-                    static const bool k16 = getenv("SMG_C1_K16") != nullptr;      // dev A/B: BK = 16 past 576 channels (round 1's rule)
+                    static const int k16 = getenv("SMG_C1_K16") ? atoi(getenv("SMG_C1_K16")) : 1 << 30;      // dev A/B: BK = 16 past this many channels
+                    static const int mid = getenv("SMG_C1_MID") ? atoi(getenv("SMG_C1_MID")) : 0;                     // dev A/B
+                    static const int deep_min = getenv("SMG_C1_DEEP") ? atoi(getenv("SMG_C1_DEEP")) : 1 << 30;       // dev A/B
                     if (pl.HWp % 128 == 0 && wg128 >= small_wgs) run(CfgP128x128{});
+                    else if (pl.HWp % 128 == 0 && wg128 >= deep_min && d.cin % 32 == 0) run(CfgP128x128d{});
                     else if (wg64 < small_wgs) run(CfgP32x64{});
-                    else if (k16 && d.cin > 576) run(CfgP64x64k16{});
+                    else if (mid == 3) run(CfgP64x64w{});
+                    else if (mid == 1) run(CfgP64x128{});
+                    else if (mid == 2 && d.cin % 32 == 0) run(CfgP64x128d{});
+                    else if (d.cin > k16) run(CfgP64x64k16{});
                     else run(CfgP64x64{});
                 }
                 const BnTab t2 = bn_table(e, e->sb_tab[b][i], e->max_streams, s0, kBottleneck, P + d.n2.w, P + d.n2.b);
@@ -923,7 +932,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
             } else {   // conv2 (3x3) data gradient -> dy of relu2/norm2 (D2) + norm2 sums (generic implicit GEMM)
                 auto run = [&](auto tag) {
                     using Cfg = decltype(tag);
-                    BwdDataP<Cfg, true, E_STORE> p{};
+                    BwdDataP<Cfg, true, E_STORE, false> p{};
                     p.gbuf = GSb; p.ldg = kGrowth; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kGrowth;
                     p.wp = e->packed_u + e->pk_g3d[b][i]; p.K8tot = 9 * kGrowth / 8; p.ldn = kBottleneck; p.wcol0 = 0; p.N = kBottleneck;
                     p.mbuf = bt; p.ldm = kBottleneck; p.mcoff = 0; p.pm = pl;
@@ -967,7 +976,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 hipLaunchKernelGGL(reduce_partials_kernel, dim3((9 * kGrowth * kBottleneck + 255) / 256), dim3(256), 0, s2, r);
             } else {   // conv2 weight gradient (generic implicit GEMM, one launch slice per tap)
                 const int chunk = 512, cps = (pl.HWp + chunk - 1) / chunk;   // latency-bound: many short workgroups
-                BwdWeightP<CfgW32x128, W_THREE, C_3x3> p{};
+                BwdWeightP<CfgW32x128, W_THREE, C_3x3, SMG_PD_WGRAD, false> p{};
                 p.gbuf = GSb; p.ldg = kGrowth; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kGrowth;
                 p.bbuf = bt; p.ldb = kBottleneck; p.pb = pl; p.NB = kBottleneck;
                 p.bsum = fsum(e, e->st_Bt[b][i]); p.bsq = fsq(e, e->st_Bt[b][i]); p.bstride = kBottleneck;
@@ -1000,7 +1009,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
             if (d.cin > cs) {                                           // [cs, cin): per-layer accumulate
                 auto run = [&](auto tag) {
                     using Cfg = decltype(tag);
-                    BwdDataP<Cfg, false, E_ACCUM> p{};
+                    BwdDataP<Cfg, false, E_ACCUM, false> p{};
                     p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kBottleneck;
                     p.wp = e->packed_u + e->pk_d1[b][i]; p.K8tot = kBottleneck / 8; p.ldn = d.cin; p.wcol0 = cs; p.N = d.cin - cs;
                     p.mbuf = e->X[b]; p.ldm = Ct; p.mcoff = cs; p.pm = pl;
@@ -1044,7 +1053,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 int chunk, cps;
                 static const int w1_target = getenv("SMG_W1_WGS") ? atoi(getenv("SMG_W1_WGS")) : 512;            // dev A/B
                 pick_chunk(pl, NS, nt, chunk, cps, w1_target);   // 384..768 measure the same; 256 is slower
-                BwdWeightP<Cfg, W_ONE, C_IDENT> p{};
+                BwdWeightP<Cfg, W_ONE, C_IDENT, SMG_PD_WGRAD, false> p{};
                 p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck;
                 p.bbuf = e->X[b]; p.ldb = Ct; p.pb = pl; p.NB = d.cin;
                 p.bsum = fsum(e, e->st_X[b]); p.bsq = fsq(e, e->st_X[b]); p.bstride = Ct;

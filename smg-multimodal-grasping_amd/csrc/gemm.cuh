@@ -51,19 +51,31 @@
 
 // dev knobs: k-tiles of global loads in flight per policy family (register ring depth of the staging pipeline)
 #ifndef SMG_PD_FWD_SMALL
-#define SMG_PD_FWD_SMALL 1
+#define SMG_PD_FWD_SMALL 2
 #endif
 #ifndef SMG_PD_FWD_BIG
 #define SMG_PD_FWD_BIG 1
 #endif
+#ifndef SMG_PD_FWD_DEEP
+#define SMG_PD_FWD_DEEP 2
+#endif
 #ifndef SMG_PD_DGRAD
-#define SMG_PD_DGRAD 1
+#define SMG_PD_DGRAD 2
 #endif
 #ifndef SMG_PD_DGRAD_BIG
 #define SMG_PD_DGRAD_BIG 1
 #endif
 #ifndef SMG_PD_WGRAD
-#define SMG_PD_WGRAD 1
+#define SMG_PD_WGRAD 3
+#endif
+
+// The order of fragment reads and MFMAs inside a k-tile is left to hipcc (with two k-tiles of loads in flight it interleaves
+// the next tile's split / LDS stores with the MFMAs: k-loop of the 64x64 forward -17 %, of the 1x1 data gradient -27 %);
+// SMG_PIN_ORDER restores round 2's early pinned order for A/B.
+#ifdef SMG_PIN_ORDER
+#define SMG_PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SMG_PIN() do {} while (0)
 #endif
 
 namespace smg {
@@ -199,6 +211,7 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 // lane (VGPR) + a per-k-tile scalar byte offset (SGPR) - no address arithmetic on the VALU inside the k-loop (a flat
 // global_load needs a 64-bit add per load per k-tile; hipcc widens the lane offset outside the loop and cannot pick the
 // scalar-base form).  Bytes at or past `bytes` read as zero: lanes whose element does not exist carry kOOB as offset.
+__device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }   // workgroup-uniform by construction
 constexpr unsigned kOOB = 0xC0000000u;          // + any scalar offset (< 1 GiB) stays past every descriptor's extent
 constexpr unsigned kWholeBuf = 0xBFFFFFFFu;     // extent of descriptors without a tight bound
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ubase, unsigned bytes) {
@@ -338,7 +351,11 @@ __device__ __forceinline__ void block_col_reduce(T (&v)[NQ][C::TN], T* red, T (&
 // Dev instrumentation (SMG_TRACE_* in engine.hip): when set, thread 0 of every workgroup of a gemm_kernel launch
 // stores s_memtime at five points: start | parameters ready | first tile staged | k-loop done | epilogue done.
 __device__ unsigned long long* g_smg_trace = nullptr;
+#if defined(SMG_TRACE_ITER) || defined(SMG_TRACE_EPI)
+#define SMG_TRACE(slot) do {} while (0)
+#else
 #define SMG_TRACE(slot) do { if (trace) trace[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------
 // The kernel.
@@ -495,12 +512,12 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
 #pragma unroll
             for (int j = 0; j < C::TN; ++j) bh[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 0);
             if constexpr (PREC != 0) {       // single-piece modes: one term per tile
-                __builtin_amdgcn_sched_barrier(0);
+                SMG_PIN();
 #pragma unroll
                 for (int i = 0; i < C::TM; ++i)
 #pragma unroll
                     for (int j = 0; j < C::TN; ++j) acc[i][j] = mfma_1p<PREC>(ah[i], bh[j], acc[i][j]);
-                __builtin_amdgcn_sched_barrier(0);
+                SMG_PIN();
             } else {
                 {
                     u32x4 al_[C::TM], bl_[C::TN];
@@ -508,7 +525,7 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
                     for (int i = 0; i < C::TM; ++i) al_[i] = frag(A, C::LDUA, C::LDTA, wm0 + i * 32, s, 2);
 #pragma unroll
                     for (int j = 0; j < C::TN; ++j) bl_[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 2);
-                    __builtin_amdgcn_sched_barrier(0);   // keep every ds_read ahead of the MFMA block (hipcc re-interleaves them otherwise)
+                    SMG_PIN();   // keep every ds_read ahead of the MFMA block (hipcc re-interleaves them otherwise)
 #pragma unroll
                     for (int i = 0; i < C::TM; ++i)
 #pragma unroll
@@ -517,14 +534,14 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
                     for (int i = 0; i < C::TM; ++i)
 #pragma unroll
                         for (int j = 0; j < C::TN; ++j) acc[i][j] = mfma_bf16(al_[i], bh[j], acc[i][j]);
-                    __builtin_amdgcn_sched_barrier(0);
+                    SMG_PIN();
                 }
                 u32x4 am[C::TM], bm[C::TN];
 #pragma unroll
                 for (int i = 0; i < C::TM; ++i) am[i] = frag(A, C::LDUA, C::LDTA, wm0 + i * 32, s, 1);
 #pragma unroll
                 for (int j = 0; j < C::TN; ++j) bm[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 1);
-                __builtin_amdgcn_sched_barrier(0);
+                SMG_PIN();
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -532,7 +549,7 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
 #pragma unroll
                         for (int j = 0; j < C::TN; ++j)
                             acc[i][j] = mfma_bf16((g & 1) ? ah[i] : am[i], g < 2 ? bm[j] : bh[j], acc[i][j]);   // mid*mid, hi*mid, mid*hi, hi*hi
-                __builtin_amdgcn_sched_barrier(0);
+                SMG_PIN();
             }
         }
     };
@@ -554,11 +571,26 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
         // two k-tiles per trip: the LDS buffer of every access is a compile-time constant (immediate offsets, no address VALU)
         auto step = [&](int kt, auto BUF, bool more) {
             constexpr int buf = decltype(BUF)::value;
+#ifdef SMG_TRACE_ITER   // dev: sub-phase stamps of k-tile 4 instead of the whole-kernel phases (compute | load wait | store | barrier)
+            const bool tr = trace && kt == 4;
+            if (tr) trace[0] = __builtin_amdgcn_s_memtime();
+#endif
             if (more) g_load(kt + 1, ra[0], rb[0], kp[0]);
             compute(buf);
             if constexpr (P::kSegmented) p.k_hook(ctx, kt, acc, sp);   // end of a K segment: fold acc away
+#ifdef SMG_TRACE_ITER
+            if (tr) trace[1] = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tr) trace[2] = __builtin_amdgcn_s_memtime();
+#endif
             if (more) s_store(buf ^ 1, kt + 1, ra[0], rb[0], kp[0]);
+#ifdef SMG_TRACE_ITER
+            if (tr) trace[3] = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();
+#ifdef SMG_TRACE_ITER
+            if (tr) trace[4] = __builtin_amdgcn_s_memtime();
+#endif
         };
         int kt = 0;
         for (; kt + 2 <= KT; kt += 2) {
@@ -674,43 +706,56 @@ struct FwdConvP {
     static constexpr int kSwizzle = 1;
     // k-tiles of global loads in flight: the one-MFMA-tile-per-wave configurations of the small planes do 0.1 us of MFMAs per
     // k-tile against ~1 us of memory latency
-    static constexpr int kPrefetch = (Cfg::TM * Cfg::TN == 1) ? SMG_PD_FWD_SMALL : SMG_PD_FWD_BIG;
+    static constexpr bool kDeep = Cfg::BN == 128 && Cfg::BK == 32;      // one workgroup per CU: its own loads must cover the latency
+    static constexpr int kPrefetch = kDeep ? SMG_PD_FWD_DEEP : (Cfg::TM * Cfg::TN == 1) ? SMG_PD_FWD_SMALL : SMG_PD_FWD_BIG;
     static constexpr bool kSegmented = false;
     static constexpr bool kHasPrologue = MODE != F_STEM;
     static constexpr int kFresh = 32;       // growth rate: at most this many fresh channels
     // waves per SIMD the register allocator is held to: the 128x128 tile (64 accumulator registers) must stay at 3
-    static constexpr int kMinWaves = (Cfg::TM * Cfg::TN == 4 && MODE != F_POOL) ? 3 : 1;    // (the pooling fetch holds 4 float4 per row)
+    static constexpr int kMinWaves = (Cfg::TM * Cfg::TN == 4 && MODE != F_POOL && !kDeep) ? 3 : 1;    // (the pooling fetch holds 4 float4 per row)
 
     struct Ctx { int n, m0, n0; };
     struct ARow { int y, x; bool valid; unsigned off; };     // off: element offset of the row inside its stream (F_ONE)
     struct DRow {};
-    using KPrm = typename std::conditional<MODE == F_STEM, KPrm0, KPrm4>::type;
+    using KPrm = KPrm0;
     using KFin = typename std::conditional<MODE == F_STEM, KPrm0, KPrm3>::type;
 
-    __host__ __device__ int param_floats() const { return MODE == F_STEM ? 0 : 2 * kFresh; }
+    __host__ __device__ int param_floats() const { return MODE == F_STEM ? 0 : 3 * K; }       // mean | gamma*invstd | beta of all K channels
 
     __device__ bool init_ctx(Ctx& c, const VBlock& vb) const {
         int mt = vb.x, nt = vb.y;
         if (tm.nM && !tile_decode(tm, vb.x, mt, nt)) return false;
-        c.m0 = mt * Cfg::BM;
-        c.n0 = nt * Cfg::BN;
-        c.n = c.m0 / po.HWp;
+        c.m0 = sgpr(mt * Cfg::BM);          // (scalar registers for sure: the staged loads take them as scalar offsets)
+        c.n0 = sgpr(nt * Cfg::BN);
+        c.n = sgpr(c.m0 / po.HWp);
         return c.m0 - c.n * po.HWp < po.HW;
     }
-    // mean | invstd of the fresh channels: EVERY workgroup derives them from the fp64 sums and stores them in the table
-    // (all workgroups of a stream store the same bits), then reads them back like any other channel when the k-loop reaches
-    // them.  Its own stores are visible to its later loads (same CU, same L1, issued after the prologue barrier); the
-    // fresh channels are the LAST kFresh of K, i.e. never in k-tile 0, whose loads go out before this prologue
-    // (the launch site checks fresh0 >= BK).
-    __device__ void init_params(const Ctx& c, float*) const {
+    // BN parameters of this stream's K channels -> LDS, once per workgroup: (mean, gamma*invstd, beta) from the fp32 tables;
+    // the fresh channels (the last kFresh) from the fp64 sums, and the first tile of every stream stores those in the table.
+    // The staging threads then read their channel quad's parameters from LDS per k-tile (reading them from the tables per
+    // k-tile was 16 KB of L1 traffic per workgroup and k-tile, twice the A operand).
+    __device__ void init_params(const Ctx& c, float* sp) const {
         if constexpr (MODE != F_STEM) {
-            static_assert(kPrefetch == 1, "the fresh tile must be fetched after the prologue");
             const int t = threadIdx.x;
+            const float* tmean = tab_mean(bt, c.n);
+            const float* tinv = tab_invstd(bt, c.n);
+            for (int ch = 4 * t; ch < K && ch < fresh0; ch += 1024) {
+                const f32x4 m = ldv4(tmean + ch), iv = ldv4(tinv + ch), g = ldv4(bt.gamma + ch), be = ldv4(bt.beta + ch);
+                *reinterpret_cast<f32x4*>(sp + ch) = m;
+                *reinterpret_cast<f32x4*>(sp + K + ch) = g * iv;
+                *reinterpret_cast<f32x4*>(sp + 2 * K + ch) = be;
+            }
             if (fresh0 < K && t < kFresh) {
+                const int ch = fresh0 + t;
                 float mean, invstd;
-                bn_moments(fsum, fsq, (int64_t)c.n * fstride + fresh0 + t, 1.0 / (double)ps.HW, eps, mean, invstd);
-                tw_mean[(int64_t)c.n * bt.ld + fresh0 + t] = mean;
-                tw_invstd[(int64_t)c.n * bt.ld + fresh0 + t] = invstd;
+                bn_moments(fsum, fsq, (int64_t)c.n * fstride + ch, 1.0 / (double)ps.HW, eps, mean, invstd);
+                sp[ch] = mean;
+                sp[K + ch] = bt.gamma[ch] * invstd;
+                sp[2 * K + ch] = bt.beta[ch];
+                if (c.n0 == 0 && c.m0 == c.n * po.HWp) {
+                    tw_mean[(int64_t)c.n * bt.ld + ch] = mean;
+                    tw_invstd[(int64_t)c.n * bt.ld + ch] = invstd;
+                }
             }
         }
     }
@@ -737,25 +782,15 @@ struct FwdConvP {
         else return kt * Cfg::BK;
     }
     __device__ int a_chan(int kt, int q) const { return a_chan0(kt) + 4 * q; }
-    // BN parameters of this thread's channel quad for k-tile kt (L1 / L2 resident tables; fetched with the tile's loads)
-    __device__ KPrm k_fetch(const Ctx& c, int kt, int q) const {
-        KPrm k;
-        if constexpr (MODE != F_STEM) {
-            const int ch0 = a_chan0(kt);
-            const unsigned qo = 16u * (unsigned)q, so = 4u * (unsigned)ch0;
-            k.mean = bloadv4(tab_mean(bt, c.n), kWholeBuf, qo, so);    // (fresh channels: stale table values, replaced in k_finish)
-            k.invstd = bloadv4(tab_invstd(bt, c.n), kWholeBuf, qo, so);
-            k.gamma = bloadv4(bt.gamma, kWholeBuf, qo, so);
-            k.beta = bloadv4(bt.beta, kWholeBuf, qo, so);
-        }
-        return k;
-    }
-    __device__ KFin k_finish(const Ctx&, const KPrm& k, int, int, const float*) const {
+    __device__ KPrm k_fetch(const Ctx&, int, int) const { return KPrm{}; }
+    // BN parameters of this thread's channel quad for k-tile kt, from the workgroup's LDS copy
+    __device__ KFin k_finish(const Ctx&, const KPrm&, int kt, int q, const float* sp) const {
         KFin f;
         if constexpr (MODE != F_STEM) {
-            f.mean = k.mean;
-            f.scale = k.gamma * k.invstd;
-            f.beta = k.beta;
+            const int ch = a_chan(kt, q);
+            f.mean = ldv4(sp + ch);
+            f.scale = ldv4(sp + K + ch);
+            f.beta = ldv4(sp + 2 * K + ch);
         }
         return f;
     }
@@ -896,7 +931,7 @@ struct FwdConvP {
 // ------------------------------------------------------------------------------------
 enum { E_STORE = 0, E_ACCUM = 1, E_UNPOOL = 2 };
 
-template <class Cfg_, bool SHIFT3, int EMODE>
+template <class Cfg_, bool SHIFT3, int EMODE, bool AFF = true>
 struct BwdDataP {
     using Cfg = Cfg_;
     static_assert(Cfg::AT, "data-gradient form");
@@ -923,8 +958,18 @@ struct BwdDataP {
     static constexpr bool kHasPrologue = true;
     static constexpr int kMinWaves = 1;
 
-    struct Ctx { int n, m0, n0; };
-    struct ARow { int y, x; bool valid; };
+    // AFF = false: the gradient operand is finished (xbuf unused).  Pointwise and finished -> descriptor loads, rows outside
+    // the plane carry the out-of-range offset and read as zero (no mask, no address arithmetic in the k-loop).
+    static constexpr bool kFast = !SHIFT3 && !AFF;
+    // Whole tiles inside the plane fetch the epilogue's operands (the mask source x and, for E_ACCUM, the old G') at the START
+    // of the workgroup, into registers: the K loop of a 1x1 data gradient is 8 k-tiles, and an epilogue that only then starts
+    // its loads costs more cycles than that loop (measured: 10k of 24k per workgroup).
+    static constexpr bool kEarly = EMODE != E_UNPOOL;
+    struct Ctx {
+        int n, m0, n0; bool whole;
+        float xv[kEarly ? Cfg::TM : 1][kEarly ? Cfg::TN : 1][16], gold[(kEarly && EMODE == E_ACCUM) ? Cfg::TM : 1][(kEarly && EMODE == E_ACCUM) ? Cfg::TN : 1][16];
+    };
+    struct ARow { int y, x; bool valid; unsigned off; };
     struct DRow {};
     using KPrm = KPrm0;
     using KFin = KPrm0;
@@ -938,10 +983,36 @@ struct BwdDataP {
     __device__ bool init_ctx(Ctx& c, const VBlock& vb) const {
         int mt = vb.x, nt = vb.y;
         if (tm.nM && !tile_decode(tm, vb.x, mt, nt)) return false;
-        c.m0 = mt * Cfg::BM;
-        c.n0 = nt * Cfg::BN;
-        c.n = c.m0 / pa.HWp;
-        return c.m0 - c.n * pa.HWp < pa.HW;
+        c.m0 = sgpr(mt * Cfg::BM);          // (scalar registers for sure: the staged loads take them as scalar offsets)
+        c.n0 = sgpr(nt * Cfg::BN);
+        c.n = sgpr(c.m0 / pa.HWp);
+        const int pbase = c.m0 - c.n * pa.HWp;
+        if (pbase >= pa.HW) return false;
+        c.whole = kEarly && pbase + Cfg::BM <= pa.HW && c.n0 + Cfg::BN <= N;
+        if constexpr (kEarly) {
+            if (c.whole) {
+                const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
+                const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
+                const float* xb = mbuf + (int64_t)c.m0 * ldm + mcoff + c.n0;
+                const float* gb = dst + (int64_t)c.m0 * ldd + dcoff + c.n0;
+#pragma unroll
+                for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < Cfg::TN; ++j) {
+                        const int cj = wn0 + j * 32 + l31;
+                        unsigned ox = (unsigned)((wm0 + i * 32 + 4 * half) * ldm + cj);
+                        unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + cj);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            c.xv[i][j][r] = xb[ox];
+                            if constexpr (EMODE == E_ACCUM) c.gold[i][j][r] = gb[og];
+                            ox += (r & 3) == 3 ? 5u * (unsigned)ldm : (unsigned)ldm;
+                            og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
+                        }
+                    }
+            }
+        }
+        return true;
     }
     __device__ void init_params(const Ctx& c, float* sp) const {
         const double inv = 1.0 / (double)pa.HW;
@@ -979,6 +1050,7 @@ struct BwdDataP {
         r.valid = p < pa.HW;
         r.y = p / pa.W;
         r.x = p - r.y * pa.W;
+        r.off = r.valid ? 4u * (unsigned)(p * ldg) : kOOB;
     }
     using ARaw = RawT<2>;       // gradient + (when xbuf is set) the raw activation its BN normalised
     using BRaw = u32x4;
@@ -988,6 +1060,11 @@ struct BwdDataP {
     }
     __device__ ARaw a_fetch(const Ctx& c, const ARow& r, int kt, int q) const {
         ARaw o;
+        if constexpr (kFast) {
+            o.ok = true;
+            o.v[0] = bload4(gbuf + (int64_t)c.n * pa.HWp * ldg + gcoff, kWholeBuf, r.off + 16u * (unsigned)q, 4u * (unsigned)(kt * Cfg::BK));
+            return o;
+        }
         int yy = r.y, xx = r.x;
         o.ok = r.valid;
         if constexpr (SHIFT3) {
@@ -1003,19 +1080,24 @@ struct BwdDataP {
         return o;
     }
     __device__ float4 a_xform(const Ctx&, const ARaw& o, const KPrm&, int kt, int q, const float* sp) const {
+        if constexpr (kFast) return o.v[0];
         if (!o.ok) return zero4();
         if (!xbuf) return o.v[0];                      // gradient already BN-corrected (bn_bwd_apply_kernel)
         return affine2(o.v[0], o.v[1], sp + a_chan(kt, q), KA);
     }
     __device__ ARaw a_fetch_d(const Ctx&, const DRow&, int, int, int) const { return ARaw{}; }
     __device__ BRaw b_unit(const Ctx& c, int kt, int piece, int k8, int r) const {
-        return wp[((int64_t)piece * K8tot + kt * Cfg::K8 + k8) * ldn + wcol0 + c.n0 + r];
+        return bload_u4(wp, kWholeBuf, 16u * (unsigned)((piece * K8tot + k8) * ldn + r), 16u * (unsigned)(kt * Cfg::K8 * ldn + wcol0 + c.n0));
     }
     __device__ u32x4 b_unit_xform(const Ctx&, const BRaw& o, int) const { return o; }
     __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, float* sp, bool active) const {
         const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
         const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
         const float* ep = sp + 4 * KA;
+#ifdef SMG_TRACE_EPI    // dev: stamps inside the epilogue (start | stores issued | column sums reduced | atomics issued)
+        unsigned long long* etr = (g_smg_trace && threadIdx.x == 0) ? g_smg_trace + 8 * (size_t)blockIdx.x : nullptr;
+        if (etr) etr[0] = __builtin_amdgcn_s_memtime();
+#endif
         float v[2][Cfg::TN];
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) v[0][j] = v[1][j] = 0.f;
@@ -1027,34 +1109,23 @@ struct BwdDataP {
             const bool cok = col < N;
             const float sc = ep[cj], sh = ep[Cfg::BN + cj], mean = ep[2 * Cfg::BN + cj], invstd = ep[3 * Cfg::BN + cj];
             const float gam = ep[4 * Cfg::BN + cj];
-            if (EMODE != E_UNPOOL && active && pbase + Cfg::BM <= pa.HW && c.n0 + Cfg::BN <= N) {
-                // Whole tile inside the plane: no per-element predicates, uniform tile bases + running 32-bit lane
-                // offsets (saddr loads / stores) instead of 16 precomputed 64-bit addresses per strip.
-                const float* xb = mbuf + (int64_t)c.m0 * ldm + mcoff + c.n0;
+            if (kEarly && active && c.whole) {
+                // Whole tile inside the plane: no per-element predicates, operands already in registers (init_ctx), a uniform
+                // tile base + running 32-bit lane offset for the stores.
                 float* gb = dst + (int64_t)c.m0 * ldd + dcoff + c.n0;
 #pragma unroll
                 for (int i = 0; i < Cfg::TM; ++i) {
-                    float xv[16], gold[16];
-                    unsigned ox = (unsigned)((wm0 + i * 32 + 4 * half) * ldm + cj);
                     unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + cj);
-                    const unsigned og0 = og;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {                   // every load of the strip first (the stores alias them)
-                        xv[r] = xb[ox];
-                        if constexpr (EMODE == E_ACCUM) gold[r] = gb[og]; else gold[r] = 0.f;
-                        ox += (r & 3) == 3 ? 5u * (unsigned)ldm : (unsigned)ldm;
-                        og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
-                    }
-                    og = og0;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float dy = bn1(xv[r], mean, sc, sh) > 0.f ? acc[i][j][r] : 0.f;
-                        if constexpr (EMODE == E_STORE) gb[og] = dy; else gb[og] = gold[r] + gam * dy;
+                        const float xr = c.xv[kEarly ? i : 0][kEarly ? j : 0][r];
+                        const float dy = bn1(xr, mean, sc, sh) > 0.f ? acc[i][j][r] : 0.f;
+                        if constexpr (EMODE == E_STORE) gb[og] = dy;
+                        else gb[og] = c.gold[(kEarly && EMODE == E_ACCUM) ? i : 0][(kEarly && EMODE == E_ACCUM) ? j : 0][r] + gam * dy;
                         og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
                         v[0][j] += dy;
-                        v[1][j] += dy * ((xv[r] - mean) * invstd);
+                        v[1][j] += dy * ((xr - mean) * invstd);
                     }
-                    __builtin_amdgcn_sched_barrier(0);                // one strip of loads in flight at a time
                 }
             } else
 #pragma unroll
@@ -1114,7 +1185,13 @@ struct BwdDataP {
             }
         }
         float tot[2];
+#ifdef SMG_TRACE_EPI
+        if (etr) etr[1] = __builtin_amdgcn_s_memtime();
+#endif
         block_col_reduce<Cfg, 2, float>(v, smem, tot);
+#ifdef SMG_TRACE_EPI
+        if (etr) etr[2] = __builtin_amdgcn_s_memtime();
+#endif
         if (t < Cfg::BN && c.n0 + t < N) {
             const int col = c.n0 + t;
             const float wgt = (EMODE == E_STORE) ? 1.f : ep[4 * Cfg::BN + t];
@@ -1124,6 +1201,9 @@ struct BwdDataP {
             atomicAdd(dbeta + col, tot[0]);
             atomicAdd(dgamma + col, tot[1]);
         }
+#ifdef SMG_TRACE_EPI
+        if (etr) { etr[3] = __builtin_amdgcn_s_memtime(); etr[4] = etr[3] + 1; }
+#endif
     }
 };
 
@@ -1168,15 +1248,16 @@ struct BwdDataGroupP {
     static constexpr int kPrefetch = (Cfg::TM * Cfg::TN <= 1) ? SMG_PD_DGRAD : SMG_PD_DGRAD_BIG;
     static constexpr bool kSegmented = true;
     static constexpr bool kHasPrologue = true;
-    static constexpr int kMinWaves = 3;       // 160 registers without spilling: 3 workgroups per CU instead of 2 (-0.4 ms per step)
+    static constexpr int kMinWaves = 2;       // (x, the running sum and the old G' of the tile live in registers)
 
     struct Ctx {
-        int n, m0, n0;
+        int n, m0, n0; bool whole;
         float x[Cfg::TM][Cfg::TN][16];                  // raw activation of this lane's accumulator elements
+        float gold[Cfg::TM][Cfg::TN][16];               // old G' of whole tiles, fetched with x at the start (the epilogue only adds and stores)
         float run[Cfg::TM][Cfg::TN][16];                // sum_i gamma_i * dy_i
         float ls[GROUP_MAX][2][Cfg::TN];                // per-segment column partials (sum dy, sum dy*(x-mean))
     };
-    struct ARow { int p; bool valid; };
+    struct ARow { unsigned off; };      // byte offset of the row inside the tile; rows outside the plane: kOOB (read as zero)
     struct DRow {};
     using KPrm = KPrm0;
     using KFin = KPrm0;
@@ -1208,11 +1289,12 @@ struct BwdDataGroupP {
     __device__ bool init_ctx(Ctx& c, const VBlock& vb) const {
         int mt = vb.x, nt = vb.y;
         if (tm.nM && !tile_decode(tm, vb.x, mt, nt)) return false;
-        c.m0 = mt * Cfg::BM;
-        c.n0 = nt * Cfg::BN;
-        c.n = c.m0 / pa.HWp;
+        c.m0 = sgpr(mt * Cfg::BM);          // (scalar registers for sure: the staged loads take them as scalar offsets)
+        c.n0 = sgpr(nt * Cfg::BN);
+        c.n = sgpr(c.m0 / pa.HWp);
         const int pbase = c.m0 - c.n * pa.HWp;
         if (pbase >= pa.HW) return false;
+        c.whole = pbase + Cfg::BM <= pa.HW && c.n0 + Cfg::BN <= N;
         // this lane's x elements: in flight under the first K segment
         const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
         const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
@@ -1229,6 +1311,21 @@ struct BwdDataGroupP {
                     const float v = mbuf[(int64_t)(c.m0 + (ok ? row : 0)) * ldm + (ok ? col : 0)];
                     c.x[i][j][r] = ok ? v : 0.f;
                     c.run[i][j][r] = 0.f;
+                    c.gold[i][j][r] = 0.f;
+                }
+        }
+        if (c.whole) {
+            const float* gb = dst + (int64_t)c.m0 * ldd + c.n0;
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+                for (int i = 0; i < Cfg::TM; ++i) {
+                    unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + wn0 + j * 32 + l31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        c.gold[i][j][r] = gb[og];
+                        og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
+                    }
                 }
         }
 #pragma unroll
@@ -1240,23 +1337,24 @@ struct BwdDataGroupP {
     __device__ int kps() const { return KA / Cfg::BK; }                   // k-tiles per segment
     __device__ int ktiles(const Ctx&) const { return nseg * kps(); }
     __device__ void a_row_init(const Ctx& c, ARow& r, int line) const {
-        r.p = c.m0 + line;
-        r.valid = r.p - c.n * pa.HWp < pa.HW;
+        r.off = c.m0 + line - c.n * pa.HWp < pa.HW ? 4u * (unsigned)(line * ldg) : kOOB;
     }
     using ARaw = RawT<1>;
     using BRaw = u32x4;
-    __device__ ARaw a_fetch(const Ctx&, const ARow& r, int kt, int q) const {
+    __device__ ARaw a_fetch(const Ctx& c, const ARow& r, int kt, int q) const {
         ARaw o;
-        const int s = kt / kps(), ch = (kt - s * kps()) * Cfg::BK + 4 * q;
-        o.ok = r.valid;
-        o.v[0] = ld4(seg[s].g + (int64_t)r.p * ldg + ch);                // rows of the plane padding exist; zeroed below
+        const int s = kt / kps(), ch0 = (kt - s * kps()) * Cfg::BK;
+        o.ok = true;
+        o.v[0] = bload4(seg[s].g + (int64_t)c.m0 * ldg, kWholeBuf, r.off + 16u * (unsigned)q, 4u * (unsigned)ch0);
         return o;
     }
-    __device__ float4 a_xform(const Ctx&, const ARaw& o, const KPrm&, int, int, const float*) const { return o.ok ? o.v[0] : zero4(); }
+    __device__ float4 a_xform(const Ctx&, const ARaw& o, const KPrm&, int, int, const float*) const { return o.v[0]; }
     __device__ ARaw a_fetch_d(const Ctx&, const DRow&, int, int, int) const { return ARaw{}; }
     __device__ BRaw b_unit(const Ctx& c, int kt, int piece, int k8, int r) const {
-        const int s = kt / kps(), k8g = (kt - s * kps()) * Cfg::K8 + k8;
-        return seg[s].wp[((int64_t)piece * (KA / 8) + k8g) * seg[s].ldn + c.n0 + r];       // rows past N: never stored
+        const int s = kt / kps(), k80 = (kt - s * kps()) * Cfg::K8;
+        const unsigned ldn16 = 16u * (unsigned)seg[s].ldn;                                  // (the row pitch changes with the segment)
+        return bload_u4(seg[s].wp, kWholeBuf, __umul24((unsigned)(piece * (KA / 8) + k8), ldn16) + 16u * (unsigned)r,
+                        (unsigned)k80 * ldn16 + 16u * (unsigned)c.n0);                     // rows past N: never stored
     }
     __device__ u32x4 b_unit_xform(const Ctx&, const BRaw& o, int) const { return o; }
 
@@ -1303,28 +1401,19 @@ struct BwdDataGroupP {
             const int col = c.n0 + cj;
             const float mean = sp[cj], invstd = sp[Cfg::BN + cj];
             float a0 = 0.f, a1 = 0.f;
-            if (pbase + Cfg::BM <= pa.HW && c.n0 + Cfg::BN <= N) {        // whole tile inside the plane: see E_ACCUM
+            if (c.whole) {        // whole tile inside the plane: see E_ACCUM
                 float* gb = dst + (int64_t)c.m0 * ldd + c.n0;
 #pragma unroll
                 for (int i = 0; i < Cfg::TM; ++i) {
-                    float gold[16];
                     unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + cj);
-                    const unsigned og0 = og;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        gold[r] = gb[og];
-                        og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
-                    }
-                    og = og0;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float run = c.run[i][j][r];
-                        gb[og] = gold[r] + run;
+                        gb[og] = c.gold[i][j][r] + run;
                         og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
                         a0 += run;
                         a1 = fmaf(run, (c.x[i][j][r] - mean) * invstd, a1);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else
 #pragma unroll
@@ -1382,7 +1471,7 @@ struct BwdDataGroupP {
 enum { W_ONE = 0, W_THREE = 1, W_POOL = 2, W_STEM = 3 };
 enum { C_IDENT = 0, C_3x3 = 1, C_STEM = 2 };
 
-template <class Cfg_, int BMODE, int CMAP, int PD_ = SMG_PD_WGRAD>
+template <class Cfg_, int BMODE, int CMAP, int PD_ = SMG_PD_WGRAD, bool AFF = true>
 struct BwdWeightP {
     using Cfg = Cfg_;
     static_assert(!Cfg::AT, "weight-gradient form");
@@ -1440,17 +1529,17 @@ struct BwdWeightP {
     __device__ bool init_ctx(Ctx& c, const VBlock& vb) const {
         int z = vb.z, tile = vb.y * gx + vb.x;
         if (tm.nM && !tile_decode(tm, vb.x, z, tile)) return false;
-        c.z = z;
-        c.m0 = (tile % gx) * Cfg::BM;
-        c.n0 = (tile / gx) * Cfg::BN;
-        c.tap = z / n_chunks;
+        c.z = sgpr(z);
+        c.m0 = sgpr((tile % gx) * Cfg::BM);
+        c.n0 = sgpr((tile / gx) * Cfg::BN);
+        c.tap = sgpr(z / n_chunks);
         const int ci = z - c.tap * n_chunks;
-        c.n = ci / chunks_per_stream;
-        c.p0 = (ci - c.n * chunks_per_stream) * chunk;
+        c.n = sgpr(ci / chunks_per_stream);
+        c.p0 = sgpr((ci - c.n * chunks_per_stream) * chunk);
         if (c.p0 >= pa.HW) return false;
         int len = pa.HWp - c.p0;
         len = len < chunk ? len : chunk;
-        c.kt = len / Cfg::BK;
+        c.kt = sgpr(len / Cfg::BK);
         return true;
     }
     __device__ void init_params(const Ctx& c, float* sp) const {
@@ -1496,9 +1585,17 @@ struct BwdWeightP {
     __device__ ARaw a_fetch(const Ctx&, const ARow&, int, int) const { return ARaw{}; }
     // Unconditional loads from clamped addresses (pixel 0 / channel 0 of the stream where the slot lies outside the plane or
     // the matrix; zeroed at the LDS store): a branch around a staged load makes hipcc drain vmcnt(0) between load groups.
-    __device__ ARaw a_fetch_d(const Ctx& c, const DRow& r, int, int, int q) const {
+    // AFF = false (finished gradient): descriptor loads bounded to the HW rows of the stream - pixels past the plane and
+    // channel quads past MA read as zero, nothing to mask and no address arithmetic per k-tile.
+    __device__ ARaw a_fetch_d(const Ctx& c, const DRow& r, int kt, int kr, int q) const {
         ARaw o;
         const int ch = c.m0 + 4 * q;
+        if constexpr (!AFF) {
+            o.ok = true;
+            o.v[0] = bload4(gbuf + (int64_t)c.n * pa.HWp * ldg + gcoff, 4u * (unsigned)(pa.HW * ldg - gcoff),
+                            ch < MA ? 4u * (unsigned)(kr * ldg + ch) : kOOB, 4u * (unsigned)((c.p0 + kt * Cfg::BK) * ldg));
+            return o;
+        }
         o.ok = r.p < pa.HW && ch < MA;
         const int64_t pix = (int64_t)c.n * pa.HWp + (o.ok ? r.p : 0);
         const int chc = o.ok ? ch : 0;
@@ -1507,16 +1604,21 @@ struct BwdWeightP {
         return o;
     }
     __device__ float4 a_xform(const Ctx&, const ARaw& o, const KPrm&, int, int q, const float* sp) const {
+        if constexpr (!AFF) return o.v[0];
         if (!o.ok) return zero4();
         if (!xbuf) return o.v[0];
         return affine2(o.v[0], o.v[1], sp + 4 * q, Cfg::BM);
     }
-    __device__ BRaw b_fetch(const Ctx& c, const DRow& r, int, int, int q) const {
+    __device__ BRaw b_fetch(const Ctx& c, const DRow& r, int kt, int kr, int q) const {
         BRaw o;
         const int ch = c.n0 + 4 * q;
         o.ok = r.p < pa.HW && ch < NB;
         if constexpr (BMODE == W_ONE) {
-            o.v[0] = ld4(bbuf + ((int64_t)c.n * pb.HWp + (o.ok ? r.p : 0)) * ldb + (o.ok ? ch : 0));
+            // bounded to the HW rows (zero past them: the A rows there are zero, this keeps the product finite); channel quads
+            // past NB read the neighbouring channels of the row - their columns are never stored
+            o.ok = true;
+            o.v[0] = bload4(bbuf + (int64_t)c.n * pb.HWp * ldb, 4u * (unsigned)(pb.HW * ldb), 4u * (unsigned)(kr * ldb + ch),
+                            4u * (unsigned)((c.p0 + kt * Cfg::BK) * ldb));
         } else if constexpr (BMODE == W_THREE) {
             const int yy = r.y + c.tap / 3 - 1, xx = r.x + c.tap % 3 - 1;
             o.ok = o.ok && (unsigned)yy < (unsigned)pb.H && (unsigned)xx < (unsigned)pb.W;
@@ -1539,8 +1641,9 @@ struct BwdWeightP {
         if constexpr (BMODE == W_STEM) {
             return o.ok ? o.v[0] : zero4();
         } else {
-            if (!o.ok) return zero4();
             const float* pr = sp + 4 * Cfg::BM + 4 * q;
+            if constexpr (BMODE == W_ONE) return bnrelu4(o.v[0], pr, Cfg::BN);
+            if (!o.ok) return zero4();
             if constexpr (BMODE == W_POOL) {
                 float4 s = bnrelu4(o.v[0], pr, Cfg::BN);
                 s = add4(s, bnrelu4(o.v[1], pr, Cfg::BN));
