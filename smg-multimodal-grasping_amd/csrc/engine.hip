@@ -590,12 +590,18 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
         ProfScope ps(e, cs, K_OTHER, 0);
         hipLaunchKernelGGL(bn_stat_kernel, dim3((rows * C + 255) / 256), dim3(256), 0, cs, a);
     };
-    auto trunk_chain = [&](const int s0, const int ns, hipStream_t cs) -> int {
+    // Units [u_lo, u_hi) of the chain: unit 0 = input preparation + stem + pool0, then one unit per dense layer and per
+    // transition.  The caller alternates the chains unit by unit, so that both have work queued from the start (a chain
+    // enqueued whole keeps the host busy for ~1.3 ms, during which the other chain's HIP stream sits empty).
+    auto trunk_chain = [&](const int s0, const int ns, hipStream_t cs, const int u_lo, const int u_hi) -> int {
+        int unit = 0;
+        auto on = [&]() { const bool r = unit >= u_lo && unit < u_hi; ++unit; return r; };
         auto xs = [&](int b) { return e->X[b] + (int64_t)s0 * e->p_blk[b].HWp * kBlockCtot[b]; };
         auto st_off = [&](double* base, int stride) { return base + (int64_t)s0 * stride; };
         float* img4 = e->img4 + (int64_t)s0 * e->p_img.HWp * 4;
         float* stem = e->stem + (int64_t)s0 * e->p_stem.HWp * 64;
-        {   // K1 input preparation
+        const bool head_unit = on();
+        if (head_unit) {   // K1 input preparation
             PrepArgs a;
             a.images_nchw = B->images_nchw_dev; a.heightmaps = B->heightmaps_dev; a.hm = B->hm_size; a.pad = pad; a.S = e->S;
             a.mean = B->image_mean; a.stdv = B->image_std;
@@ -605,7 +611,7 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
             ProfScope ps(e, cs, K_OTHER, 0);
             hipLaunchKernelGGL(prep_rotate_kernel, dim3((e->S * e->S + 255) / 256, ns), dim3(256), 0, cs, a);
         }
-        {   // stem conv0 7x7/2
+        if (head_unit) {   // stem conv0 7x7/2
             auto run = [&](auto tag) {
                 using Cfg = decltype(tag);
                 FwdConvP<Cfg, F_STEM> p{};
@@ -618,7 +624,7 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
             };
             if (e->p_stem.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
         }
-        {   // norm0 + relu0 + pool0
+        if (head_unit) {   // norm0 + relu0 + pool0
             Pool0Args a;
             a.stem = stem; a.ps = e->p_stem; a.ssum = st_off(fsum(e, e->st_stem), 64); a.ssq = st_off(fsq(e, e->st_stem), 64);
             a.gamma = P + T.norm0.w; a.beta = P + T.norm0.b; a.eps = kEps;
@@ -634,6 +640,7 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
             const int Ct = kBlockCtot[b];
             double* xsum = st_off(fsum(e, e->st_X[b]), Ct); double* xsq = st_off(fsq(e, e->st_X[b]), Ct);
             for (size_t i = 0; i < T.layers[b].size(); ++i) {
+                if (!on()) continue;
                 const DenseLayerRef& d = T.layers[b][i];
                 float* bt = e->Bt + e->bt_off[b][i] + (int64_t)s0 * pl.HWp * kBottleneck;
                 double* bsum = st_off(fsum(e, e->st_Bt[b][i]), kBottleneck); double* bsq = st_off(fsq(e, e->st_Bt[b][i]), kBottleneck);
@@ -707,7 +714,7 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
                     if (pl.HWp % 128 == 0) run(CfgP128x32{}); else run(CfgP64x32{});
                 }
             }
-            if (b < 3) {   // transition: norm + relu + (avgpool2 commuted in front of) conv 1x1
+            if (b < 3 && on()) {   // transition: norm + relu + (avgpool2 commuted in front of) conv 1x1
                 const Plane pn = e->p_blk[b + 1];
                 const int Cn = kBlockCtot[b + 1];
                 const BnTab tt = bn_table(e, e->sx_tab[b], e->max_streams, s0, Ct, P + T.tnorm[b].w, P + T.tnorm[b].b);
@@ -733,12 +740,16 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
         const int h = NS / 2;
         HIP_OK(hipEventRecord(e->ev_misc, st));                 // packed weights + batch description are ready
         HIP_OK(hipStreamWaitEvent(e->side, e->ev_misc, 0));
-        if (trunk_chain(0, h, st)) return -5;
-        if (trunk_chain(h, NS - h, e->side)) return -5;
+        int n_units = 1 + 3;
+        for (int b = 0; b < 4; ++b) n_units += (int)T.layers[b].size();
+        for (int u = 0; u < n_units; ++u) {
+            if (trunk_chain(0, h, st, u, u + 1)) return -5;
+            if (trunk_chain(h, NS - h, e->side, u, u + 1)) return -5;
+        }
         HIP_OK(hipEventRecord(e->ev_end, e->side));             // join before the head reads every stream's features
         HIP_OK(hipStreamWaitEvent(st, e->ev_end, 0));
     } else {
-        if (trunk_chain(0, NS, st)) return -5;                  // profiling: one chain, per-kernel times stay per layer
+        if (trunk_chain(0, NS, st, 0, 1 << 30)) return -5;      // profiling: one chain, per-kernel times stay per layer
     }
     e->prof_stage = -1;
     const Plane p4 = e->p_blk[3];
