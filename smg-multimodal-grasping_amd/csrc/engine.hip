@@ -1057,13 +1057,13 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 };
                 if (pl.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
             }
-            {   // conv1 weight gradient.  ~384 workgroups: it shares the chip with the data-gradient chain on the other
+            {   // conv1 weight gradient.  ~320 workgroups: it shares the chip with the data-gradient chain on the other
                 // stream, and every workgroup ends with 128 x 64 fp32 atomics (measured: atomics beat partial tiles here)
                 using Cfg = CfgW128x64;
                 const int nt = (d.cin + Cfg::BN - 1) / Cfg::BN;
                 int chunk, cps;
-                static const int w1_target = getenv("SMG_W1_WGS") ? atoi(getenv("SMG_W1_WGS")) : 512;            // dev A/B
-                pick_chunk(pl, NS, nt, chunk, cps, w1_target);   // 384..768 measure the same; 256 is slower
+                static const int w1_target = getenv("SMG_W1_WGS") ? atoi(getenv("SMG_W1_WGS")) : 320;            // dev A/B
+                pick_chunk(pl, NS, nt, chunk, cps, w1_target);   // 256..384 measure the same (22.46 ms per step), 512: 22.6, 768: 22.8, 1024: 23.2
                 BwdWeightP<Cfg, W_ONE, C_IDENT, SMG_PD_WGRAD, false> p{};
                 p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck;
                 p.bbuf = e->X[b]; p.ldb = Ct; p.pb = pl; p.NB = d.cin;

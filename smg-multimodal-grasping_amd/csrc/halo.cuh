@@ -309,7 +309,7 @@ template <int TS> struct HaloDgradSGeo : HaloGeo<TS> {
     static constexpr int B_UNITS = NCW * HDS_BU;                         // per buffer
     static constexpr int B_N = (B_UNITS + 255) / 256;                    // 2 / 3
     static constexpr int B_PAD = B_N * 256;                              // units per buffer incl. the padding the last copy round touches
-    __host__ __device__ static constexpr int smem_bytes(int C) { return (A_UNITS + 2 * B_PAD) * 16 + (4 * C + 256 + 128) * 4; }
+    __host__ __device__ static constexpr int smem_bytes(int C) { return (A_UNITS + 3 * B_PAD) * 16 + (4 * C + 256 + 128) * 4; }
 };
 
 template <int TS, int PREC = 0>
@@ -318,8 +318,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
     constexpr int MT = G::MT, NCW = G::NCW, A_N = G::A_N, B_N = G::B_N, LDH = G::LDH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* As = reinterpret_cast<char*>(smem);                            // [piece][k8][LDH] units
-    char* Bs = As + G::A_UNITS * 16;                                     // [2][NCW][piece][k8][32] units
-    float* prm = reinterpret_cast<float*>(Bs + 2 * G::B_PAD * 16);       // scale | beta | mean | invstd, C each
+    char* Bs = As + G::A_UNITS * 16;                                     // [3][NCW][piece][k8][32] units
+    float* prm = reinterpret_cast<float*>(Bs + 3 * G::B_PAD * 16);       // scale | beta | mean | invstd, C each
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
     const int wq = wave % G::WQ, wc = wave / G::WQ;     // pixel slice, output-channel chunk of the stage
     const int n = blockIdx.y;
@@ -337,15 +337,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
     grad_src_params(a.g, n, a.pl.HW, gp);
     const int cg0 = blockIdx.z * a.cg_per_wg;
     const int NSTAGE = a.cg_per_wg * 9;                // channel-chunk groups x 9 taps
-    u32x4 rb[B_N];
-    auto g_load = [&](int stage) {                     // stage = cgroup * 9 + tap; cgroup holds NCW chunks
+    // Weight stages: stage = cgroup * 9 + tap (a cgroup holds NCW chunks).  Three register slots and three LDS buffers,
+    // indexed by stage % 3 (compile-time inside the three-stage trip): the loads of stage s + 2 are issued at stage s and
+    // stored to LDS at stage s + 1, so a stage never waits for the loads it issued itself (round 2a: 3.9k cycles per stage
+    // for 0.8k of MFMA issue).  Unconditional, tail-clamped loads keep the number of loads in flight equal on every path.
+    u32x4 rb[3][B_N];
+    unsigned b_voff[B_N];
+#pragma unroll
+    for (int i = 0; i < B_N; ++i) {
+        const int idx = t + 256 * i;                                       // past B_UNITS: padding (slack behind the packed array)
+        const int j = min(idx / HDS_BU, NCW - 1), rem = idx - j * HDS_BU;
+        b_voff[i] = 16u * (unsigned)(j * 9 * HDS_BU + rem);
+    }
+    auto g_load = [&](int stage, u32x4 (&r)[B_N]) {
         const int cg = cg0 + stage / 9, tap = stage % 9;
 #pragma unroll
-        for (int i = 0; i < B_N; ++i) {
-            const int idx = t + 256 * i;                                   // past B_UNITS: padding (slack behind the packed array)
-            const int j = min(idx / HDS_BU, NCW - 1), rem = idx - j * HDS_BU;
-            rb[i] = a.wu[((int64_t)(cg * NCW + j) * 9 + tap) * HDS_BU + rem];
-        }
+        for (int i = 0; i < B_N; ++i) r[i] = bload_u4(a.wu, kWholeBuf, b_voff[i], 16u * (unsigned)((cg * NCW * 9 + tap) * HDS_BU));
     };
     // gradient halo (zero outside the image), split at the store
     const float* g_n = a.g.g + (int64_t)n * a.pl.HWp * a.g.ldg;
@@ -382,16 +389,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
             }
         }
     }
-    auto s_store = [&](int buf) {
+    auto s_store = [&](int buf, const u32x4 (&r)[B_N]) {
 #pragma unroll
-        for (int i = 0; i < B_N; ++i) *reinterpret_cast<u32x4*>(Bs + (buf * G::B_PAD + t + 256 * i) * 16) = rb[i];
+        for (int i = 0; i < B_N; ++i) *reinterpret_cast<u32x4*>(Bs + (buf * G::B_PAD + t + 256 * i) * 16) = r[i];
     };
     int abase[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) abase[m] = G::row(wq, m, l31) * G::W + G::col(l31);
 
-    g_load(0);
-    s_store(0);
+    g_load(0, rb[0]);
+    g_load(NSTAGE > 1 ? 1 : 0, rb[1]);
+    s_store(0, rb[0]);
     __syncthreads();
     f32x16 acc[MT];
     float xvp[MT][16];                        // TS == 8: prefetched one stage ahead
@@ -406,16 +414,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
                 xv[m][r] = ok ? a.mbuf[((int64_t)n * a.pl.HWp + py * a.pl.W + px) * C + c] : 0.f;
             }
     };
-    for (int stage = 0; stage < NSTAGE; ++stage) {
-        const int tap = stage % 9, buf = stage & 1;
-        const int dy = tap / 3, dx = tap - 3 * dy;
-        if (tap == 0) {
+    for (int s3 = 0; s3 < NSTAGE; s3 += 3) {           // NSTAGE is a multiple of 9: three stages (one kernel row) per trip
+      const int dy = (s3 / 3) % 3;
+      if (dy == 0) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-        }
-        if (stage + 1 < NSTAGE) g_load(stage + 1);
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+      }
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int stage = s3 + dx, buf = dx, tap = 3 * dy + dx;
+        g_load(stage + 2 < NSTAGE ? stage + 2 : NSTAGE - 1, rb[(dx + 2) % 3]);
         if constexpr (TS == 8) {
             if (tap == 8) load_mask(((cg0 + stage / 9) * NCW + wc) * 32 + l31, xvp);   // in flight under the last MFMA block
         }
@@ -460,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
             for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[m], bh, acc[m]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (stage + 1 < NSTAGE) s_store(buf ^ 1);       // the other buffer: last read one stage ago, behind a barrier
+        s_store((dx + 1) % 3, rb[(dx + 1) % 3]);        // that buffer was last read two stages ago (at the very end: a dead store)
         if (tap == 8) {
             // epilogue of this wave's output-channel chunk: ReLU mask, store dy, BN(norm2) backward sums
             const int c = ((cg0 + stage / 9) * NCW + wc) * 32 + l31;
@@ -502,6 +512,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
             }
         }
         __syncthreads();
+      }
     }
 }
 
