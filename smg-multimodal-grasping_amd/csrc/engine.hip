@@ -211,6 +211,45 @@ struct ProfScope {
         default: { constexpr int PREC = 0; CALL; } break;                 \
     }
 
+// Dev instrumentation: per-workgroup phase stamps of ONE launch (SMG_TRACE_KIND = kernel class, SMG_TRACE_SKIP = how many
+// launches of that class to skip).  The kernels store s_memtime at up to five points (slots 0..4) and the device-wide
+// 100 MHz counter at start / end (slots 5, 6) through g_smg_trace; the scope prints the mean phase lengths.
+struct TraceScope {
+    hipStream_t st; int kind; dim3 grid; unsigned long long* tbuf = nullptr; size_t n_wg = 0;
+    TraceScope(hipStream_t s, int k, dim3 g) : st(s), kind(k), grid(g) {
+        static const int tr_kind = getenv("SMG_TRACE_KIND") ? atoi(getenv("SMG_TRACE_KIND")) : -1;
+        static const int tr_skip = getenv("SMG_TRACE_SKIP") ? atoi(getenv("SMG_TRACE_SKIP")) : 0;
+        static int tr_seen = 0;
+        if (!(kind == tr_kind && tr_seen++ == tr_skip)) return;
+        n_wg = (size_t)grid.x * grid.y * grid.z;
+        (void)hipMalloc((void**)&tbuf, n_wg * 64);
+        (void)hipMemsetAsync(tbuf, 0, n_wg * 64, st);
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_smg_trace), &tbuf, sizeof(tbuf), 0, hipMemcpyHostToDevice, st);
+    }
+    ~TraceScope() {
+        if (!tbuf) return;
+        unsigned long long* nul = nullptr;
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_smg_trace), &nul, sizeof(nul), 0, hipMemcpyHostToDevice, st);
+        std::vector<unsigned long long> h(n_wg * 8);
+        (void)hipMemcpyAsync(h.data(), tbuf, n_wg * 64, hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(tbuf);
+        // phases in shader cycles (s_memtime, per-XCD base); span / residency from the device-wide 100 MHz counter
+        double sum[4] = {0, 0, 0, 0}, life = 0; size_t live = 0; unsigned long long t_min = ~0ull, t_max = 0;
+        for (size_t w = 0; w < n_wg; ++w) {
+            const unsigned long long* r = &h[w * 8];
+            if (!r[4]) continue;
+            ++live;
+            for (int k = 0; k < 4; ++k) sum[k] += (double)(r[k + 1] - r[k]);
+            t_min = std::min(t_min, r[5]); t_max = std::max(t_max, r[6]);
+            life += (double)(r[6] - r[5]);
+        }
+        const double span = (double)(t_max - t_min) * 0.01, resid = life / (double)(t_max - t_min) / 256.0;
+        fprintf(stderr, "[smg trace] kind %d grid %ux%ux%u live %zu: init %.0f | first tile %.0f | k-loop %.0f | epilogue %.0f cycles/WG (mean); span %.1f us, %.2f workgroups resident per CU, mean life %.1f us\n",
+                kind, grid.x, grid.y, grid.z, live, sum[0] / live, sum[1] / live, sum[2] / live, sum[3] / live, span, resid, life / live * 0.01);
+    }
+};
+
 template <class P>
 static void launch_gemm(smg_engine* e, hipStream_t st, P p, dim3 grid, int kind, double flops) {
     const size_t smem = (size_t)(P::Cfg::TILE_FLOATS + p.param_floats()) * sizeof(float);
@@ -235,41 +274,10 @@ static void launch_gemm(smg_engine* e, hipStream_t st, P p, dim3 grid, int kind,
             grid = dim3(8 * ((grid.z + 7) / 8) * tiles, 1, 1);
         }
     }
-    static const int tr_kind = getenv("SMG_TRACE_KIND") ? atoi(getenv("SMG_TRACE_KIND")) : -1;   // dev: phase timestamps of one launch
-    static const int tr_skip = getenv("SMG_TRACE_SKIP") ? atoi(getenv("SMG_TRACE_SKIP")) : 0;
-    static int tr_seen = 0;
-    const bool tracing = kind == tr_kind && tr_seen++ == tr_skip;
-    unsigned long long* tbuf = nullptr;
-    const size_t n_wg = (size_t)grid.x * grid.y * grid.z;
-    if (tracing) {
-        (void)hipMalloc((void**)&tbuf, n_wg * 64);
-        (void)hipMemsetAsync(tbuf, 0, n_wg * 64, st);
-        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_smg_trace), &tbuf, sizeof(tbuf), 0, hipMemcpyHostToDevice, st);
-    }
+    TraceScope ts(st, kind, grid);
     {
         ProfScope ps(e, st, kind, flops);
-        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_kernel<P, PREC>), dim3((unsigned)n_wg), dim3(256), smem, st, p, (int)grid.x, (int)grid.y));
-    }
-    if (tracing) {
-        unsigned long long* nul = nullptr;
-        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_smg_trace), &nul, sizeof(nul), 0, hipMemcpyHostToDevice, st);
-        std::vector<unsigned long long> h(n_wg * 8);
-        (void)hipMemcpyAsync(h.data(), tbuf, n_wg * 64, hipMemcpyDeviceToHost, st);
-        (void)hipStreamSynchronize(st);
-        (void)hipFree(tbuf);
-        // phases in shader cycles (s_memtime, per-XCD base); span / residency from the device-wide 100 MHz counter
-        double sum[4] = {0, 0, 0, 0}, life = 0; size_t live = 0; unsigned long long t_min = ~0ull, t_max = 0;
-        for (size_t w = 0; w < n_wg; ++w) {
-            const unsigned long long* r = &h[w * 8];
-            if (!r[4]) continue;
-            ++live;
-            for (int k = 0; k < 4; ++k) sum[k] += (double)(r[k + 1] - r[k]);
-            t_min = std::min(t_min, r[5]); t_max = std::max(t_max, r[6]);
-            life += (double)(r[6] - r[5]);
-        }
-        const double span = (double)(t_max - t_min) * 0.01, resid = life / (double)(t_max - t_min) / 256.0;
-        fprintf(stderr, "[smg trace] kind %d grid %ux%ux%u live %zu: init %.0f | first tile %.0f | k-loop %.0f | epilogue %.0f cycles/WG (mean); span %.1f us, %.2f workgroups resident per CU\n",
-                kind, grid.x, grid.y, grid.z, live, sum[0] / live, sum[1] / live, sum[2] / live, sum[3] / live, span, resid);
+        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_kernel<P, PREC>), dim3((unsigned)(grid.x * grid.y * grid.z)), dim3(256), smem, st, p, (int)grid.x, (int)grid.y));
     }
 }
 
@@ -931,6 +939,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 a.wu = e->packed_u + e->pk_hd[b][i]; a.bt = bn_table(e, e->sb_tab[b][i], e->max_streams, 0, kBottleneck, P + d.n2.w, P + d.n2.b);
                 BY(e, 4.0 * NS * pl.HW * (kGrowth + 2 * kBottleneck));      // gradient in, mask source in, dy out
                 ProfScope ps(e, st, K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+                TraceScope ts(st, K_D3, halo_tile(pl, NS) == 16 ? dim3((pl.H / 16) * (pl.W / 16), NS) : dim3(((pl.H + 7) / 8) * ((pl.W + 7) / 8), NS, kBottleneck / 64));
                 if (halo_tile(pl, NS) == 16) {
                     a.tiles_x = pl.W / 16; a.cg_per_wg = kBottleneck / 32;
                     PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_dgrad_kernel<16, PREC>), dim3((pl.H / 16) * a.tiles_x, NS), dim3(256),

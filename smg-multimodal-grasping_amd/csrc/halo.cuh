@@ -326,6 +326,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
     const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
     const int y0 = ty * TS, x0 = tx * TS;
     const int C = a.C;
+    // dev stamps (SMG_TRACE_KIND=5): start | halo staged | first output-channel group's 9 stages | its epilogue | end
+    unsigned long long* trace = (g_smg_trace && t == 0) ? g_smg_trace + 8 * ((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) : nullptr;
+    if (trace) { trace[0] = __builtin_amdgcn_s_memtime(); trace[5] = __builtin_amdgcn_s_memrealtime(); }
     for (int k = t; k < C; k += 256) {                  // norm2 parameters of this stream (layer table of the forward)
         const float invstd = tab_invstd(a.bt, n)[k];
         prm[k] = a.bt.gamma[k] * invstd;
@@ -401,6 +404,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
     g_load(NSTAGE > 1 ? 1 : 0, rb[1]);
     s_store(0, rb[0]);
     __syncthreads();
+    if (trace) trace[1] = __builtin_amdgcn_s_memtime();
     f32x16 acc[MT];
     float xvp[MT][16];                        // TS == 8: prefetched one stage ahead
     auto load_mask = [&](int c, float (&xv)[MT][16]) {   // mask / xhat source of this wave's output tile
@@ -438,40 +442,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
         auto fb = [&](int ks, int pc) -> u32x4 {
             return *reinterpret_cast<const u32x4*>(Bw + ((pc * 4 + 2 * ks + half) * 32 + l31) * 16);
         };
+        if constexpr (PREC != 0) {                          // single-piece modes: one term per k16-step
+            u32x4 ah[2][MT], bh[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            u32x4 ah[MT], al[MT], bh, bl;
+            for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) { ah[m] = fa(m, ks, 0); if constexpr (PREC == 0) al[m] = fa(m, ks, 2); }
-            bh = fb(ks, 0); if constexpr (PREC == 0) bl = fb(ks, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PREC != 0) {                      // single-piece modes: one term
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = mfma_1p<PREC>(ah[m], bh, acc[m]);
-                __builtin_amdgcn_sched_barrier(0);
-                continue;
+                for (int m = 0; m < MT; ++m) ah[ks][m] = fa(m, ks, 0);
+                bh[ks] = fb(ks, 0);
             }
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[m], bl, acc[m]);
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(al[m], bh, acc[m]);
-            u32x4 am[MT], bm;
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_1p<PREC>(ah[ks][m], bh[ks], acc[m]);
+        } else {
+            // every fragment of the stage is requested up front (18 ds_read_b128, 72 registers): one LDS round trip per stage
+            // instead of four read -> wait -> MFMA phases; hipcc waits per operand (lgkmcnt(N)) as the MFMAs come up
+            u32x4 af[2][MT][NPIECE], bf[2][NPIECE];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) am[m] = fa(m, ks, 1);
-            bm = fb(ks, 1);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(am[m], bm, acc[m]);
+                for (int pc = 0; pc < NPIECE; ++pc) {
+                    const int pp = pc == 1 ? 2 : pc == 2 ? 1 : 0;            // hi, lo, mid: the order the terms need them
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[m], bm, acc[m]);
+                    for (int m = 0; m < MT; ++m) af[ks][m][pp] = fa(m, ks, pp);
+                    bf[ks][pp] = fb(ks, pp);
+                }
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};     // hi*lo, lo*hi, mid*mid, hi*mid, mid*hi, hi*hi
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(am[m], bh, acc[m]);
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[m], bh, acc[m]);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int g = 0; g < 6; ++g)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(af[ks][m][PA[g]], bf[ks][PB[g]], acc[m]);
         }
         s_store((dx + 1) % 3, rb[(dx + 1) % 3]);        // that buffer was last read two stages ago (at the very end: a dead store)
         if (tap == 8) {
+            if (trace && s3 == 6) trace[2] = __builtin_amdgcn_s_memtime();
             // epilogue of this wave's output-channel chunk: ReLU mask, store dy, BN(norm2) backward sums
             const int c = ((cg0 + stage / 9) * NCW + wc) * 32 + l31;
             const float sc = prm[c], be = prm[C + c], mean = prm[2 * C + c], invstd = prm[3 * C + c];
@@ -510,10 +516,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x
                 const int ch = ((cg0 + stage / 9) * NCW + j) * 32 + cc;
                 atomicAdd((q ? a.o2 : a.o1) + (int64_t)n * a.ostride + ch, (double)tot);
             }
+            if (trace && s3 == 6) trace[3] = __builtin_amdgcn_s_memtime();
         }
         __syncthreads();
       }
     }
+    if (trace) { trace[4] = __builtin_amdgcn_s_memtime(); trace[6] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 
