@@ -625,6 +625,22 @@ struct BnBwdApplyArgs {
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs a) {
     __shared__ float prm[4 * 128];
     const int n = blockIdx.y, t = threadIdx.x;
+    const int qpr = a.C / 4;                      // float4 per row
+    const int rows_per_pass = 256 / qpr;
+    const int cq = t % qpr;
+    const int r0 = blockIdx.x * 64 + t / qpr;
+    // 64 rows per workgroup: up to 8 row slots per thread.  The data loads go out FIRST (unconditional, clamped row) so that
+    // they share one memory round trip with the parameter prologue below; all loads before any store (the output may alias
+    // the gradient input - it does for the in-place norm2 case).
+    float4 gv[8], xv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int r = r0 + k * rows_per_pass;
+        if (k * rows_per_pass >= 64) break;            // (workgroup-uniform: C = 32 uses two slots, C = 128 all eight)
+        const int64_t pix = (int64_t)n * a.pl.HWp + (r < a.pl.HW ? r : 0);
+        gv[k] = ld4(a.g + pix * a.ldg + a.gcoff + 4 * cq);
+        xv[k] = ld4(a.x + pix * a.ldx + a.xcoff + 4 * cq);
+    }
     if (t < a.C) {
         const double inv = 1.0 / (double)a.pl.HW;
         float mean, invstd;
@@ -640,22 +656,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs 
         }
     }
     __syncthreads();
-    const int qpr = a.C / 4;                      // float4 per row
-    const int rows_per_pass = 256 / qpr;
-    const int cq = t % qpr;
-    const int r0 = blockIdx.x * 64 + t / qpr;
-    // 64 rows per workgroup: up to 8 row slots per thread; loads of all slots first (the output may
-    // alias the gradient input - it does for the in-place norm2 case - so they cannot be hoisted
-    // past the stores by the compiler)
-    float4 gv[8], xv[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int r = r0 + k * rows_per_pass;
-        const bool ok = k * rows_per_pass < 64 && r < a.pl.HW;
-        const int64_t pix = (int64_t)n * a.pl.HWp + (ok ? r : 0);
-        gv[k] = ok ? ld4(a.g + pix * a.ldg + a.gcoff + 4 * cq) : zero4();
-        xv[k] = ok ? ld4(a.x + pix * a.ldx + a.xcoff + 4 * cq) : zero4();
-    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int r = r0 + k * rows_per_pass;
