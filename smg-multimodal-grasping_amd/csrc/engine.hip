@@ -1098,7 +1098,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
             {
                 int chunk, cps;
                 pick_chunk(pl, NS, (C0 / 128) * (Cp / 128), chunk, cps);
-                BwdWeightP<CfgW128x128, W_POOL, C_IDENT> p{};
+                BwdWeightP<CfgW128x128, W_POOL, C_IDENT, 1> p{};      // (one k-tile in flight: the pooling fetch holds 4 float4 per slot, three tiles of them leave one workgroup per CU)
                 p.gbuf = e->G[b]; p.ldg = Ct; p.gcoff = 0; p.xbuf = e->X[b]; p.ldx = Ct; p.xcoff = 0; p.pa = pl; p.MA = C0;
                 p.xsum = fsum(e, e->st_X[b]); p.xsq = fsq(e, e->st_X[b]); p.xstride = Ct;
                 p.s1 = b1(e, e->bs_X[b]); p.s2 = b2(e, e->bs_X[b]); p.sstride = Ct; p.scoff = 0; p.agamma = nullptr;

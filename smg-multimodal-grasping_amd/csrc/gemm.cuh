@@ -401,6 +401,7 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
     typename P::KPrm kp[PD];
     typename P::ARow arow[C::A_N];
     typename P::DRow da[C::A_N], db[C::AT ? 1 : C::B_N];
+    KPrm3 bfix{};          // weight gradient: BN parameters of this thread's (fixed) B channel quad, read from LDS once
     if constexpr (C::AT) {
 #pragma unroll
         for (int i = 0; i < C::A_N; ++i) p.a_row_init(ctx, arow[i], al + i * C::A_STEP);
@@ -473,7 +474,7 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
             for (int i = 0; i < C::B_N; ++i) {
                 const int kr = bl + i * C::B_STEP;
                 if (C::B_FULL || kr < C::BK) {
-                    const Split4 s = split4<PREC>(p.b_xform(ctx, xb[i], kt, bq, sp));
+                    const Split4 s = split4<PREC>(p.b_xform(ctx, xb[i], kt, bq, sp, bfix));
 #pragma unroll
                     for (int pc = 0; pc < (PREC ? 1 : NPIECE); ++pc)
                         *reinterpret_cast<uint2*>(B + ((pc * C::BK + kr) * C::LDTB + 4 * bq) * 2) = s.p[pc];
@@ -563,6 +564,7 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
     }
     p.init_params(ctx, sp);
     if constexpr (P::kHasPrologue) __syncthreads();
+    if constexpr (!C::AT) bfix = p.b_fix(ctx, bq, sp);
     SMG_TRACE(1);
     if (KT > 0) s_store(0, 0, ra[0], rb[0], kp[0]);
     __syncthreads();
@@ -1637,21 +1639,31 @@ struct BwdWeightP {
         }
         return o;
     }
-    __device__ float4 b_xform(const Ctx&, const BRaw& o, int, int q, const float* sp) const {
+    // mean | gamma*invstd | beta of the B channel quad this thread stages in every k-tile (loop-invariant: one LDS read)
+    __device__ KPrm3 b_fix(const Ctx&, int q, const float* sp) const {
+        KPrm3 f{};
+        if constexpr (BMODE != W_STEM) {
+            const float* pr = sp + 4 * Cfg::BM + 4 * q;
+            f.mean = ldv4(pr);
+            f.scale = ldv4(pr + Cfg::BN);
+            f.beta = ldv4(pr + 2 * Cfg::BN);
+        }
+        return f;
+    }
+    __device__ float4 b_xform(const Ctx&, const BRaw& o, int, int, const float*, const KPrm3& f) const {
         if constexpr (BMODE == W_STEM) {
             return o.ok ? o.v[0] : zero4();
         } else {
-            const float* pr = sp + 4 * Cfg::BM + 4 * q;
-            if constexpr (BMODE == W_ONE) return bnrelu4(o.v[0], pr, Cfg::BN);
+            if constexpr (BMODE == W_ONE) return bnrelu4(o.v[0], f);
             if (!o.ok) return zero4();
             if constexpr (BMODE == W_POOL) {
-                float4 s = bnrelu4(o.v[0], pr, Cfg::BN);
-                s = add4(s, bnrelu4(o.v[1], pr, Cfg::BN));
-                s = add4(s, bnrelu4(o.v[2], pr, Cfg::BN));
-                s = add4(s, bnrelu4(o.v[3], pr, Cfg::BN));
+                float4 s = bnrelu4(o.v[0], f);
+                s = add4(s, bnrelu4(o.v[1], f));
+                s = add4(s, bnrelu4(o.v[2], f));
+                s = add4(s, bnrelu4(o.v[3], f));
                 return make_float4(s.x * 0.25f, s.y * 0.25f, s.z * 0.25f, s.w * 0.25f);
             } else {
-                return bnrelu4(o.v[0], pr, Cfg::BN);
+                return bnrelu4(o.v[0], f);
             }
         }
     }
