@@ -174,8 +174,17 @@ def main():
     sync = parallel.allreduce_grads if distributed else None
     rots = list(range(R))
 
+    # inputs resident in HBM before the timed region (the heightmaps as float64, the labels as float32): the numpy form
+    # of the same call costs a pageable host-to-device copy per step, which also stalls the host behind the previous step
+    depth_d = torch.from_numpy(np.ascontiguousarray(depth, dtype=np.float64)).to(dev)
+    mdepth_d = torch.from_numpy(np.ascontiguousarray(mdepth, dtype=np.float64)).to(dev)
+    labels_d = torch.as_tensor(np.asarray(labels, dtype=np.float32), device=dev)
+
+    def on_dev(a, dtype=np.float64):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(dev)
+
     def step():
-        return tr.train_batch(depth, mdepth, 0, rots, labels, grad_sync=sync)
+        return tr.train_batch(depth_d, mdepth_d, 0, rots, labels_d, grad_sync=sync)
 
     def barrier():
         if distributed:
@@ -219,6 +228,13 @@ def main():
         step()
         out["host_enqueue_ms_per_step"] = (time.perf_counter() - t_h) * 1e3
         torch.cuda.synchronize(dev)
+        # the same step fed from host numpy arrays (what code/main.py hands to Trainer.backprop): PCIe-inclusive rate
+        n_h = max(3, args.steps // 4)
+        t_h = time.perf_counter()
+        for _ in range(n_h):
+            tr.train_batch(depth, mdepth, 0, rots, labels)
+        torch.cuda.synchronize(dev)
+        out["ms_per_step_host_inputs"] = (time.perf_counter() - t_h) / n_h * 1e3
         import models
         eng = models._ENGINES[(local_rank, 640, 1)]
         # forward-only sweep (BASELINE.json configs[1]), reported beside the headline number
@@ -242,14 +258,15 @@ def main():
             d_b = np.stack([c[0] for c in sc])
             m_b = np.stack([c[0] * c[1][0] for c in sc])
             lab_b = synthetic.uniform(7, "bench/labels_b", nb * R, 0.0, 1.5)
+            d_bd, m_bd, lab_bd = on_dev(d_b), on_dev(m_b), on_dev(lab_b, np.float32)
             rots_b = [rots] * nb
             for _ in range(2):
-                tr.train_batch(d_b, m_b, 0, rots_b, lab_b)
+                tr.train_batch(d_bd, m_bd, 0, rots_b, lab_bd)
             torch.cuda.synchronize(dev)
             t2 = time.perf_counter()
             n_b = max(3, args.steps // 3)
             for _ in range(n_b):
-                tr.train_batch(d_b, m_b, 0, rots_b, lab_b)
+                tr.train_batch(d_bd, m_bd, 0, rots_b, lab_bd)
             torch.cuda.synchronize(dev)
             ms_b = (time.perf_counter() - t2) / n_b * 1e3
             out["batched"] = {"scenes_per_step": nb, "samples_per_step": nb * R, "ms_per_step": ms_b,
@@ -266,11 +283,12 @@ def main():
             # ---- config 3: E + S + ES heads, forward + Huber backward, 16 rotations, bf16 MFMA operands ----------------
             md2 = depth * (masks[1] + masks[2])
             lab1 = synthetic.uniform(5, "bench/labels_c3", 1, 0.0, 1.5)
+            md2_d, lab1_d = on_dev(md2), on_dev(lab1, np.float32)
 
             def three_heads():
-                tr.train_batch(depth, mdepth, 0, rots, labels)
-                tr.train_batch(depth, mdepth, 1, rots, labels)
-                tr.train_batch(depth, md2, 2, [0], lab1)              # ES: rotation 0 only (code/models.py:418)
+                tr.train_batch(depth_d, mdepth_d, 0, rots, labels_d)
+                tr.train_batch(depth_d, mdepth_d, 1, rots, labels_d)
+                tr.train_batch(depth_d, md2_d, 2, [0], lab1_d)              # ES: rotation 0 only (code/models.py:418)
 
             def q_sweeps():
                 return np.concatenate([tr.model.run(st_, rots, R, heightmaps=x_d, mean=tr.image_mean, std=tr.image_std,
@@ -293,7 +311,8 @@ def main():
             sc = [synthetic.heightmap_scene(200 + k) for k in range(nb)]
             d8 = np.stack([c[0] for c in sc]); m8 = np.stack([c[0] * c[1][0] for c in sc])
             lab8 = synthetic.uniform(8, "bench/labels_c4", nb * R, 0.0, 1.5)
-            ms8 = timed(lambda: tr.train_batch(d8, m8, 0, [rots] * nb, lab8), 2)
+            d8_d, m8_d, lab8_d = on_dev(d8), on_dev(m8), on_dev(lab8, np.float32)
+            ms8 = timed(lambda: tr.train_batch(d8_d, m8_d, 0, [rots] * nb, lab8_d), 2)
             cfg["config4_share_8_scenes"] = {"scenes_per_step": nb, "samples_per_step": nb * R, "streams": nb * (R + 1), "ms_per_step": ms8,
                                              "passes_per_s": nb / (ms8 * 1e-3), "pass_tflops_algorithmic": PASS_GFLOP * nb / ms8,
                                              "engine_workspace_gb": models._ENGINES[(local_rank, 640, 1)].workspace_bytes / 1e9}
@@ -302,11 +321,12 @@ def main():
             mdb = dbig * mbig[0]
             tr.model.gnum_rotations = tr.model.snum_rotations = 32
             r5, l5 = [5, 6, 7, 8], [0.3, 1.9, 0.1, 0.7]
-            _, qb32 = tr.train_batch(dbig, mdb, 0, r5, l5, return_q=True)
-            ms5_32 = timed(lambda: tr.train_batch(dbig, mdb, 0, r5, l5), 2)
+            dbig_d, mdb_d, l5_d = on_dev(dbig), on_dev(mdb), on_dev(l5, np.float32)
+            _, qb32 = tr.train_batch(dbig_d, mdb_d, 0, r5, l5_d, return_q=True)
+            ms5_32 = timed(lambda: tr.train_batch(dbig_d, mdb_d, 0, r5, l5_d), 2)
             tr.model.set_precision("fp16")
-            _, qb16 = tr.train_batch(dbig, mdb, 0, r5, l5, return_q=True)
-            ms5_16 = timed(lambda: tr.train_batch(dbig, mdb, 0, r5, l5), 2)
+            _, qb16 = tr.train_batch(dbig_d, mdb_d, 0, r5, l5_d, return_q=True)
+            ms5_16 = timed(lambda: tr.train_batch(dbig_d, mdb_d, 0, r5, l5_d), 2)
             tr.model.set_precision("fp32")
             tr.model.gnum_rotations = tr.model.snum_rotations = R
             a32, a16 = qb32.reshape(4, -1).cpu().numpy(), qb16.reshape(4, -1).cpu().numpy()

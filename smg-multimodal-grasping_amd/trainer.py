@@ -362,13 +362,22 @@ class Trainer(object):
         model = self.model
         self.optimizer.zero_grad()
         model._require_gpu()
-        d = np.asarray(depth_heightmap, dtype=np.float64)
-        m = np.asarray(m_depth_heightmap, dtype=np.float64)
-        if d.ndim == 2:
-            d, m, rotations = d[None], m[None], [list(rotations)]
-        hm = np.empty((2 * d.shape[0],) + d.shape[1:], dtype=np.float64)
-        hm[0::2], hm[1::2] = d, m
-        hm = torch.from_numpy(hm).to(model._flat_params.device)
+        if torch.is_tensor(depth_heightmap) and depth_heightmap.is_cuda:
+            # device-resident inputs (float64 heightmaps, float32 labels): nothing crosses PCIe and - unlike a pageable
+            # host-to-device copy - nothing makes the host wait for the previous step's kernels
+            d = depth_heightmap.to(dtype=torch.float64)
+            m = m_depth_heightmap.to(device=d.device, dtype=torch.float64)
+            if d.dim() == 2:
+                d, m, rotations = d[None], m[None], [list(rotations)]
+            hm = torch.stack((d, m), dim=1).reshape((2 * d.shape[0],) + tuple(d.shape[1:])).contiguous()
+        else:
+            d = np.asarray(depth_heightmap, dtype=np.float64)
+            m = np.asarray(m_depth_heightmap, dtype=np.float64)
+            if d.ndim == 2:
+                d, m, rotations = d[None], m[None], [list(rotations)]
+            hm = np.empty((2 * d.shape[0],) + d.shape[1:], dtype=np.float64)
+            hm[0::2], hm[1::2] = d, m
+            hm = torch.from_numpy(hm).to(model._flat_params.device)
         num = model.gnum_rotations                     # code/models.py:522,545,568 (gnum for every style)
         rots = [[0 if style == 2 else int(r) for r in rs] for rs in rotations]
         q = model.run(style, rots, num, heightmaps=hm, mean=self.image_mean, std=self.image_std, keep_for_backward=True)
@@ -376,7 +385,10 @@ class Trainer(object):
         dev = q.device
         eng, token, trunk_id, head_id = model._saved
         stream = torch.cuda.current_stream(dev).cuda_stream
-        lab = torch.as_tensor(np.asarray(labels, dtype=np.float32).reshape(-1), device=dev)
+        if torch.is_tensor(labels):
+            lab = labels.to(device=dev, dtype=torch.float32).reshape(-1)
+        else:
+            lab = torch.as_tensor(np.asarray(labels, dtype=np.float32).reshape(-1), device=dev)
         if lab.numel() != n:
             raise ValueError("one label per (scene, rotation) sample")
         loss = torch.empty(n, dtype=torch.float32, device=dev)

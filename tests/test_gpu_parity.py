@@ -487,6 +487,30 @@ def test_multi_scene_batch_equals_sum_of_single_scene_gradients(gpu, case):
         assert ws < 120e9
 
 
+def test_train_batch_device_resident_inputs_equal_host_inputs(gpu):
+    """bench.py feeds train_batch device-resident heightmaps / labels (no PCIe copy, no host stall per step): same Q values,
+    losses and gradients - bit for bit - as the numpy form of the call, for one scene and for a stack of scenes."""
+    from trainer import Trainer
+    import synthetic
+    tr = Trainer('reinforcement', 0.5, False, None, False)
+    sd = synthetic.make_state_dict(orc.state_layout(1), 4)
+    tr.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    tr.model.gnum_rotations = tr.model.snum_rotations = 16
+    tr.optimizer.lr = 0.0
+    dev = tr.model._flat_params.device
+    scenes = [synthetic.heightmap_scene(s) for s in (21, 22)]
+    d = np.stack([sc[0] for sc in scenes]); m = np.stack([sc[0] * sc[1][0] for sc in scenes])
+    for dh, mh, rots, labels in ((d[0], m[0], [0, 5, 11], [0.3, 1.2, 0.05]), (d, m, [[1, 2], [7, 8, 15]], [0.1, 0.9, 2.0, 0.4, 0.6])):
+        loss_h, q_h = tr.train_batch(dh, mh, 0, rots, labels, return_q=True)
+        g_h = tr.model.flat_grads().clone()
+        loss_d, q_d = tr.train_batch(torch.from_numpy(dh).to(dev), torch.from_numpy(mh).to(dev), 0, rots,
+                                     torch.tensor(labels, dtype=torch.float32, device=dev), return_q=True)
+        assert torch.equal(q_h, q_d) and torch.equal(loss_h, loss_d)
+        g_d = tr.model.flat_grads()
+        # the weight gradients of the 1x1 convolutions are summed with fp32 atomics: equal up to their order
+        assert float((g_h - g_d).double().norm()) <= 1e-5 * float(g_h.double().norm())
+
+
 def test_large_input_dense_qmap(gpu):
     """Config-5 path: a 640x640 heightmap -> S = 1824: odd plane sizes (57x57), average-pool rows
     the pooling never reads, and a dense 38x38 Q map per sample."""
