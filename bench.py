@@ -323,10 +323,10 @@ def main():
             r5, l5 = [5, 6, 7, 8], [0.3, 1.9, 0.1, 0.7]
             dbig_d, mdb_d, l5_d = on_dev(dbig), on_dev(mdb), on_dev(l5, np.float32)
             _, qb32 = tr.train_batch(dbig_d, mdb_d, 0, r5, l5_d, return_q=True)
-            ms5_32 = timed(lambda: tr.train_batch(dbig_d, mdb_d, 0, r5, l5_d), 2)
+            ms5_32 = timed(lambda: tr.train_batch(dbig_d, mdb_d, 0, r5, l5_d), 4)
             tr.model.set_precision("fp16")
             _, qb16 = tr.train_batch(dbig_d, mdb_d, 0, r5, l5_d, return_q=True)
-            ms5_16 = timed(lambda: tr.train_batch(dbig_d, mdb_d, 0, r5, l5_d), 2)
+            ms5_16 = timed(lambda: tr.train_batch(dbig_d, mdb_d, 0, r5, l5_d), 4)
             tr.model.set_precision("fp32")
             tr.model.gnum_rotations = tr.model.snum_rotations = R
             a32, a16 = qb32.reshape(4, -1).cpu().numpy(), qb16.reshape(4, -1).cpu().numpy()

@@ -99,7 +99,7 @@ struct smg_engine {
     // gradients
     float* G[4] = {}; float* GS[kRing] = {}; float* D2[kRing] = {}; float* part = nullptr; int64_t part_floats = 0;
     // second stream for the weight-gradient kernels (independent of the data-gradient chain)
-    hipStream_t side = nullptr, side_lo = nullptr; hipEvent_t ev_gs[kRing] = {}, ev_d2[kRing] = {}, ev_side[kRing] = {}, ev_misc = nullptr, ev_end = nullptr; float* DY0 = nullptr; float* DH1 = nullptr; float* DF = nullptr;
+    hipStream_t side = nullptr; hipEvent_t ev_gs[kRing] = {}, ev_d2[kRing] = {}, ev_side[kRing] = {}, ev_misc = nullptr, ev_end = nullptr; float* DY0 = nullptr; float* DH1 = nullptr; float* DF = nullptr;
     // statistics arenas (doubles). fwd: [sum | sumsq] halves; bwd: [s1 | s2] halves
     double* fstat = nullptr; int64_t fstat_span = 0;
     double* bstat = nullptr; int64_t bstat_span = 0;
@@ -347,13 +347,6 @@ static int engine_build(smg_engine* e) {
     HIP_OK(hipEventCreateWithFlags(&e->ev_misc, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&e->ev_end, hipEventDisableTiming));
     HIP_OK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-    {   // the backward's weight-gradient stream: lowest priority, so that the data-gradient chain (the critical path) gets
-        // freed CU slots first and the weight gradients fill what is left
-        int lo = 0, hi = 0;
-        HIP_OK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        static const bool flat = getenv("SMG_SIDE_PRIO_FLAT") != nullptr;      // dev A/B
-        HIP_OK(hipStreamCreateWithPriority(&e->side_lo, hipStreamNonBlocking, flat ? 0 : lo));
-    }
     e->part_floats = (int64_t)24 << 20;   // partial weight-gradient tiles: 96 MB, or what the 3x3 launches of a full batch want
     for (int b = 0; b < 4; ++b) {
         const Plane& pl = e->p_blk[b];
@@ -841,7 +834,9 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
     // gradient ranges, so they run on a second stream beside it (their MFMA/L2-bound phases overlap the
     // HBM-bound epilogues of the data-gradient kernels).  While profiling everything is serialised on
     // `st` so that per-kernel durations stay clean.
-    const hipStream_t s2 = e->prof ? st : e->side_lo;
+    // (a lowest-priority stream for the weight gradients gains 0.2 ms per step with one engine alive, and LOSES 10 ms as soon
+    // as a second engine - two more streams - exists in the process: the streams then share hardware queues and serialise)
+    const hipStream_t s2 = e->prof ? st : e->side;
     auto fork = [&](hipEvent_t ev) -> int {      // side stream continues after everything enqueued on st so far
         HIP_OK(hipEventRecord(ev, st));
         HIP_OK(hipStreamWaitEvent(s2, ev, 0));
@@ -1246,7 +1241,6 @@ void smg_engine_destroy(smg_engine* e) {
     if (e->ev_misc) (void)hipEventDestroy(e->ev_misc);
     if (e->ev_end) (void)hipEventDestroy(e->ev_end);
     if (e->side) (void)hipStreamDestroy(e->side);
-    if (e->side_lo) (void)hipStreamDestroy(e->side_lo);
     for (auto& r : e->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     delete e;
