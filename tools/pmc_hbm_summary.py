@@ -9,8 +9,10 @@ import glob
 import json
 import sys
 
-TRAIN_STEPS = 4    # bench.py --steps 2 --warmup 1 + the host-enqueue probe step
-FORWARDS = 9       # + 5 forward-only sweeps
+# training steps / forwards in the profiled bench run: counted from the trace (one loss_kernel per training step, one
+# prep_rotate_kernel per forward chain, two chains per forward)
+TRAIN_STEPS = 4
+FORWARDS = 9
 FWD_ONLY = ("prep_rotate", "pack_weights", "pool0_kernel", "feat_kernel", "value_conv", "bn_update", "bn_stat", "FwdConvP<", "conv3x3_halo_fwd")
 
 
@@ -23,14 +25,25 @@ def kclass(name):
         return {" 0": "conv1x1_fwd", " 1": "conv3x3_fwd", " 2": "transition_fwd", " 3": "stem7x7_fwd"}.get(tail.replace(",", ""), "conv1x1_fwd")
     if "BwdDataGroupP" in name: return "conv1x1_dgrad"
     if "BwdDataP<" in name:
-        args = name.split("BwdDataP<", 1)[1].split(">", 2)[1]
-        if "true" in args: return "conv3x3_dgrad"
-        return {"0": "head_conv0_dgrad", "1": "conv1x1_dgrad", "2": "transition_dgrad"}.get(args.split(",")[-1].strip(), "conv1x1_dgrad")
+        args = [a.strip() for a in name.split("BwdDataP<", 1)[1].split(">", 2)[1].split(",") if a.strip()]     # SHIFT3, EMODE, AFF
+        if args[0] == "true": return "conv3x3_dgrad"
+        return {"0": "head_conv0_dgrad", "1": "conv1x1_dgrad", "2": "transition_dgrad"}.get(args[1], "conv1x1_dgrad")
     if "BwdWeightP<" in name:
         args = [a.strip() for a in name.split("BwdWeightP<", 1)[1].split(">", 2)[1].split(",") if a.strip()]
         return {"0": "conv1x1_wgrad", "1": "conv3x3_wgrad", "2": "transition_wgrad", "3": "stem_wgrad"}.get(args[0], "conv1x1_wgrad")
     if "smg::" in name: return "elementwise"
     return None
+
+
+def count_steps(d):
+    global TRAIN_STEPS, FORWARDS
+    losses = preps = 0
+    for fn in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(fn)):
+            losses += "loss_kernel" in r["Kernel_Name"]
+            preps += "prep_rotate_kernel" in r["Kernel_Name"]
+    if losses and preps:
+        TRAIN_STEPS, FORWARDS = losses, preps // 2
 
 
 def load(d, counter):
@@ -52,6 +65,7 @@ def load(d, counter):
 
 
 def main():
+    count_steps(sys.argv[1])
     fetch, nf, fstep = load(sys.argv[1], "FETCH_SIZE")
     write, _, wstep = load(sys.argv[2], "WRITE_SIZE")
     out = {}
@@ -62,7 +76,7 @@ def main():
                   "gb_per_train_step": (2.0 * fstep[k] + wstep.get(k, 0.0)) / 1e9}
     json.dump(out, open(sys.argv[3] + ".json", "w"), indent=1)
     with open(sys.argv[3] + ".md", "w") as md:
-        md.write("| kernel class | launches (4 train steps + 5 forward sweeps) | FETCH_SIZE x2 (MB / launch) | WRITE_SIZE (MB / launch) | GB per training step |\n|---|---|---|---|---|\n")
+        md.write("| kernel class | launches (%d train steps + %d forward sweeps) | FETCH_SIZE x2 (MB / launch) | WRITE_SIZE (MB / launch) | GB per training step |\n|---|---|---|---|---|\n" % (TRAIN_STEPS, FORWARDS - TRAIN_STEPS))
         for k, v in out.items():
             md.write("| %s | %d | %.1f | %.1f | %.2f |\n" % (k, v["launches"], v["fetch_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6, v["gb_per_train_step"]))
         md.write("\ntotal %.1f GB per training step (one forward + one backward + Adam)\n" % sum(v["gb_per_train_step"] for v in out.values()))
