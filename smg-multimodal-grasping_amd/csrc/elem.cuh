@@ -440,11 +440,12 @@ __global__ __launch_bounds__(256) void norm5_bwd_kernel(const Norm5BwdArgs a) {
     }
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     const int u0 = a.user_ptr[s], u1 = a.user_ptr[s + 1];
-    if (u0 == u1) {
-        for (int p = p0; p < p1; ++p)
-            *reinterpret_cast<float4*>(a.G4 + ((int64_t)s * a.p4.HWp + p) * 1024 + c5) = zero4();
-        return;
-    }
+    // G4 of the chunk's pixels accumulates in registers over the users of the stream (the masked stream feeds all 16 pairs: a
+    // read-modify-write of G4 per user was a chain of 16 dependent global round trips per pixel, 187 us for this kernel)
+    constexpr int CH = 16;                               // pixels per workgroup (= a.chunk, checked at the launch)
+    float4 gacc[CH];
+#pragma unroll
+    for (int q = 0; q < CH; ++q) gacc[q] = zero4();
     for (int u = u0; u < u1; ++u) {
         const int j = a.user_pair[u], ch = a.user_slot[u] * 1024 + c5;
         float cf[16];   // a[4], q1[4], mean[4], k[4]
@@ -458,19 +459,25 @@ __global__ __launch_bounds__(256) void norm5_bwd_kernel(const Norm5BwdArgs a) {
             cf[8 + c] = mean;
             cf[12 + c] = invstd * q2;
         }
-        for (int p = p0; p < p1; ++p) {
-            const int64_t fr = ((int64_t)j * a.p4.HWp + p) * 2048 + ch;
-            const float4 d = affine2(ld4(a.DF + fr), ld4(a.F + fr), cf, 4);
-            const int64_t xr = ((int64_t)s * a.p4.HWp + p) * 1024 + c5;
-            const float4 xv = ld4(a.x4 + xr);
-            const float dd[4] = {d.x, d.y, d.z, d.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
-            float4 g = (u == u0) ? zero4() : ld4(a.G4 + xr);
-            g.x += g5[0] * dd[0]; g.y += g5[1] * dd[1]; g.z += g5[2] * dd[2]; g.w += g5[3] * dd[3];
-            *reinterpret_cast<float4*>(a.G4 + xr) = g;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { s1[c] += dd[c]; s2[c] += dd[c] * ((xx[c] - mean5[c]) * inv5[c]); }
+        for (int q = 0; q < CH; ++q) {
+            const int p = p0 + q;
+            if (p < p1) {
+                const int64_t fr = ((int64_t)j * a.p4.HWp + p) * 2048 + ch;
+                const float4 d = affine2(ld4(a.DF + fr), ld4(a.F + fr), cf, 4);
+                const int64_t xr = ((int64_t)s * a.p4.HWp + p) * 1024 + c5;
+                const float4 xv = ld4(a.x4 + xr);
+                const float dd[4] = {d.x, d.y, d.z, d.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
+                gacc[q].x += g5[0] * dd[0]; gacc[q].y += g5[1] * dd[1]; gacc[q].z += g5[2] * dd[2]; gacc[q].w += g5[3] * dd[3];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { s1[c] += dd[c]; s2[c] += dd[c] * ((xx[c] - mean5[c]) * inv5[c]); }
+            }
         }
     }
+#pragma unroll
+    for (int q = 0; q < CH; ++q)
+        if (p0 + q < p1) *reinterpret_cast<float4*>(a.G4 + ((int64_t)s * a.p4.HWp + p0 + q) * 1024 + c5) = gacc[q];
+    if (u0 == u1) return;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         atomicAdd(a.SA + (int64_t)s * 1024 + c5 + c, (double)(g5[c] * s1[c]));
