@@ -20,6 +20,7 @@
 #include "elem.cuh"
 #include "gemm.cuh"
 #include "halo.cuh"
+#include "ws.cuh"
 #include "plan.h"
 
 using namespace smg;
@@ -675,6 +676,26 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
                     static const int k16 = getenv("SMG_C1_K16") ? atoi(getenv("SMG_C1_K16")) : 1 << 30;      // dev A/B: BK = 16 past this many channels
                     static const int mid = getenv("SMG_C1_MID") ? atoi(getenv("SMG_C1_MID")) : 0;                     // dev A/B
                     static const int deep_min = getenv("SMG_C1_DEEP") ? atoi(getenv("SMG_C1_DEEP")) : 1 << 30;       // dev A/B
+                    static const bool ws_on = !(getenv("SMG_C1_WS") && atoi(getenv("SMG_C1_WS")) == 0);      // wave-specialised 64x64x32 (ws.cuh); SMG_C1_WS=0: the generic kernel (A/B, cross-check)
+                    if (ws_on && !(pl.HWp % 128 == 0 && wg128 >= small_wgs) && wg64 >= small_wgs && d.cin % 32 == 0 && pl.HWp % 64 == 0) {
+                        Fwd1x1WsArgs a{};
+                        a.src = xs(b); a.lds_ = Ct; a.pl = pl; a.K = d.cin;
+                        a.bt = t1; a.fresh0 = i == 0 ? d.cin : d.cin - kGrowth; a.fsum = xsum; a.fsq = xsq; a.fstride = Ct; a.eps = kEps;
+                        a.tw_mean = const_cast<float*>(t1.mean); a.tw_invstd = const_cast<float*>(t1.invstd);
+                        a.wp = e->packed_u + e->pk_c1[b][i]; a.N = kBottleneck;
+                        a.dst = bt; a.ldd = kBottleneck; a.dsum = bsum; a.dsq = bsq; a.dstride = kBottleneck;
+                        const int nM = ns * pl.HWp / 64, nN = kBottleneck / 64;
+                        a.tm = TileMap{nM, nN, 0};
+                        BY(e, 4.0 * ns * pl.HW * (d.cin + kBottleneck));
+                        ProfScope ps(e, cs, K_C1, 2.0 * ns * pl.HW * d.cin * kBottleneck);
+                        const size_t smem = WsGeo::smem_bytes(d.cin);
+                        static bool raised[64][3] = {};
+                        if (!raised[e->device & 63][e->prec]) {
+                            PREC_DISPATCH(e, (void)hipFuncSetAttribute((const void*)conv1x1_fwd_ws_kernel<PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                            raised[e->device & 63][e->prec] = true;
+                        }
+                        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_fwd_ws_kernel<PREC>), dim3(8 * ((nM + 7) / 8) * nN), dim3(512), smem, cs, a));
+                    } else
                     if (pl.HWp % 128 == 0 && wg128 >= small_wgs) run(CfgP128x128{});
                     else if (pl.HWp % 128 == 0 && wg128 >= deep_min && d.cin % 32 == 0) run(CfgP128x128d{});
                     else if (wg64 < small_wgs) run(CfgP32x64{});
