@@ -36,9 +36,13 @@ def analyze(a, b, label):
     for g in gaps[:8]: print('      %.1f us after %s before %s' % (g[0]/1e3, g[1], g[2]))
     byq = collections.Counter(q for *_, q in seg)
     print('   queues:', dict(byq))
-if len(ends) >= 6:
+# steps of the timed loop (device-resident inputs): the 4th and 5th Adam pairs; under rocprofv3 the HOST is slower than in
+# a plain run (every launch is intercepted), so gaps at the step boundaries and before Adam are the profiler's, not the step's
+if len(ends) >= 12:
+    analyze(ends[7] + 1, ends[9] + 1, 'step')
+    analyze(ends[9] + 1, ends[11] + 1, 'next')
+elif len(ends) >= 6:
     analyze(ends[3] + 1, ends[5] + 1, 'step')
-    analyze(ends[5] + 1, ends[7] + 1 if len(ends) > 7 else len(ev), 'next')
 
 def solo(a, b):
     """time with exactly one kernel in flight, by kernel name"""
@@ -58,4 +62,5 @@ def solo(a, b):
     for n, v in acc.most_common(14): print('      %7.3f  %s' % (v / 1e6, n))
     print('   time shared (ms, split evenly):')
     for n, v in acc2.most_common(10): print('      %7.3f  %s' % (v / 1e6, n))
-if len(ends) >= 6: solo(ends[3] + 1, ends[5] + 1)
+if len(ends) >= 12: solo(ends[7] + 1, ends[9] + 1)
+elif len(ends) >= 6: solo(ends[3] + 1, ends[5] + 1)
