@@ -56,6 +56,9 @@
 #ifndef SMG_PD_FWD_BIG
 #define SMG_PD_FWD_BIG 1
 #endif
+#ifndef SMG_FWD_BIG_MINWAVES      // waves per SIMD the 128x128 forward is held to (register cap 512 / n)
+#define SMG_FWD_BIG_MINWAVES 3
+#endif
 #ifndef SMG_PD_FWD_DEEP
 #define SMG_PD_FWD_DEEP 2
 #endif
@@ -63,7 +66,7 @@
 #define SMG_PD_DGRAD 2
 #endif
 #ifndef SMG_PD_DGRAD_BIG
-#define SMG_PD_DGRAD_BIG 1
+#define SMG_PD_DGRAD_BIG 2
 #endif
 #ifndef SMG_PD_WGRAD
 #define SMG_PD_WGRAD 3
@@ -714,7 +717,7 @@ struct FwdConvP {
     static constexpr bool kHasPrologue = MODE != F_STEM;
     static constexpr int kFresh = 32;       // growth rate: at most this many fresh channels
     // waves per SIMD the register allocator is held to: the 128x128 tile (64 accumulator registers) must stay at 3
-    static constexpr int kMinWaves = (Cfg::TM * Cfg::TN == 4 && MODE != F_POOL && !kDeep) ? 3 : 1;    // (the pooling fetch holds 4 float4 per row)
+    static constexpr int kMinWaves = (Cfg::TM * Cfg::TN == 4 && MODE != F_POOL && !kDeep) ? SMG_FWD_BIG_MINWAVES : 1;    // (the pooling fetch holds 4 float4 per row)
 
     struct Ctx { int n, m0, n0; };
     struct ARow { int y, x; bool valid; unsigned off; };     // off: element offset of the row inside its stream (F_ONE)
