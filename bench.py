@@ -94,7 +94,17 @@ def cpu_baseline(seed, n_samples, labels, thread_settings):
         for r in range(n_samples):
             orc.train_step(net, opt, x, mx, 0, r % R, float(labels[r % R]))
         out[nt] = (time.perf_counter() - t0) / n_samples * R             # seconds per 16-sample pass
-    return out
+    # forward-only sweep (config 2) on the reference's schedule at the best thread setting: 2 of the 16 rotations
+    # (each = rotated stream + masked stream, no grad), extrapolated
+    best = min(out, key=lambda k: out[k])
+    torch.set_num_threads(best)
+    with torch.no_grad():
+        orc.forward(net, x, mx, 0, True, 0)
+        t0 = time.perf_counter()
+        for r in (3, 9):
+            orc.forward(net, x, mx, 0, True, r)
+        sweep = (time.perf_counter() - t0) / 2 * R
+    return out, sweep
 
 
 def physical_cores():
@@ -407,7 +417,7 @@ def main():
             # threads = physical cores and two smaller settings; the best one is reported
             pc = physical_cores()
             settings = sorted({pc, max(1, pc // 2), min(pc, 16)}, reverse=True)
-            secs = cpu_baseline(0, args.cpu_samples, labels, settings)
+            secs, cpu_sweep = cpu_baseline(0, args.cpu_samples, labels, settings)
             best = min(secs, key=lambda k: secs[k])
             out["cpu_baseline"] = {
                 "value": 1.0 / secs[best], "unit": "passes/s", "cores": best, "kind": "port",
@@ -416,6 +426,7 @@ def main():
                           "the thread settings tried" % (args.cpu_samples, R / args.cpu_samples),
                 "seconds_per_pass": secs[best], "physical_cores": pc, "logical_cpus": os.cpu_count(),
                 "seconds_per_pass_by_threads": {str(k): v for k, v in secs.items()},
+                "sweep_fwd_seconds": cpu_sweep,       # 16-rotation forward-only sweep (2 rotations timed, x8), same thread setting
             }
     if rank == 0:
         print(json.dumps(out))
