@@ -15,7 +15,7 @@ rep = {
     'C4MS': '%.0f' % c['config4_share_8_scenes']['ms_per_step'], 'C4PS': '%.1f' % c['config4_share_8_scenes']['passes_per_s'],
     'C3MS': '%.1f' % c['config3_three_heads_bf16']['ms'], 'C3F32': '%.1f' % c['config3_three_heads_bf16']['ms_fp32_class'],
     'C5MS': '%.1f' % c['config5_share_1824_fp16']['ms_per_step'], 'C5F32': '%.1f' % c['config5_share_1824_fp16']['ms_fp32_class'],
-    'CPUS': '%.1f' % d['cpu_baseline']['seconds_per_pass'], 'HOSTMS': '%.1f' % d.get('ms_per_step_host_inputs', float('nan')), 'ENQ': '%.1f' % d.get('host_enqueue_ms_per_step', float('nan')), 'TABLE': '\n'.join(tab), 'STEPFRAC': '%.2f' % r['step']['frac'],
+    'CPUS': '%.1f' % d['cpu_baseline']['seconds_per_pass'], 'CPUSWEEP': '%.1f' % d['cpu_baseline'].get('sweep_fwd_seconds', float('nan')), 'HOSTMS': '%.1f' % d.get('ms_per_step_host_inputs', float('nan')), 'ENQ': '%.1f' % d.get('host_enqueue_ms_per_step', float('nan')), 'TABLE': '\n'.join(tab), 'STEPFRAC': '%.2f' % r['step']['frac'],
 }
 for k, v in rep.items(): tpl = tpl.replace('@' + k + '@', v)
 open(sys.argv[3], 'w').write(tpl)
