@@ -40,7 +40,11 @@ typedef struct smg_engine smg_engine;
 
 /* ---- library ------------------------------------------------------------------ */
 const char* smg_last_error(void);
+/* ABI revision of this header: a binding must refuse a library whose smg_version() differs (stale .so) and should
+ * compare its own struct sizes with smg_abi_struct_bytes(0 = smg_batch, 1 = smg_net) before the first call. */
+#define SMG_ABI_VERSION 3
 int smg_version(void);
+int smg_abi_struct_bytes(int which);
 
 /* ---- state layout (replaces nn.Module.state_dict() ordering of
  *      code/models.py:301-358 reinforcement_net / :15-69 reactive_net) ------------- */
@@ -150,6 +154,11 @@ int smg_backward(smg_engine* e, const smg_net* net, const float* dq_dev, void* s
  *   1  bf16 operands, 2  fp16 operands: one MFMA term per product (BASELINE.json configs 3 and 5).
  * Activations, gradients, BN statistics and every accumulation stay fp32.  Takes effect with the next smg_forward. */
 int smg_engine_set_precision(smg_engine* e, int precision);
+
+/* Engine switches by name.  "deterministic" (0 / 1): the 1x1-convolution weight gradients (conv1 of every dense layer,
+ * the largest gradient tensors) are reduced from partial tiles in a fixed order instead of fp32 atomics, so the convolution
+ * weight gradients of two identical calls are bit-identical like the reference's (code/trainer.py:350-351 on one device). */
+int smg_engine_set_option(smg_engine* e, const char* name, int value);
 
 /* Heightmap generation in front of the path (utils.get_heightmap, code/utils.py:38-68): the robot-frame height of every
  * camera pixel (get_pointcloud + cam_pose, :12-47) warped onto the table plane (cv2.warpPerspective, INTER_LINEAR,

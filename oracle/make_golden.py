@@ -130,6 +130,81 @@ def g9_object_loops(G, ref_net):
     print("G9", gra, suc, gs)
 
 
+def g5_g6_trainer_steps(G, ref_trainer, lay1):
+    """G5/G6: three optimizer steps driven the way Trainer.backprop drives the reference model (code/trainer.py:338-383):
+    grasp, suction, then grasp_then_suction.  The ES step uses the two-object mask of code/trainer.py:370
+    (`depth * (mask[g] + mask[s])`, objects 1 and 2) like Trainer.backprop builds it, so the product's
+    Trainer.backprop('grasp_then_suction', ...) -> Adam path is pinned against the reference's trajectory."""
+    with cuda_reported_available():
+        tr = ref_trainer.Trainer("reinforcement", 0.5, False, None, False)
+    sd0 = synthetic.make_state_dict(lay1, 0)
+    tr.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd0.items()})
+    tr.model_target.load_state_dict(tr.model.state_dict())
+    tr.model.gnum_rotations = tr.model.snum_rotations = 16
+    tr.model_target.gnum_rotations = tr.model_target.snum_rotations = 16
+
+    # Trainer.forward divides by image_std = 0 as released; the golden steps therefore
+    # drive the reference model the way Trainer.backprop does (trainer.py:338-383),
+    # with the finite normalisation applied by orc.preprocess.
+    depth, masks, x, mx = scene_inputs(0, [0])
+    _, _, _, mx_es = scene_inputs(0, [1, 2])
+    pnames = [n for n, _ in tr.model.named_parameters()]
+    steps = [  # (style, rotation, label)  labels chosen so both Huber branches occur
+        (0, 3, 0.4),
+        (1, 9, 7.5),
+        (2, 0, -3.0),
+    ]
+    for si, (style, rot, label) in enumerate(steps):
+        tr.optimizer.zero_grad()
+        q = tr.model.forward(x, mx_es if style == 2 else mx, style, False, rot)
+        prob = (tr.model.gra_prob, tr.model.suc_prob, tr.model.gs_prob)[style]
+        if abs(prob[0, 0, 0, 0] - label) < 1:
+            loss = 0.5 * ((prob[0, 0, 0, 0] - label) ** 2)
+        else:
+            loss = abs(prob[0, 0, 0, 0] - label) - 0.5
+        loss = loss.sum()
+        loss.backward()
+        G["g5_step%d_q" % si] = np.asarray(float(q), dtype=np.float32)
+        G["g5_step%d_loss" % si] = np.asarray(float(loss), dtype=np.float32)
+        gn, has = [], []
+        for n, p in tr.model.named_parameters():
+            has.append(p.grad is not None)
+            gn.append(float(p.grad.double().norm()) if p.grad is not None else 0.0)
+        G["g5_step%d_gradnorm" % si] = np.asarray(gn)
+        G["g5_step%d_hasgrad" % si] = np.asarray(has)
+        trunk = orc.STYLE_TRUNK[style]
+        head = orc.STYLE_HEAD[style]
+        hp = head.split("net")[0]
+        for key in (trunk + ".features.conv0.weight", trunk + ".features.norm0.weight",
+                    trunk + ".features.denseblock1.denselayer1.conv1.weight",
+                    trunk + ".features.denseblock1.denselayer6.conv2.weight",
+                    trunk + ".features.denseblock2.denselayer12.norm1.weight",
+                    trunk + ".features.denseblock2.denselayer12.norm1.bias",
+                    trunk + ".features.transition2.conv.weight",
+                    trunk + ".features.denseblock3.denselayer24.conv1.weight",
+                    trunk + ".features.denseblock4.denselayer16.norm2.bias",
+                    trunk + ".features.norm5.weight",
+                    "%s.%s-val-norm0.weight" % (head, hp), "%s.%s-val-conv0.weight" % (head, hp),
+                    "%s.%s-val-norm1.bias" % (head, hp), "%s.%s-val-conv1.weight" % (head, hp)):
+            p = dict(tr.model.named_parameters())[key]
+            pi = probe_idx(p.numel(), 16, "g5/" + key)
+            G["g5_step%d_grad_%s" % (si, key)] = p.grad.numpy().ravel()[pi].copy()
+        tr.optimizer.step()
+        for key in (trunk + ".features.conv0.weight", trunk + ".features.denseblock3.denselayer5.conv2.weight",
+                    trunk + ".features.norm5.bias", "%s.%s-val-conv1.weight" % (head, hp)):
+            p = dict(tr.model.named_parameters())[key]
+            pi = probe_idx(p.numel(), 16, "g6/" + key)
+            G["g6_step%d_param_%s" % (si, key)] = p.detach().numpy().ravel()[pi].copy()
+        print("G5 step", si, float(q), float(loss))
+    G["g5_param_names"] = np.asarray(pnames)
+    # target network after divergence (SURVEY.md 8a-10): model has taken 3 steps, target none
+    qt = tr.model_target.forward(x, mx, 0, True, 3)
+    qm = tr.model.forward(x, mx, 0, True, 3)
+    G["g4_target_rot3"] = np.asarray(float(qt), dtype=np.float32)
+    G["g4_model_after3_rot3"] = np.asarray(float(qm), dtype=np.float32)
+    return tr, x, mx
+
+
 def ref_net_factory(ref_models):
     lay1, lay3 = orc.state_layout(1), orc.state_layout(3)
 
@@ -152,6 +227,25 @@ def extend_only():
     path = os.path.join(OUT, "reference_vectors.npz")
     G = dict(np.load(path, allow_pickle=False))
     g9_object_loops(G, ref_net_factory(ref_models))
+    np.savez_compressed(path, **G)
+    print("wrote", path, len(G), "arrays")
+
+
+def extend_g5():
+    """`python -m oracle.make_golden g5`: regenerate the G5/G6 training steps (and the target-network values that follow
+    them) inside the existing file; steps 0 and 1 must reproduce the stored values bit for bit."""
+    install_shims()
+    importlib.import_module("models")
+    ref_trainer = importlib.import_module("trainer")
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    path = os.path.join(OUT, "reference_vectors.npz")
+    old = dict(np.load(path, allow_pickle=False))
+    G = dict(old)
+    g5_g6_trainer_steps(G, ref_trainer, orc.state_layout(1))
+    for k in old:
+        if k.startswith(("g5_step0", "g5_step1", "g6_step0", "g6_step1")):
+            assert np.array_equal(old[k], G[k]), "regenerated %s differs from the stored fixture" % k
     np.savez_compressed(path, **G)
     print("wrote", path, len(G), "arrays")
 
@@ -279,73 +373,7 @@ def main():
         G["g7_%s_rv" % key] = sd[key + ".running_var"].numpy().copy()
         G["g7_%s_nbt" % key] = np.asarray(int(sd[key + ".num_batches_tracked"]))
 
-    # ---------------- G5/G6: training steps through the reference Trainer ------------
-    with cuda_reported_available():
-        tr = ref_trainer.Trainer("reinforcement", 0.5, False, None, False)
-    sd0 = synthetic.make_state_dict(lay1, 0)
-    tr.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd0.items()})
-    tr.model_target.load_state_dict(tr.model.state_dict())
-    tr.model.gnum_rotations = tr.model.snum_rotations = 16
-    tr.model_target.gnum_rotations = tr.model_target.snum_rotations = 16
-
-    # Trainer.forward divides by image_std = 0 as released; the golden steps therefore
-    # drive the reference model the way Trainer.backprop does (trainer.py:338-383),
-    # with the finite normalisation applied by orc.preprocess.
-    depth, masks, x, mx = scene_inputs(0, [0])
-    pnames = [n for n, _ in tr.model.named_parameters()]
-    steps = [  # (style, rotation, label)  labels chosen so both Huber branches occur
-        (0, 3, 0.4),
-        (1, 9, 7.5),
-        (2, 0, -3.0),
-    ]
-    for si, (style, rot, label) in enumerate(steps):
-        tr.optimizer.zero_grad()
-        q = tr.model.forward(x, mx, style, False, rot)
-        prob = (tr.model.gra_prob, tr.model.suc_prob, tr.model.gs_prob)[style]
-        if abs(prob[0, 0, 0, 0] - label) < 1:
-            loss = 0.5 * ((prob[0, 0, 0, 0] - label) ** 2)
-        else:
-            loss = abs(prob[0, 0, 0, 0] - label) - 0.5
-        loss = loss.sum()
-        loss.backward()
-        G["g5_step%d_q" % si] = np.asarray(float(q), dtype=np.float32)
-        G["g5_step%d_loss" % si] = np.asarray(float(loss), dtype=np.float32)
-        gn, has = [], []
-        for n, p in tr.model.named_parameters():
-            has.append(p.grad is not None)
-            gn.append(float(p.grad.double().norm()) if p.grad is not None else 0.0)
-        G["g5_step%d_gradnorm" % si] = np.asarray(gn)
-        G["g5_step%d_hasgrad" % si] = np.asarray(has)
-        trunk = orc.STYLE_TRUNK[style]
-        head = orc.STYLE_HEAD[style]
-        hp = head.split("net")[0]
-        for key in (trunk + ".features.conv0.weight", trunk + ".features.norm0.weight",
-                    trunk + ".features.denseblock1.denselayer1.conv1.weight",
-                    trunk + ".features.denseblock1.denselayer6.conv2.weight",
-                    trunk + ".features.denseblock2.denselayer12.norm1.weight",
-                    trunk + ".features.denseblock2.denselayer12.norm1.bias",
-                    trunk + ".features.transition2.conv.weight",
-                    trunk + ".features.denseblock3.denselayer24.conv1.weight",
-                    trunk + ".features.denseblock4.denselayer16.norm2.bias",
-                    trunk + ".features.norm5.weight",
-                    "%s.%s-val-norm0.weight" % (head, hp), "%s.%s-val-conv0.weight" % (head, hp),
-                    "%s.%s-val-norm1.bias" % (head, hp), "%s.%s-val-conv1.weight" % (head, hp)):
-            p = dict(tr.model.named_parameters())[key]
-            pi = probe_idx(p.numel(), 16, "g5/" + key)
-            G["g5_step%d_grad_%s" % (si, key)] = p.grad.numpy().ravel()[pi].copy()
-        tr.optimizer.step()
-        for key in (trunk + ".features.conv0.weight", trunk + ".features.denseblock3.denselayer5.conv2.weight",
-                    trunk + ".features.norm5.bias", "%s.%s-val-conv1.weight" % (head, hp)):
-            p = dict(tr.model.named_parameters())[key]
-            pi = probe_idx(p.numel(), 16, "g6/" + key)
-            G["g6_step%d_param_%s" % (si, key)] = p.detach().numpy().ravel()[pi].copy()
-        print("G5 step", si, float(q), float(loss))
-    G["g5_param_names"] = np.asarray(pnames)
-    # target network after divergence: model has taken 3 steps, target none
-    qt = tr.model_target.forward(x, mx, 0, True, 3)
-    qm = tr.model.forward(x, mx, 0, True, 3)
-    G["g4_target_rot3"] = np.asarray(float(qt), dtype=np.float32)
-    G["g4_model_after3_rot3"] = np.asarray(float(qm), dtype=np.float32)
+    tr, x, mx = g5_g6_trainer_steps(G, ref_trainer, lay1)
 
     # ---------------- G8: reactive ---------------------------------------------------
     with cuda_reported_available():
@@ -379,5 +407,7 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g9":
         extend_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g5":
+        extend_g5()
     else:
         main()

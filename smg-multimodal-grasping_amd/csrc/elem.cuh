@@ -756,7 +756,15 @@ __global__ void heightmap_warp_kernel(const HeightmapArgs a) {
                                    tap(y0 + 1, x0 + 1) * (double)w11;
 }
 
-// Largest value and its index (lowest index on ties, like np.argmax): one workgroup.
+// Largest value and its index, exactly like np.argmax: lowest index on ties, and a NaN beats every number (the FIRST NaN
+// wins) - a diverged network surfaces as a NaN best value instead of an arbitrary but valid-looking action.  One workgroup.
+__device__ __forceinline__ bool argmax_better(float x, int i, float bx, int bi) {
+    if (bi == 0x7fffffff) return true;                  // nothing held yet
+    const bool xn = x != x, bn = bx != bx;
+    if (xn != bn) return xn;
+    if (xn) return i < bi;
+    return x > bx || (x == bx && i < bi);
+}
 __global__ __launch_bounds__(256) void argmax_kernel(const float* v, int n, int* idx_out, float* val_out) {
     __shared__ float bv[256];
     __shared__ int bi[256];
@@ -764,14 +772,14 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* v, int n, int*
     float best = -INFINITY; int at = 0x7fffffff;
     for (int i = t; i < n; i += 256) {
         const float x = v[i];
-        if (x > best || (x == best && i < at) || at == 0x7fffffff) { if (x > best || at == 0x7fffffff || (x == best && i < at)) { best = x; at = i; } }
+        if (argmax_better(x, i, best, at)) { best = x; at = i; }
     }
     bv[t] = best; bi[t] = at;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if (t < s) {
             const float x = bv[t + s]; const int j = bi[t + s];
-            if (j != 0x7fffffff && (bi[t] == 0x7fffffff || x > bv[t] || (x == bv[t] && j < bi[t]))) { bv[t] = x; bi[t] = j; }
+            if (j != 0x7fffffff && argmax_better(x, j, bv[t], bi[t])) { bv[t] = x; bi[t] = j; }
         }
         __syncthreads();
     }

@@ -132,6 +132,7 @@ struct smg_engine {
     int64_t workspace_bytes = 0;
     int n_cu = 256;            // compute units of the device (persistent-launch sizing)
     int prec = 0;              // operand precision of the matrix products: 0 fp32-class split, 1 bf16, 2 fp16 (smg_engine_set_precision)
+    bool deterministic = false;   // smg_engine_set_option("deterministic"): 1x1 weight gradients as partial tiles + fixed-order reduce instead of fp32 atomics
     bool generic3x3 = false;   // SMG_GENERIC_3X3=1: dense-layer 3x3 convs through the generic implicit GEMM (A/B testing)
     // profiling
     bool prof = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> ev_pool;
@@ -1104,7 +1105,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
                 p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
                 p.dw = Gr + d.c1.w; p.ldw_out = d.cin;
                 BY(e, 4.0 * NS * pl.HW * (kBottleneck + d.cin));
-                launch_wgrad(e, s2, p, dim3(1, nt, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck, 1, C_IDENT, false);
+                launch_wgrad(e, s2, p, dim3(1, nt, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck, 1, C_IDENT, e->deterministic);
                 HIP_OK(hipEventRecord(e->ev_side[db], s2));
             }
         }
@@ -1196,7 +1197,12 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
 extern "C" {
 
 const char* smg_last_error(void) { return g_err.c_str(); }
-int smg_version(void) { return 1; }
+int smg_version(void) { return SMG_ABI_VERSION; }
+int smg_abi_struct_bytes(int which) {
+    if (which == 0) return (int)sizeof(smg_batch);
+    if (which == 1) return (int)sizeof(smg_net);
+    return fail(-22, "smg_abi_struct_bytes: 0 = smg_batch, 1 = smg_net");
+}
 
 int smg_layout_count(int head_out) { return (int)layout_for(head_out).entries.size(); }
 int64_t smg_layout_param_floats(int head_out) { return layout_for(head_out).n_params; }
@@ -1308,6 +1314,13 @@ int smg_engine_set_precision(smg_engine* e, int precision) {
     e->prec = precision;
     e->have_fwd = false;        // activations saved by a forward of another precision are not backward-compatible
     return 0;
+}
+
+int smg_engine_set_option(smg_engine* e, const char* name, int value) {
+    if (!e || !name) return fail(-22, "NULL argument");
+    const std::string s(name);
+    if (s == "deterministic") { e->deterministic = value != 0; return 0; }
+    return fail(-22, "unknown engine option '" + s + "'");
 }
 
 int smg_heightmap(const double* depth_img_dev, int h, int w, const double* intrinsics3x3, const double* cam_pose4x4,

@@ -182,6 +182,10 @@ class _AffordanceNet(nn.Module):
             fn = lambda t: t.to(dev)                                     # noqa: E731
         elif probe.dtype != torch.float32:
             raise TypeError("the affordance engine stores fp32 and computes in fp32 / bf16 / fp16 operands; got %s" % probe.dtype)
+        elif self.precision != "fp32" and fn(torch.zeros(1, dtype=torch.float16, device=self._flat_params.device)).dtype == torch.float32:
+            # model.float() / .to(torch.float32) after a .half(): a dtype cast (it turns a half probe into fp32; a device
+            # move leaves it half) - back to the fp32-class products
+            self.set_precision("fp32")
         self._flat_params = fn(self._flat_params)
         self._flat_bufs = fn(self._flat_bufs)
         nbt = fn(self._flat_nbt)

@@ -31,6 +31,8 @@ class SmgBatch(C.Structure):
     ]
 
 
+ABI_VERSION = 3     # SMG_ABI_VERSION of include/smg_hip.h this binding was written against
+
 _lib = None
 
 
@@ -47,6 +49,12 @@ def lib():
     L = C.CDLL(LIB_PATH)
     L.smg_last_error.restype = C.c_char_p
     L.smg_version.restype = C.c_int
+    if not hasattr(L, "smg_abi_struct_bytes") or L.smg_version() != ABI_VERSION:
+        raise SmgError("%s is ABI version %d, this binding needs %d: rebuild it (make -C csrc)" % (LIB_PATH, L.smg_version(), ABI_VERSION))
+    L.smg_abi_struct_bytes.argtypes = [C.c_int]
+    for which, ty in ((0, SmgBatch), (1, SmgNet)):
+        if L.smg_abi_struct_bytes(which) != C.sizeof(ty):
+            raise SmgError("%s: struct %s is %d bytes in the library, %d in this binding" % (LIB_PATH, ty.__name__, L.smg_abi_struct_bytes(which), C.sizeof(ty)))
     L.smg_layout_count.argtypes = [C.c_int]
     for f in (L.smg_layout_param_floats, L.smg_layout_buffer_floats, L.smg_layout_nbt_count):
         f.argtypes = [C.c_int]
@@ -65,6 +73,7 @@ def lib():
     L.smg_loss.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.smg_backward.argtypes = [C.c_void_p, C.POINTER(SmgNet), C.c_void_p, C.c_void_p]
     L.smg_engine_set_precision.argtypes = [C.c_void_p, C.c_int]
+    L.smg_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.smg_heightmap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.smg_argmax.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -83,7 +92,7 @@ def lib():
 
 
 EXPORTS = (
-    "smg_last_error", "smg_version", "smg_layout_count", "smg_layout_param_floats", "smg_layout_buffer_floats",
+    "smg_last_error", "smg_version", "smg_abi_struct_bytes", "smg_engine_set_option", "smg_layout_count", "smg_layout_param_floats", "smg_layout_buffer_floats",
     "smg_layout_nbt_count", "smg_layout_entry", "smg_layout_trunk_range", "smg_layout_head_range",
     "smg_engine_create", "smg_engine_destroy", "smg_engine_workspace_bytes", "smg_engine_geometry",
     "smg_forward", "smg_loss", "smg_backward", "smg_adam_step", "smg_argmax", "smg_heightmap", "smg_engine_set_precision", "smg_debug_read",
@@ -155,8 +164,13 @@ class Engine(object):
     def set_precision(self, name):
         """Operand precision of the matrix products: 'fp32' (3-piece bf16 split, fp32-class; default), 'bf16' or
         'fp16' (single-piece operands; fp32 storage and accumulation)."""
-        check(lib().smg_engine_set_precision(self.h, PRECISIONS[str(name).replace("torch.", "")]))
-        self.precision = str(name).replace("torch.", "")
+        code = PRECISIONS[str(name).replace("torch.", "")]
+        check(lib().smg_engine_set_precision(self.h, code))
+        self.precision = PRECISION_NAMES[code]          # canonical name: callers compare against 'fp32' / 'bf16' / 'fp16'
+
+    def set_option(self, name, value):
+        """Engine switches by name (smg_engine_set_option), e.g. ('deterministic', 1)."""
+        check(lib().smg_engine_set_option(self.h, name.encode(), int(value)))
 
     @property
     def workspace_bytes(self):
@@ -240,6 +254,7 @@ class Engine(object):
 
 
 PRECISIONS = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "fp16": 2, "float16": 2, "half": 2}
+PRECISION_NAMES = {0: "fp32", 1: "bf16", 2: "fp16"}
 
 
 def heightmap(depth_img, h, w, intrinsics, cam_pose, inv_homography, out_w, out_h, out, stream):

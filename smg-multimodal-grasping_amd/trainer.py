@@ -388,7 +388,12 @@ class Trainer(object):
         if torch.is_tensor(labels):
             lab = labels.to(device=dev, dtype=torch.float32).reshape(-1)
         else:
-            lab = torch.as_tensor(np.asarray(labels, dtype=np.float32).reshape(-1), device=dev)
+            lab_h = np.asarray(labels, dtype=np.float32).reshape(-1)
+            if self.method == 'reactive' and not np.isin(lab_h, (0.0, 1.0, 2.0)).all():
+                # torch's nll_loss (code/utils.py:311) raises on a class index outside [0, 3); the loss kernel would
+                # silently treat it as the weight-0 class.  (Device-resident labels are not read back: same contract.)
+                raise ValueError("reactive labels must be class indices 0, 1 or 2")
+            lab = torch.as_tensor(lab_h, device=dev)
         if lab.numel() != n:
             raise ValueError("one label per (scene, rotation) sample")
         loss = torch.empty(n, dtype=torch.float32, device=dev)

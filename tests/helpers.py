@@ -62,3 +62,36 @@ def q_close(q, ref, scale=None):
     scale = np.abs(ref).max() if scale is None else scale
     tol = 1e-3 * np.maximum(np.abs(ref), 5e-2 * scale)
     return bool((np.abs(q - ref) <= tol).all()), float(np.abs(q - ref).max())
+
+
+def grads_within_fp32_class(prod_named_params, oracle_named_params, g64, factor=3.0, what=""):
+    """The gradient yardstick of the parity suite.  `g64` = fp64 oracle gradients {name: tensor} (the truth),
+    `oracle_named_params` = the fp32 PyTorch-CPU oracle after its own backward, `prod_named_params` = the product.
+    Per tensor: the product's error within `factor` x what fp32 costs PyTorch-CPU itself - its error on this very tensor,
+    or (where it got lucky on one tensor) its typical error, the 90th percentile of its relative errors over all tensors.
+    In aggregate: the median relative error within `factor` x the oracle's median.
+    Also checks that exactly the tensors of g64 received a gradient.  Returns (rel_prod, rel_oracle, worst5)."""
+    po = dict(oracle_named_params)
+    gmax = max(float(g.norm()) for g in g64.values())
+    rel_p, rel_o, rows = [], [], []
+    for name, p in prod_named_params:
+        if name not in g64:
+            assert p.grad is None, "unexpected gradient on " + name
+            continue
+        assert p.grad is not None, "missing gradient on " + name
+        t = g64[name].numpy()
+        e_prod = np.sqrt(((p.grad.cpu().double().numpy() - t) ** 2).sum())
+        e_orc = np.sqrt(((po[name].grad.double().numpy() - t) ** 2).sum())
+        nrm = np.sqrt((t * t).sum())
+        rel_p.append(e_prod / max(nrm, 1e-30))
+        rel_o.append(e_orc / max(nrm, 1e-30))
+        rows.append((name, e_prod, e_orc, nrm))
+    assert len(rows) == len(g64), (len(rows), len(g64))
+    typical = float(np.percentile(rel_o, 90))
+    worst = sorted(((e_prod / max(factor * max(e_orc, typical * nrm) + 1e-6 * gmax, 1e-30), name, e_prod, e_orc, nrm)
+                    for name, e_prod, e_orc, nrm in rows), reverse=True)
+    for ratio, name, e_prod, e_orc, nrm in worst[:5]:
+        print("grad check %s %-70s |err| %.3e  fp32-oracle |err| %.3e  |g| %.3e  (%.2f of the bound)" % (what, name, e_prod, e_orc, nrm, ratio))
+    assert worst[0][0] <= 1.0, "%s: |err| %.3e vs fp32-oracle |err| %.3e, |g| %.3e" % worst[0][1:]
+    assert np.median(rel_p) <= factor * np.median(rel_o) + 1e-4, (np.median(rel_p), np.median(rel_o))
+    return np.asarray(rel_p), np.asarray(rel_o), worst[:5]

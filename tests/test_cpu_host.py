@@ -166,3 +166,36 @@ def test_trainer_preload_resumes_logs(tmp_path):
     assert np.asarray(t.clearance_log).shape == (3, 1)
     assert np.allclose(t.episode_success_log, logs["episode_success"][:n])
     assert np.asarray(t.training_loss_log).shape == (n, 2)
+
+
+def test_abi_version_and_struct_sizes_are_checked():
+    """A stale libsmg_hip.so (older smg_batch / entry points) must be refused at load time instead of reading a short
+    struct: the binding compares smg_version() with the header's SMG_ABI_VERSION and its ctypes struct sizes with
+    smg_abi_struct_bytes()."""
+    hdr = open(os.path.join(REPO, "include", "smg_hip.h")).read()
+    ver = int(re.search(r"#define\s+SMG_ABI_VERSION\s+(\d+)", hdr).group(1))
+    L = smg_hip.lib()
+    assert L.smg_version() == ver == smg_hip.ABI_VERSION
+    assert L.smg_abi_struct_bytes(0) == ctypes.sizeof(smg_hip.SmgBatch)
+    assert L.smg_abi_struct_bytes(1) == ctypes.sizeof(smg_hip.SmgNet)
+    assert L.smg_abi_struct_bytes(7) < 0
+
+
+def test_dtype_casts_select_and_restore_the_operand_precision():
+    """model.half() / .bfloat16() keep the fp32 master copy and select single-term products; a later .float() /
+    .to(torch.float32) goes back to the fp32-class products; device moves change nothing."""
+    import models
+    net = models.reinforcement_net(False)
+    assert net.precision == "fp32"
+    net.half()
+    assert net.precision == "fp16" and net._flat_params.dtype == torch.float32
+    net.to("cpu")
+    assert net.precision == "fp16"
+    net.float()
+    assert net.precision == "fp32"
+    net.bfloat16()
+    assert net.precision == "bf16"
+    net.to(torch.float32)
+    assert net.precision == "fp32" and net._flat_params.dtype == torch.float32
+    net.set_precision("bfloat16")
+    assert net.precision == "bf16"                         # canonical names only

@@ -21,7 +21,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import MEAN, STD, nhwc_plane, oracle_net, orc, probe_idx, q_close, scene, scene_tensors
+from helpers import grads_within_fp32_class, MEAN, STD, nhwc_plane, oracle_net, orc, probe_idx, q_close, scene, scene_tensors
 
 pytestmark = pytest.mark.gpu
 
@@ -214,35 +214,11 @@ def test_g5_backward_gradients(gpu, golden, style, rot, label):
     loss = 0.5 * d ** 2 if abs(float(d.detach())) < 1 else abs(d) - 0.5       # code/trainer.py:345-348
     loss.backward()                                                            # autograd -> smg_backward
     assert abs(float(qp.detach()) - q64) <= 1e-3 * max(abs(q64), 1e-2)
-    po = dict(on.named_parameters())
-    gmax = max(float(g.norm()) for g in g64.values())
-    n_checked = 0
-    rel_p, rel_o, worst = [], [], []
-    for name, p in net.named_parameters():
-        if name not in g64:
-            assert p.grad is None, "unexpected gradient on " + name
-            continue
-        assert p.grad is not None, "missing gradient on " + name
-        t = g64[name].numpy()
-        e_prod = np.sqrt(((p.grad.cpu().double().numpy() - t) ** 2).sum())
-        e_orc = np.sqrt(((po[name].grad.double().numpy() - t) ** 2).sum())
-        nrm = np.sqrt((t * t).sum())
-        rel_p.append(e_prod / max(nrm, 1e-30))
-        rel_o.append(e_orc / max(nrm, 1e-30))
-        worst.append((name, e_prod, e_orc, nrm))
-        n_checked += 1
-    assert n_checked == 368
-    # Per tensor: within 3x what fp32 costs PyTorch-CPU itself - its error on this very tensor, or (where it got lucky
-    # on one tensor) its typical error: the 90th percentile of its relative errors over the 368 tensors.
-    typical = float(np.percentile(rel_o, 90))
-    worst = sorted(((e_prod / max(3.0 * max(e_orc, typical * nrm) + 1e-6 * gmax, 1e-30), name, e_prod, e_orc, nrm)
-                    for name, e_prod, e_orc, nrm in worst), reverse=True)
-    for ratio, name, e_prod, e_orc, nrm in worst[:5]:
-        print("grad check %-70s |err| %.3e  fp32-oracle |err| %.3e  |g| %.3e  (%.2f of the bound)" % (name, e_prod, e_orc, nrm, ratio))
-    assert worst[0][0] <= 1.0, "%s: |err| %.3e vs fp32-oracle |err| %.3e, |g| %.3e" % worst[0][1:]
-    # in aggregate: the median error within 3x the oracle's median (measured 0.3x .. 2.3x, tests/gpu_gradnoise.py - the
-    # step is chaotic at this level: any change of summation order moves every tensor by ~5e-3)
-    assert np.median(rel_p) <= 3.0 * np.median(rel_o) + 1e-4, (np.median(rel_p), np.median(rel_o))
+    # Per tensor within 3x the fp32 oracle's own error (or its 90th-percentile relative error), the median within 3x the
+    # oracle's median (measured 0.3x .. 2.3x, tests/gpu_gradnoise.py - the step is chaotic at this level: any change of
+    # summation order moves every tensor by ~5e-3)
+    rel_p, _, _ = grads_within_fp32_class(net.named_parameters(), on.named_parameters(), g64, 3.0, "g5 style %d" % style)
+    assert len(rel_p) == 368
     # the same tensors the reference produced gradients for
     has = golden["g5_step0_hasgrad"] if style == 0 else None
     if has is not None:
@@ -265,29 +241,30 @@ def test_g5_g6_trainer_steps_vs_reference(gpu, golden):
     actions = [("grasp", 3, 0.4), ("suction", 9, 7.5), ("grasp_then_suction", 0, -3.0)]
     for si, (action, rot, label) in enumerate(actions):
         om = masks.copy()
-        loss = tr.backprop(depth, action, (0, rot), (0, rot), (0, rot), (0, rot), label, om, None, None, None)
+        # the ES step masks with objects 1 + 2 (code/trainer.py:370), like the golden run
+        g_id, s_id = ((1, rot), (2, rot)) if action == "grasp_then_suction" else ((0, rot), (0, rot))
+        loss = tr.backprop(depth, action, (0, rot), (0, rot), g_id, s_id, label, om, None, None, None)
         assert om.ndim == 4                                       # in-place reshape, code/trainer.py:336
         assert isinstance(loss, np.ndarray) and loss.shape == ()
         style = {"grasp": 0, "suction": 1, "grasp_then_suction": 2}[action]
         q = float((tr.model.gra_prob, tr.model.suc_prob, tr.model.gs_prob)[style].reshape(-1)[0])
-        # style 2 masks with objects 0+0 here; the golden run used mask 0 for every step
-        if action != "grasp_then_suction":
-            assert abs(q - float(golden["g5_step%d_q" % si])) <= 2e-3 * max(abs(float(golden["g5_step%d_q" % si])), 0.1)
-            assert abs(float(loss) - float(golden["g5_step%d_loss" % si])) <= 2e-3 * max(float(golden["g5_step%d_loss" % si]), 0.1)
-            # Adam: on a segment's first step every weight moves by +-lr (sign of its gradient), so a
-            # probe can only be off by a full 2e-4 where fp32 noise flips the sign of a ~zero gradient
-            params = dict(tr.model.named_parameters())
-            pre = "g6_step%d_param_" % si
-            diffs = []
-            for k in [k for k in golden.files if k.startswith(pre)]:
-                p = params[k[len(pre):]]
-                pi = probe_idx(p.numel(), 16, "g6/" + k[len(pre):])
-                dk = np.abs(p.detach().cpu().numpy().ravel()[pi] - golden[k])
-                assert dk.max() <= 2.1e-4
-                if "norm5" not in k:      # d/d(norm5.bias) is identically 0 (the head's BN removes it):
-                    diffs.append(dk)      # its Adam update is pure rounding noise on both sides
-            diffs = np.concatenate(diffs)
-            assert (diffs < 2e-6).mean() >= 0.9, diffs
+        assert abs(q - float(golden["g5_step%d_q" % si])) <= 2e-3 * max(abs(float(golden["g5_step%d_q" % si])), 0.1)
+        assert abs(float(loss) - float(golden["g5_step%d_loss" % si])) <= 2e-3 * max(float(golden["g5_step%d_loss" % si]), 0.1)
+        # Adam: on a segment's first step every weight moves by +-lr (sign of its gradient), so a
+        # probe can only be off by a full 2e-4 where fp32 noise flips the sign of a ~zero gradient.  (The ES step is the
+        # SECOND step of suctionnet_val - code/models.py:582 - so its head probes test a real two-step Adam trajectory.)
+        params = dict(tr.model.named_parameters())
+        pre = "g6_step%d_param_" % si
+        diffs = []
+        for k in [k for k in golden.files if k.startswith(pre)]:
+            p = params[k[len(pre):]]
+            pi = probe_idx(p.numel(), 16, "g6/" + k[len(pre):])
+            dk = np.abs(p.detach().cpu().numpy().ravel()[pi] - golden[k])
+            assert dk.max() <= 2.1e-4, (k, dk)
+            if "norm5" not in k:      # d/d(norm5.bias) is identically 0 (the head's BN removes it):
+                diffs.append(dk)      # its Adam update is pure rounding noise on both sides
+        diffs = np.concatenate(diffs)
+        assert (diffs < 2e-6).mean() >= 0.9, diffs
     d = depth
     qt = tr.forward(d, d * masks[0], 0, True, True, 3)
     assert isinstance(qt, np.ndarray) and qt.shape == (1,) and qt.dtype == np.float64
@@ -668,11 +645,21 @@ def test_g9_batched_object_evaluation_vs_reference(gpu, golden):
 
 
 def test_g8_reactive_gradients_and_adam(gpu, golden):
-    """Reactive net train step: weighted-CE gradients reach the same 368 tensors, with norms matching
-    the reference's (same fp32-noise yardstick as the Huber case: 3e-2 per tensor, 1e-2 in the median)."""
-    import synthetic
-    net = product_net(0, out_ch=3, R=1)
+    """Reactive net train step (code/trainer.py:282-332): weighted-CE loss vs the reference's value, and all 368 gradient
+    tensors TENSOR-WISE against the fp64 oracle with the yardstick of the Huber case (3x the fp32 oracle's own error);
+    the gradient norms also against the reference's own (golden G8)."""
+    on = oracle_net(0, out_ch=3, R=1)
     x, mx = scene_tensors(0, [0])
+    o64 = copy.deepcopy(on).double()
+    o64.zero_grad()
+    trunk, head = getattr(o64, orc.STYLE_TRUNK[0]).features, getattr(o64, orc.STYLE_HEAD[0])
+    q64 = head(torch.cat((trunk(x.double()), trunk(mx.double())), 1))          # reactive_net: rotation 0 = identity
+    orc.reactive_loss(q64, 1).backward()
+    g64 = {n: p.grad for n, p in o64.named_parameters() if p.grad is not None}
+    on.zero_grad()
+    qo = orc.forward(on, x, mx, 0, False, 0)
+    orc.reactive_loss(qo, 1).backward()
+    net = product_net(0, out_ch=3, R=1)
     net.zero_grad()
     q = net.forward(x, mx, 0, False, 0)                       # branch C, rotation 0
     w = torch.tensor([1.0, 1.0, 0.0], device=q.device)
@@ -680,12 +667,13 @@ def test_g8_reactive_gradients_and_adam(gpu, golden):
     loss = torch.nn.functional.nll_loss(torch.log_softmax(q[0].view(1, 3, 1, 1), dim=1), label, weight=w).sum()
     loss.backward()                                            # torch autograd on the 3 logits -> smg_backward
     assert abs(float(loss.detach()) - float(golden["g8_loss"])) < 2e-3
+    rel_p, _, _ = grads_within_fp32_class(net.named_parameters(), on.named_parameters(), g64, 3.0, "reactive")
+    assert len(rel_p) == 368
     ref = golden["g8_gradnorm"]
     mine = np.asarray([float(p.grad.double().norm()) if p.grad is not None else 0.0 for p in net.parameters()])
     assert ((mine > 0) == (ref > 0)).all()
     big = ref > 1e-3 * ref.max()
     rel = np.abs(mine[big] - ref[big]) / ref[big]
-    # (the stem's conv0 / norm0 sit at the end of the backward chain and carry the most fp32 noise: up to 7e-2 measured)
     assert rel.max() < 1e-1 and np.percentile(rel, 95) < 2e-2 and np.median(rel) < 1e-2, (rel.max(), np.percentile(rel, 95), np.median(rel))
 
 
@@ -746,25 +734,8 @@ def test_backward_other_input_size_ragged_planes(gpu):
     (qp * wq.cuda()).sum().backward()
     ok, worst = q_close(qp.detach().cpu().numpy().ravel(), q64.detach().numpy().ravel())
     assert ok, worst
-    po = dict(on.named_parameters())
-    gmax = max(float(g.norm()) for g in g64.values())
-    rel_p, rel_o, n_checked = [], [], 0
-    for name, p in net.named_parameters():
-        if name not in g64:
-            assert p.grad is None, "unexpected gradient on " + name
-            continue
-        assert p.grad is not None, "missing gradient on " + name
-        t = g64[name].numpy()
-        e_prod = np.sqrt(((p.grad.cpu().double().numpy() - t) ** 2).sum())
-        e_orc = np.sqrt(((po[name].grad.double().numpy() - t) ** 2).sum())
-        nrm = np.sqrt((t * t).sum())
-        rel_p.append(e_prod / max(nrm, 1e-30))
-        rel_o.append(e_orc / max(nrm, 1e-30))
-        assert e_prod <= 5.0 * e_orc + 2e-2 * nrm + 1e-6 * gmax, \
-            "%s: |err| %.3e vs fp32-oracle |err| %.3e, |g| %.3e" % (name, e_prod, e_orc, nrm)
-        n_checked += 1
-    assert n_checked == 368
-    assert np.median(rel_p) <= 4.0 * np.median(rel_o) + 1e-3, (np.median(rel_p), np.median(rel_o))
+    rel_p, _, _ = grads_within_fp32_class(net.named_parameters(), on.named_parameters(), g64, 3.0, "S=704")
+    assert len(rel_p) == 368
 
 
 _VARIANT_SCRIPT = r"""
@@ -884,3 +855,141 @@ def test_data_parallel_two_ranks_equal_single_process_batch(gpu):
     assert q_dp.shape == (16,)
     np.testing.assert_allclose(q_dp, q_one, rtol=0, atol=3e-5)
     assert best_dp == int(np.argmax(q_one))
+
+
+def _fp32_chain(a32, w32):
+    """out[m][n] = sum_k a[m][k] * w[n][k] as a k-ordered fp32 multiply-add chain (one rounding per product and per add):
+    the plain fp32 arithmetic the split-MFMA products are held to."""
+    acc = np.zeros((a32.shape[0], w32.shape[0]), dtype=np.float32)
+    for k in range(a32.shape[1]):
+        acc = (acc + a32[:, k:k + 1] * w32[None, :, k]).astype(np.float32)
+    return acc
+
+
+@pytest.mark.parametrize("block,layer", [(1, 1), (2, 12), (3, 24)])
+def test_layer_products_within_fp32_chain_error(gpu, block, layer):
+    """GEMM-level gate on the PRODUCT's kernels at real layer shapes (K = 64 / 480 / 992 for the 1x1, K = 1152 for the 3x3):
+    the raw output of one dense layer's conv1 (BN + ReLU + 3-piece bf16 split + six MFMA terms) and conv2, read back from
+    the engine, against the same layer evaluated in fp64 from the engine's own input buffer.  The error must stay within 2x
+    that of a plain fp32 multiply-add chain over the same operands - i.e. the split products are fp32-class arithmetic,
+    independent of how the gradient gates of the end-to-end tests are set."""
+    net = product_net(0)
+    x, mx = scene_tensors(0, [0])
+    net.forward(x, mx, 0, True, 3)
+    eng = engine_of(net)
+    NS, H, HWp = eng.max_streams, eng.H[1 + block], eng.HWp[1 + block]
+    Ct = (256, 512, 1024, 1024)[block - 1]
+    cin = (64, 128, 256, 512)[block - 1] + 32 * (layer - 1)
+    X = eng.debug_read("x%d" % block).reshape(NS, HWp, Ct)[0, :H * H, :]
+    BT = eng.debug_read("bt%d_%d" % (block, layer)).reshape(NS, HWp, 128)[0, :H * H, :]
+    sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    pre = "grasp_depth_trunk.features.denseblock%d.denselayer%d." % (block, layer)
+
+    def bn_relu(v, g, b, dt):
+        v64 = v.astype(np.float64)
+        mean, var = v64.mean(0), v64.var(0)
+        inv = 1.0 / np.sqrt(var + 1e-5)
+        if dt == np.float64:
+            return np.maximum((v64 - mean) * inv * g.astype(np.float64) + b.astype(np.float64), 0.0)
+        sc = (g.astype(np.float64) * inv).astype(np.float32)
+        return np.maximum((v - mean.astype(np.float32)) * sc + b, np.float32(0)).astype(np.float32)
+
+    # conv1: 1x1, cin -> 128
+    w1 = sd[pre + "conv1.weight"].reshape(128, cin)
+    a64 = bn_relu(X[:, :cin], sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], np.float64)
+    a32 = bn_relu(X[:, :cin], sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], np.float32)
+    ref = a64 @ w1.astype(np.float64).T
+    mag = np.abs(a64) @ np.abs(w1.astype(np.float64)).T + 1e-30
+    e_prod = np.sqrt((((BT.astype(np.float64) - ref) / mag) ** 2).mean())
+    e_chain = np.sqrt((((_fp32_chain(a32, w1).astype(np.float64) - ref) / mag) ** 2).mean())
+    print("conv1 block %d layer %d K %d: err/sum|ab| rms product %.3e, fp32 chain %.3e" % (block, layer, cin, e_prod, e_chain))
+    assert e_prod <= 2.0 * e_chain, (e_prod, e_chain)
+
+    # conv2: 3x3 pad 1, 128 -> 32 (the layer's slice of the block buffer), on a 48-row band (keeps the fp32 chain cheap)
+    w2 = sd[pre + "conv2.weight"]                                      # [32][128][3][3]
+    b64 = bn_relu(BT, sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], np.float64).reshape(H, H, 128)
+    b32 = bn_relu(BT, sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], np.float32).reshape(H, H, 128)
+    rows = min(H, 48)
+
+    def im2col(a):
+        p = np.zeros((H + 2, H + 2, 128), dtype=a.dtype)
+        p[1:-1, 1:-1] = a
+        return np.concatenate([p[dy:dy + rows, dx:dx + H].reshape(rows * H, 128) for dy in range(3) for dx in range(3)], axis=1)
+    wk = np.concatenate([w2[:, :, dy, dx] for dy in range(3) for dx in range(3)], axis=1)     # [32][9*128], tap-major like im2col
+    c64, c32 = im2col(b64), im2col(b32)
+    out = X[:, cin:cin + 32].reshape(H, H, 32)[:rows].reshape(rows * H, 32)
+    ref = c64 @ wk.astype(np.float64).T
+    mag = np.abs(c64) @ np.abs(wk.astype(np.float64)).T + 1e-30
+    e_prod = np.sqrt((((out.astype(np.float64) - ref) / mag) ** 2).mean())
+    e_chain = np.sqrt((((_fp32_chain(c32, wk).astype(np.float64) - ref) / mag) ** 2).mean())
+    print("conv2 block %d layer %d K 1152: err/sum|ab| rms product %.3e, fp32 chain %.3e" % (block, layer, e_prod, e_chain))
+    assert e_prod <= 2.0 * e_chain, (e_prod, e_chain)
+
+
+def test_deterministic_option_gives_bit_identical_conv_weight_gradients(gpu):
+    """smg_engine_set_option("deterministic", 1): the 1x1 weight gradients are reduced from partial tiles in a fixed order
+    instead of fp32 atomics.  Two identical training calls then give bit-identical gradients for every convolution weight
+    (the reference's backward on one device is deterministic, code/trainer.py:350-351); without the switch the 1x1 weight
+    gradients differ in the last bits.  (BatchNorm affine gradients are still summed over workgroups with fp32 atomics in
+    either mode: equal to 1e-5.)"""
+    from trainer import Trainer
+    import synthetic
+    import models
+    tr = Trainer('reinforcement', 0.5, False, None, False)
+    sd = synthetic.make_state_dict(orc.state_layout(1), 5)
+    tr.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    tr.model.gnum_rotations = tr.model.snum_rotations = 16
+    tr.optimizer.lr = 0.0
+    depth, masks = synthetic.heightmap_scene(6)
+    rots, labels = [0, 3, 7, 12], [0.2, 1.7, 0.6, 0.9]
+    tr.train_batch(depth, depth * masks[0], 0, rots, labels)
+    eng = engine_of(tr.model)
+    conv = [(n, p) for n, p in tr.model.named_parameters() if p.dim() == 4 and "grasp" in n]
+
+    def run():
+        tr.train_batch(depth, depth * masks[0], 0, rots, labels)
+        return {n: p.grad.clone() for n, p in conv}, tr.model.flat_grads().clone()
+    try:
+        eng.set_option("deterministic", 1)
+        g1, f1 = run()
+        g2, f2 = run()
+    finally:
+        eng.set_option("deterministic", 0)
+    differing = [n for n in g1 if not torch.equal(g1[n], g2[n])]
+    assert not differing, differing[:5]
+    assert float((f1 - f2).double().norm()) <= 1e-5 * float(f1.double().norm())
+    g3, f3 = run()                                            # default mode: same values up to the atomics' order
+    assert float((f1 - f3).double().norm()) <= 1e-5 * float(f1.double().norm())
+    with pytest.raises(Exception):
+        eng.set_option("no-such-option", 1)
+
+
+def test_argmax_matches_numpy_including_nan(gpu):
+    """smg_argmax = np.argmax (code/main.py:172-173): lowest index on ties, and the first NaN wins."""
+    import smg_hip
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(3)
+    cases = [rng.randn(1000).astype(np.float32), np.zeros(700, np.float32), np.asarray([-np.inf] * 5, np.float32)]
+    a = rng.randn(513).astype(np.float32); a[77] = a[400] = a.max() + 1; cases.append(a)
+    b = rng.randn(900).astype(np.float32); b[650] = np.nan; b[301] = np.nan; b[5] = np.inf; cases.append(b)
+    c = rng.randn(300).astype(np.float32); c[299] = np.nan; cases.append(c)
+    for v in cases:
+        t = torch.from_numpy(v).to(dev)
+        idx = torch.zeros(1, dtype=torch.int32, device=dev); val = torch.zeros(1, dtype=torch.float32, device=dev)
+        smg_hip.argmax(t.data_ptr(), t.numel(), idx.data_ptr(), val.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        want = int(np.argmax(v))
+        assert int(idx.item()) == want, (int(idx.item()), want)
+        got = float(val.item())
+        assert (np.isnan(got) and np.isnan(v[want])) or got == float(v[want])
+
+
+def test_reactive_labels_outside_the_classes_are_rejected(gpu):
+    from trainer import Trainer
+    import synthetic
+    tr = Trainer('reactive', 0.5, False, None, False)
+    depth, masks = synthetic.heightmap_scene(0)
+    for bad in (3, -1, 0.5, float("nan")):
+        with pytest.raises(ValueError):
+            tr.train_batch(depth, depth * masks[0], 0, [0], [bad])
+    loss = tr.train_batch(depth, depth * masks[0], 0, [0], [2])          # class 2 = "no loss" (weight 0)
+    assert float(loss[0]) == 0.0

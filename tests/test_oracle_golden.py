@@ -118,11 +118,12 @@ def test_g5_g6_training_steps(golden):
     target = orc.clone_target(net)
     opt = orc.make_adam(net)
     x, mx = scene_inputs(0, [0])
+    _, mx_es = scene_inputs(0, [1, 2])            # the ES step's two-object mask (code/trainer.py:370)
     names = [n for n, _ in net.named_parameters()]
     assert names == [str(s) for s in golden["g5_param_names"]]
     for si, (style, rot, label) in enumerate([(0, 3, 0.4), (1, 9, 7.5), (2, 0, -3.0)]):
         opt.zero_grad()
-        q = orc.forward(net, x, mx, style, False, rot)
+        q = orc.forward(net, x, mx_es if style == 2 else mx, style, False, rot)
         loss = orc.huber(q[0, 0, 0, 0], label).sum()
         loss.backward()
         np.testing.assert_allclose(float(q), golden["g5_step%d_q" % si], **TOL)
