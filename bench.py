@@ -43,7 +43,44 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA peak (MI355X_MICROARCH.m
 SPLIT_TERMS = 6                       # v_mfma_f32_32x32x16_bf16 per fp32 product (gemm.cuh): the convolutions' MFMA roof is 2500 / 6
 PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / SPLIT_TERMS
 PEAK_HBM_GBS = 8000.0                 # HBM3E peak (MI355X_MICROARCH.md; ~6300 achievable)
-PMC_FILE = "pmc_r02_hbm_traffic.json"
+PMC_FILE = "pmc_r03_hbm_traffic.json"                     # tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes
+SERIAL_CSV = "rocprof_r03_kernel_stats_serialized.csv"    # rocprofv3 --kernel-trace --stats of `bench.py --train-only --serialize`
+PASS5_GFLOP = 36767.6                 # S=1824, R=32 fwd+bwd pass, masked stream de-duplicated
+# rocprofv3 kernel-name fragments that make up each class of roofline.per_kernel (profiles/*kernel_stats*.csv)
+CLASS_SYMBOLS = {
+    "stem7x7_fwd": ["FwdConvP<", ", 3>"], "conv1x1_fwd": ["FwdConvP<*, 0>", "conv1x1_fwd_ws_kernel"],
+    "conv3x3_fwd": ["conv3x3_halo_fwd_kernel"], "transition_fwd": ["FwdConvP<*, 2>"],
+    "conv3x3_dgrad": ["conv3x3_halo_dgrad_kernel"], "conv3x3_wgrad": ["conv3x3_halo_wgrad_kernel", "reduce_partials_kernel"],
+    "conv1x1_dgrad": ["BwdDataGroupP<", "BwdDataP<*, false, 1, false>"], "conv1x1_wgrad": ["BwdWeightP<*, 0, 0, 3, false>"],
+    "transition_wgrad": ["BwdWeightP<*, 2, 0, 1, true>"], "transition_dgrad": ["BwdDataP<*, false, 2, true>"],
+    "stem_wgrad": ["BwdWeightP<*, 3, 2, 3, true>", "stem_wgrad_kernel"],
+}
+
+
+def csv_class_avg_ms(symbols):
+    """Call-weighted mean launch duration (ms) of the kernels whose names match the class's fragments in the tracked
+    serialised rocprofv3 stats CSV, plus the file's provenance line - so that roofline.frac can be recomputed from
+    profiles/ alone.  None if the file is absent."""
+    import csv
+    import fnmatch
+    path = os.path.join(REPO, "profiles", SERIAL_CSV)
+    try:
+        rows = list(csv.DictReader(open(path)))
+    except OSError:
+        return None
+    calls = tot = 0.0
+    for r in rows:
+        nm = r["Name"]
+        if any(fnmatch.fnmatchcase(nm, "*" + frag + "*") for frag in symbols):
+            calls += float(r["Calls"]); tot += float(r["TotalDurationNs"])
+    if calls == 0:
+        return None
+    meta = {}
+    try:
+        meta = json.load(open(path.replace(".csv", ".meta.json")))
+    except (OSError, ValueError):
+        pass
+    return {"file": "profiles/" + SERIAL_CSV, "avg_launch_ms": tot / calls / 1e6, "calls": int(calls), **meta}
 
 
 def layout_names():
@@ -148,7 +185,16 @@ def main():
     ap.add_argument("--batched-scenes", type=int, default=4,
                     help="also time a config-4 style step with this many scenes per engine call (0 = skip)")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE.json config 3 / 4 / 5 legs")
+    ap.add_argument("--leg", choices=("headline", "config3", "config4", "config5"), default="headline",
+                    help="what a timed step is (under any --gpus N): the headline 1 scene x 16 rotations per GPU; config3 = E + S + ES "
+                         "heads in bf16 per GPU; config4 = 8 scenes x 16 rotations per GPU + all-reduce; config5 = S=1824, 4 of the "
+                         "32 rotations per GPU in fp16")
+    ap.add_argument("--scenes-per-rank", type=int, default=8, help="--leg config4: scenes per GPU per step")
+    ap.add_argument("--train-only", action="store_true", help="only the timed training steps (profiling runs: every kernel in the trace belongs to a step)")
+    ap.add_argument("--serialize", action="store_true", help="one HIP stream, launches in issue order (per-kernel durations of a rocprofv3 trace stay per kernel)")
     args = ap.parse_args()
+    if args.train_only:
+        args.cpu_samples, args.batched_scenes, args.no_configs, args.no_roofline = 0, 0, True, True
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
@@ -160,8 +206,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        backend = os.environ.get("SMG_BENCH_BACKEND", "nccl")     # "gloo": ranks sharing one GPU (tests; RCCL needs one GPU per rank)
+        local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     torch.cuda.set_device(local_rank)
@@ -181,20 +229,74 @@ def main():
     depth, masks = synthetic.heightmap_scene(rank)
     mdepth = depth * masks[0]
     labels = synthetic.uniform(rank, "bench/labels", R, 0.0, 1.5)    # both Huber branches occur
-    sync = parallel.allreduce_grads if distributed else None
     rots = list(range(R))
+
+    # gradient all-reduce between backward and Adam, timed with events on the launch stream (the collective's own stream
+    # joins it before Adam is enqueued)
+    ar_events = []
+
+    def sync(model, trunk_id, head_id):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        parallel.allreduce_grads(model, trunk_id, head_id)
+        e1.record()
+        ar_events.append((e0, e1))
+    if not distributed:
+        sync = None
 
     # inputs resident in HBM before the timed region (the heightmaps as float64, the labels as float32): the numpy form
     # of the same call costs a pageable host-to-device copy per step, which also stalls the host behind the previous step
-    depth_d = torch.from_numpy(np.ascontiguousarray(depth, dtype=np.float64)).to(dev)
-    mdepth_d = torch.from_numpy(np.ascontiguousarray(mdepth, dtype=np.float64)).to(dev)
-    labels_d = torch.as_tensor(np.asarray(labels, dtype=np.float32), device=dev)
-
     def on_dev(a, dtype=np.float64):
         return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(dev)
+    depth_d, mdepth_d, labels_d = on_dev(depth), on_dev(mdepth), on_dev(labels, np.float32)
 
-    def step():
-        return tr.train_batch(depth_d, mdepth_d, 0, rots, labels_d, grad_sync=sync)
+    leg = args.leg
+    dtype, dtype_note = "f32", "fp32 storage and results; matrix products on the bf16 MFMA as exact 3-way splits (6 terms, fp32 accumulate)"
+    if leg == "headline":
+        units_per_step, pass_gflop, input_size = 1.0, PASS_GFLOP, 640
+        workload = ("reinforcement_net style 0 (grasp trunk + graspnet_val head): 1 scene x 1 mask x 16 rotations per GPU per "
+                    "step, fwd + 16 Huber losses + bwd + Adam, S=640 (224^2 heightmap), masked stream de-duplicated (17 trunk passes)")
+
+        def step():
+            return tr.train_batch(depth_d, mdepth_d, 0, rots, labels_d, grad_sync=sync)
+    elif leg == "config4":
+        nb = args.scenes_per_rank                                     # 64 scenes over 8 GPUs = 8 per GPU (BASELINE.json configs[3])
+        sc = [synthetic.heightmap_scene(200 + nb * rank + k) for k in range(nb)]
+        d8_d, m8_d = on_dev(np.stack([c[0] for c in sc])), on_dev(np.stack([c[0] * c[1][0] for c in sc]))
+        lab8_d = on_dev(synthetic.uniform(8 + rank, "bench/labels_c4", nb * R, 0.0, 1.5), np.float32)
+        units_per_step, pass_gflop, input_size = float(nb), PASS_GFLOP, 640
+        workload = ("config 4 share: %d scenes x 16 rotations per GPU per step in ONE engine call (%d trunk streams, %d samples), fwd + Huber "
+                    "+ bwd, one gradient all-reduce, one Adam step; a pass = one scene x 16 rotations" % (nb, nb * (R + 1), nb * R))
+
+        def step():
+            return tr.train_batch(d8_d, m8_d, 0, [rots] * nb, lab8_d, grad_sync=sync)
+    elif leg == "config5":
+        dbig, mbig = synthetic.heightmap_scene(4, size=640, n_boxes=8)    # the same scene on every rank: the ranks share its 32 rotations
+        dbig_d, mdb_d = on_dev(dbig), on_dev(dbig * mbig[0])
+        tr.model.gnum_rotations = tr.model.snum_rotations = 32
+        r5 = [(4 * rank + k) % 32 for k in range(4)]                   # 8 GPUs x 4 = the 32 rotations; fewer GPUs: the same per-GPU share
+        l5_d = on_dev(synthetic.uniform(50 + rank, "bench/labels_c5", 4, 0.0, 2.0), np.float32)
+        tr.model.set_precision("fp16")
+        units_per_step, pass_gflop, input_size = 4.0 / 32.0, PASS5_GFLOP, 1824
+        dtype, dtype_note = "f16", "fp16 MFMA operands (one term per product), fp32 accumulation / BN statistics / master weights"
+        workload = ("config 5 share: 640x640 heightmap -> S=1824, 4 of the 32 rotations per GPU per step as training samples (5 trunk "
+                    "streams), dense 38x38 Q maps, Huber on [0,0,0,0], bwd, gradient all-reduce, Adam; a pass = all 32 rotations")
+
+        def step():
+            return tr.train_batch(dbig_d, mdb_d, 0, r5, l5_d, grad_sync=sync)
+    else:                                                             # config3
+        md2_d = on_dev(depth * (masks[1] + masks[2]))
+        lab1_d = on_dev(synthetic.uniform(5, "bench/labels_c3", 1, 0.0, 1.5), np.float32)
+        tr.model.set_precision("bf16")
+        units_per_step, pass_gflop, input_size = 1.0, 2.0 * PASS_GFLOP + 273.99, 640
+        dtype, dtype_note = "bf16", "bf16 MFMA operands (one term per product), fp32 accumulation / BN statistics / master weights"
+        workload = ("config 3: styles 0 and 1 with 16 rotations each + style 2 at rotation 0 per GPU per step (33 samples, 35 trunk streams), "
+                    "fwd + Huber + bwd + all-reduce + Adam per head; a pass = the three heads")
+
+        def step():
+            tr.train_batch(depth_d, mdepth_d, 0, rots, labels_d, grad_sync=sync)
+            tr.train_batch(depth_d, mdepth_d, 1, rots, labels_d, grad_sync=sync)
+            return tr.train_batch(depth_d, md2_d, 2, [0], lab1_d, grad_sync=sync)       # ES: rotation 0 only (code/models.py:418)
 
     def barrier():
         if distributed:
@@ -202,9 +304,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    import models
+    for _ in range(max(1, args.warmup) if args.serialize else args.warmup):
         step()
+    if args.serialize:
+        for eng_ in models._ENGINES.values():
+            eng_.set_option("serialize", 1)
     barrier()
+    del ar_events[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -212,26 +319,38 @@ def main():
     elapsed = time.perf_counter() - t0
     if distributed:
         import torch.distributed as dist
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        on_host = dist.get_backend() == "gloo"
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if on_host else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert bool(torch.isfinite(loss).all()), "non-finite loss in the timed region"
     ms_per_step = elapsed / args.steps * 1e3
-    passes_per_s = world * args.steps / elapsed
+    passes_per_s = world * units_per_step * args.steps / elapsed
 
     out = {
         "metric": "affordance fwd+bwd passes/sec (16-rot 224^2 RGB-D)",
         "value": passes_per_s, "unit": "passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "dtype_note": "fp32 storage and results; matrix products on the bf16 MFMA as exact 3-way splits (6 terms, fp32 accumulate)",
-        "config": {"workload": "reinforcement_net style 0 (grasp trunk + graspnet_val head): 1 scene x 1 mask x 16 rotations per GPU per "
-                               "step, fwd + 16 Huber losses + bwd + Adam, S=640 (224^2 heightmap), masked stream de-duplicated (17 trunk passes)",
-                   "rotations": R, "input_size": 640, "scenes_per_step": world, "parallelism": "dp%d" % world},
-        "pass_tflops_algorithmic": PASS_GFLOP * passes_per_s / 1e3,
+        "dtype": dtype, "data": "synthetic", "dtype_note": dtype_note,
+        "config": {"workload": workload, "leg": leg, "rotations": 32 if leg == "config5" else R, "input_size": input_size,
+                   "passes_per_step_per_gpu": units_per_step, "parallelism": "dp%d" % world},
+        "pass_tflops_algorithmic": pass_gflop * passes_per_s / 1e3,
     }
+    # whole-job roofline of the step (every N): algorithmic FLOPs of all ranks / wall time against the MFMA roof of the
+    # arithmetic in use (bf16 peak / 6 split terms for the fp32-class products, the plain peak for bf16 / fp16 operands)
+    mfma_roof = PEAK_SPLIT_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+    step_rl = {"algorithmic_tflops": out["pass_tflops_algorithmic"], "mfma_roof_tflops": mfma_roof * world,
+               "frac_of_mfma_roof": out["pass_tflops_algorithmic"] / (mfma_roof * world),
+               "frac_of_fp32_mfma_peak": out["pass_tflops_algorithmic"] / (PEAK_F32_MFMA_TFLOPS * world)}
+    if ar_events:
+        torch.cuda.synchronize(dev)
+        ar = [a.elapsed_time(b) for a, b in ar_events]
+        out["allreduce_ms"] = float(np.mean(ar))                  # per collective call (trunk + head ranges), hipEvents on the launch stream
+        out["allreduce_ms_per_step"] = float(np.sum(ar)) / args.steps
+        out["allreduce_backend"] = torch.distributed.get_backend()
+    out["roofline"] = {"step": step_rl}
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and leg == "headline" and not args.train_only:
         # host time to ENQUEUE one step (no synchronisation inside): how far the launch path is from being host-bound
         torch.cuda.synchronize(dev)
         t_h = time.perf_counter()
@@ -387,7 +506,10 @@ def main():
                     pj = json.load(f)
                 if dom in pj:
                     traffic = pj[dom]["gb_per_train_step"] * 1e9 / (n / n_prof)
-                    traffic_src = "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x 2)" % PMC_FILE
+                    meta = pj.get("_meta", {})
+                    traffic_src = ("profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` (%s training steps, commit %s), "
+                                   "FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md); bytes per training step / launches per step"
+                                   % (PMC_FILE, meta.get("command", "?"), meta.get("train_steps", "?"), meta.get("commit", "?")))
             except (OSError, ValueError, KeyError):
                 pass
             rl = roof(conv[dom])
@@ -395,6 +517,9 @@ def main():
                 "kernel": dom, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": by / n, "flops_per_launch": fl / n,
                 "avg_launch_ms": ms / n, "launches_per_step": n // n_prof,
+                "kernel_symbols": CLASS_SYMBOLS.get(dom, []),        # rocprofv3 kernel names that make up `kernel`
+                "timing": "hipEvents around every launch of the class, all launches serialised on one stream (smg_profile_enable), %d training steps" % n_prof,
+                "rocprof_serialized": csv_class_avg_ms(CLASS_SYMBOLS.get(dom, [])),   # the same class in the tracked serialised rocprofv3 CSV
                 "arithmetic": "fp32 in / fp32 out; every product = %d v_mfma_f32_32x32x16_bf16 terms of a 3-piece bf16 split (fp32-class accuracy, "
                               "tools/split_probe.hip): MFMA roof %.1f TFLOP/s fp32-equivalent" % (SPLIT_TERMS, PEAK_SPLIT_TFLOPS),
                 "all_conv_kernels": {"achieved": conv_fl / (conv_ms * 1e-3) / 1e12, "frac_of_split_mfma_roof": conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_SPLIT_TFLOPS,
@@ -410,8 +535,7 @@ def main():
             })
             # whole step: the sum of the per-class roofline times against the measured step
             floor_s = sum(max(v[2] * SPLIT_TERMS / (PEAK_BF16_MFMA_TFLOPS * 1e12), v[3] / (PEAK_HBM_GBS * 1e9)) for v in prof.values()) / n_prof
-            rl["step"] = {"roofline_ms": floor_s * 1e3, "measured_ms": ms_per_step, "frac": floor_s * 1e3 / ms_per_step,
-                          "algorithmic_tflops": PASS_GFLOP / ms_per_step, "frac_of_fp32_mfma_peak": PASS_GFLOP / ms_per_step / PEAK_F32_MFMA_TFLOPS}
+            rl["step"] = dict(step_rl, roofline_ms=floor_s * 1e3, measured_ms=ms_per_step, frac=floor_s * 1e3 / ms_per_step)
             out["roofline"] = rl
         if args.cpu_samples > 0:
             # threads = physical cores and two smaller settings; the best one is reported

@@ -157,7 +157,8 @@ int smg_engine_set_precision(smg_engine* e, int precision);
 
 /* Engine switches by name.  "deterministic" (0 / 1): the 1x1-convolution weight gradients (conv1 of every dense layer,
  * the largest gradient tensors) are reduced from partial tiles in a fixed order instead of fp32 atomics, so the convolution
- * weight gradients of two identical calls are bit-identical like the reference's (code/trainer.py:350-351 on one device). */
+ * weight gradients of two identical calls are bit-identical like the reference's (code/trainer.py:350-351 on one device).
+ * "serialize" (0 / 1): every kernel on the caller's stream in issue order instead of two concurrent chains (profiling). */
 int smg_engine_set_option(smg_engine* e, const char* name, int value);
 
 /* Heightmap generation in front of the path (utils.get_heightmap, code/utils.py:38-68): the robot-frame height of every

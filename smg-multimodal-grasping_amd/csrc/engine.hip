@@ -132,6 +132,8 @@ struct smg_engine {
     int64_t workspace_bytes = 0;
     int n_cu = 256;            // compute units of the device (persistent-launch sizing)
     int prec = 0;              // operand precision of the matrix products: 0 fp32-class split, 1 bf16, 2 fp16 (smg_engine_set_precision)
+    bool serialize = false;       // smg_engine_set_option("serialize"): every launch on the caller's stream in issue order (profiling: a trace's
+                                  // per-kernel durations are not inflated by a kernel of the other chain sharing the chip)
     bool deterministic = false;   // smg_engine_set_option("deterministic"): 1x1 weight gradients as partial tiles + fixed-order reduce instead of fp32 atomics
     bool generic3x3 = false;   // SMG_GENERIC_3X3=1: dense-layer 3x3 convs through the generic implicit GEMM (A/B testing)
     // profiling
@@ -766,7 +768,7 @@ static int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_
         return 0;
     };
     static const bool one_chain = getenv("SMG_FWD_ONE_CHAIN") != nullptr;      // dev: A/B switch
-    if (NS >= 2 && !e->prof && !one_chain) {
+    if (NS >= 2 && !e->prof && !e->serialize && !one_chain) {
         const int h = NS / 2;
         HIP_OK(hipEventRecord(e->ev_misc, st));                 // packed weights + batch description are ready
         HIP_OK(hipStreamWaitEvent(e->side, e->ev_misc, 0));
@@ -858,7 +860,7 @@ static int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipSt
     // `st` so that per-kernel durations stay clean.
     // (a lowest-priority stream for the weight gradients gains 0.2 ms per step with one engine alive, and LOSES 10 ms as soon
     // as a second engine - two more streams - exists in the process: the streams then share hardware queues and serialise)
-    const hipStream_t s2 = e->prof ? st : e->side;
+    const hipStream_t s2 = (e->prof || e->serialize) ? st : e->side;
     auto fork = [&](hipEvent_t ev) -> int {      // side stream continues after everything enqueued on st so far
         HIP_OK(hipEventRecord(ev, st));
         HIP_OK(hipStreamWaitEvent(s2, ev, 0));
@@ -1320,6 +1322,7 @@ int smg_engine_set_option(smg_engine* e, const char* name, int value) {
     if (!e || !name) return fail(-22, "NULL argument");
     const std::string s(name);
     if (s == "deterministic") { e->deterministic = value != 0; return 0; }
+    if (s == "serialize") { e->serialize = value != 0; return 0; }
     return fail(-22, "unknown engine option '" + s + "'");
 }
 

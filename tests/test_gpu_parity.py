@@ -993,3 +993,25 @@ def test_reactive_labels_outside_the_classes_are_rejected(gpu):
             tr.train_batch(depth, depth * masks[0], 0, [0], [bad])
     loss = tr.train_batch(depth, depth * masks[0], 0, [0], [2])          # class 2 = "no loss" (weight 0)
     assert float(loss[0]) == 0.0
+
+
+def test_bench_two_ranks_config4_leg_on_one_gpu(gpu):
+    """`python bench.py --gpus 2 --leg config4`: the launcher starts two ranks as a child process (here both on this GPU,
+    gradients exchanged over gloo - RCCL wants one GPU per rank), every rank trains on its own scenes, one all-reduce
+    between backward and Adam; the N > 1 line carries n_gpus, the all-reduce time and the whole-job step roofline."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from helpers import REPO
+    env = dict(os.environ, SMG_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--leg", "config4", "--scenes-per-rank", "2",
+                        "--steps", "2", "--warmup", "1", "--train-only"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["leg"] == "config4" and out["scaling"] == "weak"
+    assert out["allreduce_ms"] > 0 and out["allreduce_backend"] == "gloo"
+    st = out["roofline"]["step"]
+    assert 0 < st["frac_of_mfma_roof"] < 1 and st["mfma_roof_tflops"] > 800          # 2 x 416.7
+    assert abs(out["value"] - 2 * 2 * 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]    # passes/s of the whole job

@@ -1,6 +1,6 @@
 """Aggregate rocprofv3 FETCH_SIZE / WRITE_SIZE counter_collection CSVs per kernel class (bench.py's class names).
 
-usage: pmc_hbm_summary.py <fetch_dir> <write_dir> <out_prefix>
+usage: pmc_hbm_summary.py <fetch_dir> <write_dir> <out_prefix> [commit] [command]
 FETCH_SIZE is doubled (gfx950: 128-B requests tallied at 64 B, MI355X_MICROARCH.md section HBM); both counters are in KB.
 """
 import collections
@@ -13,10 +13,11 @@ import sys
 # prep_rotate_kernel per forward chain, two chains per forward)
 TRAIN_STEPS = 4
 FORWARDS = 9
-FWD_ONLY = ("prep_rotate", "pack_weights", "pool0_kernel", "feat_kernel", "value_conv", "bn_update", "bn_stat", "FwdConvP<", "conv3x3_halo_fwd")
+FWD_ONLY = ("prep_rotate", "pack_weights", "pool0_kernel", "feat_kernel", "value_conv", "bn_update", "bn_stat", "FwdConvP<", "conv3x3_halo_fwd", "conv1x1_fwd_ws")
 
 
 def kclass(name):
+    if "conv1x1_fwd_ws_kernel" in name: return "conv1x1_fwd"
     if "conv3x3_halo_fwd" in name: return "conv3x3_fwd"
     if "conv3x3_halo_dgrad" in name: return "conv3x3_dgrad"
     if "conv3x3_halo_wgrad" in name or "reduce_partials" in name: return "conv3x3_wgrad"
@@ -41,9 +42,9 @@ def count_steps(d):
     for fn in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(fn)):
             losses += "loss_kernel" in r["Kernel_Name"]
-            preps += "prep_rotate_kernel" in r["Kernel_Name"]
+            preps += "pack_weights_kernel" in r["Kernel_Name"]        # one per forward
     if losses and preps:
-        TRAIN_STEPS, FORWARDS = losses, preps // 2
+        TRAIN_STEPS, FORWARDS = losses, preps
 
 
 def load(d, counter):
@@ -74,8 +75,13 @@ def main():
         w = write.get(k, 0.0) / nf[k]
         out[k] = {"launches": nf[k], "fetch_bytes_per_launch": f, "write_bytes_per_launch": w, "hbm_bytes_per_launch": f + w,
                   "gb_per_train_step": (2.0 * fstep[k] + wstep.get(k, 0.0)) / 1e9}
-    json.dump(out, open(sys.argv[3] + ".json", "w"), indent=1)
+    total = sum(v["gb_per_train_step"] for v in out.values())
+    dump = dict(out)
+    dump["_meta"] = {"commit": sys.argv[4] if len(sys.argv) > 4 else "?", "command": sys.argv[5] if len(sys.argv) > 5 else "?",
+                     "train_steps": TRAIN_STEPS, "forwards": FORWARDS, "total_gb_per_train_step": total}
+    json.dump(dump, open(sys.argv[3] + ".json", "w"), indent=1)
     with open(sys.argv[3] + ".md", "w") as md:
+        md.write("commit %s, `%s`\n\n" % (dump["_meta"]["commit"], dump["_meta"]["command"]))
         md.write("| kernel class | launches (%d train steps + %d forward sweeps) | FETCH_SIZE x2 (MB / launch) | WRITE_SIZE (MB / launch) | GB per training step |\n|---|---|---|---|---|\n" % (TRAIN_STEPS, FORWARDS - TRAIN_STEPS))
         for k, v in out.items():
             md.write("| %s | %d | %.1f | %.1f | %.2f |\n" % (k, v["launches"], v["fetch_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6, v["gb_per_train_step"]))
