@@ -1,0 +1,371 @@
+// backward.hip - the backward walk: replaces loss.backward() of Trainer.backprop (code/trainer.py:350-351).
+#include "engine.h"
+
+// ------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------
+// Pixel-chunk size of a weight-gradient launch: enough workgroups to fill the chip
+// (~768) but no more - every workgroup ends with one fp32 atomicAdd per output element.
+static void pick_chunk(const Plane& pl, int n_planes, int tiles_per_chunk, int& chunk, int& cps, int target = 768) {
+    const int want = (target + tiles_per_chunk - 1) / tiles_per_chunk;
+    cps = (want + n_planes - 1) / n_planes;
+    if (cps < 1) cps = 1;
+    chunk = ((pl.HWp + cps - 1) / cps + 63) / 64 * 64;
+    cps = (pl.HWp + chunk - 1) / chunk;
+}
+
+int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t st) {
+    if (!e->have_fwd) return fail(-22, "smg_backward without a preceding smg_forward");
+    if (!net->grads) return fail(-22, "net.grads is NULL");
+    const Layout& L = *e->L;
+    const TrunkRef& T = L.trunk[e->f_trunk];
+    const HeadRef& Hd = L.head[e->f_head];
+    const int NS = e->f_streams, NP = e->f_pairs;
+    const float* P = net->params;
+    float* Gr = net->grads;
+    const Plane p4 = e->p_blk[3];
+    HIP_OK(hipMemsetAsync(e->bstat, 0, 2 * e->bstat_span * sizeof(double), st));
+    // Weight-gradient kernels only read what the data-gradient chain produces and write disjoint
+    // gradient ranges, so they run on a second stream beside it (their MFMA/L2-bound phases overlap the
+    // HBM-bound epilogues of the data-gradient kernels).  While profiling everything is serialised on
+    // `st` so that per-kernel durations stay clean.
+    // (a lowest-priority stream for the weight gradients gains 0.2 ms per step with one engine alive, and LOSES 10 ms as soon
+    // as a second engine - two more streams - exists in the process: the streams then share hardware queues and serialise)
+    const hipStream_t s2 = (e->prof || e->serialize) ? st : e->side;
+    auto fork = [&](hipEvent_t ev) -> int {      // side stream continues after everything enqueued on st so far
+        HIP_OK(hipEventRecord(ev, st));
+        HIP_OK(hipStreamWaitEvent(s2, ev, 0));
+        return 0;
+    };
+    int layer_no = 0;
+
+    {   // value conv backward + relu1 + norm1 sums
+        ValueBwdArgs a;
+        a.h1 = e->H1; a.p4 = p4; a.hsum = fsum(e, e->st_H1); a.hsq = fsq(e, e->st_H1);
+        a.gamma = P + Hd.n1.w; a.beta = P + Hd.n1.b; a.eps = kEps; a.w2p = e->packed_f + e->pk_head1;
+        a.dq = dq; a.out_ch = e->head_out; a.OH = e->OH; a.OW = e->OW; a.dh1 = e->DH1;
+        a.o1 = b1(e, e->bs_H1); a.o2 = b2(e, e->bs_H1); a.dbeta = Gr + Hd.n1.b; a.dgamma = Gr + Hd.n1.w; a.dw2 = Gr + Hd.c1.w;
+        ProfScope ps(e, st, K_OTHER, 0);
+        hipLaunchKernelGGL(value_bwd_kernel, dim3((p4.HW + 63) / 64, NP), dim3(256), 0, st, a);
+    }
+    int chunk4, cps4;
+    pick_chunk(p4, NP, 2 * kFeat / 64, chunk4, cps4);
+    {   // head conv0 weight gradient
+        BwdWeightP<CfgW64x64, W_ONE, C_IDENT> p{};
+        p.gbuf = e->DH1; p.ldg = kHeadMid; p.gcoff = 0; p.xbuf = e->H1; p.ldx = kHeadMid; p.xcoff = 0; p.pa = p4; p.MA = kHeadMid;
+        p.xsum = fsum(e, e->st_H1); p.xsq = fsq(e, e->st_H1); p.xstride = kHeadMid;
+        p.s1 = b1(e, e->bs_H1); p.s2 = b2(e, e->bs_H1); p.sstride = kHeadMid; p.scoff = 0; p.agamma = P + Hd.n1.w;
+        p.bbuf = e->F; p.ldb = 2 * kFeat; p.pb = p4; p.NB = 2 * kFeat;
+        p.bsum = fsum(e, e->st_F); p.bsq = fsq(e, e->st_F); p.bstride = 2 * kFeat; p.bgamma = P + Hd.n0.w; p.bbeta = P + Hd.n0.b;
+        p.eps = kEps; p.chunk = chunk4; p.chunks_per_stream = cps4; p.n_chunks = NP * cps4;
+        p.dw = Gr + Hd.c0.w; p.ldw_out = 2 * kFeat;
+        if (fork(e->ev_misc)) return -5;
+        BY(e, 4.0 * NP * p4.HW * (2 * kHeadMid + 2 * kFeat));
+        launch_wgrad(e, s2, p, dim3(1, 2 * kFeat / 64, NP * cps4), K_HW0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid, 1, C_IDENT);
+    }
+    {   // head conv0 data gradient + relu0 + norm0 sums
+        auto run = [&](auto tag) {
+                using Cfg = decltype(tag);
+                BwdDataP<Cfg, false, E_STORE> p{};
+        p.gbuf = e->DH1; p.ldg = kHeadMid; p.gcoff = 0; p.xbuf = e->H1; p.ldx = kHeadMid; p.xcoff = 0; p.pa = p4; p.KA = kHeadMid;
+        p.xsum = fsum(e, e->st_H1); p.xsq = fsq(e, e->st_H1); p.xstride = kHeadMid;
+        p.s1 = b1(e, e->bs_H1); p.s2 = b2(e, e->bs_H1); p.sstride = kHeadMid; p.scoff = 0; p.agamma = P + Hd.n1.w;
+        p.wp = e->packed_u + e->pk_hd0; p.K8tot = kHeadMid / 8; p.ldn = 2 * kFeat; p.wcol0 = 0; p.N = 2 * kFeat;
+        p.mbuf = e->F; p.ldm = 2 * kFeat; p.mcoff = 0; p.pm = p4;
+        p.msum = fsum(e, e->st_F); p.msq = fsq(e, e->st_F); p.mstride = 2 * kFeat; p.egamma = P + Hd.n0.w; p.ebeta = P + Hd.n0.b;
+        p.dst = e->DF; p.ldd = 2 * kFeat; p.dcoff = 0;
+        p.o1 = b1(e, e->bs_F); p.o2 = b2(e, e->bs_F); p.ostride = 2 * kFeat; p.ocoff = 0;
+        p.dbeta = Gr + Hd.n0.b; p.dgamma = Gr + Hd.n0.w; p.eps = kEps;
+        BY(e, 4.0 * NP * p4.HW * (2 * kHeadMid + 2 * 2 * kFeat));
+        launch_gemm(e, st, p, dim3(NP * p4.HWp / Cfg::BM, 2 * kFeat / Cfg::BN), K_HD0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid);
+            };
+            if (p4.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
+    }
+    {   // head norm0 backward + concat backward + norm5 backward -> G'_4
+        Norm5BwdArgs a;
+        a.DF = e->DF; a.F = e->F; a.p4 = p4; a.fsum = fsum(e, e->st_F); a.fsq = fsq(e, e->st_F);
+        a.f1 = b1(e, e->bs_F); a.f2 = b2(e, e->bs_F); a.hgamma = P + Hd.n0.w;
+        a.x4 = e->X[3]; a.xsum = fsum(e, e->st_X[3]); a.xsq = fsq(e, e->st_X[3]); a.gamma5 = P + T.norm5.w; a.eps = kEps;
+        a.user_ptr = e->d_user_ptr; a.user_pair = e->d_user_pair; a.user_slot = e->d_user_slot;
+        a.G4 = e->G[3]; a.SA = b1(e, e->bs_X[3]); a.SB = b2(e, e->bs_X[3]);
+        a.dbeta5 = Gr + T.norm5.b; a.dgamma5 = Gr + T.norm5.w; a.chunk = 16;
+        ProfScope ps(e, st, K_OTHER, 0);
+        hipLaunchKernelGGL(norm5_bwd_kernel, dim3(1, NS, (p4.HW + 15) / 16), dim3(256), 0, st, a);
+    }
+    for (int b = 3; b >= 0; --b) {
+        e->prof_stage = b;
+        const Plane pl = e->p_blk[b];
+        const int Ct = kBlockCtot[b];
+        for (int i = (int)T.layers[b].size() - 1; i >= 0; --i) {
+            const DenseLayerRef& d = T.layers[b][i];
+            float* bt = e->Bt + e->bt_off[b][i];
+            const int db = layer_no % kRing;
+            float* GSb = e->GS[db];
+            float* D2b = e->D2[db];
+            if (layer_no >= kRing) HIP_OK(hipStreamWaitEvent(st, e->ev_side[db], 0));   // side stream done with these buffers (kRing layers ago)
+            ++layer_no;
+            // This layer's finished output-slice gradient GS = invstd*(G' - SA/n - xhat*SB/n), materialised once (dense
+            // [px][32]) for the 3x3 data- and weight-gradient kernels.  They can also apply it while loading the G' / X
+            // slices (GradSrc with x set; SMG_GS_FUSED=1): one launch less on the dependency chain, but measured 0.5 ms
+            // per step slower - two strided 128-B-per-pixel reads replace one dense one in both consumers.
+            GradSrc gsrc{};
+            gsrc.g = e->G[b] + d.cin; gsrc.ldg = Ct; gsrc.x = e->X[b] + d.cin; gsrc.ldx = Ct;
+            gsrc.xsum = fsum(e, e->st_X[b]) + d.cin; gsrc.xsq = fsq(e, e->st_X[b]) + d.cin;
+            gsrc.s1 = b1(e, e->bs_X[b]) + d.cin; gsrc.s2 = b2(e, e->bs_X[b]) + d.cin; gsrc.sstride = Ct; gsrc.eps = kEps;
+            static const bool gs_env_fused = getenv("SMG_GS_FUSED") != nullptr;
+            static const int gs_fused_hw = getenv("SMG_GS_FUSED_HW") ? atoi(getenv("SMG_GS_FUSED_HW")) : 0;   // dev A/B: fuse on planes up to this many pixels
+            const bool gs_mat = !gs_env_fused && NS > 4 && pl.HW > gs_fused_hw;      // few streams: launch-bound, the fused form wins (8.78 -> 8.56 ms per sample)
+            if (e->generic3x3 || gs_mat) {
+                BnBwdApplyArgs a{};
+                a.g = e->G[b]; a.ldg = Ct; a.gcoff = d.cin; a.x = e->X[b]; a.ldx = Ct; a.xcoff = d.cin; a.pl = pl; a.C = kGrowth;
+                a.xsum = fsum(e, e->st_X[b]); a.xsq = fsq(e, e->st_X[b]); a.xstride = Ct;
+                a.s1 = b1(e, e->bs_X[b]); a.s2 = b2(e, e->bs_X[b]); a.sstride = Ct; a.scoff = d.cin; a.gamma = nullptr; a.eps = kEps;
+                a.out = GSb; a.ldo = kGrowth;
+                BY(e, 4.0 * NS * pl.HW * 3 * kGrowth);
+                ProfScope ps(e, st, K_OTHER, 0);
+                hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(pl.HWp / 64, NS), dim3(256), 0, st, a);
+                if (gs_mat) { gsrc = GradSrc{}; gsrc.g = GSb; gsrc.ldg = kGrowth; }
+            }
+            if (fork(e->ev_gs[db])) return -5;
+            if (!e->generic3x3) {
+                // conv2 (3x3) data gradient with the gradient halo resident in LDS (halo.cuh)
+                Halo3x3DgradArgs a;
+                a.g = gsrc; a.pl = pl; a.C = kBottleneck;
+                a.mbuf = bt;
+                a.dst = D2b; a.o1 = b1(e, e->bs_Bt[b][i]); a.o2 = b2(e, e->bs_Bt[b][i]); a.ostride = kBottleneck;
+                a.wu = e->packed_u + e->pk_hd[b][i]; a.bt = bn_table(e, e->sb_tab[b][i], e->max_streams, 0, kBottleneck, P + d.n2.w, P + d.n2.b);
+                BY(e, 4.0 * NS * pl.HW * (kGrowth + 2 * kBottleneck));      // gradient in, mask source in, dy out
+                ProfScope ps(e, st, K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+                TraceScope ts(st, K_D3, halo_tile(pl, NS) == 16 ? dim3((pl.H / 16) * (pl.W / 16), NS) : dim3(((pl.H + 7) / 8) * ((pl.W + 7) / 8), NS, kBottleneck / 64));
+                if (halo_tile(pl, NS) == 16) {
+                    static bool raised[64][3] = {};          // the 16x16 kernel needs more than the default 64 KB of dynamic LDS
+                    if (!raised[e->device & 63][e->prec]) {
+                        PREC_DISPATCH(e, (void)hipFuncSetAttribute((const void*)conv3x3_halo_dgrad_kernel<16, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloDgradSGeo<16>::smem_bytes(kBottleneck)));
+                        raised[e->device & 63][e->prec] = true;
+                    }
+                    a.tiles_x = pl.W / 16; a.cg_per_wg = kBottleneck / 32;
+                    PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_dgrad_kernel<16, PREC>), dim3((pl.H / 16) * a.tiles_x, NS), dim3(256),
+                                       HaloDgradSGeo<16>::smem_bytes(kBottleneck), st, a));
+                } else {
+                    a.tiles_x = (pl.W + 7) / 8; a.cg_per_wg = 1;      // small planes: one 64-channel group per workgroup
+                    PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_dgrad_kernel<8, PREC>), dim3(((pl.H + 7) / 8) * a.tiles_x, NS, kBottleneck / 64), dim3(256),
+                                       HaloDgradSGeo<8>::smem_bytes(kBottleneck), st, a));
+                }
+            } else {   // conv2 (3x3) data gradient -> dy of relu2/norm2 (D2) + norm2 sums (generic implicit GEMM)
+                auto run = [&](auto tag) {
+                    using Cfg = decltype(tag);
+                    BwdDataP<Cfg, true, E_STORE, false> p{};
+                    p.gbuf = GSb; p.ldg = kGrowth; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kGrowth;
+                    p.wp = e->packed_u + e->pk_g3d[b][i]; p.K8tot = 9 * kGrowth / 8; p.ldn = kBottleneck; p.wcol0 = 0; p.N = kBottleneck;
+                    p.mbuf = bt; p.ldm = kBottleneck; p.mcoff = 0; p.pm = pl;
+                    p.msum = fsum(e, e->st_Bt[b][i]); p.msq = fsq(e, e->st_Bt[b][i]); p.mstride = kBottleneck;
+                    p.egamma = P + d.n2.w; p.ebeta = P + d.n2.b;
+                    p.dst = D2b; p.ldd = kBottleneck; p.dcoff = 0;
+                    p.o1 = b1(e, e->bs_Bt[b][i]); p.o2 = b2(e, e->bs_Bt[b][i]); p.ostride = kBottleneck; p.ocoff = 0;
+                    p.dbeta = Gr + d.n2.b; p.dgamma = Gr + d.n2.w; p.eps = kEps;
+                    BY(e, 4.0 * NS * pl.HW * (kGrowth + 2 * kBottleneck));
+                    launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, kBottleneck / Cfg::BN), K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+                };
+                if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
+            }
+            if (!e->generic3x3) {
+                // conv2 weight gradient with the activation halo resident in LDS (halo.cuh)
+                const int ts = halo_tile(pl, NS);
+                Halo3x3WgradArgs a;
+                a.g = gsrc; a.pl = pl; a.src = bt; a.C = kBottleneck;
+                const int th = 8;                              // tiles are ts x 8 pixels
+                a.bt = bn_table(e, e->sb_tab[b][i], e->max_streams, 0, kBottleneck, P + d.n2.w, P + d.n2.b);
+                a.part = e->part; a.tiles_x = (pl.W + ts - 1) / ts; a.n_tiles = ((pl.H + th - 1) / th) * a.tiles_x;
+                a.tiles_per_wg = w3_tiles_per_wg(a.n_tiles, ts, NS, e->part_floats, (double)ts / th);
+                const int groups = (a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+                if ((int64_t)groups * NS * 9 * 32 * kBottleneck > e->part_floats) return fail(-12, "partial-gradient workspace too small");
+                {
+                    BY(e, 4.0 * NS * pl.HW * (kGrowth + kBottleneck));
+                    ProfScope ps(e, s2, K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+                    if (ts == 16) {
+                        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_wgrad_kernel<16, PREC>), dim3(groups, kBottleneck / 32, NS), dim3(256),
+                                                            HaloWgradSGeo<16>::smem_bytes(), s2, a));
+                    } else {
+                        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_wgrad_kernel<8, PREC>), dim3(groups, kBottleneck / 32, NS), dim3(256),
+                                                            HaloWgradSGeo<8>::smem_bytes(), s2, a));
+                    }
+                }
+                ReduceArgs r;
+                r.part = e->part; r.Z = groups * NS; r.taps = 9; r.rows = kGrowth; r.cols = kBottleneck; r.ldp = kBottleneck;
+                r.z_stride = (int64_t)9 * kGrowth * kBottleneck; r.tap_stride = (int64_t)kGrowth * kBottleneck;
+                r.dw = Gr + d.c2.w; r.ldw_out = kBottleneck * 9; r.cmap = C_3x3;
+                ProfScope ps(e, s2, K_W3, 0);
+                hipLaunchKernelGGL(reduce_partials_kernel, dim3((9 * kGrowth * kBottleneck + 255) / 256), dim3(256), 0, s2, r);
+            } else {   // conv2 weight gradient (generic implicit GEMM, one launch slice per tap)
+                const int chunk = 512, cps = (pl.HWp + chunk - 1) / chunk;   // latency-bound: many short workgroups
+                BwdWeightP<CfgW32x128, W_THREE, C_3x3, SMG_PD_WGRAD, false> p{};
+                p.gbuf = GSb; p.ldg = kGrowth; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kGrowth;
+                p.bbuf = bt; p.ldb = kBottleneck; p.pb = pl; p.NB = kBottleneck;
+                p.bsum = fsum(e, e->st_Bt[b][i]); p.bsq = fsq(e, e->st_Bt[b][i]); p.bstride = kBottleneck;
+                p.bgamma = P + d.n2.w; p.bbeta = P + d.n2.b; p.eps = kEps;
+                p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
+                p.dw = Gr + d.c2.w; p.ldw_out = kBottleneck * 9;
+                BY(e, 4.0 * NS * pl.HW * (kGrowth + kBottleneck));
+                launch_wgrad(e, s2, p, dim3(1, 1, 9 * NS * cps), K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth, 9, C_3x3);
+            }
+            {   // norm2 backward applied once, in place: D2 <- gamma2*invstd*(dy - s1/n - xhat*s2/n)
+                BnBwdApplyArgs a{};
+                a.g = D2b; a.ldg = kBottleneck; a.gcoff = 0; a.x = bt; a.ldx = kBottleneck; a.xcoff = 0; a.pl = pl; a.C = kBottleneck;
+                a.xsum = fsum(e, e->st_Bt[b][i]); a.xsq = fsq(e, e->st_Bt[b][i]); a.xstride = kBottleneck;
+                a.s1 = b1(e, e->bs_Bt[b][i]); a.s2 = b2(e, e->bs_Bt[b][i]); a.sstride = kBottleneck; a.scoff = 0;
+                a.gamma = P + d.n2.w; a.eps = kEps; a.out = D2b; a.ldo = kBottleneck;
+                if (!e->generic3x3) { a.dbeta = Gr + d.n2.b; a.dgamma = Gr + d.n2.w; }   // the halo dgrad leaves these to us
+                BY(e, 4.0 * NS * pl.HW * 3 * kBottleneck);
+                ProfScope ps(e, st, K_OTHER, 0);
+                hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(pl.HWp / 64, NS), dim3(256), 0, st, a);
+            }
+            if (fork(e->ev_d2[db])) return -5;
+            // conv1 (1x1) data gradient -> relu1/norm1 backward accumulated into G'.  Layers are grouped (kGroup,
+            // from the top of the block): inside a group only the channels the group itself produced - needed by
+            // the very next layer - are accumulated per layer; everything below the group's lowest layer is done
+            // once for the whole group by BwdDataGroupP (gemm.cuh), which touches G' and x once instead of once
+            // per layer.
+            const int L = (int)T.layers[b].size();
+            const int g_lo = i - ((L - 1 - i) % kGroup == kGroup - 1 ? 0 : std::min(i, kGroup - 1 - (L - 1 - i) % kGroup));
+            const int cs = T.layers[b][g_lo].cin;                       // channels below the group
+            if (d.cin > cs) {                                           // [cs, cin): per-layer accumulate
+                auto run = [&](auto tag) {
+                    using Cfg = decltype(tag);
+                    BwdDataP<Cfg, false, E_ACCUM, false> p{};
+                    p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kBottleneck;
+                    p.wp = e->packed_u + e->pk_d1[b][i]; p.K8tot = kBottleneck / 8; p.ldn = d.cin; p.wcol0 = cs; p.N = d.cin - cs;
+                    p.mbuf = e->X[b]; p.ldm = Ct; p.mcoff = cs; p.pm = pl;
+                    p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct;
+                    p.egamma = P + d.n1.w + cs; p.ebeta = P + d.n1.b + cs;
+                    p.dst = e->G[b]; p.ldd = Ct; p.dcoff = cs;
+                    p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.ocoff = cs;
+                    p.dbeta = Gr + d.n1.b + cs; p.dgamma = Gr + d.n1.w + cs; p.eps = kEps;
+                    BY(e, 4.0 * NS * pl.HW * (kBottleneck + 3.0 * p.N));          // dy in; x in, G' read + written
+                    launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, (p.N + Cfg::BN - 1) / Cfg::BN), K_D1, 2.0 * NS * pl.HW * p.N * kBottleneck);
+                };
+                if (pl.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
+            }
+            if (i == g_lo) {                                            // [0, cs): the whole group at once
+                auto run = [&](auto tag) {
+                    using Cfg = decltype(tag);
+                    BwdDataGroupP<Cfg> p{};
+                    const int g_hi = L - 1 - ((L - 1 - g_lo) / kGroup) * kGroup;      // top layer of this group
+                    p.nseg = g_hi - g_lo + 1;
+                    for (int k = 0; k < p.nseg; ++k) {                  // layer g_lo + k ran (k layers) before this one
+                        const DenseLayerRef& dk = T.layers[b][g_lo + k];
+                        const int slot = (layer_no - 1 - k + kRing * 4) % kRing;
+                        p.seg[k].g = e->D2[slot]; p.seg[k].wp = e->packed_u + e->pk_d1[b][g_lo + k]; p.seg[k].ldn = dk.cin;
+                        p.seg[k].gamma = P + dk.n1.w; p.seg[k].beta = P + dk.n1.b;
+                        p.seg[k].dbeta = Gr + dk.n1.b; p.seg[k].dgamma = Gr + dk.n1.w;
+                    }
+                    p.ldg = kBottleneck; p.pa = pl; p.KA = kBottleneck; p.N = cs;
+                    p.mbuf = e->X[b]; p.ldm = Ct;
+                    p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct;
+                    p.dst = e->G[b]; p.ldd = Ct;
+                    p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.eps = kEps;
+                    BY(e, 4.0 * NS * pl.HW * ((double)p.nseg * kBottleneck + 3.0 * cs));
+                    launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, (cs + Cfg::BN - 1) / Cfg::BN), K_D1, 2.0 * NS * pl.HW * cs * kBottleneck * p.nseg);
+                };
+                if (pl.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
+            }
+            {   // conv1 weight gradient.  ~320 workgroups: it shares the chip with the data-gradient chain on the other
+                // stream, and every workgroup ends with 128 x 64 fp32 atomics (measured: atomics beat partial tiles here)
+                using Cfg = CfgW128x64;
+                const int nt = (d.cin + Cfg::BN - 1) / Cfg::BN;
+                int chunk, cps;
+                static const int w1_target = getenv("SMG_W1_WGS") ? atoi(getenv("SMG_W1_WGS")) : 320;            // dev A/B
+                pick_chunk(pl, NS, nt, chunk, cps, w1_target);   // 256..384 measure the same (22.46 ms per step), 512: 22.6, 768: 22.8, 1024: 23.2
+                BwdWeightP<Cfg, W_ONE, C_IDENT, SMG_PD_WGRAD, false> p{};
+                p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck;
+                p.bbuf = e->X[b]; p.ldb = Ct; p.pb = pl; p.NB = d.cin;
+                p.bsum = fsum(e, e->st_X[b]); p.bsq = fsq(e, e->st_X[b]); p.bstride = Ct;
+                p.bgamma = P + d.n1.w; p.bbeta = P + d.n1.b; p.eps = kEps;
+                p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
+                p.dw = Gr + d.c1.w; p.ldw_out = d.cin;
+                BY(e, 4.0 * NS * pl.HW * (kBottleneck + d.cin));
+                launch_wgrad(e, s2, p, dim3(1, nt, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck, 1, C_IDENT, e->deterministic);
+                HIP_OK(hipEventRecord(e->ev_side[db], s2));
+            }
+        }
+        if (b > 0) {   // transition b-1: X[b-1] (all channels) -> X[b][:, 0:C0]
+            const Plane pp = e->p_blk[b - 1];
+            const int Cp = kBlockCtot[b - 1], C0 = kBlockCin[b];
+            {
+                int chunk, cps;
+                pick_chunk(pl, NS, (C0 / 128) * (Cp / 128), chunk, cps);
+                BwdWeightP<CfgW128x128, W_POOL, C_IDENT, 1> p{};      // (one k-tile in flight: the pooling fetch holds 4 float4 per slot, three tiles of them leave one workgroup per CU)
+                p.gbuf = e->G[b]; p.ldg = Ct; p.gcoff = 0; p.xbuf = e->X[b]; p.ldx = Ct; p.xcoff = 0; p.pa = pl; p.MA = C0;
+                p.xsum = fsum(e, e->st_X[b]); p.xsq = fsq(e, e->st_X[b]); p.xstride = Ct;
+                p.s1 = b1(e, e->bs_X[b]); p.s2 = b2(e, e->bs_X[b]); p.sstride = Ct; p.scoff = 0; p.agamma = nullptr;
+                p.bbuf = e->X[b - 1]; p.ldb = Cp; p.pb = pp; p.NB = Cp;
+                p.bsum = fsum(e, e->st_X[b - 1]); p.bsq = fsq(e, e->st_X[b - 1]); p.bstride = Cp;
+                p.bgamma = P + T.tnorm[b - 1].w; p.bbeta = P + T.tnorm[b - 1].b; p.eps = kEps;
+                p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
+                p.dw = Gr + T.tconv[b - 1].w; p.ldw_out = Cp;
+                if (fork(e->ev_misc)) return -5;
+                BY(e, 4.0 * NS * (2.0 * pl.HW * C0 + (double)pp.HW * Cp));
+                launch_wgrad(e, s2, p, dim3(C0 / 128, Cp / 128, NS * cps), K_TW, 2.0 * NS * pl.HW * Cp * C0, 1, C_IDENT);
+            }
+            if (pp.H != 2 * pl.H || pp.W != 2 * pl.W) {
+                ProfScope ps(e, st, K_OTHER, 0);
+                hipLaunchKernelGGL(zero_uncovered_kernel, dim3(256, NS), dim3(256), 0, st, e->G[b - 1], Cp, pp, 2 * pl.H, 2 * pl.W, Cp);
+            }
+            {
+                auto run = [&](auto tag) {
+                using Cfg = decltype(tag);
+                BwdDataP<Cfg, false, E_UNPOOL> p{};
+                p.gbuf = e->G[b]; p.ldg = Ct; p.gcoff = 0; p.xbuf = e->X[b]; p.ldx = Ct; p.xcoff = 0; p.pa = pl; p.KA = C0;
+                p.xsum = fsum(e, e->st_X[b]); p.xsq = fsq(e, e->st_X[b]); p.xstride = Ct;
+                p.s1 = b1(e, e->bs_X[b]); p.s2 = b2(e, e->bs_X[b]); p.sstride = Ct; p.scoff = 0; p.agamma = nullptr;
+                p.wp = e->packed_u + e->pk_td[b - 1]; p.K8tot = C0 / 8; p.ldn = Cp; p.wcol0 = 0; p.N = Cp;
+                p.mbuf = e->X[b - 1]; p.ldm = Cp; p.mcoff = 0; p.pm = pp;
+                p.msum = fsum(e, e->st_X[b - 1]); p.msq = fsq(e, e->st_X[b - 1]); p.mstride = Cp;
+                p.egamma = P + T.tnorm[b - 1].w; p.ebeta = P + T.tnorm[b - 1].b;
+                p.dst = e->G[b - 1]; p.ldd = Cp; p.dcoff = 0;
+                p.o1 = b1(e, e->bs_X[b - 1]); p.o2 = b2(e, e->bs_X[b - 1]); p.ostride = Cp; p.ocoff = 0;
+                p.dbeta = Gr + T.tnorm[b - 1].b; p.dgamma = Gr + T.tnorm[b - 1].w; p.eps = kEps;
+                BY(e, 4.0 * NS * (2.0 * pl.HW * C0 + 2.0 * pp.HW * Cp));
+                launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, Cp / Cfg::BN), K_TD, 2.0 * NS * pl.HW * Cp * C0);
+            };
+            run(CfgP64x128{});   // the 128-row variant of the unpool epilogue spills registers
+            }
+        }
+    }
+    e->prof_stage = -1;
+    {   // pool0 / relu0 backward + norm0 sums
+        Pool0BwdArgs a;
+        a.G1 = e->G[0]; a.X1 = e->X[0]; a.ld1 = kBlockCtot[0]; a.p1 = e->p_blk[0];
+        a.xsum = fsum(e, e->st_X[0]); a.xsq = fsq(e, e->st_X[0]); a.xstride = kBlockCtot[0];
+        a.SA = b1(e, e->bs_X[0]); a.SB = b2(e, e->bs_X[0]); a.sstride = kBlockCtot[0];
+        a.argmax = e->argmax; a.stem = e->stem; a.ps = e->p_stem;
+        a.ssum = fsum(e, e->st_stem); a.ssq = fsq(e, e->st_stem);
+        a.gamma = P + T.norm0.w; a.beta = P + T.norm0.b; a.eps = kEps;
+        a.DY0 = e->DY0; a.o1 = b1(e, e->bs_stem); a.o2 = b2(e, e->bs_stem);
+        a.dbeta = Gr + T.norm0.b; a.dgamma = Gr + T.norm0.w;
+        ProfScope ps(e, st, K_OTHER, 0);
+        if (e->p_stem.H % 8 || e->p_stem.W % 8) return fail(-22, "stem plane must tile by 8 (input_size multiple of 16)");
+        a.tiles_per_wg = 8;          // 4..20 measure the same; 1 costs 0.7 ms per step in atomics
+        const int n_t = (e->p_stem.H / 8) * (e->p_stem.W / 8);
+        hipLaunchKernelGGL(pool0_bwd_kernel, dim3((n_t + a.tiles_per_wg - 1) / a.tiles_per_wg, NS), dim3(256), 0, st, a);
+    }
+    {   // conv0 weight gradient (no data gradient: the image needs none)
+        const Plane ps_ = e->p_stem;
+        int chunk, cps;
+        pick_chunk(ps_, NS, 1, chunk, cps);
+        BwdWeightP<CfgW64x256, W_STEM, C_STEM> p{};
+        p.gbuf = e->DY0; p.ldg = 64; p.gcoff = 0; p.xbuf = e->stem; p.ldx = 64; p.xcoff = 0; p.pa = ps_; p.MA = 64;
+        p.xsum = fsum(e, e->st_stem); p.xsq = fsq(e, e->st_stem); p.xstride = 64;
+        p.s1 = b1(e, e->bs_stem); p.s2 = b2(e, e->bs_stem); p.sstride = 64; p.scoff = 0; p.agamma = P + T.norm0.w;
+        p.bbuf = e->img4; p.ldb = 4; p.pb = e->p_img; p.NB = 196;
+        p.eps = kEps; p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
+        p.dw = Gr + T.conv0.w; p.ldw_out = 147;
+        if (fork(e->ev_misc)) return -5;
+        BY(e, 4.0 * NS * (2.0 * ps_.HW * 64 + (double)e->p_img.HW * 4));
+        launch_wgrad(e, s2, p, dim3(1, 1, NS * cps), K_SW, 2.0 * NS * ps_.HW * 64 * 147, 1, C_STEM);
+    }
+    HIP_OK(hipEventRecord(e->ev_end, s2));          // join: everything after the backward sees every gradient
+    HIP_OK(hipStreamWaitEvent(st, e->ev_end, 0));
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+

@@ -35,7 +35,7 @@ __device__ __forceinline__ float lin_coord(int i, int S, float step) {
     return (i < S / 2) ? fmaf(step, (float)i, -1.f) : fmaf(-step, (float)(S - 1 - i), 1.f);
 }
 
-__global__ void prep_rotate_kernel(const PrepArgs a) {
+static __global__ void prep_rotate_kernel(const PrepArgs a) {
     const int s = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const int S = a.S;
@@ -95,7 +95,7 @@ __global__ void prep_rotate_kernel(const PrepArgs a) {
 enum { PK_T1 = 0, PK_D1 = 1, PK_3F = 2, PK_3D = 3, PK_STEM = 4, PK_HEAD = 5, PK_HF = 6, PK_HD = 7 };
 struct PackDesc { int64_t src, dst; int cout, cin, mode, K8tot, N, count; };   // dst: unit offset (split modes) / float offset (fp32 modes)
 
-__global__ void pack_weights_kernel(const PackDesc* descs, const float* params, u32x4* packed_u, float* packed_f, const int prec) {
+static __global__ void pack_weights_kernel(const PackDesc* descs, const float* params, u32x4* packed_u, float* packed_f, const int prec) {
     const PackDesc d = descs[blockIdx.y];
     const float* s = params + d.src;
     if (d.mode == PK_HEAD) {                       // fp32 dst[o][tap][c] = src[o][c][tap] (value convolution)
@@ -176,7 +176,7 @@ struct BnStatArgs {
     float* mean; float* invstd; int ld;                        // tables [row][ld]
     int c0, C, rows;                                           // channels [c0, c0 + C)
 };
-__global__ void bn_stat_kernel(const BnStatArgs a) {
+static __global__ void bn_stat_kernel(const BnStatArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.rows * a.C) return;
     const int n = idx / a.C, c = a.c0 + idx - n * a.C;
@@ -200,7 +200,7 @@ struct Pool0Args {
     unsigned char* argmax;                  // [n][po.HWp][64]
 };
 
-__global__ __launch_bounds__(256) void pool0_kernel(const Pool0Args a) {
+static __global__ __launch_bounds__(256) void pool0_kernel(const Pool0Args a) {
     __shared__ float prm[192];
     __shared__ double red[2][16][64];
     const int n = blockIdx.y, t = threadIdx.x, cq = t & 15, slot = t >> 4;
@@ -260,7 +260,7 @@ struct FeatArgs {
     int chunk;
 };
 
-__global__ __launch_bounds__(256) void feat_kernel(const FeatArgs a) {
+static __global__ __launch_bounds__(256) void feat_kernel(const FeatArgs a) {
     const int j = blockIdx.y, cq = blockIdx.x * 256 + threadIdx.x;   // channel quad of 2048/4
     const int ch = 4 * cq, slot = ch >> 10, c5 = ch & 1023;
     const int s = slot ? a.pair_b[j] : a.pair_a[j];
@@ -304,7 +304,7 @@ struct ValueArgs {
     float* q; int out_ch, OH, OW;
 };
 
-__global__ __launch_bounds__(256) void value_conv_kernel(const ValueArgs a) {
+static __global__ __launch_bounds__(256) void value_conv_kernel(const ValueArgs a) {
     __shared__ float prm[192];
     __shared__ float red[256];
     const int t = threadIdx.x, cq = t & 15, slot = t >> 4;
@@ -353,7 +353,7 @@ struct ValueBwdArgs {
     float* dw2;                               // native [out][64][20][20]
 };
 
-__global__ __launch_bounds__(256) void value_bwd_kernel(const ValueBwdArgs a) {
+static __global__ __launch_bounds__(256) void value_bwd_kernel(const ValueBwdArgs a) {
     __shared__ float prm[256];
     __shared__ float red[2][16][64];
     const int j = blockIdx.y, t = threadIdx.x, cq = t & 15, slot = t >> 4;
@@ -428,7 +428,7 @@ struct Norm5BwdArgs {
     int chunk;
 };
 
-__global__ __launch_bounds__(256) void norm5_bwd_kernel(const Norm5BwdArgs a) {
+static __global__ __launch_bounds__(256) void norm5_bwd_kernel(const Norm5BwdArgs a) {
     const int s = blockIdx.y, c5 = 4 * threadIdx.x;      // 256 threads x 4 = 1024 channels
     const int p0 = blockIdx.z * a.chunk, p1 = min(p0 + a.chunk, a.p4.HW);
     const double inv = 1.0 / (double)a.p4.HW;
@@ -507,7 +507,7 @@ struct Pool0BwdArgs {
     int tiles_per_wg;                                        // consecutive 8x8 tiles per workgroup (one flush of the sums)
 };
 
-__global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArgs a) {
+static __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArgs a) {
     // Workgroup = an 8x8 tile of stem pixels x 64 channels.  The <= 5x5 pooled pixels whose windows
     // cover the tile are finalised (BN-backward-corrected) ONCE into LDS together with their argmax;
     // every stem pixel then picks its <= 4 windows from LDS.  (The gather straight from global memory
@@ -629,7 +629,7 @@ struct BnBwdApplyArgs {
                                                   // (one fp32 atomic per stream and channel instead of one per producer tile)
 };
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs a) {
+static __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs a) {
     __shared__ float prm[4 * 128];
     const int n = blockIdx.y, t = threadIdx.x;
     const int qpr = a.C / 4;                      // float4 per row
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs 
 
 // Zero the rows/columns of a gradient plane that an odd-sized 2x2/stride-2 average
 // pool never reads (they receive no gradient from the transition).
-__global__ void zero_uncovered_kernel(float* G, int ld, Plane p, int Hc, int Wc, int C) {
+static __global__ void zero_uncovered_kernel(float* G, int ld, Plane p, int Hc, int Wc, int C) {
     const int n = blockIdx.y;
     const int64_t total = (int64_t)p.HW * (C / 4);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -689,7 +689,7 @@ __global__ void zero_uncovered_kernel(float* G, int ld, Plane p, int Hc, int Wc,
 // Losses (code/trainer.py:345-348 Huber on element [0,0,0,0]; :296-299 +
 // code/utils.py:306-313 class-weighted cross entropy, weights {1,1,0}).
 // ------------------------------------------------------------------------------------
-__global__ void loss_kernel(int mode, const float* q, const float* labels, int n_pairs, int per_pair,
+static __global__ void loss_kernel(int mode, const float* q, const float* labels, int n_pairs, int per_pair,
                             float* loss, float* dq) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_pairs) return;
@@ -733,7 +733,7 @@ struct HeightmapArgs {
     double mi[9];                           // INVERSE of the source -> heightmap homography
     double* out; int ow, oh;
 };
-__global__ void heightmap_warp_kernel(const HeightmapArgs a) {
+static __global__ void heightmap_warp_kernel(const HeightmapArgs a) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= a.ow) return;
     const double xd = (double)x, yd = (double)y;
@@ -765,7 +765,7 @@ __device__ __forceinline__ bool argmax_better(float x, int i, float bx, int bi) 
     if (xn) return i < bi;
     return x > bx || (x == bx && i < bi);
 }
-__global__ __launch_bounds__(256) void argmax_kernel(const float* v, int n, int* idx_out, float* val_out) {
+static __global__ __launch_bounds__(256) void argmax_kernel(const float* v, int n, int* idx_out, float* val_out) {
     __shared__ float bv[256];
     __shared__ int bi[256];
     const int t = threadIdx.x;
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* v, int n, int*
 // ------------------------------------------------------------------------------------
 struct BnUpdDesc { int64_t rm, rv, nbt; int64_t stat_off; int stride, coff, C, count, head; };
 
-__global__ void bn_update_kernel(const BnUpdDesc* descs, const double* stats_sum, const double* stats_sq,
+static __global__ void bn_update_kernel(const BnUpdDesc* descs, const double* stats_sum, const double* stats_sq,
                                  float* bufs, int64_t* nbt, const int* seq_trunk, int n_trunk,
                                  const int* seq_head, int n_head) {
     const BnUpdDesc d = descs[blockIdx.y];
@@ -819,7 +819,7 @@ __global__ void bn_update_kernel(const BnUpdDesc* descs, const double* stats_sum
 // ------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam, no amsgrad, no weight decay).
 // ------------------------------------------------------------------------------------
-__global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+static __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                             float eps, float bc1, float bc2_sqrt) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i];

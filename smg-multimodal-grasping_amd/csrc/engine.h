@@ -1,0 +1,321 @@
+// engine.h - shared by the translation units of libsmg_hip.so (engine.hip: workspace + C ABI, forward.hip, backward.hip):
+// the engine's state, tile configurations and launch helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/smg_hip.h"
+#include "elem.cuh"
+#include "gemm.cuh"
+#include "halo.cuh"
+#include "ws.cuh"
+#include "plan.h"
+
+using namespace smg;
+
+// ------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------
+int smg_fail(int code, const std::string& msg);      // engine.hip: sets the thread's smg_last_error() text, returns code
+static inline int fail(int code, const std::string& msg) { return smg_fail(code, msg); }
+#define HIP_OK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail(-5, std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+    } while (0)
+
+static const Layout& layout_for(int head_out) {
+    static Layout L1 = build_layout(1);
+    static Layout L3 = build_layout(3);
+    return head_out == 3 ? L3 : L1;
+}
+
+// ------------------------------------------------------------------------------------
+// GEMM tile configurations (BM, BN, BK, waves M x N, A pixel-major?)
+// ------------------------------------------------------------------------------------
+// big stages (pixel planes that are multiples of 128 rows)
+using CfgP128x128 = GemmCfg<128, 128, 16, 2, 2, 1, true>;    // 1x1 fwd, transitions, 3x3 dgrad
+using CfgP128x32 = GemmCfg<128, 32, 32, 4, 1, 1, true>;      // 3x3 fwd (N = growth 32)
+using CfgP128x64 = GemmCfg<128, 64, 16, 2, 2, 1, true>;      // stem, head conv0, 1x1 dgrad
+// small stages (late blocks: few pixels per stream -> 64-row tiles, 4x the workgroups)
+using CfgP64x64 = GemmCfg<64, 64, 32, 2, 2, 1, true>;        // 1x1 fwd / dgrad, transitions
+using CfgP64x64k16 = GemmCfg<64, 64, 16, 2, 2, 1, true>;     // 1x1 fwd with many input channels: 29 KB LDS incl. BN parameters
+using CfgP32x64 = GemmCfg<32, 64, 32, 1, 2, 2, true>;        // 1x1 fwd of a launch too small to fill the chip: 2x the workgroups, half the K chain per wave
+using CfgP128x128d = GemmCfg<128, 128, 32, 2, 2, 1, true>;   // 1x1 fwd of launches with fewer 128-row tiles than CUs: one workgroup per CU, deep register prefetch
+using CfgP64x128d = GemmCfg<64, 128, 32, 2, 2, 1, true>;     // the same for planes that tile by 64 rows only (40^2)
+using CfgP64x64w = GemmCfg<64, 64, 32, 1, 2, 2, true>;       // 64x64 with 64x32 wave tiles over half the k-steps each: 25% fewer fragment reads per MFMA
+using CfgP64x128 = GemmCfg<64, 128, 16, 2, 2, 1, true>;      // 3x3 dgrad, late 1x1 fwd / transitions (A operand read once)
+using CfgP64x32 = GemmCfg<64, 32, 64, 2, 1, 2, true>;        // 3x3 fwd, k-tile split over 2 waves
+// weight gradients (reduction over pixels)
+using CfgW32x128 = GemmCfg<32, 128, 32, 1, 4, 1, false>;     // 3x3 wgrad (32 x 128 per tap)
+using CfgW128x64 = GemmCfg<128, 64, 16, 2, 2, 1, false>;     // 1x1 wgrad (128 x cin)
+using CfgW128x128 = GemmCfg<128, 128, 16, 2, 2, 1, false>;   // transition wgrad
+using CfgW64x64 = GemmCfg<64, 64, 16, 2, 2, 1, false>;       // head conv0 wgrad
+using CfgW64x256 = GemmCfg<64, 256, 16, 2, 2, 1, false>;     // stem wgrad: all 196 (tap, channel) columns in one tile
+
+enum Kind {
+    K_STEM = 0, K_C1, K_C3, K_TRANS, K_HEAD0, K_D3, K_W3, K_D1, K_W1, K_TW, K_TD, K_SW, K_HW0, K_HD0, K_OTHER, K_COUNT
+};
+static const char* kKindNames[K_COUNT] = {"stem7x7_fwd", "conv1x1_fwd", "conv3x3_fwd", "transition_fwd", "head_conv0_fwd",
+                                          "conv3x3_dgrad", "conv3x3_wgrad", "conv1x1_dgrad", "conv1x1_wgrad",
+                                          "transition_wgrad", "transition_dgrad", "stem_wgrad", "head_conv0_wgrad",
+                                          "head_conv0_dgrad", "elementwise"};
+
+// Backward ring: the finished bottleneck gradients (D2) of one layer group stay alive until the group's joint
+// 1x1 data-gradient kernel has read them, while the side stream may still be two layers behind.
+constexpr int kGroup = GROUP_MAX;          // dense layers per 1x1-dgrad group
+constexpr int kRing = kGroup + 2;
+
+struct ProfRec { hipEvent_t a, b; int kind; double flops; int stage; double bytes; };
+
+struct StatArr { int64_t off; int stride; };   // into a double arena: sum at off, sumsq at off + span
+
+// ------------------------------------------------------------------------------------
+// engine
+// ------------------------------------------------------------------------------------
+struct smg_engine {
+    int device = 0, S = 0, max_streams = 0, max_pairs = 0, head_out = 1;
+    Plane p_img, p_stem, p_blk[4];
+    int OH = 1, OW = 1;
+    const Layout* L = nullptr;
+
+    // activations
+    float* img4 = nullptr; float* stem = nullptr; float* X[4] = {}; float* Bt = nullptr;
+    std::vector<int64_t> bt_off[4];          // float offset of each layer's bottleneck buffer
+    unsigned char* argmax = nullptr;
+    float* F = nullptr; float* H1 = nullptr;
+    // gradients
+    float* G[4] = {}; float* GS[kRing] = {}; float* D2[kRing] = {}; float* part = nullptr; int64_t part_floats = 0;
+    // second stream for the weight-gradient kernels (independent of the data-gradient chain)
+    hipStream_t side = nullptr; hipEvent_t ev_gs[kRing] = {}, ev_d2[kRing] = {}, ev_side[kRing] = {}, ev_misc = nullptr, ev_end = nullptr; float* DY0 = nullptr; float* DH1 = nullptr; float* DF = nullptr;
+    // statistics arenas (doubles). fwd: [sum | sumsq] halves; bwd: [s1 | s2] halves
+    double* fstat = nullptr; int64_t fstat_span = 0;
+    double* bstat = nullptr; int64_t bstat_span = 0;
+    StatArr st_stem, st_X[4], st_F, st_H1; std::vector<StatArr> st_Bt[4];
+    StatArr bs_stem, bs_X[4], bs_F, bs_H1; std::vector<StatArr> bs_Bt[4];
+    // packed weights: split bf16 units for the MFMA GEMMs (packed_u) and fp32 K-major layouts for the halo 3x3
+    // kernels / the value convolution (packed_f)
+    u32x4* packed_u = nullptr; int64_t packed_units = 0;
+    float* packed_f = nullptr; int64_t packed_floats = 0;
+    PackDesc* d_pack = nullptr; std::vector<PackDesc> h_pack[3]; std::vector<PackDesc> h_pack_head[3];
+    int pack_stride = 0, bnupd_stride = 0, n_bnupd = 0;   // d_pack / d_bnupd hold one table per (trunk, head)
+    int64_t pk_conv0 = 0, pk_head0 = 0, pk_hd0 = 0, pk_head1 = 0;
+    std::vector<int64_t> pk_c1[4], pk_d1[4], pk_g3f[4], pk_g3d[4], pk_hf[4], pk_hd[4]; int64_t pk_t[3] = {}, pk_td[3] = {};
+    int max_pack = 0;
+    // BN statistics as fp32 tables (mean | invstd, [rows][C] each): one per dense-block buffer, one per bottleneck, one
+    // for the head's features; written by the first consumer of a channel (BnTab, gemm.cuh), kept until the backward
+    float* stab = nullptr; int64_t stab_floats = 0;
+    int64_t sx_tab[4] = {}, sb_tab[4][24] = {}, sf_tab = 0;
+    // bn update descriptors
+    BnUpdDesc* d_bnupd = nullptr;
+    // last forward
+    bool have_fwd = false; int f_trunk = 0, f_head = 0, f_streams = 0, f_pairs = 0;
+    int* d_stream_image = nullptr; int* d_stream_rot = nullptr; int* d_pair_a = nullptr; int* d_pair_b = nullptr;
+    int* d_seq_t = nullptr; int* d_seq_h = nullptr; int* d_user_ptr = nullptr; int* d_user_pair = nullptr; int* d_user_slot = nullptr;
+    float* d_affine = nullptr;
+    // batch description staging: one pinned ping-pong host block -> one device block per forward
+    int* d_stage = nullptr; int* h_stage[2] = {}; hipEvent_t ev_stage[2] = {}; int stage_ints = 0, stage_turn = 0;
+    int so_image = 0, so_rot = 0, so_pa = 0, so_pb = 0, so_seq_t = 0, so_seq_h = 0, so_uptr = 0, so_upair = 0, so_uslot = 0, so_aff = 0, so_ma = 0, so_mb = 0;
+    int64_t workspace_bytes = 0;
+    int n_cu = 256;            // compute units of the device (persistent-launch sizing)
+    int prec = 0;              // operand precision of the matrix products: 0 fp32-class split, 1 bf16, 2 fp16 (smg_engine_set_precision)
+    bool serialize = false;       // smg_engine_set_option("serialize"): every launch on the caller's stream in issue order (profiling: a trace's
+                                  // per-kernel durations are not inflated by a kernel of the other chain sharing the chip)
+    bool deterministic = false;   // smg_engine_set_option("deterministic"): 1x1 weight gradients as partial tiles + fixed-order reduce instead of fp32 atomics
+    bool generic3x3 = false;   // SMG_GENERIC_3X3=1: dense-layer 3x3 convs through the generic implicit GEMM (A/B testing)
+    // profiling
+    bool prof = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> ev_pool;
+    // totals per kind in slot 0, and the share of dense block b (kernels issued inside its layer loops) in slot 1 + b
+    double prof_ms[5][K_COUNT] = {}; int64_t prof_n[5][K_COUNT] = {}; double prof_flops[5][K_COUNT] = {}; double prof_bytes[5][K_COUNT] = {}; int prof_stage = -1;
+    double next_bytes = 0;     // algorithmic HBM bytes of the next profiled launch (set with BY() right before it)
+};
+
+// Tile side of the LDS-halo 3x3 kernels for a plane: 16 where it tiles exactly, else 8 (ragged edges masked) - and 8
+// as well when the launch would have fewer than 320 16x16 tiles (few streams per call; 80x80 planes of a 9-stream
+// forward chain): four times the workgroups fill the chip (forward sweep 9.05 -> 8.77 ms, single-rotation forward
+// 4.3 -> 3.6 ms).
+static inline int halo_tile(const Plane& p, int n_streams = 1 << 20) {
+    if (p.H % 16 || p.W % 16) return 8;
+    static const int min16 = getenv("SMG_HALO16_MIN") ? atoi(getenv("SMG_HALO16_MIN")) : 320;      // dev A/B
+    return (int64_t)(p.H / 16) * (p.W / 16) * n_streams >= min16 ? 16 : 8;
+}
+
+// 3x3 weight-gradient halo kernel: tiles per workgroup.  The launch runs in rounds of 512 resident workgroups (2 per
+// CU), each lasting tiles_per_wg tile-times plus a fixed prologue + 9-tap flush (~0.6 of a 16x16 tile-time, measured);
+// take the run length with the shortest total (e.g. 100 tiles x 17 streams -> 7, 25 tiles -> 4), then lengthen it
+// until the partial tiles fit the workspace.
+static int w3_tiles_per_wg(int n_tiles, int ts, int n_streams, int64_t part_floats, double fix_scale = 1.0) {
+    const double fix = (ts == 16 ? 0.6 : 2.4) * fix_scale;
+    double best = 1e30;
+    int tpw_best = 1;
+    for (int tpw = 1; tpw <= n_tiles; ++tpw) {
+        const int g = (n_tiles + tpw - 1) / tpw;
+        const int rounds = (g * (kBottleneck / 32) * n_streams + 511) / 512;
+        const double cost = rounds * (tpw + fix);
+        if (cost < best - 1e-9) { best = cost; tpw_best = tpw; }
+    }
+    while (tpw_best < n_tiles && (int64_t)((n_tiles + tpw_best - 1) / tpw_best) * n_streams * 9 * 32 * kBottleneck > part_floats) ++tpw_best;
+    return tpw_best;
+}
+
+static Plane make_plane(int H, int W) {
+    Plane p; p.H = H; p.W = W; p.HW = H * W; p.HWp = (p.HW + 63) / 64 * 64; return p;
+}
+
+template <class T>
+static int dev_alloc(smg_engine* e, T** out, int64_t count) {
+    void* p = nullptr;
+    hipError_t err = hipMalloc(&p, (size_t)count * sizeof(T));
+    if (err != hipSuccess) return fail(-12, std::string("hipMalloc ") + std::to_string(count * sizeof(T)) + " B: " + hipGetErrorString(err));
+    e->workspace_bytes += count * (int64_t)sizeof(T);
+    *out = (T*)p;
+    return 0;
+}
+#define ALLOC(ptr, count) do { int _r = dev_alloc(e, &(ptr), (count)); if (_r) return _r; } while (0)
+
+// ------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------
+static hipEvent_t prof_event(smg_engine* e) {
+    if (!e->ev_pool.empty()) { hipEvent_t ev = e->ev_pool.back(); e->ev_pool.pop_back(); return ev; }
+    hipEvent_t ev; (void)hipEventCreate(&ev); return ev;
+}
+// Algorithmic HBM bytes of the launch that follows: what the kernel must move once (inputs read once, outputs written
+// once, fp32), the yardstick of bench.py's HBM roofline.
+#define BY(e, x) ((e)->next_bytes = (double)(x))
+struct ProfScope {
+    smg_engine* e; hipStream_t st; int kind; double flops, bytes; hipEvent_t a{}, b{};
+    ProfScope(smg_engine* e_, hipStream_t s, int k, double f) : e(e_), st(s), kind(k), flops(f), bytes(e_->next_bytes) {
+        e->next_bytes = 0;
+        if (e->prof) { a = prof_event(e); b = prof_event(e); (void)hipEventRecord(a, st); }
+    }
+    ~ProfScope() {
+        if (e->prof) { (void)hipEventRecord(b, st); e->recs.push_back({a, b, kind, flops, e->prof_stage, bytes}); }
+    }
+};
+
+// Runs CALL with a compile-time PREC equal to the engine's run-time precision setting.
+#define PREC_DISPATCH(e, CALL)                                            \
+    switch ((e)->prec) {                                                  \
+        case 1: { constexpr int PREC = 1; CALL; } break;                  \
+        case 2: { constexpr int PREC = 2; CALL; } break;                  \
+        default: { constexpr int PREC = 0; CALL; } break;                 \
+    }
+
+// Dev instrumentation: per-workgroup phase stamps of ONE launch (SMG_TRACE_KIND = kernel class, SMG_TRACE_SKIP = how many
+// launches of that class to skip).  The kernels store s_memtime at up to five points (slots 0..4) and the device-wide
+// 100 MHz counter at start / end (slots 5, 6) through g_smg_trace; the scope prints the mean phase lengths.
+struct TraceScope {
+    hipStream_t st; int kind; dim3 grid; unsigned long long* tbuf = nullptr; size_t n_wg = 0;
+    TraceScope(hipStream_t s, int k, dim3 g) : st(s), kind(k), grid(g) {
+        static const int tr_kind = getenv("SMG_TRACE_KIND") ? atoi(getenv("SMG_TRACE_KIND")) : -1;
+        static const int tr_skip = getenv("SMG_TRACE_SKIP") ? atoi(getenv("SMG_TRACE_SKIP")) : 0;
+        static int tr_seen = 0;
+        if (!(kind == tr_kind && tr_seen++ == tr_skip)) return;
+        n_wg = (size_t)grid.x * grid.y * grid.z;
+        (void)hipMalloc((void**)&tbuf, n_wg * 64);
+        (void)hipMemsetAsync(tbuf, 0, n_wg * 64, st);
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_smg_trace), &tbuf, sizeof(tbuf), 0, hipMemcpyHostToDevice, st);
+    }
+    ~TraceScope() {
+        if (!tbuf) return;
+        unsigned long long* nul = nullptr;
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_smg_trace), &nul, sizeof(nul), 0, hipMemcpyHostToDevice, st);
+        std::vector<unsigned long long> h(n_wg * 8);
+        (void)hipMemcpyAsync(h.data(), tbuf, n_wg * 64, hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(tbuf);
+        // phases in shader cycles (s_memtime, per-XCD base); span / residency from the device-wide 100 MHz counter
+        double sum[4] = {0, 0, 0, 0}, life = 0; size_t live = 0; unsigned long long t_min = ~0ull, t_max = 0;
+        for (size_t w = 0; w < n_wg; ++w) {
+            const unsigned long long* r = &h[w * 8];
+            if (!r[4]) continue;
+            ++live;
+            for (int k = 0; k < 4; ++k) sum[k] += (double)(r[k + 1] - r[k]);
+            t_min = std::min(t_min, r[5]); t_max = std::max(t_max, r[6]);
+            life += (double)(r[6] - r[5]);
+        }
+        const double span = (double)(t_max - t_min) * 0.01, resid = life / (double)(t_max - t_min) / 256.0;
+        fprintf(stderr, "[smg trace] kind %d grid %ux%ux%u live %zu: init %.0f | first tile %.0f | k-loop %.0f | epilogue %.0f cycles/WG (mean); span %.1f us, %.2f workgroups resident per CU, mean life %.1f us\n",
+                kind, grid.x, grid.y, grid.z, live, sum[0] / live, sum[1] / live, sum[2] / live, sum[3] / live, span, resid, life / live * 0.01);
+    }
+};
+
+template <class P>
+static void launch_gemm(smg_engine* e, hipStream_t st, P p, dim3 grid, int kind, double flops) {
+    const size_t smem = (size_t)(P::Cfg::TILE_FLOATS + p.param_floats()) * sizeof(float);
+    if (smem > 64 * 1024) {      // more dynamic LDS than the default limit: raise it once per (instantiation, device)
+        static bool raised[64][3] = {};
+        if (!raised[e->device & 63][e->prec]) {
+            PREC_DISPATCH(e, (void)hipFuncSetAttribute((const void*)gemm_kernel<P, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised[e->device & 63][e->prec] = true;
+        }
+    }
+    p.tm = TileMap{0, 0, 0};
+    if constexpr (P::kSwizzle == 1) {            // x = M tiles, y = N tiles sharing one A operand
+        if (grid.y > 1 && grid.z == 1) {
+            p.tm = TileMap{(int)grid.x, (int)grid.y, 0};
+            grid = dim3(8 * ((grid.x + 7) / 8) * grid.y, 1, 1);
+        }
+    } else {                                     // weight gradient: z = pixel chunks, x*y = tiles sharing them
+        p.gx = grid.x; p.gy = grid.y;
+        const int tiles = grid.x * grid.y;
+        if (tiles > 1) {
+            p.tm = TileMap{(int)grid.z, tiles, (int)grid.x};
+            grid = dim3(8 * ((grid.z + 7) / 8) * tiles, 1, 1);
+        }
+    }
+    TraceScope ts(st, kind, grid);
+    {
+        ProfScope ps(e, st, kind, flops);
+        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_kernel<P, PREC>), dim3((unsigned)(grid.x * grid.y * grid.z)), dim3(256), smem, st, p, (int)grid.x, (int)grid.y));
+    }
+}
+
+// Weight-gradient launch: partial tiles to the workspace + one reduce kernel (falls back to
+// atomics if the workspace is too small for this launch).
+template <class P>
+static void launch_wgrad(smg_engine* e, hipStream_t st, P& p, dim3 grid, int kind, double flops, int taps, int cmap, bool use_part = true) {
+    using C = typename P::Cfg;
+    const int64_t ldp = (int64_t)grid.y * C::BN, rowsp = (int64_t)grid.x * C::BM;
+    const int64_t need = (int64_t)grid.z * rowsp * ldp;
+    p.part = (use_part && need <= e->part_floats) ? e->part : nullptr;
+    launch_gemm(e, st, p, grid, kind, flops);
+    if (p.part) {
+        ReduceArgs r;
+        r.part = e->part; r.Z = p.n_chunks; r.taps = taps; r.rows = p.MA; r.cols = p.NB; r.ldp = (int)ldp;
+        r.z_stride = rowsp * ldp; r.tap_stride = (int64_t)p.n_chunks * rowsp * ldp;
+        r.dw = p.dw; r.ldw_out = p.ldw_out; r.cmap = cmap;
+        const int total = taps * p.MA * p.NB;
+        ProfScope ps(e, st, kind, 0);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((total + 255) / 256), dim3(256), 0, st, r);
+    }
+}
+
+static inline double* fsum(smg_engine* e, const StatArr& s) { return e->fstat + s.off; }
+static inline double* fsq(smg_engine* e, const StatArr& s) { return e->fstat + e->fstat_span + s.off; }
+static inline double* b1(smg_engine* e, const StatArr& s) { return e->bstat + s.off; }
+static inline double* b2(smg_engine* e, const StatArr& s) { return e->bstat + e->bstat_span + s.off; }
+
+static const float kEps = 1e-5f;
+
+// BN statistics table at float offset `at` of the table arena ([rows_max][C] mean, then invstd), from row r0 on, with the
+// affine parameters of the consuming BatchNorm
+static BnTab bn_table(smg_engine* e, int64_t at, int rows_max, int r0, int C, const float* gamma, const float* beta) {
+    BnTab t;
+    t.mean = e->stab + at + (int64_t)r0 * C; t.invstd = t.mean + (int64_t)rows_max * C; t.ld = C; t.gamma = gamma; t.beta = beta;
+    return t;
+}
+
+
+int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, const smg_batch* B, float* q_out, hipStream_t st);
+int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t st);

@@ -353,7 +353,7 @@ __device__ __forceinline__ void block_col_reduce(T (&v)[NQ][C::TN], T* red, T (&
 
 // Dev instrumentation (SMG_TRACE_* in engine.hip): when set, thread 0 of every workgroup of a gemm_kernel launch
 // stores s_memtime at five points: start | parameters ready | first tile staged | k-loop done | epilogue done.
-__device__ unsigned long long* g_smg_trace = nullptr;
+static __device__ unsigned long long* g_smg_trace = nullptr;      // (one copy per translation unit; TraceScope sets its own)
 #if defined(SMG_TRACE_ITER) || defined(SMG_TRACE_EPI)
 #define SMG_TRACE(slot) do {} while (0)
 #else
@@ -666,7 +666,7 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
 // grid) was measured and rejected: hipcc hoists the per-thread addressing out of the tile loop (+50..70 VGPRs, one
 // workgroup less per CU) and the launch is not dispatch-bound.
 template <class P, int PREC = 0>
-__global__ __launch_bounds__(256, P::kMinWaves) void gemm_kernel(const P p, const int vgx, const int vgy) {
+static __global__ __launch_bounds__(256, P::kMinWaves) void gemm_kernel(const P p, const int vgx, const int vgy) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     VBlock vb;
     vb.linear = blockIdx.x;
@@ -1727,7 +1727,7 @@ struct ReduceArgs {
     const float* part; int Z, taps, rows, cols, ldp; int64_t z_stride, tap_stride;
     float* dw; int ldw_out, cmap;
 };
-__global__ void reduce_partials_kernel(const ReduceArgs a) {
+static __global__ void reduce_partials_kernel(const ReduceArgs a) {
     const int total = a.taps * a.rows * a.cols;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const int tap = e / (a.rows * a.cols);

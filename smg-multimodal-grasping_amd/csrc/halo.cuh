@@ -76,7 +76,7 @@ template <int TS> struct HaloFwdSGeo : HaloGeo<TS> {
 };
 
 template <int TS, int PREC = 0>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const Halo3x3FwdArgs a) {
+static __global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const Halo3x3FwdArgs a) {
     using G = HaloFwdSGeo<TS>;
     constexpr int MT = G::MT, A_N = G::A_N, B_N = G::B_N, LDH = G::LDH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -313,7 +313,7 @@ template <int TS> struct HaloDgradSGeo : HaloGeo<TS> {
 };
 
 template <int TS, int PREC = 0>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x3DgradArgs a) {
+static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x3DgradArgs a) {
     using G = HaloDgradSGeo<TS>;
     constexpr int MT = G::MT, NCW = G::NCW, A_N = G::A_N, B_N = G::B_N, LDH = G::LDH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -556,7 +556,7 @@ template <int TW> struct HaloWgradSGeo {
 };
 
 template <int TW, int PREC = 0>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const Halo3x3WgradArgs a) {
+static __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const Halo3x3WgradArgs a) {
     using G = HaloWgradSGeo<TW>;
     constexpr int B_N = G::B_N, A_N = G::A_N;
     extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -38,7 +38,7 @@ struct WsGeo {
 };
 
 template <int PREC = 0>
-__global__ __launch_bounds__(512, 1) void conv1x1_fwd_ws_kernel(const Fwd1x1WsArgs a) {
+static __global__ __launch_bounds__(512, 1) void conv1x1_fwd_ws_kernel(const Fwd1x1WsArgs a) {
     using G = WsGeo;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* As = reinterpret_cast<char*>(smem);

@@ -654,7 +654,9 @@ def test_g8_reactive_gradients_and_adam(gpu, golden):
     o64.zero_grad()
     trunk, head = getattr(o64, orc.STYLE_TRUNK[0]).features, getattr(o64, orc.STYLE_HEAD[0])
     q64 = head(torch.cat((trunk(x.double()), trunk(mx.double())), 1))          # reactive_net: rotation 0 = identity
-    orc.reactive_loss(q64, 1).backward()
+    lab = torch.ones((1, 1, 1), dtype=torch.long)
+    torch.nn.functional.nll_loss(torch.log_softmax(q64[0].view(1, 3, 1, 1), dim=1), lab,
+                                 weight=torch.tensor([1.0, 1.0, 0.0], dtype=torch.float64)).sum().backward()   # orc.reactive_loss in fp64
     g64 = {n: p.grad for n, p in o64.named_parameters() if p.grad is not None}
     on.zero_grad()
     qo = orc.forward(on, x, mx, 0, False, 0)
