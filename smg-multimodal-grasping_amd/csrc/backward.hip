@@ -51,7 +51,8 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
     int chunk4, cps4;
     pick_chunk(p4, NP, 2 * kFeat / 64, chunk4, cps4);
     {   // head conv0 weight gradient
-        BwdWeightP<CfgW64x64, W_ONE, C_IDENT> p{};
+        auto go = [&](auto ptag) -> int {
+        BwdWeightP<CfgW64x64, W_ONE, C_IDENT, SMG_PD_WGRAD, true, decltype(ptag)::value, true> p{};      // fp32 head buffers in every mode
         p.gbuf = e->DH1; p.ldg = kHeadMid; p.gcoff = 0; p.xbuf = e->H1; p.ldx = kHeadMid; p.xcoff = 0; p.pa = p4; p.MA = kHeadMid;
         p.xsum = fsum(e, e->st_H1); p.xsq = fsq(e, e->st_H1); p.xstride = kHeadMid;
         p.s1 = b1(e, e->bs_H1); p.s2 = b2(e, e->bs_H1); p.sstride = kHeadMid; p.scoff = 0; p.agamma = P + Hd.n1.w;
@@ -62,11 +63,14 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         if (fork(e->ev_misc)) return -5;
         BY(e, 4.0 * NP * p4.HW * (2 * kHeadMid + 2 * kFeat));
         launch_wgrad(e, s2, p, dim3(1, 2 * kFeat / 64, NP * cps4), K_HW0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid, 1, C_IDENT);
+        return 0;
+        };
+        PREC_DISPATCH(e, if (go(PTAG)) return -5);
     }
     {   // head conv0 data gradient + relu0 + norm0 sums
-        auto run = [&](auto tag) {
+        auto run = [&](auto tag, auto ptag) {
                 using Cfg = decltype(tag);
-                BwdDataP<Cfg, false, E_STORE> p{};
+                BwdDataP<Cfg, false, E_STORE, true, decltype(ptag)::value, true> p{};      // fp32 head buffers in every mode
         p.gbuf = e->DH1; p.ldg = kHeadMid; p.gcoff = 0; p.xbuf = e->H1; p.ldx = kHeadMid; p.xcoff = 0; p.pa = p4; p.KA = kHeadMid;
         p.xsum = fsum(e, e->st_H1); p.xsq = fsq(e, e->st_H1); p.xstride = kHeadMid;
         p.s1 = b1(e, e->bs_H1); p.s2 = b2(e, e->bs_H1); p.sstride = kHeadMid; p.scoff = 0; p.agamma = P + Hd.n1.w;
@@ -79,7 +83,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         BY(e, 4.0 * NP * p4.HW * (2 * kHeadMid + 2 * 2 * kFeat));
         launch_gemm(e, st, p, dim3(NP * p4.HWp / Cfg::BM, 2 * kFeat / Cfg::BN), K_HD0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid);
             };
-            if (p4.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
+            PREC_DISPATCH(e, if (p4.HWp % 128 == 0) run(CfgP128x128{}, PTAG); else run(CfgP64x128{}, PTAG));
     }
     {   // head norm0 backward + concat backward + norm5 backward -> G'_4
         Norm5BwdArgs a;
@@ -90,7 +94,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         a.G4 = e->G[3]; a.SA = b1(e, e->bs_X[3]); a.SB = b2(e, e->bs_X[3]);
         a.dbeta5 = Gr + T.norm5.b; a.dgamma5 = Gr + T.norm5.w; a.chunk = 16;
         ProfScope ps(e, st, K_OTHER, 0);
-        hipLaunchKernelGGL(norm5_bwd_kernel, dim3(1, NS, (p4.HW + 15) / 16), dim3(256), 0, st, a);
+        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(norm5_bwd_kernel<PREC>), dim3(1, NS, (p4.HW + 15) / 16), dim3(256), 0, st, a));
     }
     for (int b = 3; b >= 0; --b) {
         e->prof_stage = b;
@@ -98,7 +102,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         const int Ct = kBlockCtot[b];
         for (int i = (int)T.layers[b].size() - 1; i >= 0; --i) {
             const DenseLayerRef& d = T.layers[b][i];
-            float* bt = e->Bt + e->bt_off[b][i];
+            float* bt = el(e, e->Bt, e->bt_off[b][i]);
             const int db = layer_no % kRing;
             float* GSb = e->GS[db];
             float* D2b = e->D2[db];
@@ -109,7 +113,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             // slices (GradSrc with x set; SMG_GS_FUSED=1): one launch less on the dependency chain, but measured 0.5 ms
             // per step slower - two strided 128-B-per-pixel reads replace one dense one in both consumers.
             GradSrc gsrc{};
-            gsrc.g = e->G[b] + d.cin; gsrc.ldg = Ct; gsrc.x = e->X[b] + d.cin; gsrc.ldx = Ct;
+            gsrc.g = el(e, e->G[b], d.cin); gsrc.ldg = Ct; gsrc.x = el(e, e->X[b], d.cin); gsrc.ldx = Ct;
             gsrc.xsum = fsum(e, e->st_X[b]) + d.cin; gsrc.xsq = fsq(e, e->st_X[b]) + d.cin;
             gsrc.s1 = b1(e, e->bs_X[b]) + d.cin; gsrc.s2 = b2(e, e->bs_X[b]) + d.cin; gsrc.sstride = Ct; gsrc.eps = kEps;
             static const bool gs_env_fused = getenv("SMG_GS_FUSED") != nullptr;
@@ -123,7 +127,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 a.out = GSb; a.ldo = kGrowth;
                 BY(e, 4.0 * NS * pl.HW * 3 * kGrowth);
                 ProfScope ps(e, st, K_OTHER, 0);
-                hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(pl.HWp / 64, NS), dim3(256), 0, st, a);
+                PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_bwd_apply_kernel<PREC>), dim3(pl.HWp / 64, NS), dim3(256), 0, st, a));
                 if (gs_mat) { gsrc = GradSrc{}; gsrc.g = GSb; gsrc.ldg = kGrowth; }
             }
             if (fork(e->ev_gs[db])) return -5;
@@ -140,16 +144,16 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 if (halo_tile(pl, NS) == 16) {
                     static bool raised[64][3] = {};          // the 16x16 kernel needs more than the default 64 KB of dynamic LDS
                     if (!raised[e->device & 63][e->prec]) {
-                        PREC_DISPATCH(e, (void)hipFuncSetAttribute((const void*)conv3x3_halo_dgrad_kernel<16, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, HaloDgradSGeo<16>::smem_bytes(kBottleneck)));
+                        PREC_DISPATCH(e, (void)hipFuncSetAttribute((const void*)conv3x3_halo_dgrad_kernel<16, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, (HaloDgradSGeo<16, PREC>::smem_bytes(kBottleneck))));
                         raised[e->device & 63][e->prec] = true;
                     }
                     a.tiles_x = pl.W / 16; a.cg_per_wg = kBottleneck / 32;
                     PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_dgrad_kernel<16, PREC>), dim3((pl.H / 16) * a.tiles_x, NS), dim3(256),
-                                       HaloDgradSGeo<16>::smem_bytes(kBottleneck), st, a));
+                                       (HaloDgradSGeo<16, PREC>::smem_bytes(kBottleneck)), st, a));
                 } else {
                     a.tiles_x = (pl.W + 7) / 8; a.cg_per_wg = 1;      // small planes: one 64-channel group per workgroup
                     PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_dgrad_kernel<8, PREC>), dim3(((pl.H + 7) / 8) * a.tiles_x, NS, kBottleneck / 64), dim3(256),
-                                       HaloDgradSGeo<8>::smem_bytes(kBottleneck), st, a));
+                                       (HaloDgradSGeo<8, PREC>::smem_bytes(kBottleneck)), st, a));
                 }
             } else {   // conv2 (3x3) data gradient -> dy of relu2/norm2 (D2) + norm2 sums (generic implicit GEMM)
                 auto run = [&](auto tag) {
@@ -184,10 +188,10 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                     ProfScope ps(e, s2, K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
                     if (ts == 16) {
                         PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_wgrad_kernel<16, PREC>), dim3(groups, kBottleneck / 32, NS), dim3(256),
-                                                            HaloWgradSGeo<16>::smem_bytes(), s2, a));
+                                                            (HaloWgradSGeo<16, PREC>::smem_bytes()), s2, a));
                     } else {
                         PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_wgrad_kernel<8, PREC>), dim3(groups, kBottleneck / 32, NS), dim3(256),
-                                                            HaloWgradSGeo<8>::smem_bytes(), s2, a));
+                                                            (HaloWgradSGeo<8, PREC>::smem_bytes()), s2, a));
                     }
                 }
                 ReduceArgs r;
@@ -217,7 +221,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 if (!e->generic3x3) { a.dbeta = Gr + d.n2.b; a.dgamma = Gr + d.n2.w; }   // the halo dgrad leaves these to us
                 BY(e, 4.0 * NS * pl.HW * 3 * kBottleneck);
                 ProfScope ps(e, st, K_OTHER, 0);
-                hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(pl.HWp / 64, NS), dim3(256), 0, st, a);
+                PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_bwd_apply_kernel<PREC>), dim3(pl.HWp / 64, NS), dim3(256), 0, st, a));
             }
             if (fork(e->ev_d2[db])) return -5;
             // conv1 (1x1) data gradient -> relu1/norm1 backward accumulated into G'.  Layers are grouped (kGroup,
@@ -229,9 +233,9 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             const int g_lo = i - ((L - 1 - i) % kGroup == kGroup - 1 ? 0 : std::min(i, kGroup - 1 - (L - 1 - i) % kGroup));
             const int cs = T.layers[b][g_lo].cin;                       // channels below the group
             if (d.cin > cs) {                                           // [cs, cin): per-layer accumulate
-                auto run = [&](auto tag) {
+                auto run = [&](auto tag, auto ptag) {
                     using Cfg = decltype(tag);
-                    BwdDataP<Cfg, false, E_ACCUM, false> p{};
+                    BwdDataP<Cfg, false, E_ACCUM, false, decltype(ptag)::value> p{};
                     p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kBottleneck;
                     p.wp = e->packed_u + e->pk_d1[b][i]; p.K8tot = kBottleneck / 8; p.ldn = d.cin; p.wcol0 = cs; p.N = d.cin - cs;
                     p.mbuf = e->X[b]; p.ldm = Ct; p.mcoff = cs; p.pm = pl;
@@ -243,12 +247,12 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                     BY(e, 4.0 * NS * pl.HW * (kBottleneck + 3.0 * p.N));          // dy in; x in, G' read + written
                     launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, (p.N + Cfg::BN - 1) / Cfg::BN), K_D1, 2.0 * NS * pl.HW * p.N * kBottleneck);
                 };
-                if (pl.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
+                PREC_DISPATCH(e, if (pl.HWp % 128 == 0) run(CfgP128x64{}, PTAG); else run(CfgP64x64{}, PTAG));
             }
             if (i == g_lo) {                                            // [0, cs): the whole group at once
-                auto run = [&](auto tag) {
+                auto run = [&](auto tag, auto ptag) {
                     using Cfg = decltype(tag);
-                    BwdDataGroupP<Cfg> p{};
+                    BwdDataGroupP<Cfg, decltype(ptag)::value> p{};
                     const int g_hi = L - 1 - ((L - 1 - g_lo) / kGroup) * kGroup;      // top layer of this group
                     p.nseg = g_hi - g_lo + 1;
                     for (int k = 0; k < p.nseg; ++k) {                  // layer g_lo + k ran (k layers) before this one
@@ -266,7 +270,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                     BY(e, 4.0 * NS * pl.HW * ((double)p.nseg * kBottleneck + 3.0 * cs));
                     launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, (cs + Cfg::BN - 1) / Cfg::BN), K_D1, 2.0 * NS * pl.HW * cs * kBottleneck * p.nseg);
                 };
-                if (pl.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
+                PREC_DISPATCH(e, if (pl.HWp % 128 == 0) run(CfgP128x64{}, PTAG); else run(CfgP64x64{}, PTAG));
             }
             {   // conv1 weight gradient.  ~320 workgroups: it shares the chip with the data-gradient chain on the other
                 // stream, and every workgroup ends with 128 x 64 fp32 atomics (measured: atomics beat partial tiles here)
@@ -275,7 +279,8 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 int chunk, cps;
                 static const int w1_target = getenv("SMG_W1_WGS") ? atoi(getenv("SMG_W1_WGS")) : 320;            // dev A/B
                 pick_chunk(pl, NS, nt, chunk, cps, w1_target);   // 256..384 measure the same (22.46 ms per step), 512: 22.6, 768: 22.8, 1024: 23.2
-                BwdWeightP<Cfg, W_ONE, C_IDENT, SMG_PD_WGRAD, false> p{};
+                auto go = [&](auto ptag) {
+                BwdWeightP<Cfg, W_ONE, C_IDENT, SMG_PD_WGRAD, false, decltype(ptag)::value> p{};
                 p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck;
                 p.bbuf = e->X[b]; p.ldb = Ct; p.pb = pl; p.NB = d.cin;
                 p.bsum = fsum(e, e->st_X[b]); p.bsq = fsq(e, e->st_X[b]); p.bstride = Ct;
@@ -284,6 +289,8 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 p.dw = Gr + d.c1.w; p.ldw_out = d.cin;
                 BY(e, 4.0 * NS * pl.HW * (kBottleneck + d.cin));
                 launch_wgrad(e, s2, p, dim3(1, nt, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck, 1, C_IDENT, e->deterministic);
+                };
+                PREC_DISPATCH(e, go(PTAG));
                 HIP_OK(hipEventRecord(e->ev_side[db], s2));
             }
         }
@@ -293,7 +300,8 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             {
                 int chunk, cps;
                 pick_chunk(pl, NS, (C0 / 128) * (Cp / 128), chunk, cps);
-                BwdWeightP<CfgW128x128, W_POOL, C_IDENT, 1> p{};      // (one k-tile in flight: the pooling fetch holds 4 float4 per slot, three tiles of them leave one workgroup per CU)
+                auto go = [&](auto ptag) -> int {
+                BwdWeightP<CfgW128x128, W_POOL, C_IDENT, 1, true, decltype(ptag)::value> p{};      // (one k-tile in flight: the pooling fetch holds 4 float4 per slot, three tiles of them leave one workgroup per CU)
                 p.gbuf = e->G[b]; p.ldg = Ct; p.gcoff = 0; p.xbuf = e->X[b]; p.ldx = Ct; p.xcoff = 0; p.pa = pl; p.MA = C0;
                 p.xsum = fsum(e, e->st_X[b]); p.xsq = fsq(e, e->st_X[b]); p.xstride = Ct;
                 p.s1 = b1(e, e->bs_X[b]); p.s2 = b2(e, e->bs_X[b]); p.sstride = Ct; p.scoff = 0; p.agamma = nullptr;
@@ -305,15 +313,18 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 if (fork(e->ev_misc)) return -5;
                 BY(e, 4.0 * NS * (2.0 * pl.HW * C0 + (double)pp.HW * Cp));
                 launch_wgrad(e, s2, p, dim3(C0 / 128, Cp / 128, NS * cps), K_TW, 2.0 * NS * pl.HW * Cp * C0, 1, C_IDENT);
+                return 0;
+                };
+                PREC_DISPATCH(e, if (go(PTAG)) return -5);
             }
             if (pp.H != 2 * pl.H || pp.W != 2 * pl.W) {
                 ProfScope ps(e, st, K_OTHER, 0);
-                hipLaunchKernelGGL(zero_uncovered_kernel, dim3(256, NS), dim3(256), 0, st, e->G[b - 1], Cp, pp, 2 * pl.H, 2 * pl.W, Cp);
+                PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(zero_uncovered_kernel<PREC>), dim3(256, NS), dim3(256), 0, st, (void*)e->G[b - 1], Cp, pp, 2 * pl.H, 2 * pl.W, Cp));
             }
             {
-                auto run = [&](auto tag) {
+                auto run = [&](auto tag, auto ptag) {
                 using Cfg = decltype(tag);
-                BwdDataP<Cfg, false, E_UNPOOL> p{};
+                BwdDataP<Cfg, false, E_UNPOOL, true, decltype(ptag)::value> p{};
                 p.gbuf = e->G[b]; p.ldg = Ct; p.gcoff = 0; p.xbuf = e->X[b]; p.ldx = Ct; p.xcoff = 0; p.pa = pl; p.KA = C0;
                 p.xsum = fsum(e, e->st_X[b]); p.xsq = fsq(e, e->st_X[b]); p.xstride = Ct;
                 p.s1 = b1(e, e->bs_X[b]); p.s2 = b2(e, e->bs_X[b]); p.sstride = Ct; p.scoff = 0; p.agamma = nullptr;
@@ -327,7 +338,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 BY(e, 4.0 * NS * (2.0 * pl.HW * C0 + 2.0 * pp.HW * Cp));
                 launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, Cp / Cfg::BN), K_TD, 2.0 * NS * pl.HW * Cp * C0);
             };
-            run(CfgP64x128{});   // the 128-row variant of the unpool epilogue spills registers
+            PREC_DISPATCH(e, run(CfgP64x128{}, PTAG));   // the 128-row variant of the unpool epilogue spills registers
             }
         }
     }
@@ -346,13 +357,14 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         if (e->p_stem.H % 8 || e->p_stem.W % 8) return fail(-22, "stem plane must tile by 8 (input_size multiple of 16)");
         a.tiles_per_wg = 8;          // 4..20 measure the same; 1 costs 0.7 ms per step in atomics
         const int n_t = (e->p_stem.H / 8) * (e->p_stem.W / 8);
-        hipLaunchKernelGGL(pool0_bwd_kernel, dim3((n_t + a.tiles_per_wg - 1) / a.tiles_per_wg, NS), dim3(256), 0, st, a);
+        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(pool0_bwd_kernel<PREC>), dim3((n_t + a.tiles_per_wg - 1) / a.tiles_per_wg, NS), dim3(256), 0, st, a));
     }
     {   // conv0 weight gradient (no data gradient: the image needs none)
         const Plane ps_ = e->p_stem;
         int chunk, cps;
         pick_chunk(ps_, NS, 1, chunk, cps);
-        BwdWeightP<CfgW64x256, W_STEM, C_STEM> p{};
+        auto go = [&](auto ptag) -> int {
+        BwdWeightP<CfgW64x256, W_STEM, C_STEM, SMG_PD_WGRAD, true, decltype(ptag)::value> p{};      // (fp32 image / stem plane in every mode)
         p.gbuf = e->DY0; p.ldg = 64; p.gcoff = 0; p.xbuf = e->stem; p.ldx = 64; p.xcoff = 0; p.pa = ps_; p.MA = 64;
         p.xsum = fsum(e, e->st_stem); p.xsq = fsq(e, e->st_stem); p.xstride = 64;
         p.s1 = b1(e, e->bs_stem); p.s2 = b2(e, e->bs_stem); p.sstride = 64; p.scoff = 0; p.agamma = P + T.norm0.w;
@@ -362,6 +374,9 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         if (fork(e->ev_misc)) return -5;
         BY(e, 4.0 * NS * (2.0 * ps_.HW * 64 + (double)e->p_img.HW * 4));
         launch_wgrad(e, s2, p, dim3(1, 1, NS * cps), K_SW, 2.0 * NS * ps_.HW * 64 * 147, 1, C_STEM);
+        return 0;
+        };
+        PREC_DISPATCH(e, if (go(PTAG)) return -5);
     }
     HIP_OK(hipEventRecord(e->ev_end, s2));          // join: everything after the backward sees every gradient
     HIP_OK(hipStreamWaitEvent(st, e->ev_end, 0));

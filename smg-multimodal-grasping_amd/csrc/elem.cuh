@@ -95,6 +95,10 @@ static __global__ void prep_rotate_kernel(const PrepArgs a) {
 enum { PK_T1 = 0, PK_D1 = 1, PK_3F = 2, PK_3D = 3, PK_STEM = 4, PK_HEAD = 5, PK_HF = 6, PK_HD = 7 };
 struct PackDesc { int64_t src, dst; int cout, cin, mode, K8tot, N, count; };   // dst: unit offset (split modes) / float offset (fp32 modes)
 
+// prec: the engine's precision mode.  Operand kind of a pack: the forward packs (PK_T1, PK_STEM, PK_3F, PK_HF) take the
+// forward kind (3-piece split / bf16 / fp16), the data-gradient packs (PK_D1, PK_3D, PK_HD) the backward kind (split / bf16).
+// Single-piece kinds store ONE piece (the kernels copy a third of the bytes); the halo forward image then holds 32 channels
+// per chunk instead of 16 (halo_ck).
 static __global__ void pack_weights_kernel(const PackDesc* descs, const float* params, u32x4* packed_u, float* packed_f, const int prec) {
     const PackDesc d = descs[blockIdx.y];
     const float* s = params + d.src;
@@ -108,31 +112,40 @@ static __global__ void pack_weights_kernel(const PackDesc* descs, const float* p
         }
         return;
     }
+    const bool bwd = d.mode == PK_D1 || d.mode == PK_3D || d.mode == PK_HD;
+    const int op = bwd ? (prec ? 1 : 0) : prec;    // 0 split, 1 bf16, 2 fp16
+    const int np = op ? 1 : NPIECE;
     const int total = d.K8tot * d.N;               // units per piece
     u32x4* o = packed_u + d.dst;
+    auto put = [&](const float (&v)[8], int64_t base, int64_t pstride) {
+        const float4 v0 = make_float4(v[0], v[1], v[2], v[3]), v1 = make_float4(v[4], v[5], v[6], v[7]);
+        const Split4 lo = op == 0 ? split4<0>(v0) : op == 1 ? split4<1>(v0) : split4<2>(v0);
+        const Split4 hi = op == 0 ? split4<0>(v1) : op == 1 ? split4<1>(v1) : split4<2>(v1);
+#pragma unroll
+        for (int pc = 0; pc < NPIECE; ++pc)
+            if (pc < np) o[base + pc * pstride] = u32x4{lo.p[pc].x, lo.p[pc].y, hi.p[pc].x, hi.p[pc].y};
+    };
     if (d.mode == PK_HF || d.mode == PK_HD) {
         // LDS-halo 3x3 kernels: the image of one stage, per stage (halo.cuh)
-        //   PK_HF forward       [chunk = c/16][piece][tap][k8 (2)][n (32)]   unit = 8 input channels c of output channel n
-        //   PK_HD data gradient [cgroup = c/32][tap][piece][k8 (4)][c (32)]  unit = 8 output channels n of input channel c
+        //   PK_HF forward       [chunk = c/CK][piece][tap][k8 (CK/8)][n (32)]  unit = 8 input channels c of output channel n
+        //   PK_HD data gradient [cgroup = c/32][tap][piece][k8 (4)][c (32)]    unit = 8 output channels n of input channel c
+        const int k8c = (prec ? 32 : 16) / 8;      // halo_ck(prec) / 8
         for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
             float v[8];
             int64_t base, pstride;
             if (d.mode == PK_HF) {
-                const int n = e & 31, k8 = (e >> 5) & 1, tap = (e >> 6) % 9, chunk = e / 576;
+                const int n = e & 31, k8 = (e >> 5) % k8c, tap = (e / (32 * k8c)) % 9, chunk = e / (9 * 32 * k8c);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = s[((int64_t)n * d.cin + chunk * 16 + 8 * k8 + j) * 9 + tap];
-                base = ((int64_t)chunk * NPIECE * 9 + tap) * 64 + k8 * 32 + n; pstride = 9 * 64;
+                for (int j = 0; j < 8; ++j) v[j] = s[((int64_t)n * d.cin + chunk * 8 * k8c + 8 * k8 + j) * 9 + tap];
+                pstride = 9 * k8c * 32;
+                base = ((int64_t)chunk * np * 9 + tap) * (k8c * 32) + k8 * 32 + n;
             } else {
                 const int c = e & 31, k8 = (e >> 5) & 3, tap = (e >> 7) % 9, cg = e / 1152;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = s[((int64_t)(8 * k8 + j) * d.cin + cg * 32 + c) * 9 + tap];
-                base = (((int64_t)cg * 9 + tap) * NPIECE) * 128 + k8 * 32 + c; pstride = 128;
+                base = (((int64_t)cg * 9 + tap) * np) * 128 + k8 * 32 + c; pstride = 128;
             }
-            const float4 v0 = make_float4(v[0], v[1], v[2], v[3]), v1 = make_float4(v[4], v[5], v[6], v[7]);
-            const Split4 lo = prec == 0 ? split4<0>(v0) : prec == 1 ? split4<1>(v0) : split4<2>(v0);
-            const Split4 hi = prec == 0 ? split4<0>(v1) : prec == 1 ? split4<1>(v1) : split4<2>(v1);
-#pragma unroll
-            for (int pc = 0; pc < NPIECE; ++pc) o[base + pc * pstride] = u32x4{lo.p[pc].x, lo.p[pc].y, hi.p[pc].x, hi.p[pc].y};
+            put(v, base, pstride);
         }
         return;
     }
@@ -157,11 +170,7 @@ static __global__ void pack_weights_kernel(const PackDesc* descs, const float* p
                 v[j] = (c < 3 && tap < 49) ? s[((int64_t)n * 3 + c) * 49 + tap] : 0.f;
             }
         }
-        const float4 v0 = make_float4(v[0], v[1], v[2], v[3]), v1 = make_float4(v[4], v[5], v[6], v[7]);
-            const Split4 lo = prec == 0 ? split4<0>(v0) : prec == 1 ? split4<1>(v0) : split4<2>(v0);
-            const Split4 hi = prec == 0 ? split4<0>(v1) : prec == 1 ? split4<1>(v1) : split4<2>(v1);
-#pragma unroll
-        for (int pc = 0; pc < NPIECE; ++pc) o[(int64_t)pc * total + e] = u32x4{lo.p[pc].x, lo.p[pc].y, hi.p[pc].x, hi.p[pc].y};
+        put(v, e, total);
     }
 }
 
@@ -195,12 +204,14 @@ struct Pool0Args {
     const float* stem; Plane ps;           // [n][HWp][64]
     const double* ssum; const double* ssq;  // [n][64]
     const float* gamma; const float* beta; float eps;
-    float* x1; int ldx; Plane po;
+    void* x1; int ldx; Plane po;            // block-1 buffer (activation storage of the mode)
     double* dsum; double* dsq; int dstride;
     unsigned char* argmax;                  // [n][po.HWp][64]
 };
 
+template <int PREC>
 static __global__ __launch_bounds__(256) void pool0_kernel(const Pool0Args a) {
+    using XT = act_t<PREC>;
     __shared__ float prm[192];
     __shared__ double red[2][16][64];
     const int n = blockIdx.y, t = threadIdx.x, cq = t & 15, slot = t >> 4;
@@ -229,7 +240,7 @@ static __global__ __launch_bounds__(256) void pool0_kernel(const Pool0Args a) {
                 if (vv[c] > best[c]) { best[c] = vv[c]; bi[c] = k; }
         }
         const int64_t o = (int64_t)n * a.po.HWp + p;
-        *reinterpret_cast<float4*>(a.x1 + o * a.ldx + 4 * cq) = make_float4(best[0], best[1], best[2], best[3]);
+        stq<XT>(a.x1, o * a.ldx + 4 * cq, make_float4(best[0], best[1], best[2], best[3]));
         if (a.argmax) *reinterpret_cast<uchar4*>(a.argmax + o * 64 + 4 * cq) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
 #pragma unroll
         for (int c = 0; c < 4; ++c) { s[c] += (double)best[c]; ss[c] += (double)best[c] * (double)best[c]; }
@@ -251,7 +262,7 @@ static __global__ __launch_bounds__(256) void pool0_kernel(const Pool0Args a) {
 // per-(pair, channel) statistics the head's norm0 needs.
 // ------------------------------------------------------------------------------------
 struct FeatArgs {
-    const float* x4; Plane p4;              // [n][HWp][1024]
+    const void* x4; Plane p4;               // [n][HWp][1024] (activation storage of the mode)
     const double* xsum; const double* xsq;  // [n][1024]
     const float* gamma; const float* beta; float eps;   // norm5
     const int* pair_a; const int* pair_b;
@@ -260,7 +271,9 @@ struct FeatArgs {
     int chunk;
 };
 
+template <int PREC>
 static __global__ __launch_bounds__(256) void feat_kernel(const FeatArgs a) {
+    using XT = act_t<PREC>;
     const int j = blockIdx.y, cq = blockIdx.x * 256 + threadIdx.x;   // channel quad of 2048/4
     const int ch = 4 * cq, slot = ch >> 10, c5 = ch & 1023;
     const int s = slot ? a.pair_b[j] : a.pair_a[j];
@@ -276,7 +289,7 @@ static __global__ __launch_bounds__(256) void feat_kernel(const FeatArgs a) {
     const int p0 = blockIdx.z * a.chunk;
     const int p1 = min(p0 + a.chunk, a.p4.HW);
     for (int p = p0; p < p1; ++p) {
-        const float4 v = ld4(a.x4 + ((int64_t)s * a.p4.HWp + p) * 1024 + c5);
+        const float4 v = ldq<XT>(a.x4, ((int64_t)s * a.p4.HWp + p) * 1024 + c5);
         float4 o;
         o.x = bn1(v.x, mu[0], sc[0], be[0]); o.y = bn1(v.y, mu[1], sc[1], be[1]);
         o.z = bn1(v.z, mu[2], sc[2], be[2]); o.w = bn1(v.w, mu[3], sc[3], be[3]);
@@ -419,16 +432,19 @@ struct Norm5BwdArgs {
     const double* fsum; const double* fsq;          // F statistics [pair][2048]
     const double* f1; const double* f2;             // sums of dy0, dy0*xhat [pair][2048]
     const float* hgamma;                            // head norm0 gamma [2048]
-    const float* x4; const double* xsum; const double* xsq;   // [n][HWp][1024], [n][1024]
+    const void* x4; const double* xsum; const double* xsq;    // [n][HWp][1024] (activation storage), [n][1024]
     const float* gamma5; float eps;
     const int* user_ptr; const int* user_pair; const int* user_slot;  // CSR over streams
-    float* G4;                                      // [n][HWp][1024]
+    void* G4;                                       // [n][HWp][1024] (gradient storage of the mode)
     double* SA; double* SB;                         // [n][1024]
     float* dbeta5; float* dgamma5;
     int chunk;
 };
 
+template <int PREC>
 static __global__ __launch_bounds__(256) void norm5_bwd_kernel(const Norm5BwdArgs a) {
+    using XT = act_t<PREC>;
+    using GT = grd_t<PREC>;
     const int s = blockIdx.y, c5 = 4 * threadIdx.x;      // 256 threads x 4 = 1024 channels
     const int p0 = blockIdx.z * a.chunk, p1 = min(p0 + a.chunk, a.p4.HW);
     const double inv = 1.0 / (double)a.p4.HW;
@@ -466,7 +482,7 @@ static __global__ __launch_bounds__(256) void norm5_bwd_kernel(const Norm5BwdArg
                 const int64_t fr = ((int64_t)j * a.p4.HWp + p) * 2048 + ch;
                 const float4 d = affine2(ld4(a.DF + fr), ld4(a.F + fr), cf, 4);
                 const int64_t xr = ((int64_t)s * a.p4.HWp + p) * 1024 + c5;
-                const float4 xv = ld4(a.x4 + xr);
+                const float4 xv = ldq<XT>(a.x4, xr);
                 const float dd[4] = {d.x, d.y, d.z, d.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
                 gacc[q].x += g5[0] * dd[0]; gacc[q].y += g5[1] * dd[1]; gacc[q].z += g5[2] * dd[2]; gacc[q].w += g5[3] * dd[3];
 #pragma unroll
@@ -476,7 +492,7 @@ static __global__ __launch_bounds__(256) void norm5_bwd_kernel(const Norm5BwdArg
     }
 #pragma unroll
     for (int q = 0; q < CH; ++q)
-        if (p0 + q < p1) *reinterpret_cast<float4*>(a.G4 + ((int64_t)s * a.p4.HWp + p0 + q) * 1024 + c5) = gacc[q];
+        if (p0 + q < p1) stq<GT>(a.G4, ((int64_t)s * a.p4.HWp + p0 + q) * 1024 + c5, gacc[q]);
     if (u0 == u1) return;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -494,7 +510,7 @@ static __global__ __launch_bounds__(256) void norm5_bwd_kernel(const Norm5BwdArg
 // the <= 4 pooled windows covering it and takes those whose argmax points at it.
 // ------------------------------------------------------------------------------------
 struct Pool0BwdArgs {
-    const float* G1; const float* X1; int ld1; Plane p1;     // block-1 buffers
+    const void* G1; const void* X1; int ld1; Plane p1;       // block-1 buffers (gradient / activation storage of the mode)
     const double* xsum; const double* xsq; int xstride;      // block-1 stats
     const double* SA; const double* SB; int sstride;
     const unsigned char* argmax;                             // [n][p1.HWp][64]
@@ -507,7 +523,10 @@ struct Pool0BwdArgs {
     int tiles_per_wg;                                        // consecutive 8x8 tiles per workgroup (one flush of the sums)
 };
 
+template <int PREC>
 static __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArgs a) {
+    using XT = act_t<PREC>;
+    using GT = grd_t<PREC>;
     // Workgroup = an 8x8 tile of stem pixels x 64 channels.  The <= 5x5 pooled pixels whose windows
     // cover the tile are finalised (BN-backward-corrected) ONCE into LDS together with their argmax;
     // every stem pixel then picks its <= 4 windows from LDS.  (The gather straight from global memory
@@ -557,8 +576,8 @@ static __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArg
         const int wy = wy0 + pp / 5, wx = wx0 + pp % 5;
         okq[k] = item < 400 && wy < a.p1.H && wx < a.p1.W;
         const int64_t pr = (int64_t)n * a.p1.HWp + (okq[k] ? wy * a.p1.W + wx : 0);
-        gq[k] = ld4(a.G1 + pr * a.ld1 + 4 * q);
-        xq[k] = ld4(a.X1 + pr * a.ld1 + 4 * q);
+        gq[k] = ldq<GT>(a.G1, pr * a.ld1 + 4 * q);
+        xq[k] = ldq<XT>(a.X1, pr * a.ld1 + 4 * q);
         aq[k] = *reinterpret_cast<const uchar4*>(a.argmax + pr * 64 + 4 * q);
     }
     __syncthreads();                                        // prm ready; previous tile's gl / al consumed
@@ -618,18 +637,21 @@ static __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArg
 // weight-gradient GEMMs that follow then stream ONE array instead of two.
 // ------------------------------------------------------------------------------------
 struct BnBwdApplyArgs {
-    const float* g; int ldg, gcoff;
-    const float* x; int ldx, xcoff;
+    const void* g; int ldg, gcoff;                // gradient storage of the mode
+    const void* x; int ldx, xcoff;                // activation storage of the mode
     Plane pl; int C;
     const double* xsum; const double* xsq; int xstride;
     const double* s1; const double* s2; int sstride, scoff;
     const float* gamma; float eps;
-    float* out; int ldo;
+    void* out; int ldo;
     float* dbeta; float* dgamma;                  // if set: the affine gradients, dbeta += sum_n s1[n], dgamma += sum_n s2[n]
                                                   // (one fp32 atomic per stream and channel instead of one per producer tile)
 };
 
+template <int PREC>
 static __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs a) {
+    using XT = act_t<PREC>;
+    using GT = grd_t<PREC>;
     __shared__ float prm[4 * 128];
     const int n = blockIdx.y, t = threadIdx.x;
     const int qpr = a.C / 4;                      // float4 per row
@@ -645,8 +667,8 @@ static __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApp
         const int r = r0 + k * rows_per_pass;
         if (k * rows_per_pass >= 64) break;            // (workgroup-uniform: C = 32 uses two slots, C = 128 all eight)
         const int64_t pix = (int64_t)n * a.pl.HWp + (r < a.pl.HW ? r : 0);
-        gv[k] = ld4(a.g + pix * a.ldg + a.gcoff + 4 * cq);
-        xv[k] = ld4(a.x + pix * a.ldx + a.xcoff + 4 * cq);
+        gv[k] = ldq<GT>(a.g, pix * a.ldg + a.gcoff + 4 * cq);
+        xv[k] = ldq<XT>(a.x, pix * a.ldx + a.xcoff + 4 * cq);
     }
     if (t < a.C) {
         const double inv = 1.0 / (double)a.pl.HW;
@@ -668,20 +690,22 @@ static __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApp
         const int r = r0 + k * rows_per_pass;
         if (k * rows_per_pass < 64 && r < a.pl.HW) {
             const int64_t pix = (int64_t)n * a.pl.HWp + r;
-            *reinterpret_cast<float4*>(a.out + pix * a.ldo + 4 * cq) = affine2(gv[k], xv[k], prm + 4 * cq, a.C);
+            stq<GT>(a.out, pix * a.ldo + 4 * cq, affine2(gv[k], xv[k], prm + 4 * cq, a.C));
         }
     }
 }
 
 // Zero the rows/columns of a gradient plane that an odd-sized 2x2/stride-2 average
 // pool never reads (they receive no gradient from the transition).
-static __global__ void zero_uncovered_kernel(float* G, int ld, Plane p, int Hc, int Wc, int C) {
+template <int PREC>
+static __global__ void zero_uncovered_kernel(void* G, int ld, Plane p, int Hc, int Wc, int C) {
+    using GT = grd_t<PREC>;
     const int n = blockIdx.y;
     const int64_t total = (int64_t)p.HW * (C / 4);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int pix = (int)(i / (C / 4)), cq = (int)(i - (int64_t)pix * (C / 4));
         const int y = pix / p.W, x = pix - y * p.W;
-        if (y >= Hc || x >= Wc) *reinterpret_cast<float4*>(G + ((int64_t)n * p.HWp + pix) * ld + 4 * cq) = zero4();
+        if (y >= Hc || x >= Wc) stq<GT>(G, ((int64_t)n * p.HWp + pix) * ld + 4 * cq, zero4());
     }
 }
 

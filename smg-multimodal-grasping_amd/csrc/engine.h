@@ -89,8 +89,10 @@ struct smg_engine {
     const Layout* L = nullptr;
 
     // activations
+    // (X, Bt, G, GS, D2 hold fp32 elements in mode 0 and 16-bit elements in modes 1 / 2: they are allocated for fp32 and
+    // addressed through el(); everything else is fp32 in every mode)
     float* img4 = nullptr; float* stem = nullptr; float* X[4] = {}; float* Bt = nullptr;
-    std::vector<int64_t> bt_off[4];          // float offset of each layer's bottleneck buffer
+    std::vector<int64_t> bt_off[4];          // ELEMENT offset of each layer's bottleneck buffer
     unsigned char* argmax = nullptr;
     float* F = nullptr; float* H1 = nullptr;
     // gradients
@@ -127,7 +129,7 @@ struct smg_engine {
     int so_image = 0, so_rot = 0, so_pa = 0, so_pb = 0, so_seq_t = 0, so_seq_h = 0, so_uptr = 0, so_upair = 0, so_uslot = 0, so_aff = 0, so_ma = 0, so_mb = 0;
     int64_t workspace_bytes = 0;
     int n_cu = 256;            // compute units of the device (persistent-launch sizing)
-    int prec = 0;              // operand precision of the matrix products: 0 fp32-class split, 1 bf16, 2 fp16 (smg_engine_set_precision)
+    int prec = 0;              // precision mode: 0 fp32 storage + fp32-class split products, 1 bf16 storage, 2 fp16 activations + bf16 gradients (smg_engine_set_precision)
     bool serialize = false;       // smg_engine_set_option("serialize"): every launch on the caller's stream in issue order (profiling: a trace's
                                   // per-kernel durations are not inflated by a kernel of the other chain sharing the chip)
     bool deterministic = false;   // smg_engine_set_option("deterministic"): 1x1 weight gradients as partial tiles + fixed-order reduce instead of fp32 atomics
@@ -203,7 +205,9 @@ struct ProfScope {
     }
 };
 
-// Runs CALL with a compile-time PREC equal to the engine's run-time precision setting.
+// Runs CALL with a compile-time PREC equal to the engine's run-time precision mode (0 fp32-class, 1 bf16 storage, 2 fp16
+// activations + bf16 gradients; gemm.cuh).  PTAG is PREC as a type, for generic lambdas that build a policy.
+#define PTAG std::integral_constant<int, PREC>{}
 #define PREC_DISPATCH(e, CALL)                                            \
     switch ((e)->prec) {                                                  \
         case 1: { constexpr int PREC = 1; CALL; } break;                  \
@@ -252,12 +256,12 @@ struct TraceScope {
 
 template <class P>
 static void launch_gemm(smg_engine* e, hipStream_t st, P p, dim3 grid, int kind, double flops) {
-    const size_t smem = (size_t)(P::Cfg::TILE_FLOATS + p.param_floats()) * sizeof(float);
+    const size_t smem = (size_t)(GeoOf<P>::TILE_FLOATS + p.param_floats()) * sizeof(float);
     if (smem > 64 * 1024) {      // more dynamic LDS than the default limit: raise it once per (instantiation, device)
-        static bool raised[64][3] = {};
-        if (!raised[e->device & 63][e->prec]) {
-            PREC_DISPATCH(e, (void)hipFuncSetAttribute((const void*)gemm_kernel<P, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised[e->device & 63][e->prec] = true;
+        static bool raised[64] = {};
+        if (!raised[e->device & 63]) {
+            (void)hipFuncSetAttribute((const void*)gemm_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised[e->device & 63] = true;
         }
     }
     p.tm = TileMap{0, 0, 0};
@@ -277,7 +281,7 @@ static void launch_gemm(smg_engine* e, hipStream_t st, P p, dim3 grid, int kind,
     TraceScope ts(st, kind, grid);
     {
         ProfScope ps(e, st, kind, flops);
-        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_kernel<P, PREC>), dim3((unsigned)(grid.x * grid.y * grid.z)), dim3(256), smem, st, p, (int)grid.x, (int)grid.y));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_kernel<P>), dim3((unsigned)(grid.x * grid.y * grid.z)), dim3(256), smem, st, p, (int)grid.x, (int)grid.y);
     }
 }
 
@@ -301,6 +305,10 @@ static void launch_wgrad(smg_engine* e, hipStream_t st, P& p, dim3 grid, int kin
     }
 }
 
+// element `elems` of a mode-typed buffer (X, Bt, G, GS, D2): 4-byte elements in mode 0, 2-byte elements in modes 1 / 2
+static inline float* el(const smg_engine* e, float* base, int64_t elems) {
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (e->prec ? 2 : 4) * elems);
+}
 static inline double* fsum(smg_engine* e, const StatArr& s) { return e->fstat + s.off; }
 static inline double* fsq(smg_engine* e, const StatArr& s) { return e->fstat + e->fstat_span + s.off; }
 static inline double* b1(smg_engine* e, const StatArr& s) { return e->bstat + s.off; }

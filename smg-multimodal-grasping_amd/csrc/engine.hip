@@ -326,7 +326,8 @@ int smg_backward(smg_engine* e, const smg_net* net, const float* dq_dev, void* s
 
 int smg_engine_set_precision(smg_engine* e, int precision) {
     if (!e) return fail(-22, "engine is NULL");
-    if (precision < 0 || precision > 2) return fail(-22, "precision must be 0 (fp32-class split), 1 (bf16 operands) or 2 (fp16 operands)");
+    if (precision < 0 || precision > 2) return fail(-22, "precision must be 0 (fp32 storage, fp32-class split products), 1 (bf16 storage) or 2 (fp16 activations, bf16 gradients)");
+    if (precision && e->generic3x3) return fail(-22, "SMG_GENERIC_3X3 (the generic implicit-GEMM 3x3 path) exists in the fp32-class mode only");
     e->prec = precision;
     e->have_fwd = false;        // activations saved by a forward of another precision are not backward-compatible
     return 0;
@@ -412,7 +413,28 @@ int64_t smg_debug_read(smg_engine* e, const char* name, float* host_out, int64_t
     if (cap < n) n = cap;
     HIP_OK(hipSetDevice(e->device));
     HIP_OK(hipStreamSynchronize((hipStream_t)stream));
-    HIP_OK(hipMemcpy(host_out, src, n * sizeof(float), hipMemcpyDeviceToHost));
+    const bool typed = e->prec != 0 && (s[0] == 'x' || s[0] == 'g' || s.substr(0, 2) == "bt");   // 16-bit storage in modes 1 / 2
+    if (!typed) {
+        HIP_OK(hipMemcpy(host_out, src, n * sizeof(float), hipMemcpyDeviceToHost));
+        return n;
+    }
+    std::vector<unsigned short> raw((size_t)n);
+    HIP_OK(hipMemcpy(raw.data(), src, n * sizeof(unsigned short), hipMemcpyDeviceToHost));
+    const bool f16 = e->prec == 2 && s[0] != 'g';               // activations of mode 2; gradients are bf16 in both 16-bit modes
+    for (int64_t i = 0; i < n; ++i) {
+        unsigned u;
+        const unsigned h = raw[(size_t)i];
+        if (!f16) u = h << 16;
+        else {
+            const unsigned sign = (h & 0x8000u) << 16, ex = (h >> 10) & 31u, man = h & 1023u;
+            if (ex == 0) {
+                float v = (float)man * (1.0f / 16777216.0f);        // subnormal: man * 2^-24
+                std::memcpy(&u, &v, 4); u |= sign;
+            } else if (ex == 31) u = sign | 0x7F800000u | (man << 13);
+            else u = sign | ((ex + 112u) << 23) | (man << 13);
+        }
+        std::memcpy(&host_out[i], &u, 4);
+    }
     return n;
 }
 

@@ -86,7 +86,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
     auto trunk_chain = [&](const int s0, const int ns, hipStream_t cs, const int u_lo, const int u_hi) -> int {
         int unit = 0;
         auto on = [&]() { const bool r = unit >= u_lo && unit < u_hi; ++unit; return r; };
-        auto xs = [&](int b) { return e->X[b] + (int64_t)s0 * e->p_blk[b].HWp * kBlockCtot[b]; };
+        auto xs = [&](int b) { return el(e, e->X[b], (int64_t)s0 * e->p_blk[b].HWp * kBlockCtot[b]); };
         auto st_off = [&](double* base, int stride) { return base + (int64_t)s0 * stride; };
         float* img4 = e->img4 + (int64_t)s0 * e->p_img.HWp * 4;
         float* stem = e->stem + (int64_t)s0 * e->p_stem.HWp * 64;
@@ -102,9 +102,9 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
             hipLaunchKernelGGL(prep_rotate_kernel, dim3((e->S * e->S + 255) / 256, ns), dim3(256), 0, cs, a);
         }
         if (head_unit) {   // stem conv0 7x7/2
-            auto run = [&](auto tag) {
+            auto run = [&](auto tag, auto ptag) {
                 using Cfg = decltype(tag);
-                FwdConvP<Cfg, F_STEM> p{};
+                FwdConvP<Cfg, F_STEM, decltype(ptag)::value> p{};
                 p.src = img4; p.lds_ = 4; p.ps = e->p_img; p.po = e->p_stem; p.K = 0;
                 p.wp = e->packed_u + e->pk_conv0; p.K8tot = 224 / 8; p.N = 64;
                 p.dst = stem; p.ldd = 64; p.dcoff = 0;
@@ -112,7 +112,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                 BY(e, 4.0 * ns * ((double)e->p_img.HW * 4 + (double)e->p_stem.HW * 64));
                 launch_gemm(e, cs, p, dim3(ns * e->p_stem.HWp / Cfg::BM, 1), K_STEM, 2.0 * ns * e->p_stem.HW * 64 * 147);
             };
-            if (e->p_stem.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
+            PREC_DISPATCH(e, if (e->p_stem.HWp % 128 == 0) run(CfgP128x64{}, PTAG); else run(CfgP64x64{}, PTAG));
         }
         if (head_unit) {   // norm0 + relu0 + pool0
             Pool0Args a;
@@ -122,7 +122,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
             a.dsum = st_off(fsum(e, e->st_X[0]), kBlockCtot[0]); a.dsq = st_off(fsq(e, e->st_X[0]), kBlockCtot[0]); a.dstride = kBlockCtot[0];
             a.argmax = e->argmax + (int64_t)s0 * e->p_blk[0].HWp * 64;
             ProfScope ps(e, cs, K_OTHER, 0);
-            hipLaunchKernelGGL(pool0_kernel, dim3(e->p_blk[0].HWp / 64, ns), dim3(256), 0, cs, a);
+            PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(pool0_kernel<PREC>), dim3(e->p_blk[0].HWp / 64, ns), dim3(256), 0, cs, a));
         }
         for (int b = 0; b < 4; ++b) {
             e->prof_stage = b;
@@ -132,14 +132,14 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
             for (size_t i = 0; i < T.layers[b].size(); ++i) {
                 if (!on()) continue;
                 const DenseLayerRef& d = T.layers[b][i];
-                float* bt = e->Bt + e->bt_off[b][i] + (int64_t)s0 * pl.HWp * kBottleneck;
+                float* bt = el(e, e->Bt, e->bt_off[b][i] + (int64_t)s0 * pl.HWp * kBottleneck);
                 double* bsum = st_off(fsum(e, e->st_Bt[b][i]), kBottleneck); double* bsq = st_off(fsq(e, e->st_Bt[b][i]), kBottleneck);
                 {   // norm1 + relu + conv1 (1x1, cin -> 128)
                     const BnTab t1 = bn_table(e, e->sx_tab[b], e->max_streams, s0, Ct, P + d.n1.w, P + d.n1.b);
                     if (i == 0) bn_stat(cs, t1, ns, xsum, xsq, Ct, 0, d.cin, pl.HW);     // block input: from pool0 / the transition
-                    auto run = [&](auto tag) {
+                    auto run_p = [&](auto tag, auto ptag) {
                         using Cfg = decltype(tag);
-                        FwdConvP<Cfg, F_ONE> p{};
+                        FwdConvP<Cfg, F_ONE, decltype(ptag)::value> p{};
                         p.src = xs(b); p.lds_ = Ct; p.ps = pl; p.po = pl; p.K = d.cin;
                         p.bt = t1; p.fresh0 = i == 0 ? d.cin : d.cin - kGrowth; p.fsum = xsum; p.fsq = xsq; p.fstride = Ct; p.eps = kEps;
                         p.tw_mean = const_cast<float*>(t1.mean); p.tw_invstd = const_cast<float*>(t1.invstd);
@@ -149,6 +149,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                         BY(e, 4.0 * ns * pl.HW * (d.cin + kBottleneck));
                         launch_gemm(e, cs, p, dim3(ns * pl.HWp / Cfg::BM, kBottleneck / Cfg::BN), K_C1, 2.0 * ns * pl.HW * d.cin * kBottleneck);
                     };
+                    auto run = [&](auto tag) { PREC_DISPATCH(e, run_p(tag, PTAG)); };
                     // 128x128 tiles where the plane tiles by 128 rows and the launch still fills the chip; else 64x64 (BK = 32) -
                     // and when even that leaves most CUs idle (few streams per call, or the 20x20 planes), 32x64 tiles with
                     // the k-tile split over wave pairs: twice the workgroups, half the serial K chain.
@@ -158,7 +159,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                     static const int mid = getenv("SMG_C1_MID") ? atoi(getenv("SMG_C1_MID")) : 0;                     // dev A/B
                     static const int deep_min = getenv("SMG_C1_DEEP") ? atoi(getenv("SMG_C1_DEEP")) : 1 << 30;       // dev A/B
                     static const bool ws_on = !(getenv("SMG_C1_WS") && atoi(getenv("SMG_C1_WS")) == 0);      // wave-specialised 64x64x32 (ws.cuh); SMG_C1_WS=0: the generic kernel (A/B, cross-check)
-                    if (ws_on && !(pl.HWp % 128 == 0 && wg128 >= small_wgs) && wg64 >= small_wgs && d.cin % 32 == 0 && pl.HWp % 64 == 0) {
+                    if (ws_on && e->prec == 0 && !(pl.HWp % 128 == 0 && wg128 >= small_wgs) && wg64 >= small_wgs && d.cin % 32 == 0 && pl.HWp % 64 == 0) {
                         Fwd1x1WsArgs a{};
                         a.src = xs(b); a.lds_ = Ct; a.pl = pl; a.K = d.cin;
                         a.bt = t1; a.fresh0 = i == 0 ? d.cin : d.cin - kGrowth; a.fsum = xsum; a.fsq = xsq; a.fstride = Ct; a.eps = kEps;
@@ -170,12 +171,12 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                         BY(e, 4.0 * ns * pl.HW * (d.cin + kBottleneck));
                         ProfScope ps(e, cs, K_C1, 2.0 * ns * pl.HW * d.cin * kBottleneck);
                         const size_t smem = WsGeo::smem_bytes(d.cin);
-                        static bool raised[64][3] = {};
-                        if (!raised[e->device & 63][e->prec]) {
-                            PREC_DISPATCH(e, (void)hipFuncSetAttribute((const void*)conv1x1_fwd_ws_kernel<PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                            raised[e->device & 63][e->prec] = true;
+                        static bool raised[64] = {};
+                        if (!raised[e->device & 63]) {
+                            (void)hipFuncSetAttribute((const void*)conv1x1_fwd_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                            raised[e->device & 63] = true;
                         }
-                        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_fwd_ws_kernel<PREC>), dim3(8 * ((nM + 7) / 8) * nN), dim3(512), smem, cs, a));
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_fwd_ws_kernel<0>), dim3(8 * ((nM + 7) / 8) * nN), dim3(512), smem, cs, a);
                     } else
                     if (pl.HWp % 128 == 0 && wg128 >= small_wgs) run(CfgP128x128{});
                     else if (pl.HWp % 128 == 0 && wg128 >= deep_min && d.cin % 32 == 0) run(CfgP128x128d{});
@@ -202,11 +203,11 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                     if (halo_tile(pl, ns) == 16) {
                         a.tiles_x = pl.W / 16;
                         PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_fwd_kernel<16, PREC>), dim3((pl.H / 16) * a.tiles_x, ns), dim3(256),
-                                           HaloFwdSGeo<16>::smem_bytes(kBottleneck), cs, a));
+                                           (HaloFwdSGeo<16, PREC>::smem_bytes(kBottleneck)), cs, a));
                     } else {
                         a.tiles_x = (pl.W + 7) / 8;
                         PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_fwd_kernel<8, PREC>), dim3(((pl.H + 7) / 8) * a.tiles_x, ns), dim3(256),
-                                           HaloFwdSGeo<8>::smem_bytes(kBottleneck), cs, a));
+                                           (HaloFwdSGeo<8, PREC>::smem_bytes(kBottleneck)), cs, a));
                     }
                 } else {   // norm2 + relu + conv2 (3x3, 128 -> 32), appended to the block buffer (generic implicit GEMM)
                     auto run = [&](auto tag) {
@@ -228,9 +229,9 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                 const Plane pn = e->p_blk[b + 1];
                 const int Cn = kBlockCtot[b + 1];
                 const BnTab tt = bn_table(e, e->sx_tab[b], e->max_streams, s0, Ct, P + T.tnorm[b].w, P + T.tnorm[b].b);
-                auto run = [&](auto tag) {
+                auto run = [&](auto tag, auto ptag) {
                     using Cfg = decltype(tag);
-                    FwdConvP<Cfg, F_POOL> p{};
+                    FwdConvP<Cfg, F_POOL, decltype(ptag)::value> p{};
                     p.src = xs(b); p.lds_ = Ct; p.ps = pl; p.po = pn; p.K = Ct;
                     p.bt = tt; p.fresh0 = Ct - kGrowth; p.fsum = xsum; p.fsq = xsq; p.fstride = Ct; p.eps = kEps;     // the block's last layer
                     p.tw_mean = const_cast<float*>(tt.mean); p.tw_invstd = const_cast<float*>(tt.invstd);
@@ -240,7 +241,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                     BY(e, 4.0 * ns * ((double)pl.HW * Ct + (double)pn.HW * (Ct / 2)));
                     launch_gemm(e, cs, p, dim3(ns * pn.HWp / Cfg::BM, (Ct / 2) / Cfg::BN), K_TRANS, 2.0 * ns * pn.HW * Ct * (Ct / 2));
                 };
-                if (pn.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
+                PREC_DISPATCH(e, if (pn.HWp % 128 == 0) run(CfgP128x128{}, PTAG); else run(CfgP64x128{}, PTAG));
             }
         }
         return 0;
@@ -270,14 +271,14 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
         a.pair_a = e->d_pair_a; a.pair_b = e->d_pair_b; a.F = e->F;
         a.fsum = fsum(e, e->st_F); a.fsq = fsq(e, e->st_F); a.chunk = 64;
         ProfScope ps(e, st, K_OTHER, 0);
-        hipLaunchKernelGGL(feat_kernel, dim3(2, NP, (p4.HW + 63) / 64), dim3(256), 0, st, a);
+        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(feat_kernel<PREC>), dim3(2, NP, (p4.HW + 63) / 64), dim3(256), 0, st, a));
     }
     {   // head norm0 + relu + conv0 (1x1, 2048 -> 64)
         const BnTab th = bn_table(e, e->sf_tab, e->max_pairs, 0, 2 * kFeat, P + Hd.n0.w, P + Hd.n0.b);
         bn_stat(st, th, NP, fsum(e, e->st_F), fsq(e, e->st_F), 2 * kFeat, 0, 2 * kFeat, p4.HW);
-        auto run = [&](auto tag) {
+        auto run = [&](auto tag, auto ptag) {
                 using Cfg = decltype(tag);
-                FwdConvP<Cfg, F_ONE> p{};
+                FwdConvP<Cfg, F_ONE, decltype(ptag)::value, true> p{};      // fp32 feature buffers in every mode
         p.src = e->F; p.lds_ = 2 * kFeat; p.ps = p4; p.po = p4; p.K = 2 * kFeat;
         p.bt = th; p.fresh0 = 2 * kFeat; p.fsum = fsum(e, e->st_F); p.fsq = fsq(e, e->st_F); p.fstride = 2 * kFeat; p.eps = kEps;
         p.tw_mean = const_cast<float*>(th.mean); p.tw_invstd = const_cast<float*>(th.invstd);
@@ -287,7 +288,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
         BY(e, 4.0 * NP * p4.HW * (2 * kFeat + kHeadMid));
         launch_gemm(e, st, p, dim3(NP * p4.HWp / Cfg::BM, 1), K_HEAD0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid);
             };
-            if (p4.HWp % 128 == 0) run(CfgP128x64{}); else run(CfgP64x64{});
+            PREC_DISPATCH(e, if (p4.HWp % 128 == 0) run(CfgP128x64{}, PTAG); else run(CfgP64x64{}, PTAG));
     }
     {   // head norm1 + relu + conv1 (20x20 valid)
         ValueArgs a;

@@ -94,15 +94,30 @@ struct Plane { int H, W, HW, HWp; };
 // ------------------------------------------------------------------------------------
 // Split precision.
 // ------------------------------------------------------------------------------------
-constexpr int NPIECE = 3;
-// Operand precision of the matrix products (compile-time PREC of every MFMA kernel; smg_engine_set_precision picks the
-// instantiation):
-//   0  fp32-class: 3-piece bf16 split, six MFMA terms (default; what the parity suite gates)
-//   1  bf16 operands: the hi piece only, ONE v_mfma_f32_32x32x16_bf16 per product   (BASELINE.json config 3)
-//   2  fp16 operands: round-to-nearest fp16, ONE v_mfma_f32_32x32x16_f16 per product (config 5)
-// Activations, gradients, BN statistics and the accumulation stay fp32 in every mode.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr int NPIECE = 3;
+// Precision mode of an engine (compile-time PREC of every kernel; smg_engine_set_precision picks the instantiation):
+//   0  fp32 storage; every product a 3-piece bf16 split, six MFMA terms: fp32-class (default; what the parity suite gates)
+//   1  bf16 storage of activations AND gradients (dense-block buffers, bottlenecks, G', the backward ring), ONE
+//      v_mfma_f32_32x32x16_bf16 per product                                              (BASELINE.json config 3)
+//   2  fp16 storage of activations with fp16 forward products (v_mfma_f32_32x32x16_f16); gradients are stored and multiplied in
+//      bf16 (fp32 exponent range: no loss scaling, no underflow of small gradients)      (config 5)
+// In every mode BN statistics, every accumulation, the parameters, their gradients and Adam stay fp32 (fp64 for the sums).
+// Operand kind of one kernel's MFMAs (OP): 0 = 3-piece bf16 split, 1 = bf16, 2 = fp16.
+struct e_f32 { static constexpr int size = 4; };
+struct e_bf16 { static constexpr int size = 2; };
+struct e_f16 { static constexpr int size = 2; };
+template <int PREC> struct ActT { using type = e_f32; };          // storage type of activations
+template <> struct ActT<1> { using type = e_bf16; };
+template <> struct ActT<2> { using type = e_f16; };
+template <int PREC> struct GrdT { using type = e_f32; };          // storage type of activation gradients
+template <> struct GrdT<1> { using type = e_bf16; };
+template <> struct GrdT<2> { using type = e_bf16; };
+template <int PREC> using act_t = typename ActT<PREC>::type;
+template <int PREC> using grd_t = typename GrdT<PREC>::type;
+constexpr int fwd_op(int prec) { return prec; }                   // operand kind of the forward kernels
+constexpr int bwd_op(int prec) { return prec ? 1 : 0; }           // ... of the backward kernels (gradients are bf16 in both 16-bit modes)
 // bf16 pieces of 4 floats (element 0 in the low half of .x): 8 bytes per piece
 struct Split4 { uint2 p[NPIECE]; };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -124,11 +139,11 @@ __device__ __forceinline__ unsigned pack_f16(float lo_elem, float hi_elem) {
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
 // x = hi + mid + lo: the residuals x - hi and (x - hi) - mid are exact in fp32, the last one has <= 9 significant bits
-template <int PREC = 0>
+template <int OP = 0>
 __device__ __forceinline__ Split4 split4(float4 v) {
     Split4 o;
-    if constexpr (PREC != 0) {                           // single-piece modes
-        o.p[0] = PREC == 1 ? make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)) : make_uint2(pack_f16(v.x, v.y), pack_f16(v.z, v.w));
+    if constexpr (OP != 0) {                             // single-piece operands
+        o.p[0] = OP == 1 ? make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)) : make_uint2(pack_f16(v.x, v.y), pack_f16(v.z, v.w));
         o.p[1] = o.p[2] = make_uint2(0u, 0u);
         return o;
     }
@@ -149,11 +164,59 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, f32x
 __device__ __forceinline__ f32x16 mfma_f16(const u32x4& a, const u32x4& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
-// one term of a single-piece mode
-template <int PREC>
+// one term of a single-piece operand kind
+template <int OP>
 __device__ __forceinline__ f32x16 mfma_1p(const u32x4& a, const u32x4& b, f32x16 c) {
-    if constexpr (PREC == 2) return mfma_f16(a, b, c); else return mfma_bf16(a, b, c);
+    if constexpr (OP == 2) return mfma_f16(a, b, c); else return mfma_bf16(a, b, c);
 }
+// ---- typed element access: `base` + element index -> fp32 values, whatever the array stores ---------------------------
+__device__ __forceinline__ float f16_lo(unsigned u) { return (float)__builtin_bit_cast(f16x2, u).x; }
+__device__ __forceinline__ float f16_hi(unsigned u) { return (float)__builtin_bit_cast(f16x2, u).y; }
+template <class T> __device__ __forceinline__ float2 cvt2(unsigned u) {          // two packed 16-bit elements -> fp32
+    if constexpr (std::is_same<T, e_bf16>::value) return make_float2(bf16_lo(u), bf16_hi(u));
+    else return make_float2(f16_lo(u), f16_hi(u));
+}
+template <class T> __device__ __forceinline__ unsigned pack2(float a, float b) {
+    if constexpr (std::is_same<T, e_bf16>::value) return pack_bf16(a, b); else return pack_f16(a, b);
+}
+// 4 consecutive elements from element index idx (idx % 4 == 0)
+template <class T> __device__ __forceinline__ float4 ldq(const void* base, int64_t idx) {
+    if constexpr (std::is_same<T, e_f32>::value) return *reinterpret_cast<const float4*>(static_cast<const float*>(base) + idx);
+    else {
+        const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(base) + idx);
+        const float2 a = cvt2<T>(u.x), b = cvt2<T>(u.y);
+        return make_float4(a.x, a.y, b.x, b.y);
+    }
+}
+template <class T> __device__ __forceinline__ void stq(void* base, int64_t idx, float4 v) {
+    if constexpr (std::is_same<T, e_f32>::value) *reinterpret_cast<float4*>(static_cast<float*>(base) + idx) = v;
+    else *reinterpret_cast<uint2*>(static_cast<unsigned short*>(base) + idx) = make_uint2(pack2<T>(v.x, v.y), pack2<T>(v.z, v.w));
+}
+template <class T, class I> __device__ __forceinline__ float ld1(const void* base, I idx) {
+    if constexpr (std::is_same<T, e_f32>::value) return static_cast<const float*>(base)[idx];
+    else if constexpr (std::is_same<T, e_bf16>::value) return __uint_as_float((unsigned)static_cast<const unsigned short*>(base)[idx] << 16);
+    else return (float)static_cast<const _Float16*>(base)[idx];
+}
+template <class T, class I> __device__ __forceinline__ void st1(void* base, I idx, float v) {
+    if constexpr (std::is_same<T, e_f32>::value) static_cast<float*>(base)[idx] = v;
+    else if constexpr (std::is_same<T, e_bf16>::value) static_cast<unsigned short*>(base)[idx] = (unsigned short)(pack_bf16(v, 0.f) & 0xFFFFu);
+    else static_cast<_Float16*>(base)[idx] = (_Float16)v;
+}
+// a 16-byte slot as fetched: 4 fp32 elements, or 8 16-bit elements (two quads); quad h of it as fp32
+template <class T> __device__ __forceinline__ float4 slot_quad(float4 raw, int h) {
+    if constexpr (std::is_same<T, e_f32>::value) return raw;
+    else {
+        const unsigned u0 = __float_as_uint(h ? raw.z : raw.x), u1 = __float_as_uint(h ? raw.w : raw.y);
+        const float2 a = cvt2<T>(u0), b = cvt2<T>(u1);
+        return make_float4(a.x, a.y, b.x, b.y);
+    }
+}
+// two fp32 quads -> one 16-byte operand unit (8 consecutive k) of a single-piece operand kind
+template <int OP> __device__ __forceinline__ u32x4 pack_unit(float4 lo, float4 hi) {
+    if constexpr (OP == 2) return u32x4{pack_f16(lo.x, lo.y), pack_f16(lo.z, lo.w), pack_f16(hi.x, hi.y), pack_f16(hi.z, hi.w)};
+    else return u32x4{pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w)};
+}
+__device__ __forceinline__ u32x4 as_u4(float4 v) { return u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}; }
 // acc[i][j] += A_i * B_j for a TM x TN grid of tiles: six piece products, small terms first, tiles innermost so that
 // consecutive MFMAs never share an accumulator.
 template <int TM, int TN>
@@ -179,31 +242,40 @@ struct GemmCfg {
     static constexpr int KS = BK / 16 / WK;                  // MFMA k16-steps per wave per k-tile
     static_assert(KS >= 1 && KS * 16 * WK == BK, "k split");
     static constexpr int K8 = BK / 8;
-    // ---- AT: unit images [piece][k8][row] of 16-byte units.  The A rows are padded so that the ds_write_b64 of one
-    // 16-lane group (64 / BK rows x BK / 4 quads) spreads over all 32 banks.
+    // ---- AT: unit images [piece][k8][row] of 16-byte units.  The A rows are padded so that the LDS stores of one lane
+    // group (ds_write_b64: 16 lanes = 64 / BK rows x BK / 4 quads; ds_write_b128 of the 16-bit modes: 8 lanes x one unit)
+    // spread over all 32 banks.
     static constexpr int PADU = 64 / BK > 0 ? 64 / BK : 1;
     static constexpr int LDUA = BM + PADU, LDUB = BN;
     // ---- !AT: row-major [k][channel] bf16 images; row stride = 64 (mod 128) bytes keeps the four rows a transposing
     // read gathers on distinct banks
     static constexpr int LDTA = BM + ((BM * 2) % 128 == 64 ? 0 : 32), LDTB = BN + ((BN * 2) % 128 == 64 ? 0 : 32);
-    static constexpr int A_BYTES = AT ? NPIECE * K8 * LDUA * 16 : NPIECE * BK * LDTA * 2;
-    static constexpr int B_BYTES = AT ? NPIECE * K8 * LDUB * 16 : NPIECE * BK * LDTB * 2;
-    static_assert(A_BYTES % 16 == 0 && B_BYTES % 16 == 0, "16-byte aligned LDS images");
-    // staging: A (and the weight gradient's B) in float4 slots, (line, quad)
-    static constexpr int A_Q = AT ? BK / 4 : BM / 4;       // float4 per tile line
-    static constexpr int A_LINES = AT ? BM : BK;
-    static constexpr int A_STEP = 256 / A_Q;
-    static constexpr int A_N = (A_LINES + A_STEP - 1) / A_STEP;
-    static constexpr int B_Q = BN / 4;
-    static constexpr int B_STEP = 256 / B_Q;
-    static constexpr int B_N = AT ? (NPIECE * K8 * BN + 255) / 256 : (BK + B_STEP - 1) / B_STEP;    // AT: 16-byte unit copies
-    // every staging slot of a thread maps inside the tile (no run-time range check, which would also make
-    // hipcc drain vmcnt between the load groups of one k-tile)
-    static constexpr bool A_FULL = A_LINES % A_STEP == 0, B_FULL = AT ? (NPIECE * K8 * BN) % 256 == 0 : BK % B_STEP == 0;
     static constexpr int RED_FLOATS = (WK - 1) * WM * WN * TM * TN * 16 * 64;
-    static constexpr int AB_FLOATS = 2 * (A_BYTES + B_BYTES) / 4;
-    static constexpr int TILE_FLOATS = AB_FLOATS > RED_FLOATS ? AB_FLOATS : RED_FLOATS;
+    // Sizes that depend on the operand kind (NP pieces per operand: 3 for the fp32-class split, 1 for bf16 / fp16) and on
+    // how many elements one 16-byte staging slot of a thread holds (AE for the A operand, BE for the weight gradient's B
+    // operand: 4 fp32 or 8 16-bit elements).
+    template <int NP, int AE, int BE>
+    struct G {
+        static constexpr int A_BYTES = AT ? NP * K8 * LDUA * 16 : NP * BK * LDTA * 2;
+        static constexpr int B_BYTES = AT ? NP * K8 * LDUB * 16 : NP * BK * LDTB * 2;
+        static_assert(A_BYTES % 16 == 0 && B_BYTES % 16 == 0, "16-byte aligned LDS images");
+        // staging: A (and the weight gradient's B) in 16-byte slots, (line, slot)
+        static constexpr int A_Q = AT ? BK / AE : BM / AE;       // slots per tile line
+        static constexpr int A_LINES = AT ? BM : BK;
+        static constexpr int A_STEP = 256 / A_Q;
+        static constexpr int A_N = (A_LINES + A_STEP - 1) / A_STEP;
+        static constexpr int B_Q = BN / BE;
+        static constexpr int B_STEP = 256 / B_Q;
+        static constexpr int B_N = AT ? (NP * K8 * BN + 255) / 256 : (BK + B_STEP - 1) / B_STEP;    // AT: 16-byte unit copies
+        // every staging slot of a thread maps inside the tile (no run-time range check, which would also make
+        // hipcc drain vmcnt between the load groups of one k-tile)
+        static constexpr bool A_FULL = A_LINES % A_STEP == 0, B_FULL = AT ? (NP * K8 * BN) % 256 == 0 : BK % B_STEP == 0;
+        static constexpr int AB_FLOATS = 2 * (A_BYTES + B_BYTES) / 4;
+        static constexpr int TILE_FLOATS = AB_FLOATS > RED_FLOATS ? AB_FLOATS : RED_FLOATS;
+    };
 };
+// LDS geometry of policy P's kernel
+template <class P> using GeoOf = typename P::Cfg::template G<(P::kOp ? 1 : NPIECE), P::kAE, P::kBE>;
 
 // What a fetch leaves in registers: the untouched global loads (NV of them) and whether the
 // element exists at all (conv zero padding / padded pixel rows).  The BN transform is applied later,
@@ -228,6 +300,7 @@ __device__ __forceinline__ float4 bload4(const void* ubase, unsigned bytes, unsi
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 ld16(const void* base, int64_t byte_off) { return *reinterpret_cast<const float4*>(static_cast<const char*>(base) + byte_off); }
 // Per-k-tile BN parameters of a thread's channel quad (forward policies): as fetched (mean, invstd, gamma, beta) and as
 // applied (mean, gamma*invstd, beta), 4 channels each
 // (native vector types: arrays / structs of HIP's float4 class that cross a branch end up in scratch)
@@ -368,12 +441,16 @@ struct VBlock { int x, y, z, linear; };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-template <class P, int PREC>
+template <class P>
 __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* smem) {
     using C = typename P::Cfg;
+    using Z = GeoOf<P>;
+    constexpr int OP = P::kOp, NP = OP ? 1 : NPIECE, AE = P::kAE, BE = P::kBE;
+    static_assert((AE == 4 || AE == 8) && (BE == 4 || BE == 8), "16-byte staging slots");
+    static_assert(OP != 0 || (AE == 4 && BE == 4), "the fp32-class split reads fp32 storage");
     char* As = reinterpret_cast<char*>(smem);
-    char* Bs = As + 2 * C::A_BYTES;
-    float* sp = smem + C::TILE_FLOATS;
+    char* Bs = As + 2 * Z::A_BYTES;
+    float* sp = smem + Z::TILE_FLOATS;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -395,92 +472,124 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int aq = t % C::A_Q, al = t / C::A_Q;
-    const int bq = t % C::B_Q, bl = t / C::B_Q;
+    const int aq = t % Z::A_Q, al = t / Z::A_Q;
+    const int bq = t % Z::B_Q, bl = t / Z::B_Q;
     // Register ring of PD k-tiles in flight (global loads issued PD tiles ahead of their LDS store).
     constexpr int PD = P::kPrefetch;
-    typename P::ARaw ra[PD][C::A_N];
-    typename P::BRaw rb[PD][C::B_N];
+    typename P::ARaw ra[PD][Z::A_N];
+    typename P::BRaw rb[PD][Z::B_N];
     typename P::KPrm kp[PD];
-    typename P::ARow arow[C::A_N];
-    typename P::DRow da[C::A_N], db[C::AT ? 1 : C::B_N];
-    KPrm3 bfix{};          // weight gradient: BN parameters of this thread's (fixed) B channel quad, read from LDS once
+    typename P::ARow arow[Z::A_N];
+    typename P::DRow da[Z::A_N], db[C::AT ? 1 : Z::B_N];
+    KPrm3 bfix[BE / 4] = {};   // weight gradient: BN parameters of this thread's (fixed) B channel quad(s), read from LDS once
     if constexpr (C::AT) {
 #pragma unroll
-        for (int i = 0; i < C::A_N; ++i) p.a_row_init(ctx, arow[i], al + i * C::A_STEP);
+        for (int i = 0; i < Z::A_N; ++i) p.a_row_init(ctx, arow[i], al + i * Z::A_STEP);
     } else {
 #pragma unroll
-        for (int i = 0; i < C::A_N; ++i) p.d_init(ctx, da[i], al + i * C::A_STEP);
+        for (int i = 0; i < Z::A_N; ++i) p.d_init(ctx, da[i], al + i * Z::A_STEP);
 #pragma unroll
-        for (int i = 0; i < C::B_N; ++i) p.d_init(ctx, db[i], bl + i * C::B_STEP);
+        for (int i = 0; i < Z::B_N; ++i) p.d_init(ctx, db[i], bl + i * Z::B_STEP);
     }
 
-    auto g_load = [&](int kt, typename P::ARaw (&xa)[C::A_N], typename P::BRaw (&xb)[C::B_N], typename P::KPrm& xk) {
+    auto g_load = [&](int kt, typename P::ARaw (&xa)[Z::A_N], typename P::BRaw (&xb)[Z::B_N], typename P::KPrm& xk) {
         if constexpr (C::AT) {
             xk = p.k_fetch(ctx, kt, aq);
 #pragma unroll
-            for (int i = 0; i < C::A_N; ++i) xa[i] = p.a_fetch(ctx, arow[i], kt, aq);
+            for (int i = 0; i < Z::A_N; ++i)
+                if (Z::A_FULL || al + i * Z::A_STEP < C::BM) xa[i] = p.a_fetch(ctx, arow[i], kt, aq);
 #pragma unroll
-            for (int i = 0; i < C::B_N; ++i) {           // weight units [piece][k8][row]: consecutive lanes -> consecutive rows
+            for (int i = 0; i < Z::B_N; ++i) {           // weight units [piece][k8][row]: consecutive lanes -> consecutive rows
                 const int id = t + 256 * i;
                 const int r = id % C::BN, pk = id / C::BN;                 // pk = piece * K8 + k8
-                if (C::B_FULL || pk < NPIECE * C::K8) xb[i] = p.b_unit(ctx, kt, pk / C::K8, pk % C::K8, r);
+                if (Z::B_FULL || pk < NP * C::K8) xb[i] = p.b_unit(ctx, kt, pk / C::K8, pk % C::K8, r);
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < C::A_N; ++i) {
-                const int kr = al + i * C::A_STEP;
-                if (C::A_FULL || kr < C::BK) xa[i] = p.a_fetch_d(ctx, da[i], kt, kr, aq);
+            for (int i = 0; i < Z::A_N; ++i) {
+                const int kr = al + i * Z::A_STEP;
+                if (Z::A_FULL || kr < C::BK) xa[i] = p.a_fetch_d(ctx, da[i], kt, kr, aq);
                 p.d_next(ctx, da[i]);
             }
 #pragma unroll
-            for (int i = 0; i < C::B_N; ++i) {
-                const int kr = bl + i * C::B_STEP;
-                if (C::B_FULL || kr < C::BK) xb[i] = p.b_fetch(ctx, db[i], kt, kr, bq);
+            for (int i = 0; i < Z::B_N; ++i) {
+                const int kr = bl + i * Z::B_STEP;
+                if (Z::B_FULL || kr < C::BK) xb[i] = p.b_fetch(ctx, db[i], kt, kr, bq);
                 p.d_next(ctx, db[i]);
             }
         }
     };
-    // transform (BN / ReLU / BN-backward) + split + LDS store of k-tile kt
-    auto s_store = [&](int buf, int kt, const typename P::ARaw (&xa)[C::A_N], const typename P::BRaw (&xb)[C::B_N], const typename P::KPrm& xk) {
-        char* A = As + buf * C::A_BYTES;
-        char* B = Bs + buf * C::B_BYTES;
+    // transform (BN / ReLU / BN-backward) + split (or 16-bit pack) + LDS store of k-tile kt.  A staging slot is 16 bytes of
+    // the operand's storage: one channel quad (fp32: ds_write_b64 per piece) or two (16-bit storage: the two quads go through
+    // the policy's quad transform one after the other and leave as ONE 16-byte unit / row segment, ds_write_b128).
+    auto s_store = [&](int buf, int kt, const typename P::ARaw (&xa)[Z::A_N], const typename P::BRaw (&xb)[Z::B_N], const typename P::KPrm& xk) {
+        char* A = As + buf * Z::A_BYTES;
+        char* B = Bs + buf * Z::B_BYTES;
         if constexpr (C::AT) {
-            const typename P::KFin kf = p.k_finish(ctx, xk, kt, aq, sp);
+            if constexpr (AE == 4) {
+                const typename P::KFin kf = p.k_finish(ctx, xk, kt, aq, sp);
 #pragma unroll
-            for (int i = 0; i < C::A_N; ++i) {
-                const int row = al + i * C::A_STEP;
-                if (C::A_FULL || row < C::BM) {
-                    const Split4 s = split4<PREC>(p.a_xform(ctx, xa[i], kf, kt, aq, sp));
+                for (int i = 0; i < Z::A_N; ++i) {
+                    const int row = al + i * Z::A_STEP;
+                    if (Z::A_FULL || row < C::BM) {
+                        const Split4 s = split4<OP>(p.a_xform(ctx, xa[i], kf, kt, aq, sp));
 #pragma unroll
-                    for (int pc = 0; pc < (PREC ? 1 : NPIECE); ++pc)
-                        *reinterpret_cast<uint2*>(A + ((pc * C::K8 + (aq >> 1)) * C::LDUA + row) * 16 + (aq & 1) * 8) = s.p[pc];
+                        for (int pc = 0; pc < NP; ++pc)
+                            *reinterpret_cast<uint2*>(A + ((pc * C::K8 + (aq >> 1)) * C::LDUA + row) * 16 + (aq & 1) * 8) = s.p[pc];
+                    }
+                }
+            } else {
+                const typename P::KFin kf0 = p.k_finish(ctx, xk, kt, 2 * aq, sp), kf1 = p.k_finish(ctx, xk, kt, 2 * aq + 1, sp);
+#pragma unroll
+                for (int i = 0; i < Z::A_N; ++i) {
+                    const int row = al + i * Z::A_STEP;
+                    if (Z::A_FULL || row < C::BM) {
+                        u32x4 u;
+                        if constexpr (P::kARawCopy) u = as_u4(xa[i].v[0]);          // finished 16-bit operand: a straight copy
+                        else u = pack_unit<OP>(p.a_xform(ctx, p.a_quad(xa[i], 0), kf0, kt, 2 * aq, sp),
+                                               p.a_xform(ctx, p.a_quad(xa[i], 1), kf1, kt, 2 * aq + 1, sp));
+                        *reinterpret_cast<u32x4*>(A + (aq * C::LDUA + row) * 16) = u;
+                    }
                 }
             }
 #pragma unroll
-            for (int i = 0; i < C::B_N; ++i) {
+            for (int i = 0; i < Z::B_N; ++i) {
                 const int id = t + 256 * i;
-                if (C::B_FULL || id < NPIECE * C::K8 * C::BN) *reinterpret_cast<u32x4*>(B + id * 16) = p.b_unit_xform(ctx, xb[i], id % C::BN);
+                if (Z::B_FULL || id < NP * C::K8 * C::BN) *reinterpret_cast<u32x4*>(B + id * 16) = p.b_unit_xform(ctx, xb[i], id % C::BN);
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < C::A_N; ++i) {
-                const int kr = al + i * C::A_STEP;
-                if (C::A_FULL || kr < C::BK) {
-                    const Split4 s = split4<PREC>(p.a_xform(ctx, xa[i], KPrm0{}, kt, aq, sp));
+            for (int i = 0; i < Z::A_N; ++i) {
+                const int kr = al + i * Z::A_STEP;
+                if (Z::A_FULL || kr < C::BK) {
+                    if constexpr (AE == 4) {
+                        const Split4 s = split4<OP>(p.a_xform(ctx, xa[i], KPrm0{}, kt, aq, sp));
 #pragma unroll
-                    for (int pc = 0; pc < (PREC ? 1 : NPIECE); ++pc)
-                        *reinterpret_cast<uint2*>(A + ((pc * C::BK + kr) * C::LDTA + 4 * aq) * 2) = s.p[pc];
+                        for (int pc = 0; pc < NP; ++pc)
+                            *reinterpret_cast<uint2*>(A + ((pc * C::BK + kr) * C::LDTA + 4 * aq) * 2) = s.p[pc];
+                    } else {
+                        u32x4 u;
+                        if constexpr (P::kARawCopy) u = as_u4(xa[i].v[0]);
+                        else u = pack_unit<OP>(p.a_xform(ctx, p.a_quad(xa[i], 0), KPrm0{}, kt, 2 * aq, sp),
+                                               p.a_xform(ctx, p.a_quad(xa[i], 1), KPrm0{}, kt, 2 * aq + 1, sp));
+                        *reinterpret_cast<u32x4*>(A + (kr * C::LDTA + 8 * aq) * 2) = u;
+                    }
                 }
             }
 #pragma unroll
-            for (int i = 0; i < C::B_N; ++i) {
-                const int kr = bl + i * C::B_STEP;
-                if (C::B_FULL || kr < C::BK) {
-                    const Split4 s = split4<PREC>(p.b_xform(ctx, xb[i], kt, bq, sp, bfix));
+            for (int i = 0; i < Z::B_N; ++i) {
+                const int kr = bl + i * Z::B_STEP;
+                if (Z::B_FULL || kr < C::BK) {
+                    if constexpr (BE == 4) {
+                        const Split4 s = split4<OP>(p.b_xform(ctx, xb[i], kt, bq, sp, bfix[0]));
 #pragma unroll
-                    for (int pc = 0; pc < (PREC ? 1 : NPIECE); ++pc)
-                        *reinterpret_cast<uint2*>(B + ((pc * C::BK + kr) * C::LDTB + 4 * bq) * 2) = s.p[pc];
+                        for (int pc = 0; pc < NP; ++pc)
+                            *reinterpret_cast<uint2*>(B + ((pc * C::BK + kr) * C::LDTB + 4 * bq) * 2) = s.p[pc];
+                    } else {
+                        const u32x4 u = pack_unit<OP>(p.b_xform(ctx, p.b_quad(xb[i], 0), kt, 2 * bq, sp, bfix[0]),
+                                                      p.b_xform(ctx, p.b_quad(xb[i], 1), kt, 2 * bq + 1, sp, bfix[BE / 4 - 1]));
+                        *reinterpret_cast<u32x4*>(B + (kr * C::LDTB + 8 * bq) * 2) = u;
+                    }
                 }
             }
         }
@@ -503,8 +612,8 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
         }
     };
     auto compute = [&](int buf) {
-        const char* A = As + buf * C::A_BYTES;
-        const char* B = Bs + buf * C::B_BYTES;
+        const char* A = As + buf * Z::A_BYTES;
+        const char* B = Bs + buf * Z::B_BYTES;
         // Per k16-step: the hi and lo pieces of every fragment first (one LDS round trip, not one per MFMA), the two
         // hi x lo product groups, then the mid pieces - fetched under those MFMAs into the registers lo occupied - and the
         // remaining four groups.  Within a group the tiles are innermost: consecutive MFMAs never share an accumulator.
@@ -515,12 +624,12 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
             for (int i = 0; i < C::TM; ++i) ah[i] = frag(A, C::LDUA, C::LDTA, wm0 + i * 32, s, 0);
 #pragma unroll
             for (int j = 0; j < C::TN; ++j) bh[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 0);
-            if constexpr (PREC != 0) {       // single-piece modes: one term per tile
+            if constexpr (OP != 0) {         // single-piece operands: one term per tile
                 SMG_PIN();
 #pragma unroll
                 for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < C::TN; ++j) acc[i][j] = mfma_1p<PREC>(ah[i], bh[j], acc[i][j]);
+                    for (int j = 0; j < C::TN; ++j) acc[i][j] = mfma_1p<OP>(ah[i], bh[j], acc[i][j]);
                 SMG_PIN();
             } else {
                 {
@@ -567,7 +676,10 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
     }
     p.init_params(ctx, sp);
     if constexpr (P::kHasPrologue) __syncthreads();
-    if constexpr (!C::AT) bfix = p.b_fix(ctx, bq, sp);
+    if constexpr (!C::AT) {
+#pragma unroll
+        for (int h = 0; h < BE / 4; ++h) bfix[h] = p.b_fix(ctx, (BE / 4) * bq + h, sp);
+    }
     SMG_TRACE(1);
     if (KT > 0) s_store(0, 0, ra[0], rb[0], kp[0]);
     __syncthreads();
@@ -665,7 +777,7 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
 // One workgroup per virtual block (x fastest).  A persistent variant (resident workgroups striding over the virtual
 // grid) was measured and rejected: hipcc hoists the per-thread addressing out of the tile loop (+50..70 VGPRs, one
 // workgroup less per CU) and the launch is not dispatch-bound.
-template <class P, int PREC = 0>
+template <class P>
 static __global__ __launch_bounds__(256, P::kMinWaves) void gemm_kernel(const P p, const int vgx, const int vgy) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     VBlock vb;
@@ -674,7 +786,7 @@ static __global__ __launch_bounds__(256, P::kMinWaves) void gemm_kernel(const P 
     const int q = vb.linear / vgx;
     vb.y = q % vgy;
     vb.z = q / vgy;
-    gemm_tile<P, PREC>(p, vb, smem);
+    gemm_tile<P>(p, vb, smem);
 }
 
 // Accumulator element (tm, tn, reg) of this lane sits at tile row / column:
@@ -692,11 +804,18 @@ static __global__ __launch_bounds__(256, P::kMinWaves) void gemm_kernel(const P 
 // ------------------------------------------------------------------------------------
 enum { F_ONE = 0, F_THREE = 1, F_POOL = 2, F_STEM = 3 };
 
-template <class Cfg_, int MODE>
+// PREC: the engine's precision mode (storage of src / dst, operand kind).  F32IO: src and dst are fp32 buffers whatever the
+// mode (the head's feature buffers; the stem reads the fp32 image and writes the fp32 stem plane).
+template <class Cfg_, int MODE, int PREC = 0, bool F32IO_ = false>
 struct FwdConvP {
     using Cfg = Cfg_;
     static_assert(Cfg::AT, "forward form");
-    const float* src; int lds_;
+    static constexpr bool F32IO = F32IO_ || MODE == 3;      // F_STEM
+    using SrcT = typename std::conditional<F32IO, e_f32, act_t<PREC>>::type;
+    using DstT = SrcT;
+    static constexpr int kOp = fwd_op(PREC), kAE = 16 / SrcT::size, kBE = 4, ESZ = SrcT::size;
+    static constexpr bool kARawCopy = false;
+    const void* src; int lds_;
     Plane ps, po;
     int K;
     BnTab bt;                       // statistics + affine parameters of the BN in front of this conv
@@ -705,7 +824,7 @@ struct FwdConvP {
     float* tw_mean; float* tw_invstd;       // the table again, writable (designated workgroups store the fresh channels)
     const u32x4* wp; int K8tot;     // packed weight units [piece][K8tot][N] (pack_weights_kernel)
     int N;
-    float* dst; int ldd; int dcoff;
+    void* dst; int ldd; int dcoff;
     double* dsum; double* dsq; int dstride;
     TileMap tm;
     static constexpr int kSwizzle = 1;
@@ -776,7 +895,7 @@ struct FwdConvP {
         r.valid = p < po.HW;
         r.y = p / po.W;
         r.x = p - r.y * po.W;
-        r.off = 4u * (unsigned)(p * lds_);               // byte offset of the row inside its stream
+        r.off = (unsigned)ESZ * (unsigned)(p * lds_);    // byte offset of the row inside its stream
     }
     using ARaw = RawT<(MODE == F_POOL) ? 4 : 1>;
     using BRaw = u32x4;
@@ -786,7 +905,16 @@ struct FwdConvP {
         if constexpr (MODE == F_THREE) { const int kpt = K / Cfg::BK; return (kt % kpt) * Cfg::BK; }
         else return kt * Cfg::BK;
     }
-    __device__ int a_chan(int kt, int q) const { return a_chan0(kt) + 4 * q; }
+    __device__ int a_chan(int kt, int q) const { return a_chan0(kt) + 4 * q; }            // first channel of quad q of the k-tile
+    __device__ int a_slot_chan(int kt, int q) const { return a_chan0(kt) + kAE * q; }     // ... of 16-byte staging slot q
+    // quad h of a fetched slot as a slot of fp32 values (16-bit storage: the staging code transforms the two quads of a slot
+    // one after the other)
+    __device__ ARaw a_quad(const ARaw& o, int h) const {
+        ARaw r; r.ok = o.ok;
+#pragma unroll
+        for (int j = 0; j < (MODE == F_POOL ? 4 : 1); ++j) r.v[j] = slot_quad<SrcT>(o.v[j], h);
+        return r;
+    }
     __device__ KPrm k_fetch(const Ctx&, int, int) const { return KPrm{}; }
     // BN parameters of this thread's channel quad for k-tile kt, from the workgroup's LDS copy
     __device__ KFin k_finish(const Ctx&, const KPrm&, int kt, int q, const float* sp) const {
@@ -806,24 +934,24 @@ struct FwdConvP {
         if constexpr (MODE == F_ONE) {
             // rows of the plane padding are read as they are (they exist) and produce output rows nobody stores or sums
             o.ok = true;
-            o.v[0] = bload4(src + (int64_t)c.n * ps.HWp * lds_, kWholeBuf, r.off + 16u * (unsigned)q, 4u * (unsigned)(kt * Cfg::BK));
+            o.v[0] = bload4(static_cast<const char*>(src) + (int64_t)ESZ * c.n * ps.HWp * lds_, kWholeBuf, r.off + 16u * (unsigned)q, (unsigned)ESZ * (unsigned)(kt * Cfg::BK));
         } else if constexpr (MODE == F_THREE) {
             const int tap = kt / (K / Cfg::BK);
             const int yy = r.y + tap / 3 - 1, xx = r.x + tap % 3 - 1;
             o.ok = r.valid && (unsigned)yy < (unsigned)ps.H && (unsigned)xx < (unsigned)ps.W;
-            o.v[0] = ld4(src + ((int64_t)c.n * ps.HWp + (o.ok ? yy * ps.W + xx : 0)) * lds_ + a_chan(kt, q));
+            o.v[0] = ld16(src, (int64_t)ESZ * (((int64_t)c.n * ps.HWp + (o.ok ? yy * ps.W + xx : 0)) * lds_ + a_slot_chan(kt, q)));
         } else if constexpr (MODE == F_POOL) {
             o.ok = r.valid;
-            const float* b = src + ((int64_t)c.n * ps.HWp + (o.ok ? (2 * r.y) * ps.W + 2 * r.x : 0)) * lds_ + a_chan(kt, q);
-            o.v[0] = ld4(b);
-            o.v[1] = ld4(b + lds_);
-            o.v[2] = ld4(b + (int64_t)ps.W * lds_);
-            o.v[3] = ld4(b + (int64_t)(ps.W + 1) * lds_);
+            const int64_t b = (int64_t)ESZ * (((int64_t)c.n * ps.HWp + (o.ok ? (2 * r.y) * ps.W + 2 * r.x : 0)) * lds_ + a_slot_chan(kt, q));
+            o.v[0] = ld16(src, b);
+            o.v[1] = ld16(src, b + (int64_t)ESZ * lds_);
+            o.v[2] = ld16(src, b + (int64_t)ESZ * ps.W * lds_);
+            o.v[3] = ld16(src, b + (int64_t)ESZ * (ps.W + 1) * lds_);
         } else {
             const int tap = kt * (Cfg::BK / 4) + q;
             const int yy = 2 * r.y + tap / 7 - 3, xx = 2 * r.x + tap % 7 - 3;
             o.ok = r.valid && tap < 49 && (unsigned)yy < (unsigned)ps.H && (unsigned)xx < (unsigned)ps.W;
-            o.v[0] = ld4(src + ((int64_t)c.n * ps.HWp + (o.ok ? yy * ps.W + xx : 0)) * 4);
+            o.v[0] = ld16(src, 16 * ((int64_t)c.n * ps.HWp + (o.ok ? yy * ps.W + xx : 0)));
         }
         return o;
     }
@@ -872,14 +1000,14 @@ struct FwdConvP {
                     for (int j = 0; j < Cfg::TN; ++j) {
                         // uniform tile base + one running 32-bit lane offset (saddr stores): 16 precomputed 64-bit
                         // addresses per strip would cost a workgroup of occupancy
-                        float* tb = dst + (int64_t)c.m0 * ldd + dcoff + c.n0;
+                        char* tb = static_cast<char*>(dst) + (int64_t)DstT::size * ((int64_t)c.m0 * ldd + dcoff + c.n0);
                         unsigned o = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + wn0 + j * 32 + l31);
                         const float s = acc[i][j][0];
                         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {           // accumulator rows (r & 3) + 8 * (r >> 2)
                             const float x = acc[i][j][r];
-                            tb[o] = x;
+                            st1<DstT>(tb, o, x);
                             o += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
                             const float dx = x - s;
                             s1 += dx;
@@ -903,7 +1031,7 @@ struct FwdConvP {
                     const int row = SMG_ACC_ROW(wm0, i, r, half);
                     if (active && pbase + row < po.HW && col < N) {
                         const float x = acc[i][j][r];
-                        dst[(int64_t)(c.m0 + row) * ldd + dcoff + col] = x;
+                        st1<DstT>(dst, (int64_t)(c.m0 + row) * ldd + dcoff + col, x);
                         const double xd = (double)x;
                         v[0][j] += xd;
                         v[1][j] += xd * xd;
@@ -936,12 +1064,18 @@ struct FwdConvP {
 // ------------------------------------------------------------------------------------
 enum { E_STORE = 0, E_ACCUM = 1, E_UNPOOL = 2 };
 
-template <class Cfg_, bool SHIFT3, int EMODE, bool AFF = true>
+// PREC: the engine's precision mode; F32IO: every buffer is fp32 whatever the mode (the head).
+template <class Cfg_, bool SHIFT3, int EMODE, bool AFF = true, int PREC = 0, bool F32IO = false>
 struct BwdDataP {
     using Cfg = Cfg_;
     static_assert(Cfg::AT, "data-gradient form");
-    const float* gbuf; int ldg; int gcoff;
-    const float* xbuf; int ldx; int xcoff;
+    using GT = typename std::conditional<F32IO, e_f32, grd_t<PREC>>::type;      // gradients in (gbuf) and out (dst)
+    using XT = typename std::conditional<F32IO, e_f32, act_t<PREC>>::type;      // activations (xbuf, mbuf)
+    static_assert(GT::size == XT::size, "one slot geometry for the gradient and its activation");
+    static constexpr int kOp = bwd_op(PREC), kAE = 16 / GT::size, kBE = 4, GSZ = GT::size, XSZ = XT::size;
+    static constexpr bool kARawCopy = !AFF && !SHIFT3 && kAE == 8;              // finished bf16 gradient: copied to LDS as it is
+    const void* gbuf; int ldg; int gcoff;
+    const void* xbuf; int ldx; int xcoff;
     Plane pa;
     int KA;
     const double* xsum; const double* xsq; int xstride;
@@ -949,10 +1083,10 @@ struct BwdDataP {
     const float* agamma;
     const u32x4* wp; int K8tot; int ldn; int wcol0;    // packed weight units [piece][K8tot][ldn], first output column wcol0
     int N;
-    const float* mbuf; int ldm; int mcoff; Plane pm;
+    const void* mbuf; int ldm; int mcoff; Plane pm;
     const double* msum; const double* msq; int mstride;
     const float* egamma; const float* ebeta;
-    float* dst; int ldd; int dcoff;
+    void* dst; int ldd; int dcoff;
     double* o1; double* o2; int ostride; int ocoff;
     float* dbeta; float* dgamma;
     float eps;
@@ -998,8 +1132,8 @@ struct BwdDataP {
             if (c.whole) {
                 const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
                 const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
-                const float* xb = mbuf + (int64_t)c.m0 * ldm + mcoff + c.n0;
-                const float* gb = dst + (int64_t)c.m0 * ldd + dcoff + c.n0;
+                const char* xb = static_cast<const char*>(mbuf) + (int64_t)XSZ * ((int64_t)c.m0 * ldm + mcoff + c.n0);
+                const char* gb = static_cast<const char*>(dst) + (int64_t)GSZ * ((int64_t)c.m0 * ldd + dcoff + c.n0);
 #pragma unroll
                 for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -1009,8 +1143,8 @@ struct BwdDataP {
                         unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + cj);
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            c.xv[i][j][r] = xb[ox];
-                            if constexpr (EMODE == E_ACCUM) c.gold[i][j][r] = gb[og];
+                            c.xv[i][j][r] = ld1<XT>(xb, ox);
+                            if constexpr (EMODE == E_ACCUM) c.gold[i][j][r] = ld1<GT>(gb, og);
                             ox += (r & 3) == 3 ? 5u * (unsigned)ldm : (unsigned)ldm;
                             og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
                         }
@@ -1055,19 +1189,27 @@ struct BwdDataP {
         r.valid = p < pa.HW;
         r.y = p / pa.W;
         r.x = p - r.y * pa.W;
-        r.off = r.valid ? 4u * (unsigned)(p * ldg) : kOOB;
+        r.off = r.valid ? (unsigned)GSZ * (unsigned)(p * ldg) : kOOB;
     }
     using ARaw = RawT<2>;       // gradient + (when xbuf is set) the raw activation its BN normalised
     using BRaw = u32x4;
-    __device__ int a_chan(int kt, int q) const {
-        if constexpr (SHIFT3) { const int kpt = KA / Cfg::BK; return (kt % kpt) * Cfg::BK + 4 * q; }
-        else return kt * Cfg::BK + 4 * q;
+    __device__ int a_chan0(int kt) const {
+        if constexpr (SHIFT3) { const int kpt = KA / Cfg::BK; return (kt % kpt) * Cfg::BK; }
+        else return kt * Cfg::BK;
+    }
+    __device__ int a_chan(int kt, int q) const { return a_chan0(kt) + 4 * q; }             // channel quad q of the k-tile
+    __device__ ARaw a_quad(const ARaw& o, int h) const {
+        ARaw r; r.ok = o.ok;
+        r.v[0] = slot_quad<GT>(o.v[0], h);
+        r.v[1] = slot_quad<XT>(o.v[1], h);
+        return r;
     }
     __device__ ARaw a_fetch(const Ctx& c, const ARow& r, int kt, int q) const {
         ARaw o;
         if constexpr (kFast) {
             o.ok = true;
-            o.v[0] = bload4(gbuf + (int64_t)c.n * pa.HWp * ldg + gcoff, kWholeBuf, r.off + 16u * (unsigned)q, 4u * (unsigned)(kt * Cfg::BK));
+            o.v[0] = bload4(static_cast<const char*>(gbuf) + (int64_t)GSZ * ((int64_t)c.n * pa.HWp * ldg + gcoff), kWholeBuf, r.off + 16u * (unsigned)q,
+                            (unsigned)GSZ * (unsigned)(kt * Cfg::BK));
             return o;
         }
         int yy = r.y, xx = r.x;
@@ -1078,10 +1220,10 @@ struct BwdDataP {
             xx = r.x + 1 - tap % 3;
             o.ok = r.valid && (unsigned)yy < (unsigned)pa.H && (unsigned)xx < (unsigned)pa.W;
         }
-        const int ch = a_chan(kt, q);
+        const int ch = a_chan0(kt) + kAE * q;                                         // first channel of staging slot q
         const int64_t pix = (int64_t)c.n * pa.HWp + (o.ok ? yy * pa.W + xx : 0);      // unconditional loads, clamped address
-        o.v[0] = ld4(gbuf + pix * ldg + gcoff + ch);
-        if (xbuf) o.v[1] = ld4(xbuf + pix * ldx + xcoff + ch);                       // (launch-uniform)
+        o.v[0] = ld16(gbuf, (int64_t)GSZ * (pix * ldg + gcoff + ch));
+        if (xbuf) o.v[1] = ld16(xbuf, (int64_t)XSZ * (pix * ldx + xcoff + ch));      // (launch-uniform)
         return o;
     }
     __device__ float4 a_xform(const Ctx&, const ARaw& o, const KPrm&, int kt, int q, const float* sp) const {
@@ -1117,7 +1259,7 @@ struct BwdDataP {
             if (kEarly && active && c.whole) {
                 // Whole tile inside the plane: no per-element predicates, operands already in registers (init_ctx), a uniform
                 // tile base + running 32-bit lane offset for the stores.
-                float* gb = dst + (int64_t)c.m0 * ldd + dcoff + c.n0;
+                char* gb = static_cast<char*>(dst) + (int64_t)GSZ * ((int64_t)c.m0 * ldd + dcoff + c.n0);
 #pragma unroll
                 for (int i = 0; i < Cfg::TM; ++i) {
                     unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + cj);
@@ -1125,8 +1267,8 @@ struct BwdDataP {
                     for (int r = 0; r < 16; ++r) {
                         const float xr = c.xv[kEarly ? i : 0][kEarly ? j : 0][r];
                         const float dy = bn1(xr, mean, sc, sh) > 0.f ? acc[i][j][r] : 0.f;
-                        if constexpr (EMODE == E_STORE) gb[og] = dy;
-                        else gb[og] = c.gold[(kEarly && EMODE == E_ACCUM) ? i : 0][(kEarly && EMODE == E_ACCUM) ? j : 0][r] + gam * dy;
+                        if constexpr (EMODE == E_STORE) st1<GT>(gb, og, dy);
+                        else st1<GT>(gb, og, c.gold[(kEarly && EMODE == E_ACCUM) ? i : 0][(kEarly && EMODE == E_ACCUM) ? j : 0][r] + gam * dy);
                         og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
                         v[0][j] += dy;
                         v[1][j] += dy * ((xr - mean) * invstd);
@@ -1157,11 +1299,11 @@ struct BwdDataP {
                             pix0[q] = c.n * pm.HWp + (2 * y) * pm.W + 2 * x;
 #pragma unroll
                             for (int d = 0; d < 4; ++d)
-                                xv[q][d] = ok[q] ? mbuf[(int64_t)(pix0[q] + (d >> 1) * pm.W + (d & 1)) * ldm + mcoff + col] : 0.f;
+                                xv[q][d] = ok[q] ? ld1<XT>(mbuf, (int64_t)(pix0[q] + (d >> 1) * pm.W + (d & 1)) * ldm + mcoff + col) : 0.f;
                         } else {
                             pix0[q] = c.m0 + row;
-                            xv[q][0] = ok[q] ? mbuf[(int64_t)pix0[q] * ldm + mcoff + col] : 0.f;
-                            if constexpr (EMODE == E_ACCUM) gold[q] = ok[q] ? dst[(int64_t)pix0[q] * ldd + dcoff + col] : 0.f;
+                            xv[q][0] = ok[q] ? ld1<XT>(mbuf, (int64_t)pix0[q] * ldm + mcoff + col) : 0.f;
+                            if constexpr (EMODE == E_ACCUM) gold[q] = ok[q] ? ld1<GT>(dst, (int64_t)pix0[q] * ldd + dcoff + col) : 0.f;
                         }
                     }
 #pragma unroll
@@ -1173,14 +1315,14 @@ struct BwdDataP {
 #pragma unroll
                             for (int d = 0; d < 4; ++d) {
                                 const float dy = bn1(xv[q][d], mean, sc, sh) > 0.f ? up : 0.f;
-                                dst[(int64_t)(pix0[q] + (d >> 1) * pm.W + (d & 1)) * ldd + dcoff + col] = gam * dy;
+                                st1<GT>(dst, (int64_t)(pix0[q] + (d >> 1) * pm.W + (d & 1)) * ldd + dcoff + col, gam * dy);
                                 v[0][j] += dy;
                                 v[1][j] += dy * ((xv[q][d] - mean) * invstd);
                             }
                         } else {
                             const float dy = bn1(xv[q][0], mean, sc, sh) > 0.f ? av : 0.f;
-                            if constexpr (EMODE == E_STORE) dst[(int64_t)pix0[q] * ldd + dcoff + col] = dy;
-                            else dst[(int64_t)pix0[q] * ldd + dcoff + col] = gold[q] + gam * dy;
+                            if constexpr (EMODE == E_STORE) st1<GT>(dst, (int64_t)pix0[q] * ldd + dcoff + col, dy);
+                            else st1<GT>(dst, (int64_t)pix0[q] * ldd + dcoff + col, gold[q] + gam * dy);
                             v[0][j] += dy;
                             v[1][j] += dy * ((xv[q][0] - mean) * invstd);
                         }
@@ -1230,22 +1372,26 @@ struct BwdDataP {
 // ------------------------------------------------------------------------------------
 constexpr int GROUP_MAX = 4;
 struct GroupSeg {
-    const float* g;                 // finished bottleneck gradient D2_i [n][HWp][KA]
+    const void* g;                  // finished bottleneck gradient D2_i [n][HWp][KA] (fp32 / bf16 by mode)
     const u32x4* wp; int ldn;       // conv1 weight, packed data-gradient units [piece][KA/8][cin_i]
     const float* gamma; const float* beta;
     float* dbeta; float* dgamma;
 };
 
-template <class Cfg_>
+template <class Cfg_, int PREC = 0>
 struct BwdDataGroupP {
     using Cfg = Cfg_;
     static_assert(Cfg::WK == 1 && Cfg::AT, "segment hook: no in-block split-K");
+    using GT = grd_t<PREC>;      // D2 and G'
+    using XT = act_t<PREC>;      // the block buffer X
+    static constexpr int kOp = bwd_op(PREC), kAE = 16 / GT::size, kBE = 4, GSZ = GT::size;
+    static constexpr bool kARawCopy = kAE == 8;
     GroupSeg seg[GROUP_MAX]; int nseg;
     int ldg; Plane pa; int KA;
     int N;                                              // output channels [0, N)
-    const float* mbuf; int ldm;                         // block buffer X (mask / xhat source)
+    const void* mbuf; int ldm;                          // block buffer X (mask / xhat source)
     const double* msum; const double* msq; int mstride;
-    float* dst; int ldd;                                // G'
+    void* dst; int ldd;                                 // G'
     double* o1; double* o2; int ostride;                // SA / SB [n][C]
     float eps;
     TileMap tm;
@@ -1313,14 +1459,14 @@ struct BwdDataGroupP {
                     const int row = SMG_ACC_ROW(wm0, i, r, half);
                     const bool ok = pbase + row < pa.HW && col < N;
                     // unconditional load from a clamped address (a branch around it would serialise the loads)
-                    const float v = mbuf[(int64_t)(c.m0 + (ok ? row : 0)) * ldm + (ok ? col : 0)];
+                    const float v = ld1<XT>(mbuf, (int64_t)(c.m0 + (ok ? row : 0)) * ldm + (ok ? col : 0));
                     c.x[i][j][r] = ok ? v : 0.f;
                     c.run[i][j][r] = 0.f;
                     c.gold[i][j][r] = 0.f;
                 }
         }
         if (c.whole) {
-            const float* gb = dst + (int64_t)c.m0 * ldd + c.n0;
+            const char* gb = static_cast<const char*>(dst) + (int64_t)GSZ * ((int64_t)c.m0 * ldd + c.n0);
 #pragma unroll
             for (int j = 0; j < Cfg::TN; ++j)
 #pragma unroll
@@ -1328,7 +1474,7 @@ struct BwdDataGroupP {
                     unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + wn0 + j * 32 + l31);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        c.gold[i][j][r] = gb[og];
+                        c.gold[i][j][r] = ld1<GT>(gb, og);
                         og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
                     }
                 }
@@ -1342,7 +1488,7 @@ struct BwdDataGroupP {
     __device__ int kps() const { return KA / Cfg::BK; }                   // k-tiles per segment
     __device__ int ktiles(const Ctx&) const { return nseg * kps(); }
     __device__ void a_row_init(const Ctx& c, ARow& r, int line) const {
-        r.off = c.m0 + line - c.n * pa.HWp < pa.HW ? 4u * (unsigned)(line * ldg) : kOOB;
+        r.off = c.m0 + line - c.n * pa.HWp < pa.HW ? (unsigned)GSZ * (unsigned)(line * ldg) : kOOB;
     }
     using ARaw = RawT<1>;
     using BRaw = u32x4;
@@ -1350,9 +1496,10 @@ struct BwdDataGroupP {
         ARaw o;
         const int s = kt / kps(), ch0 = (kt - s * kps()) * Cfg::BK;
         o.ok = true;
-        o.v[0] = bload4(seg[s].g + (int64_t)c.m0 * ldg, kWholeBuf, r.off + 16u * (unsigned)q, 4u * (unsigned)ch0);
+        o.v[0] = bload4(static_cast<const char*>(seg[s].g) + (int64_t)GSZ * c.m0 * ldg, kWholeBuf, r.off + 16u * (unsigned)q, (unsigned)GSZ * (unsigned)ch0);
         return o;
     }
+    __device__ ARaw a_quad(const ARaw& o, int h) const { ARaw r; r.ok = o.ok; r.v[0] = slot_quad<GT>(o.v[0], h); return r; }
     __device__ float4 a_xform(const Ctx&, const ARaw& o, const KPrm&, int, int, const float*) const { return o.v[0]; }
     __device__ ARaw a_fetch_d(const Ctx&, const DRow&, int, int, int) const { return ARaw{}; }
     __device__ BRaw b_unit(const Ctx& c, int kt, int piece, int k8, int r) const {
@@ -1407,14 +1554,14 @@ struct BwdDataGroupP {
             const float mean = sp[cj], invstd = sp[Cfg::BN + cj];
             float a0 = 0.f, a1 = 0.f;
             if (c.whole) {        // whole tile inside the plane: see E_ACCUM
-                float* gb = dst + (int64_t)c.m0 * ldd + c.n0;
+                char* gb = static_cast<char*>(dst) + (int64_t)GSZ * ((int64_t)c.m0 * ldd + c.n0);
 #pragma unroll
                 for (int i = 0; i < Cfg::TM; ++i) {
                     unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + cj);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float run = c.run[i][j][r];
-                        gb[og] = c.gold[i][j][r] + run;
+                        st1<GT>(gb, og, c.gold[i][j][r] + run);
                         og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
                         a0 += run;
                         a1 = fmaf(run, (c.x[i][j][r] - mean) * invstd, a1);
@@ -1428,14 +1575,14 @@ struct BwdDataGroupP {
                 for (int r = 0; r < 16; ++r) {             // every load of the tile first (the stores alias them)
                     const int row = SMG_ACC_ROW(wm0, i, r, half);
                     const bool ok = pbase + row < pa.HW && col < N;
-                    const float g = dst[(int64_t)(c.m0 + (ok ? row : 0)) * ldd + (ok ? col : 0)];
+                    const float g = ld1<GT>(dst, (int64_t)(c.m0 + (ok ? row : 0)) * ldd + (ok ? col : 0));
                     gold[r] = ok ? g : 0.f;
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = SMG_ACC_ROW(wm0, i, r, half);
                     const float run = c.run[i][j][r];
-                    if (pbase + row < pa.HW && col < N) dst[(int64_t)(c.m0 + row) * ldd + col] = gold[r] + run;
+                    if (pbase + row < pa.HW && col < N) st1<GT>(dst, (int64_t)(c.m0 + row) * ldd + col, gold[r] + run);
                     a0 += run;                               // run == 0 on masked elements (x, acc are zero there)
                     a1 = fmaf(run, (c.x[i][j][r] - mean) * invstd, a1);
                 }
@@ -1476,17 +1623,24 @@ struct BwdDataGroupP {
 enum { W_ONE = 0, W_THREE = 1, W_POOL = 2, W_STEM = 3 };
 enum { C_IDENT = 0, C_3x3 = 1, C_STEM = 2 };
 
-template <class Cfg_, int BMODE, int CMAP, int PD_ = SMG_PD_WGRAD, bool AFF = true>
+// PREC: the engine's precision mode; F32IO: every buffer is fp32 whatever the mode (head conv0; the stem's image / plane).
+template <class Cfg_, int BMODE, int CMAP, int PD_ = SMG_PD_WGRAD, bool AFF = true, int PREC = 0, bool F32IO_ = false>
 struct BwdWeightP {
     using Cfg = Cfg_;
     static_assert(!Cfg::AT, "weight-gradient form");
-    const float* gbuf; int ldg; int gcoff;
-    const float* xbuf; int ldx; int xcoff;
+    static constexpr bool F32IO = F32IO_ || BMODE == 3;      // W_STEM
+    using GT = typename std::conditional<F32IO, e_f32, grd_t<PREC>>::type;      // output gradient (gbuf)
+    using XT = typename std::conditional<F32IO, e_f32, act_t<PREC>>::type;      // activations (xbuf, bbuf)
+    static_assert(GT::size == XT::size, "one slot geometry");
+    static constexpr int kOp = bwd_op(PREC), kAE = 16 / GT::size, kBE = 16 / XT::size, GSZ = GT::size, XSZ = XT::size;
+    static constexpr bool kARawCopy = !AFF && kAE == 8;      // finished bf16 gradient: copied to LDS as it is
+    const void* gbuf; int ldg; int gcoff;
+    const void* xbuf; int ldx; int xcoff;
     Plane pa; int MA;
     const double* xsum; const double* xsq; int xstride;
     const double* s1; const double* s2; int sstride; int scoff;
     const float* agamma;
-    const float* bbuf; int ldb; Plane pb; int NB;
+    const void* bbuf; int ldb; Plane pb; int NB;
     const double* bsum; const double* bsq; int bstride;
     const float* bgamma; const float* bbeta;
     float eps;
@@ -1594,19 +1748,31 @@ struct BwdWeightP {
     // channel quads past MA read as zero, nothing to mask and no address arithmetic per k-tile.
     __device__ ARaw a_fetch_d(const Ctx& c, const DRow& r, int kt, int kr, int q) const {
         ARaw o;
-        const int ch = c.m0 + 4 * q;
+        const int ch = c.m0 + kAE * q;                                    // first channel of staging slot q
         if constexpr (!AFF) {
             o.ok = true;
-            o.v[0] = bload4(gbuf + (int64_t)c.n * pa.HWp * ldg + gcoff, 4u * (unsigned)(pa.HW * ldg - gcoff),
-                            ch < MA ? 4u * (unsigned)(kr * ldg + ch) : kOOB, 4u * (unsigned)((c.p0 + kt * Cfg::BK) * ldg));
+            o.v[0] = bload4(static_cast<const char*>(gbuf) + (int64_t)GSZ * ((int64_t)c.n * pa.HWp * ldg + gcoff), (unsigned)GSZ * (unsigned)(pa.HW * ldg - gcoff),
+                            ch < MA ? (unsigned)GSZ * (unsigned)(kr * ldg + ch) : kOOB, (unsigned)GSZ * (unsigned)((c.p0 + kt * Cfg::BK) * ldg));
             return o;
         }
         o.ok = r.p < pa.HW && ch < MA;
         const int64_t pix = (int64_t)c.n * pa.HWp + (o.ok ? r.p : 0);
         const int chc = o.ok ? ch : 0;
-        o.v[0] = ld4(gbuf + pix * ldg + gcoff + chc);
-        if (xbuf) o.v[1] = ld4(xbuf + pix * ldx + xcoff + chc);          // (launch-uniform)
+        o.v[0] = ld16(gbuf, (int64_t)GSZ * (pix * ldg + gcoff + chc));
+        if (xbuf) o.v[1] = ld16(xbuf, (int64_t)XSZ * (pix * ldx + xcoff + chc));          // (launch-uniform)
         return o;
+    }
+    __device__ ARaw a_quad(const ARaw& o, int h) const {
+        ARaw r; r.ok = o.ok;
+        r.v[0] = slot_quad<GT>(o.v[0], h);
+        r.v[1] = slot_quad<XT>(o.v[1], h);
+        return r;
+    }
+    __device__ BRaw b_quad(const BRaw& o, int h) const {
+        BRaw r; r.ok = o.ok;
+#pragma unroll
+        for (int j = 0; j < (BMODE == W_POOL ? 4 : 1); ++j) r.v[j] = slot_quad<XT>(o.v[j], h);
+        return r;
     }
     __device__ float4 a_xform(const Ctx&, const ARaw& o, const KPrm&, int, int q, const float* sp) const {
         if constexpr (!AFF) return o.v[0];
@@ -1616,29 +1782,29 @@ struct BwdWeightP {
     }
     __device__ BRaw b_fetch(const Ctx& c, const DRow& r, int kt, int kr, int q) const {
         BRaw o;
-        const int ch = c.n0 + 4 * q;
+        const int ch = c.n0 + kBE * q;                                    // first channel of staging slot q
         o.ok = r.p < pa.HW && ch < NB;
         if constexpr (BMODE == W_ONE) {
             // bounded to the HW rows (zero past them: the A rows there are zero, this keeps the product finite); channel quads
             // past NB read the neighbouring channels of the row - their columns are never stored
             o.ok = true;
-            o.v[0] = bload4(bbuf + (int64_t)c.n * pb.HWp * ldb, 4u * (unsigned)(pb.HW * ldb), 4u * (unsigned)(kr * ldb + ch),
-                            4u * (unsigned)((c.p0 + kt * Cfg::BK) * ldb));
+            o.v[0] = bload4(static_cast<const char*>(bbuf) + (int64_t)XSZ * c.n * pb.HWp * ldb, (unsigned)XSZ * (unsigned)(pb.HW * ldb), (unsigned)XSZ * (unsigned)(kr * ldb + ch),
+                            (unsigned)XSZ * (unsigned)((c.p0 + kt * Cfg::BK) * ldb));
         } else if constexpr (BMODE == W_THREE) {
             const int yy = r.y + c.tap / 3 - 1, xx = r.x + c.tap % 3 - 1;
             o.ok = o.ok && (unsigned)yy < (unsigned)pb.H && (unsigned)xx < (unsigned)pb.W;
-            o.v[0] = ld4(bbuf + ((int64_t)c.n * pb.HWp + (o.ok ? yy * pb.W + xx : 0)) * ldb + (o.ok ? ch : 0));
+            o.v[0] = ld16(bbuf, (int64_t)XSZ * (((int64_t)c.n * pb.HWp + (o.ok ? yy * pb.W + xx : 0)) * ldb + (o.ok ? ch : 0)));
         } else if constexpr (BMODE == W_POOL) {
-            const float* b = bbuf + ((int64_t)c.n * pb.HWp + (o.ok ? (2 * r.y) * pb.W + 2 * r.x : 0)) * ldb + (o.ok ? ch : 0);
-            o.v[0] = ld4(b);
-            o.v[1] = ld4(b + ldb);
-            o.v[2] = ld4(b + (int64_t)pb.W * ldb);
-            o.v[3] = ld4(b + (int64_t)(pb.W + 1) * ldb);
+            const int64_t b = (int64_t)XSZ * (((int64_t)c.n * pb.HWp + (o.ok ? (2 * r.y) * pb.W + 2 * r.x : 0)) * ldb + (o.ok ? ch : 0));
+            o.v[0] = ld16(bbuf, b);
+            o.v[1] = ld16(bbuf, b + (int64_t)XSZ * ldb);
+            o.v[2] = ld16(bbuf, b + (int64_t)XSZ * pb.W * ldb);
+            o.v[3] = ld16(bbuf, b + (int64_t)XSZ * (pb.W + 1) * ldb);
         } else {
             const int tap = ch >> 2;
             const int yy = 2 * r.y + tap / 7 - 3, xx = 2 * r.x + tap % 7 - 3;
             o.ok = o.ok && tap < 49 && (unsigned)yy < (unsigned)pb.H && (unsigned)xx < (unsigned)pb.W;
-            o.v[0] = ld4(bbuf + ((int64_t)c.n * pb.HWp + (o.ok ? yy * pb.W + xx : 0)) * 4);
+            o.v[0] = ld16(bbuf, 16 * ((int64_t)c.n * pb.HWp + (o.ok ? yy * pb.W + xx : 0)));
         }
         return o;
     }

@@ -40,45 +40,47 @@ struct HaloGeo {
 };
 
 struct Halo3x3FwdArgs {
-    const float* src; int lds_; Plane pl;           // [n][HWp][C] raw bottleneck output
+    const void* src; int lds_; Plane pl;            // [n][HWp][C] raw bottleneck output (fp32 / bf16 / fp16 by mode)
     int C;                                          // input channels (128)
     const double* ssum; const double* ssq; int sstride;     // fp64 statistics of src (norm2 input)
     const float* gamma; const float* beta; float eps;
     float* tw_mean; float* tw_invstd;               // [n][C]: the first tile of every stream stores mean / invstd for the backward
     const u32x4* wu;                                // weight units [chunk][piece][tap][k8][n] (PK_HF)
-    float* dst; int ldd, dcoff;
+    void* dst; int ldd, dcoff;
     double* dsum; double* dsq; int dstride;
     int tiles_x;
 };
 
-constexpr int HALO_CK = 16;                // channels per chunk (one k16-step per tap)
+// Channels per chunk of the forward: one k16-step per tap for the fp32-class split (three pieces per operand), two for the
+// single-piece 16-bit modes (the same 16-byte staging slots per halo pixel: 4 x 4 fp32 or 4 x 8 16-bit channels).
+constexpr int halo_ck(int prec) { return prec ? 32 : 16; }
 
 // ------------------------------------------------------------------------------------
-// Split-precision forward (the arithmetic of gemm.cuh: three bf16 pieces per fp32 operand, six
-// v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate).
-//
-// Per 16-channel chunk (one k16-step per tap) the halo lands in LDS as units [piece][k8 (2)][halo pixel] of 16 bytes
-// (BN + ReLU + split applied once, at the store), the chunk's weights as units [piece][tap][k8][n] - pack_weights_kernel
-// writes exactly that image per chunk (PK_HF), so their staging is a copy.  A fragment is one ds_read_b128 per piece:
-// lanes 0..15 / 16..31 read two runs of 16 consecutive halo pixels.  The 128 BN parameters of the stream are derived
-// from the fp64 sums in the prologue (one channel per thread) and stored once per stream for the backward kernels.
-//   TS = 16: 4 waves x 2 pixel tiles, 60 KB LDS (2 workgroups per CU).
-//   TS = 8 : 2 waves split the pixels, the other factor of two splits the TAPS (5 + 4; a chunk is a single k16-step).
+// Forward.  Per chunk the halo lands in LDS as units [piece][k8][halo pixel] of 16 bytes (BN + ReLU + split / 16-bit pack
+// applied once, at the store), the chunk's weights as units [piece][tap][k8][n] - pack_weights_kernel writes exactly that
+// image per chunk (PK_HF), so their staging is a copy.  A fragment is one ds_read_b128 per piece: lanes 0..15 / 16..31 read
+// two runs of 16 consecutive halo pixels.  The 128 BN parameters of the stream are derived from the fp64 sums in the
+// prologue (one channel per thread) and stored once per stream for the backward kernels.
+//   TS = 16: 4 waves x 2 pixel tiles, 60 KB LDS in the fp32-class mode (2 workgroups per CU), 43 KB in the 16-bit modes.
+//   TS = 8 : 2 waves split the pixels, the other factor of two splits the TAPS (5 + 4).
 // ------------------------------------------------------------------------------------
-constexpr int HS_BU = NPIECE * 9 * 2 * 32;                  // weight units per chunk: 1728
-template <int TS> struct HaloFwdSGeo : HaloGeo<TS> {
+template <int TS, int PREC> struct HaloFwdSGeo : HaloGeo<TS> {
     using G = HaloGeo<TS>;
+    static constexpr int NP = PREC ? 1 : NPIECE, CK = halo_ck(PREC), K8C = CK / 8;
     static constexpr int LDH = G::PX;
-    static constexpr int A_UNITS = NPIECE * 2 * LDH;
-    static constexpr int A_N = (G::PX * 4 + 255) / 256;                  // float4 slots per thread: 6 / 2
-    static constexpr int B_N = (HS_BU + 255) / 256;                      // 7 (the last 64 copies of a round read / write padding)
+    static constexpr int A_UNITS = NP * K8C * LDH;
+    static constexpr int A_N = (G::PX * 4 + 255) / 256;                  // 16-byte slots per thread: 6 / 2
+    static constexpr int BU = NP * 9 * K8C * 32;                         // weight units per chunk: 1728 / 1152
+    static constexpr int B_N = (BU + 255) / 256;                         // (the last copies of a round read / write padding)
     __host__ __device__ static constexpr int smem_bytes(int C) { return (A_UNITS + B_N * 256) * 16 + 3 * C * 4; }
 };
 
 template <int TS, int PREC = 0>
 static __global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const Halo3x3FwdArgs a) {
-    using G = HaloFwdSGeo<TS>;
-    constexpr int MT = G::MT, A_N = G::A_N, B_N = G::B_N, LDH = G::LDH;
+    using G = HaloFwdSGeo<TS, PREC>;
+    using ST = act_t<PREC>;
+    constexpr int OP = fwd_op(PREC), NP = G::NP, CK = G::CK, K8C = G::K8C, KSTEP = CK / 16;
+    constexpr int MT = G::MT, A_N = G::A_N, B_N = G::B_N, LDH = G::LDH, ESZ = ST::size, E = 16 / ESZ;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* As = reinterpret_cast<char*>(smem);                // [piece][k8][LDH] units
     char* Bs = As + G::A_UNITS * 16;                         // [piece][tap][k8][32] units
@@ -89,7 +91,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const H
     const int n = blockIdx.y;
     const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
     const int y0 = ty * TS, x0 = tx * TS;
-    const int C = a.C, kq = t & 3;                           // this thread's channel quad inside every chunk
+    const int C = a.C, kq = t & 3;                           // this thread's 16-byte slot inside every chunk (E channels)
     for (int k = t; k < C; k += 256) {                       // BN parameters of this stream
         float mean, invstd;
         bn_moments(a.ssum, a.ssq, (int64_t)n * a.sstride + k, 1.0 / (double)a.pl.HW, a.eps, mean, invstd);
@@ -111,26 +113,33 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const H
         a_off[i] = ok ? (iy * a.pl.W + ix) : -1;
         a_hp[i] = (idx < G::PX * 4) ? hp : -1;
     }
-    const float* src_n = a.src + (int64_t)n * a.pl.HWp * a.lds_;
+    const char* src_n = static_cast<const char*>(a.src) + (int64_t)ESZ * n * a.pl.HWp * a.lds_;
     const u32x4* wu = a.wu;
     float4 ra[A_N]; u32x4 rb[B_N];
     auto g_load = [&](int chunk) {
-        const int c0 = chunk * HALO_CK + 4 * kq;
+        const int c0 = chunk * CK + E * kq;
 #pragma unroll
         for (int i = 0; i < A_N; ++i)                               // unconditional loads from clamped addresses
-            ra[i] = ld4(src_n + (int64_t)(a_off[i] < 0 ? 0 : a_off[i]) * a.lds_ + c0);
+            ra[i] = ld16(src_n, (int64_t)ESZ * ((int64_t)(a_off[i] < 0 ? 0 : a_off[i]) * a.lds_ + c0));
 #pragma unroll
-        for (int i = 0; i < B_N; ++i) rb[i] = wu[(int64_t)chunk * HS_BU + t + 256 * i];      // (slack behind the packed array)
+        for (int i = 0; i < B_N; ++i) rb[i] = wu[(int64_t)chunk * G::BU + t + 256 * i];      // (slack behind the packed array)
     };
     auto s_store = [&](int chunk) {
-        const float* pq = prm + chunk * HALO_CK + 4 * kq;
+        const float* pq = prm + chunk * CK + E * kq;
 #pragma unroll
         for (int i = 0; i < A_N; ++i) {
             if (a_hp[i] < 0) continue;
-            const Split4 s = split4<PREC>(a_off[i] >= 0 ? bnrelu4(ra[i], pq, C) : zero4());   // conv zero padding applies AFTER bn+relu
+            if constexpr (E == 4) {
+                const Split4 s = split4<OP>(a_off[i] >= 0 ? bnrelu4(ra[i], pq, C) : zero4());   // conv zero padding applies AFTER bn+relu
 #pragma unroll
-            for (int pc = 0; pc < (PREC ? 1 : NPIECE); ++pc)
-                *reinterpret_cast<uint2*>(As + ((pc * 2 + (kq >> 1)) * LDH + a_hp[i]) * 16 + (kq & 1) * 8) = s.p[pc];
+                for (int pc = 0; pc < NP; ++pc)
+                    *reinterpret_cast<uint2*>(As + ((pc * K8C + (kq >> 1)) * LDH + a_hp[i]) * 16 + (kq & 1) * 8) = s.p[pc];
+            } else {
+                const bool in = a_off[i] >= 0;
+                const float4 lo = in ? bnrelu4(slot_quad<ST>(ra[i], 0), pq, C) : zero4();
+                const float4 hi = in ? bnrelu4(slot_quad<ST>(ra[i], 1), pq + 4, C) : zero4();
+                *reinterpret_cast<u32x4*>(As + (kq * LDH + a_hp[i]) * 16) = pack_unit<OP>(lo, hi);
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_N; ++i) *reinterpret_cast<u32x4*>(Bs + (t + 256 * i) * 16) = rb[i];
@@ -144,14 +153,14 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const H
     int abase[MT];        // halo pixel of this lane's tile row at tap (0, 0)
 #pragma unroll
     for (int m = 0; m < MT; ++m) abase[m] = G::row(wq, m, l31) * G::W + G::col(l31);
-    auto fa = [&](int m, int tap, int pc) -> u32x4 {
-        return *reinterpret_cast<const u32x4*>(As + ((pc * 2 + half) * LDH + abase[m] + (tap / 3) * G::W + tap % 3) * 16);
+    auto fa = [&](int m, int tap, int ks, int pc) -> u32x4 {
+        return *reinterpret_cast<const u32x4*>(As + ((pc * K8C + 2 * ks + half) * LDH + abase[m] + (tap / 3) * G::W + tap % 3) * 16);
     };
-    auto fb = [&](int tap, int pc) -> u32x4 {
-        return *reinterpret_cast<const u32x4*>(Bs + (((pc * 9 + tap) * 2 + half) * 32 + l31) * 16);
+    auto fb = [&](int tap, int ks, int pc) -> u32x4 {
+        return *reinterpret_cast<const u32x4*>(Bs + (((pc * 9 + tap) * K8C + 2 * ks + half) * 32 + l31) * 16);
     };
 
-    const int NCH = C / HALO_CK;
+    const int NCH = C / CK;
     g_load(0);
     __syncthreads();                 // prm visible
     s_store(0);
@@ -160,39 +169,50 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const H
         if (ch + 1 < NCH) g_load(ch + 1);
         // per tap: hi and lo pieces, the two hi x lo groups, then the mid pieces (fetched under those MFMAs) and the rest;
         // the next tap's hi / lo pieces are requested before the last four groups of this one
-        u32x4 ah[2][MT], al[2][MT], bh[2], bl[2];
+        u32x4 ah[2][KSTEP][MT], al[2][MT], bh[2][KSTEP], bl[2];
         auto load_hl = [&](int set, int tap) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) { ah[set][m] = fa(m, tap, 0); if constexpr (PREC == 0) al[set][m] = fa(m, tap, 2); }
-            bh[set] = fb(tap, 0); if constexpr (PREC == 0) bl[set] = fb(tap, 2);
+            for (int ks = 0; ks < KSTEP; ++ks) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) ah[set][ks][m] = fa(m, tap, ks, 0);
+                bh[set][ks] = fb(tap, ks, 0);
+            }
+            if constexpr (OP == 0) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) al[set][m] = fa(m, tap, 0, 2);
+                bl[set] = fb(tap, 0, 2);
+            }
         };
         auto tap_body = [&](int set, int tap, bool more) {
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PREC != 0) {                      // single-piece modes: one term
+            if constexpr (OP != 0) {                        // single-piece operands: one term per k16-step
                 if (more) load_hl(set ^ 1, tap + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = mfma_1p<PREC>(ah[set][m], bh[set], acc[m]);
+                for (int ks = 0; ks < KSTEP; ++ks)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m] = mfma_1p<OP>(ah[set][ks][m], bh[set][ks], acc[m]);
                 return;
+            } else {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][0][m], bl[set], acc[m]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(al[set][m], bh[set][0], acc[m]);
+                u32x4 am[MT], bm;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) am[m] = fa(m, tap, 0, 1);
+                bm = fb(tap, 0, 1);
+                if (more) load_hl(set ^ 1, tap + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(am[m], bm, acc[m]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][0][m], bm, acc[m]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(am[m], bh[set][0], acc[m]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][0][m], bh[set][0], acc[m]);
             }
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][m], bl[set], acc[m]);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(al[set][m], bh[set], acc[m]);
-            u32x4 am[MT], bm;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) am[m] = fa(m, tap, 1);
-            bm = fb(tap, 1);
-            if (more) load_hl(set ^ 1, tap + 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(am[m], bm, acc[m]);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][m], bm, acc[m]);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(am[m], bh[set], acc[m]);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(ah[set][m], bh[set], acc[m]);
         };
         load_hl(0, tap0);
 #pragma unroll
@@ -234,7 +254,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const H
                 const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
                 if (TS == 16 || (py < a.pl.H && px < a.pl.W)) {      // TS == 8 tiles may hang over the edge
                     const float x = acc[m][r];
-                    a.dst[((int64_t)n * a.pl.HWp + py * a.pl.W + px) * a.ldd + a.dcoff + l31] = x;
+                    st1<ST>(a.dst, ((int64_t)n * a.pl.HWp + py * a.pl.W + px) * a.ldd + a.dcoff + l31, x);
                     const double xd = (double)x;
                     s += xd;
                     ss += xd * xd;
@@ -261,8 +281,8 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const H
 //   g = invstd * ((G' - SA/n) - (x - mean) * invstd * SB/n)
 // Statistics pointers are already offset to the slice's first channel; sstride = floats per stream.
 struct GradSrc {
-    const float* g; int ldg;
-    const float* x; int ldx;
+    const void* g; int ldg;         // gradient storage: fp32 / bf16 by mode
+    const void* x; int ldx;         // activation storage: fp32 / bf16 / fp16 by mode
     const double* xsum; const double* xsq; const double* s1; const double* s2; int sstride;
     float eps;
 };
@@ -285,8 +305,8 @@ struct Halo3x3DgradArgs {
     const u32x4* wu;                                 // weight units [c/32][tap][piece][k8][c%32] (PK_HD)
     BnTab bt;                                        // norm2 statistics of this layer (stored by the forward) + gamma / beta
     int C;                                           // bottleneck channels (128)
-    const float* mbuf;                               // raw bottleneck [n][HWp][C] (mask + xhat source)
-    float* dst;                                      // dy [n][HWp][C]
+    const void* mbuf;                                // raw bottleneck [n][HWp][C] (mask + xhat source)
+    void* dst;                                       // dy [n][HWp][C]
     double* o1; double* o2; int ostride;             // per-stream sums [n][C]
     int tiles_x;
     int cg_per_wg;                                   // output-channel groups (NCW chunks of 32) per workgroup; blockIdx.z picks the run
@@ -299,22 +319,26 @@ struct Halo3x3DgradArgs {
 // barrier per stage, prefetched into registers under the stage's MFMAs.  A stage is two k16-steps (32 gradient channels)
 // per pixel tile; after the ninth tap of a chunk the epilogue applies the ReLU mask and collects the norm2 sums.
 // ------------------------------------------------------------------------------------
-constexpr int HDS_BU = NPIECE * 4 * 32;                      // weight units per (tap, 32-channel chunk): 384
-template <int TS> struct HaloDgradSGeo : HaloGeo<TS> {
+template <int TS, int PREC> struct HaloDgradSGeo : HaloGeo<TS> {
     using G = HaloGeo<TS>;
+    static constexpr int NP = PREC ? 1 : NPIECE;
+    static constexpr int BU = NP * 4 * 32;                               // weight units per (tap, 32-channel chunk): 384 / 128
     static constexpr int LDH = G::PX;
-    static constexpr int A_UNITS = NPIECE * 4 * LDH;
-    static constexpr int A_N = (G::PX * 8 + 255) / 256;                  // float4 slots per thread: 11 / 4
+    static constexpr int A_UNITS = NP * 4 * LDH;
+    static constexpr int A_N = (G::PX * (PREC ? 4 : 8) + 255) / 256;     // 16-byte slots per thread (32 gradient channels per pixel)
     static constexpr int NCW = G::WX;                                    // output-channel chunks per stage
-    static constexpr int B_UNITS = NCW * HDS_BU;                         // per buffer
-    static constexpr int B_N = (B_UNITS + 255) / 256;                    // 2 / 3
+    static constexpr int B_UNITS = NCW * BU;                             // per buffer
+    static constexpr int B_N = (B_UNITS + 255) / 256;
     static constexpr int B_PAD = B_N * 256;                              // units per buffer incl. the padding the last copy round touches
     __host__ __device__ static constexpr int smem_bytes(int C) { return (A_UNITS + 3 * B_PAD) * 16 + (4 * C + 256 + 128) * 4; }
 };
 
 template <int TS, int PREC = 0>
 static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x3DgradArgs a) {
-    using G = HaloDgradSGeo<TS>;
+    using G = HaloDgradSGeo<TS, PREC>;
+    using GT = grd_t<PREC>;
+    using XT = act_t<PREC>;
+    constexpr int OP = bwd_op(PREC), NP = G::NP, HDS_BU = G::BU, GSZ = GT::size, XSZ = XT::size, E = 16 / GSZ, SPP = 32 / E;   // SPP: slots per pixel
     constexpr int MT = G::MT, NCW = G::NCW, A_N = G::A_N, B_N = G::B_N, LDH = G::LDH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* As = reinterpret_cast<char*>(smem);                            // [piece][k8][LDH] units
@@ -358,37 +382,45 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
         for (int i = 0; i < B_N; ++i) r[i] = bload_u4(a.wu, kWholeBuf, b_voff[i], 16u * (unsigned)((cg * NCW * 9 + tap) * HDS_BU));
     };
     // gradient halo (zero outside the image), split at the store
-    const float* g_n = a.g.g + (int64_t)n * a.pl.HWp * a.g.ldg;
-    const float* x_n = a.g.x ? a.g.x + (int64_t)n * a.pl.HWp * a.g.ldx : nullptr;
+    const char* g_n = static_cast<const char*>(a.g.g) + (int64_t)GSZ * n * a.pl.HWp * a.g.ldg;
+    const char* x_n = a.g.x ? static_cast<const char*>(a.g.x) + (int64_t)XSZ * n * a.pl.HWp * a.g.ldx : nullptr;
     {
         float4 rv[A_N], rx[A_N];
 #pragma unroll
         for (int i = 0; i < A_N; ++i) {            // every load in flight before the first LDS store
             const int idx = t + 256 * i;
-            const int hp = idx >> 3, q = idx & 7;
+            const int hp = idx / SPP, q = idx % SPP;                        // halo pixel, 16-byte slot (E channels) of its 32
             const int hy = hp / G::W, hx = hp - hy * G::W;
             const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-            const bool ok = idx < G::PX * 8 && (unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W;
+            const bool ok = idx < G::PX * SPP && (unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W;
             const int64_t pix = ok ? iy * a.pl.W + ix : 0;                 // unconditional loads, clamped address
-            rv[i] = ld4(g_n + pix * a.g.ldg + 4 * q);
-            if (x_n) rx[i] = ld4(x_n + pix * a.g.ldx + 4 * q);
+            rv[i] = ld16(g_n, (int64_t)GSZ * (pix * a.g.ldg + E * q));
+            if (x_n) rx[i] = ld16(x_n, (int64_t)XSZ * (pix * a.g.ldx + E * q));
         }
         __syncthreads();                           // gp (and prm) visible
 #pragma unroll
         for (int i = 0; i < A_N; ++i) {
             const int idx = t + 256 * i;
-            if (idx < G::PX * 8) {
-                const int hp = idx >> 3, q = idx & 7;
+            if (idx < G::PX * SPP) {
+                const int hp = idx / SPP, q = idx % SPP;
                 const int hy = hp / G::W, hx = hp - hy * G::W;
                 const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
                 const bool ok = (unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W;
-                float4 v = rv[i];
-                if (x_n) v = affine2(rv[i], rx[i], gp + 4 * q, 32);
-                if (!ok) v = zero4();
-                const Split4 sp = split4<PREC>(v);
+                if constexpr (E == 4) {
+                    float4 v = rv[i];
+                    if (x_n) v = affine2(rv[i], rx[i], gp + 4 * q, 32);
+                    if (!ok) v = zero4();
+                    const Split4 sp = split4<OP>(v);
 #pragma unroll
-                for (int pc = 0; pc < (PREC ? 1 : NPIECE); ++pc)
-                    *reinterpret_cast<uint2*>(As + ((pc * 4 + (q >> 1)) * LDH + hp) * 16 + (q & 1) * 8) = sp.p[pc];
+                    for (int pc = 0; pc < NP; ++pc)
+                        *reinterpret_cast<uint2*>(As + ((pc * 4 + (q >> 1)) * LDH + hp) * 16 + (q & 1) * 8) = sp.p[pc];
+                } else {
+                    u32x4 u = as_u4(rv[i]);                                  // finished bf16 gradient: a copy
+                    if (x_n) u = pack_unit<OP>(affine2(slot_quad<GT>(rv[i], 0), slot_quad<XT>(rx[i], 0), gp + 8 * q, 32),
+                                               affine2(slot_quad<GT>(rv[i], 1), slot_quad<XT>(rx[i], 1), gp + 8 * q + 4, 32));
+                    if (!ok) u = u32x4{0u, 0u, 0u, 0u};
+                    *reinterpret_cast<u32x4*>(As + (q * LDH + hp) * 16) = u;
+                }
             }
         }
     }
@@ -415,7 +447,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
                 const bool ok = TS == 16 || (py < a.pl.H && px < a.pl.W);     // TS == 8 tiles may hang over the edge
-                xv[m][r] = ok ? a.mbuf[((int64_t)n * a.pl.HWp + py * a.pl.W + px) * C + c] : 0.f;
+                xv[m][r] = ok ? ld1<XT>(a.mbuf, ((int64_t)n * a.pl.HWp + py * a.pl.W + px) * C + c) : 0.f;
             }
     };
     for (int s3 = 0; s3 < NSTAGE; s3 += 3) {           // NSTAGE is a multiple of 9: three stages (one kernel row) per trip
@@ -442,7 +474,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
         auto fb = [&](int ks, int pc) -> u32x4 {
             return *reinterpret_cast<const u32x4*>(Bw + ((pc * 4 + 2 * ks + half) * 32 + l31) * 16);
         };
-        if constexpr (PREC != 0) {                          // single-piece modes: one term per k16-step
+        if constexpr (OP != 0) {                            // single-piece operands: one term per k16-step
             u32x4 ah[2][MT], bh[2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -453,7 +485,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = mfma_1p<PREC>(ah[ks][m], bh[ks], acc[m]);
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_1p<OP>(ah[ks][m], bh[ks], acc[m]);
         } else {
             // every fragment of the stage is requested up front (18 ds_read_b128, 72 registers): one LDS round trip per stage
             // instead of four read -> wait -> MFMA phases; hipcc waits per operand (lgkmcnt(N)) as the MFMAs come up
@@ -491,7 +523,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
                         const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
                         if (TS == 8 && (py >= a.pl.H || px >= a.pl.W)) continue;
                         const float dyv = bn1(xv[m][r], mean, sc, be) > 0.f ? acc[m][r] : 0.f;
-                        a.dst[((int64_t)n * a.pl.HWp + py * a.pl.W + px) * C + c] = dyv;
+                        st1<GT>(a.dst, ((int64_t)n * a.pl.HWp + py * a.pl.W + px) * C + c, dyv);
                         s1 += dyv;
                         s2 += dyv * ((xv[m][r] - mean) * invstd);
                     }
@@ -527,7 +559,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
 
 struct Halo3x3WgradArgs {
     GradSrc g; Plane pl;                             // finished output gradient (32 channels)
-    const float* src; int C;                         // raw bottleneck [n][HWp][C]
+    const void* src; int C;                          // raw bottleneck [n][HWp][C]
     BnTab bt;                                        // norm2 statistics of this layer (stored by the forward) + gamma / beta
     float* part;                                     // partial sums [gridDim.x*gridDim.z][9][32][C]
     int tiles_x, n_tiles, tiles_per_wg;
@@ -543,12 +575,13 @@ struct Halo3x3WgradArgs {
 //   TW = 8 : tile  8 x 8 pixels, a k16-step is two tile rows; each wave reduces one step.
 // Three taps (one kernel row) are in flight at a time: 18 MFMAs on three independent accumulators per group.
 // ------------------------------------------------------------------------------------
-template <int TW> struct HaloWgradSGeo {
+template <int TW, int PREC> struct HaloWgradSGeo {
     static_assert(TW == 16 || TW == 8, "tile width");
+    static constexpr int NP = PREC ? 1 : NPIECE, SPP = PREC ? 4 : 8;      // pieces per operand; 16-byte slots per pixel (32 channels)
     static constexpr int TH = 8, HW_ = TW + 2, HH = TH + 2, PX = HW_ * HH, NPIX = TW * TH;
     static constexpr int KSTEPS = NPIX / 16 / 4;                          // k16-steps per wave per tile: 2 / 1
-    static constexpr int B_BYTES = NPIECE * PX * 64, A_BYTES = NPIECE * NPIX * 64;
-    static constexpr int B_N = (PX * 8 + 255) / 256, A_N = NPIX * 8 / 256;   // float4 slots per thread: 6 / 4 halo, 4 / 2 gradient
+    static constexpr int B_BYTES = NP * PX * 64, A_BYTES = NP * NPIX * 64;
+    static constexpr int B_N = (PX * SPP + 255) / 256, A_N = (NPIX * SPP + 255) / 256;   // slots per thread: halo, gradient
     static constexpr int RED_BYTES = 4 * 16 * 64 * 4;
     __host__ __device__ static constexpr int smem_bytes() {
         return (B_BYTES + A_BYTES > RED_BYTES ? B_BYTES + A_BYTES : RED_BYTES) + (96 + 128) * 4;
@@ -557,7 +590,10 @@ template <int TW> struct HaloWgradSGeo {
 
 template <int TW, int PREC = 0>
 static __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const Halo3x3WgradArgs a) {
-    using G = HaloWgradSGeo<TW>;
+    using G = HaloWgradSGeo<TW, PREC>;
+    using GT = grd_t<PREC>;
+    using XT = act_t<PREC>;
+    constexpr int OP = bwd_op(PREC), NP = G::NP, SPP = G::SPP, E = 32 / SPP, GSZ = GT::size, XSZ = XT::size;
     constexpr int B_N = G::B_N, A_N = G::A_N;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* Bh = reinterpret_cast<char*>(smem);           // [piece][PX][32] bf16: activation halo
@@ -578,9 +614,9 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const
     for (int k = 0; k < 9; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-    const float* src_n = a.src + (int64_t)n * a.pl.HWp * C + cc0;
-    const float* g_n = a.g.g + (int64_t)n * a.pl.HWp * a.g.ldg;
-    const float* x_n = a.g.x ? a.g.x + (int64_t)n * a.pl.HWp * a.g.ldx : nullptr;
+    const char* src_n = static_cast<const char*>(a.src) + (int64_t)XSZ * ((int64_t)n * a.pl.HWp * C + cc0);
+    const char* g_n = static_cast<const char*>(a.g.g) + (int64_t)GSZ * n * a.pl.HWp * a.g.ldg;
+    const char* x_n = a.g.x ? static_cast<const char*>(a.g.x) + (int64_t)XSZ * n * a.pl.HWp * a.g.ldx : nullptr;
     // transposing-read geometry: lane i of a 16-lane group fetches pixel-row (k) i/4, channel quad i%4 and receives channel i
     const int tr_row = (lane & 15) >> 2, tr_col = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
     const int tile0 = blockIdx.x * a.tiles_per_wg;
@@ -590,46 +626,66 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const
         const int y0 = ty * G::TH, x0 = tx * TW;
         __syncthreads();                              // previous tile fully consumed (and prm visible)
         {
-            float4 rv[B_N], rg[A_N];
-            bool okv[B_N];
+            float4 rv[B_N], rg[A_N], rgx[E == 4 ? 1 : A_N];
+            bool okv[B_N], okg[A_N];
 #pragma unroll
             for (int i = 0; i < B_N; ++i) {           // all loads in flight, then transform + split + store
                 const int idx = t + 256 * i;
-                const int hp = idx >> 3, q = idx & 7;
+                const int hp = idx / SPP, q = idx % SPP;
                 const int hy = hp / G::HW_, hx = hp - hy * G::HW_;
                 const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-                okv[i] = idx < G::PX * 8 && (unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W;
-                rv[i] = ld4(src_n + (int64_t)(okv[i] ? iy * a.pl.W + ix : 0) * C + 4 * q);   // unconditional, clamped; zeroed at the store
+                okv[i] = idx < G::PX * SPP && (unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W;
+                rv[i] = ld16(src_n, (int64_t)XSZ * ((int64_t)(okv[i] ? iy * a.pl.W + ix : 0) * C + E * q));   // unconditional, clamped; zeroed at the store
             }
 #pragma unroll
             for (int i = 0; i < A_N; ++i) {
                 const int idx = t + 256 * i;
-                const int px = idx >> 3, q = idx & 7;
+                const int px = idx / SPP, q = idx % SPP;
                 const int py = y0 + px / TW, pxx = x0 + px % TW;
-                const bool ok = py < a.pl.H && pxx < a.pl.W;                  // tiles may hang over the edge
-                const int64_t pix = ok ? (int64_t)py * a.pl.W + pxx : 0;
-                float4 v = ld4(g_n + pix * a.g.ldg + 4 * q);
-                if (x_n) v = affine2(v, ld4(x_n + pix * a.g.ldx + 4 * q), gp + 4 * q, 32);
-                rg[i] = ok ? v : zero4();
+                okg[i] = idx < G::NPIX * SPP && py < a.pl.H && pxx < a.pl.W;          // tiles may hang over the edge
+                const int64_t pix = okg[i] ? (int64_t)py * a.pl.W + pxx : 0;
+                rg[i] = ld16(g_n, (int64_t)GSZ * (pix * a.g.ldg + E * q));
+                if constexpr (E == 4) {
+                    if (x_n) rg[i] = affine2(rg[i], ld16(x_n, (int64_t)XSZ * (pix * a.g.ldx + E * q)), gp + 4 * q, 32);
+                } else {
+                    if (x_n) rgx[i] = ld16(x_n, (int64_t)XSZ * (pix * a.g.ldx + E * q));
+                }
             }
 #pragma unroll
             for (int i = 0; i < B_N; ++i) {
                 const int idx = t + 256 * i;
-                if (idx < G::PX * 8) {
-                    const int q = idx & 7;
-                    const Split4 sp = split4<PREC>(okv[i] ? bnrelu4(rv[i], prm + 4 * q, 32) : zero4());   // zero padding AFTER bn+relu
+                if (idx < G::PX * SPP) {
+                    const int q = idx % SPP, hp = idx / SPP;
+                    if constexpr (E == 4) {
+                        const Split4 sp = split4<OP>(okv[i] ? bnrelu4(rv[i], prm + 4 * q, 32) : zero4());   // zero padding AFTER bn+relu
 #pragma unroll
-                    for (int pc = 0; pc < (PREC ? 1 : NPIECE); ++pc)
-                        *reinterpret_cast<uint2*>(Bh + ((pc * G::PX + (idx >> 3)) * 32 + 4 * q) * 2) = sp.p[pc];
+                        for (int pc = 0; pc < NP; ++pc)
+                            *reinterpret_cast<uint2*>(Bh + ((pc * G::PX + hp) * 32 + 4 * q) * 2) = sp.p[pc];
+                    } else {
+                        const float4 lo = okv[i] ? bnrelu4(slot_quad<XT>(rv[i], 0), prm + 8 * q, 32) : zero4();
+                        const float4 hi = okv[i] ? bnrelu4(slot_quad<XT>(rv[i], 1), prm + 8 * q + 4, 32) : zero4();
+                        *reinterpret_cast<u32x4*>(Bh + (hp * 32 + 8 * q) * 2) = pack_unit<OP>(lo, hi);
+                    }
                 }
             }
 #pragma unroll
             for (int i = 0; i < A_N; ++i) {
                 const int idx = t + 256 * i;
-                const Split4 sp = split4<PREC>(rg[i]);
+                if (idx < G::NPIX * SPP) {
+                    const int q = idx % SPP, px = idx / SPP;
+                    if constexpr (E == 4) {
+                        const Split4 sp = split4<OP>(okg[i] ? rg[i] : zero4());
 #pragma unroll
-                for (int pc = 0; pc < (PREC ? 1 : NPIECE); ++pc)
-                    *reinterpret_cast<uint2*>(Ag + ((pc * G::NPIX + (idx >> 3)) * 32 + 4 * (idx & 7)) * 2) = sp.p[pc];
+                        for (int pc = 0; pc < NP; ++pc)
+                            *reinterpret_cast<uint2*>(Ag + ((pc * G::NPIX + px) * 32 + 4 * q) * 2) = sp.p[pc];
+                    } else {
+                        u32x4 u = as_u4(rg[i]);                                  // finished bf16 gradient: a copy
+                        if (x_n) u = pack_unit<OP>(affine2(slot_quad<GT>(rg[i], 0), slot_quad<XT>(rgx[i], 0), gp + 8 * q, 32),
+                                                   affine2(slot_quad<GT>(rg[i], 1), slot_quad<XT>(rgx[i], 1), gp + 8 * q + 4, 32));
+                        if (!okg[i]) u = u32x4{0u, 0u, 0u, 0u};
+                        *reinterpret_cast<u32x4*>(Ag + (px * 32 + 8 * q) * 2) = u;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -651,7 +707,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const
             u32x4 af[NPIECE];
 #pragma unroll
             for (int pc = 0; pc < NPIECE; ++pc)
-                if (pc == 0 || PREC == 0) af[pc] = tr2(ga + pc * G::NPIX * 64, 4 * 64);
+                if (pc == 0 || OP == 0) af[pc] = tr2(ga + pc * G::NPIX * 64, 4 * 64);
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 u32x4 bf[3][NPIECE];
@@ -659,11 +715,11 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const
                 for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
                     for (int pc = 0; pc < NPIECE; ++pc)
-                        if (pc == 0 || PREC == 0) bf[dx][pc] = tr2(hb + pc * G::PX * 64 + (dy * G::HW_ + dx) * 64, 4 * 64);
+                        if (pc == 0 || OP == 0) bf[dx][pc] = tr2(hb + pc * G::PX * 64 + (dy * G::HW_ + dx) * 64, 4 * 64);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (PREC != 0) {                  // single-piece modes: one term per tap
+                if constexpr (OP != 0) {                    // single-piece operands: one term per tap
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) acc[dy * 3 + dx] = mfma_1p<PREC>(af[0], bf[dx][0], acc[dy * 3 + dx]);
+                    for (int dx = 0; dx < 3; ++dx) acc[dy * 3 + dx] = mfma_1p<OP>(af[0], bf[dx][0], acc[dy * 3 + dx]);
                 } else {
                     constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll

@@ -331,31 +331,90 @@ def test_torch_optimizer_zero_grad_does_not_accumulate(gpu):
     assert abs(np.sqrt((g3 * g3).sum()) / n1 - 2.0) < 2e-2
 
 
-def test_reduced_precision_operand_modes(gpu):
-    """BASELINE.json configs 3 / 5: bf16 and fp16 MFMA operands (one term per product; fp32 storage, statistics and
-    accumulation).  Not parity modes - random-weight DenseNets amplify operand rounding - so this
-    checks that they run end to end, stay finite, stay in the neighbourhood of the fp32-class result and that the
-    default mode is restored bit for bit; bench.py reports their measured error."""
-    net = product_net(1)
-    x, mx = scene_tensors(1, [1])
+def _cos(a, b):
+    return float((a * b).sum() / max(np.sqrt((a * a).sum() * (b * b).sum()), 1e-300))
 
-    def sweep():
-        with torch.no_grad():
-            return np.asarray([float(t) for t in net.forward(x, mx, 0, True, -1)])
-    ref = sweep()
-    for prec, tol in (("bf16", 0.5), ("fp16", 0.1)):
-        net.set_precision(prec)
-        q = sweep()
-        assert np.isfinite(q).all()
-        assert np.abs(q - ref).max() <= tol * np.abs(ref).max(), (prec, np.abs(q - ref).max())
-        net.zero_grad()
-        qp = net.forward(x, mx, 0, False, 5)
-        (qp[0, 0, 0, 0] * 1.0).backward()
-        assert bool(torch.isfinite(net.flat_grads()).all())
-    net.half()                                            # the torch idiom maps to the same switch, weights stay fp32
-    assert net.precision == "fp16" and net._flat_params.dtype == torch.float32
-    net.set_precision("fp32")
-    assert (sweep() == ref).all() or np.abs(sweep() - ref).max() <= 1e-6
+
+def test_config3_three_heads_bf16_storage(gpu):
+    """BASELINE.json config 3 as stated: E + S + ES heads, forward + Huber backward + Adam, 16 rotations, bf16 STORAGE of
+    activations and gradients (dense-block buffers, bottlenecks, G', the backward ring) with single-term bf16 MFMA; fp32 BN
+    statistics, accumulation and master weights.  Not a parity mode - a random-weight 121-layer DenseNet amplifies 8-bit
+    mantissas - so the 33-sample step is held to bounds MEASURED against the fp32-class result
+    (tests/gpu_precision.py: max |dq| / max |q| 0.135 / 0.075 / 0.006 for styles 0 / 1 / 2, gradient cosine 0.86 / 0.71 / 0.93)
+    with ~1.5x headroom, and the argmax over the 16 rotations must agree."""
+    from trainer import Trainer
+    import smg_hip
+    import synthetic
+    R = 16
+    tr = Trainer('reinforcement', 0.5, False, None, False)
+    sd = synthetic.make_state_dict(orc.state_layout(1), 0)
+    tr.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    tr.model.gnum_rotations = tr.model.snum_rotations = R
+    tr.optimizer.lr = 0.0
+    depth, masks = synthetic.heightmap_scene(0)
+    rots = list(range(R))
+    labels = synthetic.uniform(0, "bench/labels", R, 0.0, 1.5)
+    work = ((0, depth * masks[0], rots, labels), (1, depth * masks[0], rots, labels), (2, depth * (masks[1] + masks[2]), [0], labels[:1]))
+
+    def run():
+        out = []
+        for style, m, rs, lab in work:
+            loss, q = tr.train_batch(depth, m, style, rs, lab, return_q=True)
+            t0, n0 = smg_hip.trunk_range(1, (1, 0, 2)[style]); h0, hn = smg_hip.head_range(1, (1, 0, 0)[style])
+            g = tr.model.flat_grads().double().cpu().numpy()
+            out.append((q.reshape(-1).cpu().numpy().astype(np.float64), np.concatenate([g[t0:t0 + n0], g[h0:h0 + hn]]), loss.cpu().numpy()))
+        return out
+    ref = run()
+    tr.model.set_precision("bf16")
+    got = run()
+    tr.model.set_precision("fp32")
+    q_bound, cos_bound = (0.20, 0.12, 0.02), (0.70, 0.55, 0.85)
+    for style in range(3):
+        q, g, loss = got[style]; qr, gr, _ = ref[style]
+        assert np.isfinite(q).all() and np.isfinite(g).all() and np.isfinite(loss).all()
+        err, c = np.abs(q - qr).max() / np.abs(qr).max(), _cos(g, gr)
+        print("config 3 bf16 style %d: max|dq|/max|q| %.4f, gradient cosine %.4f, |g| ratio %.3f" % (style, err, c, np.sqrt((g * g).sum() / (gr * gr).sum())))
+        assert err <= q_bound[style], (style, err)
+        assert c >= cos_bound[style], (style, c)
+        assert 0.7 <= np.sqrt((g * g).sum() / (gr * gr).sum()) <= 1.4
+        assert int(q.argmax()) == int(qr.argmax()), (style, int(q.argmax()), int(qr.argmax()))
+    again = run()                                          # the default mode is restored bit for bit (forward)
+    for style in range(3):
+        assert np.array_equal(again[style][0], ref[style][0])
+
+
+def test_config5_share_fp16_storage(gpu):
+    """BASELINE.json config 5's per-GPU share as stated: 640x640 heightmap -> S = 1824, 4 of the 32 rotations as one training
+    call, fp16: activations STORED in fp16 and multiplied on the fp16 MFMA in the forward; gradients stored and multiplied in
+    bf16 (fp32 exponent range - no loss scaling); fp32 statistics / accumulation / master weights.  Held to bounds measured
+    against the fp32-class result (tests/gpu_precision.py: max |dq| / max |q| 0.0033, gradient cosine 0.990) with headroom;
+    the argmax of every 38x38 Q map must agree.  model.half() is the torch idiom for the same switch."""
+    from trainer import Trainer
+    import synthetic
+    tr = Trainer('reinforcement', 0.5, False, None, False)
+    sd = synthetic.make_state_dict(orc.state_layout(1), 0)
+    tr.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    tr.model.gnum_rotations = tr.model.snum_rotations = 32
+    tr.optimizer.lr = 0.0
+    dbig, mbig = synthetic.heightmap_scene(4, size=640, n_boxes=8)
+    r5, l5 = [5, 6, 7, 8], [0.3, 1.9, 0.1, 0.7]
+
+    def run():
+        loss, q = tr.train_batch(dbig, dbig * mbig[0], 0, r5, l5, return_q=True)
+        return q.reshape(4, -1).cpu().numpy().astype(np.float64), tr.model.flat_grads().double().cpu().numpy().copy(), loss.cpu().numpy()
+    qr, gr, _ = run()
+    tr.model.half()
+    assert tr.model.precision == "fp16" and tr.model._flat_params.dtype == torch.float32
+    q, g, loss = run()
+    tr.model.float()
+    assert tr.model.precision == "fp32"
+    assert np.isfinite(q).all() and np.isfinite(g).all() and np.isfinite(loss).all()
+    err, c = np.abs(q - qr).max() / np.abs(qr).max(), _cos(g, gr)
+    print("config 5 share fp16: max|dq|/max|q| %.5f, gradient cosine %.5f" % (err, c))
+    assert err <= 0.008 and c >= 0.975, (err, c)
+    assert 0.9 <= np.sqrt((g * g).sum() / (gr * gr).sum()) <= 1.1
+    for k in range(4):
+        assert int(q[k].argmax()) == int(qr[k].argmax()), k
 
 
 def test_heightmap_generation_matches_restatement(gpu):
