@@ -144,6 +144,80 @@ def cpu_baseline(seed, n_samples, labels, thread_settings):
     return out, sweep
 
 
+def kernel_roofline(step_fn, eng, dev, terms, ms_per_step, step_rl, n_prof=3, pmc=False):
+    """Per-kernel-class roofline of `step_fn` from hipEvents recorded on the launch stream around every launch, with all
+    launches serialised on one stream (smg_profile_enable; separate, untimed passes).
+    MFMA roof: executed FLOPs x `terms` bf16 / fp16 MFMA terms per product / 2.5 PFLOP/s (6 for the fp32-class split, 1 for the
+    16-bit modes).  HBM roof: ALGORITHMIC bytes (every operand read once, every result written once, at the storage width of the
+    mode; the engine's BY() figures) / 8 TB/s.  The larger of the two times bounds the class; frac = that time / measured."""
+    eng.profile_enable(True)
+    for _ in range(n_prof):
+        step_fn()
+    torch.cuda.synchronize(dev)
+    prof = eng.profile_read()
+    stages = eng.profile_read_stages()
+    eng.profile_enable(False)
+    mfma_roof = PEAK_BF16_MFMA_TFLOPS / terms
+
+    def roof(v):
+        ms, n, fl, by = v
+        t_mfma, t_hbm = fl * terms / (PEAK_BF16_MFMA_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9)
+        bound = "mfma" if t_mfma >= t_hbm else "hbm"
+        t = ms * 1e-3
+        if bound == "mfma":
+            r = {"bound": "mfma", "achieved": fl / t / 1e12, "peak": mfma_roof, "unit": "TFLOP/s"}
+        else:
+            r = {"bound": "hbm", "achieved": by / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s"}
+        r["frac"] = max(t_mfma, t_hbm) / t
+        return r
+    conv = {k: v for k, v in prof.items() if k != "elementwise" and v[1] > 0}
+    dom = max(conv, key=lambda k: conv[k][0])
+    ms, n, fl, by = conv[dom]
+    conv_ms = sum(v[0] for v in conv.values())
+    conv_fl = sum(v[2] for v in conv.values())
+    # HBM bytes per launch of the dominant class from the committed PMC passes of this round (profiles/; rocprofv3
+    # cannot run inside this process): bytes per training step there / launches per step HERE.  None if absent.
+    traffic, traffic_src = None, None
+    if pmc:
+        try:
+            with open(os.path.join(REPO, "profiles", PMC_FILE)) as f:
+                pj = json.load(f)
+            if dom in pj:
+                traffic = pj[dom]["gb_per_train_step"] * 1e9 / (n / n_prof)
+                meta = pj.get("_meta", {})
+                traffic_src = ("profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` (%s training steps, commit %s), "
+                               "FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md); bytes per training step / launches per step"
+                               % (PMC_FILE, meta.get("command", "?"), meta.get("train_steps", "?"), meta.get("commit", "?")))
+        except (OSError, ValueError, KeyError):
+            pass
+    rl = roof(conv[dom])
+    rl.update({
+        "kernel": dom, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+        "algorithmic_bytes_per_launch": by / n, "flops_per_launch": fl / n,
+        "avg_launch_ms": ms / n, "launches_per_step": n // n_prof,
+        "kernel_symbols": CLASS_SYMBOLS.get(dom, []),        # rocprofv3 kernel names that make up `kernel`
+        "timing": "hipEvents around every launch of the class, all launches serialised on one stream (smg_profile_enable), %d training steps" % n_prof,
+        "rocprof_serialized": csv_class_avg_ms(CLASS_SYMBOLS.get(dom, [])) if pmc else None,   # the same class in the tracked serialised rocprofv3 CSV
+        "arithmetic": ("fp32 in / fp32 out; every product = 6 v_mfma_f32_32x32x16_bf16 terms of a 3-piece bf16 split (fp32-class accuracy, "
+                       "tools/split_probe.hip): MFMA roof %.1f TFLOP/s fp32-equivalent" % mfma_roof) if terms > 1 else
+                      "16-bit storage of activations and gradients, one 16-bit MFMA term per product: MFMA roof %.0f TFLOP/s, bytes counted at 2 B / element" % mfma_roof,
+        "all_conv_kernels": {"achieved": conv_fl / (conv_ms * 1e-3) / 1e12, "frac_of_mfma_roof": conv_fl / (conv_ms * 1e-3) / 1e12 / mfma_roof,
+                             "frac_of_fp32_mfma_peak": conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                             "ms_per_step": conv_ms / n_prof, "executed_gflop_per_step": conv_fl / n_prof / 1e9},
+        "elementwise_ms_per_step": prof["elementwise"][0] / n_prof,
+        "per_kernel": {k: dict(roof(v), ms_per_step=v[0] / n_prof, launches_per_step=v[1] // n_prof,
+                               tflops=(v[2] / (v[0] * 1e-3) / 1e12) if v[0] > 0 else 0.0,
+                               algorithmic_gb_per_step=v[3] / n_prof / 1e9) for k, v in prof.items() if v[1] > 0 and (v[2] > 0 or v[3] > 0)},
+        # [ms per step, TFLOP/s] inside dense block 1..4 (160^2, 80^2, 40^2, 20^2 planes at S=640)
+        "per_stage": {k: [[round(r[0] / n_prof, 4), round(r[2] / (r[0] * 1e-3) / 1e12, 2) if r[0] > 0 else 0.0] for r in rows]
+                      for k, rows in stages.items() if any(r[1] > 0 for r in rows)},
+    })
+    # whole step: the sum of the per-class roofline times against the measured step
+    floor_s = sum(max(v[2] * terms / (PEAK_BF16_MFMA_TFLOPS * 1e12), v[3] / (PEAK_HBM_GBS * 1e9)) for v in prof.values()) / n_prof
+    rl["step"] = dict(step_rl or {}, roofline_ms=floor_s * 1e3, measured_ms=ms_per_step, frac=floor_s * 1e3 / ms_per_step)
+    return rl
+
+
 def physical_cores():
     """Physical host cores: distinct (package, core id) pairs of /proc/cpuinfo."""
     try:
@@ -278,7 +352,7 @@ def main():
         l5_d = on_dev(synthetic.uniform(50 + rank, "bench/labels_c5", 4, 0.0, 2.0), np.float32)
         tr.model.set_precision("fp16")
         units_per_step, pass_gflop, input_size = 4.0 / 32.0, PASS5_GFLOP, 1824
-        dtype, dtype_note = "f16", "fp16 MFMA operands (one term per product), fp32 accumulation / BN statistics / master weights"
+        dtype, dtype_note = "f16", "fp16 storage of activations + fp16 forward MFMA, bf16 storage of gradients + bf16 backward MFMA; fp32 accumulation / BN statistics / master weights"
         workload = ("config 5 share: 640x640 heightmap -> S=1824, 4 of the 32 rotations per GPU per step as training samples (5 trunk "
                     "streams), dense 38x38 Q maps, Huber on [0,0,0,0], bwd, gradient all-reduce, Adam; a pass = all 32 rotations")
 
@@ -289,7 +363,7 @@ def main():
         lab1_d = on_dev(synthetic.uniform(5, "bench/labels_c3", 1, 0.0, 1.5), np.float32)
         tr.model.set_precision("bf16")
         units_per_step, pass_gflop, input_size = 1.0, 2.0 * PASS_GFLOP + 273.99, 640
-        dtype, dtype_note = "bf16", "bf16 MFMA operands (one term per product), fp32 accumulation / BN statistics / master weights"
+        dtype, dtype_note = "bf16", "bf16 storage of activations and gradients, one bf16 MFMA term per product; fp32 accumulation / BN statistics / master weights"
         workload = ("config 3: styles 0 and 1 with 16 rotations each + style 2 at rotation 0 per GPU per step (33 samples, 35 trunk streams), "
                     "fwd + Huber + bwd + all-reduce + Adam per head; a pass = the three heads")
 
@@ -350,6 +424,9 @@ def main():
         out["allreduce_backend"] = torch.distributed.get_backend()
     out["roofline"] = {"step": step_rl}
 
+    if rank == 0 and world == 1 and leg in ("config3", "config5") and not args.no_roofline:
+        eng = models._ENGINES[(local_rank, input_size, 1)]
+        out["roofline"] = kernel_roofline(step, eng, dev, 1, ms_per_step, step_rl)
     if rank == 0 and world == 1 and leg == "headline" and not args.train_only:
         # host time to ENQUEUE one step (no synchronisation inside): how far the launch path is from being host-bound
         torch.cuda.synchronize(dev)
@@ -428,10 +505,12 @@ def main():
             tr.model.set_precision("bf16")
             ms16 = timed(three_heads, 3)
             q16 = q_sweeps()
+            rl3 = None if args.no_roofline else kernel_roofline(three_heads, models._ENGINES[(local_rank, 640, 1)], dev, 1, ms16, None)
             tr.model.set_precision("fp32")
             cfg["config3_three_heads_bf16"] = {
+                "roofline": rl3,
                 "workload": "styles 0 and 1: 16 rotations each, style 2: rotation 0; fwd + Huber + bwd + Adam per head (33 samples, 35 + 35 trunk streams)",
-                "dtype": "bf16 MFMA operands (one term per product), fp32 activations / statistics / accumulation",
+                "dtype": "bf16 storage of activations and gradients, one bf16 MFMA term per product; fp32 BN statistics, accumulation, master weights",
                 "ms": ms16, "ms_fp32_class": ms32, "samples_per_s": 33.0 / (ms16 * 1e-3),
                 "q_max_abs_err_vs_fp32_class": float(np.abs(q16 - q_ref).max()), "q_max_abs": float(np.abs(q_ref).max()),
                 "argmax_agrees": [bool(int(q16[:R].argmax()) == int(q_ref[:R].argmax())), bool(int(q16[R:].argmax()) == int(q_ref[R:].argmax()))]}
@@ -456,12 +535,15 @@ def main():
             tr.model.set_precision("fp16")
             _, qb16 = tr.train_batch(dbig_d, mdb_d, 0, r5, l5_d, return_q=True)
             ms5_16 = timed(lambda: tr.train_batch(dbig_d, mdb_d, 0, r5, l5_d), 4)
+            rl5 = None if args.no_roofline else kernel_roofline(lambda: tr.train_batch(dbig_d, mdb_d, 0, r5, l5_d), models._ENGINES[(local_rank, 1824, 1)], dev, 1, ms5_16, None)
             tr.model.set_precision("fp32")
             tr.model.gnum_rotations = tr.model.snum_rotations = R
             a32, a16 = qb32.reshape(4, -1).cpu().numpy(), qb16.reshape(4, -1).cpu().numpy()
             cfg["config5_share_1824_fp16"] = {
                 "workload": "640x640 heightmap -> 1824x1824 input, 4 of 32 rotations as training samples (5 trunk streams), dense 38x38 Q maps, Huber on [0,0,0,0]",
-                "dtype": "fp16 MFMA operands (one term per product), fp32 activations / statistics / accumulation",
+                "dtype": "fp16 storage of activations + fp16 forward MFMA, bf16 storage of gradients + bf16 backward MFMA (one term per product); "
+                         "fp32 BN statistics, accumulation, master weights",
+                "roofline": rl5,
                 "ms_per_step": ms5_16, "ms_fp32_class": ms5_32, "algorithmic_tflops": 4 * 2225.73 / ms5_16 * (5.0 / 8.0),
                 "q_max_abs_err_vs_fp32_class": float(np.abs(a16 - a32).max()), "q_max_abs": float(np.abs(a32).max()),
                 "argmax_agrees": [bool(int(a16[k].argmax()) == int(a32[k].argmax())) for k in range(4)],
@@ -469,74 +551,8 @@ def main():
             tr.optimizer.lr = lr0
             out["configs"] = cfg
         if not args.no_roofline:
-            # per-kernel-class hipEvent timing on the launch stream (separate, untimed passes)
             eng = models._ENGINES[(local_rank, 640, 1)]        # the batched leg may have regrown the engine
-            eng.profile_enable(True)
-            n_prof = 3
-            for _ in range(n_prof):
-                step()
-            torch.cuda.synchronize(dev)
-            prof = eng.profile_read()
-            stages = eng.profile_read_stages()
-            eng.profile_enable(False)
-            # Roofline per kernel class.  MFMA roof: executed FLOPs x 6 bf16 MFMA terms / 2.5 PFLOP/s.  HBM roof: ALGORITHMIC bytes
-            # (every operand read once, every result written once, fp32; the engine's BY() figures) / 8 TB/s.  The larger of the
-            # two times bounds the class; frac = that time / the hipEvent-measured time on the launch stream.
-            def roof(v):
-                ms, n, fl, by = v
-                t_mfma, t_hbm = fl * SPLIT_TERMS / (PEAK_BF16_MFMA_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9)
-                bound = "mfma" if t_mfma >= t_hbm else "hbm"
-                t = ms * 1e-3
-                if bound == "mfma":
-                    r = {"bound": "mfma", "achieved": fl / t / 1e12, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s"}
-                else:
-                    r = {"bound": "hbm", "achieved": by / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s"}
-                r["frac"] = max(t_mfma, t_hbm) / t
-                return r
-            conv = {k: v for k, v in prof.items() if k != "elementwise" and v[1] > 0}
-            dom = max(conv, key=lambda k: conv[k][0])
-            ms, n, fl, by = conv[dom]
-            conv_ms = sum(v[0] for v in conv.values())
-            conv_fl = sum(v[2] for v in conv.values())
-            # HBM bytes per launch of the dominant class from the committed PMC passes of this round (profiles/; rocprofv3
-            # cannot run inside this process): bytes per training step there / launches per step HERE.  None if absent.
-            traffic, traffic_src = None, None
-            try:
-                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_FILE)) as f:
-                    pj = json.load(f)
-                if dom in pj:
-                    traffic = pj[dom]["gb_per_train_step"] * 1e9 / (n / n_prof)
-                    meta = pj.get("_meta", {})
-                    traffic_src = ("profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` (%s training steps, commit %s), "
-                                   "FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md); bytes per training step / launches per step"
-                                   % (PMC_FILE, meta.get("command", "?"), meta.get("train_steps", "?"), meta.get("commit", "?")))
-            except (OSError, ValueError, KeyError):
-                pass
-            rl = roof(conv[dom])
-            rl.update({
-                "kernel": dom, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": by / n, "flops_per_launch": fl / n,
-                "avg_launch_ms": ms / n, "launches_per_step": n // n_prof,
-                "kernel_symbols": CLASS_SYMBOLS.get(dom, []),        # rocprofv3 kernel names that make up `kernel`
-                "timing": "hipEvents around every launch of the class, all launches serialised on one stream (smg_profile_enable), %d training steps" % n_prof,
-                "rocprof_serialized": csv_class_avg_ms(CLASS_SYMBOLS.get(dom, [])),   # the same class in the tracked serialised rocprofv3 CSV
-                "arithmetic": "fp32 in / fp32 out; every product = %d v_mfma_f32_32x32x16_bf16 terms of a 3-piece bf16 split (fp32-class accuracy, "
-                              "tools/split_probe.hip): MFMA roof %.1f TFLOP/s fp32-equivalent" % (SPLIT_TERMS, PEAK_SPLIT_TFLOPS),
-                "all_conv_kernels": {"achieved": conv_fl / (conv_ms * 1e-3) / 1e12, "frac_of_split_mfma_roof": conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_SPLIT_TFLOPS,
-                                     "frac_of_fp32_mfma_peak": conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                     "ms_per_step": conv_ms / n_prof, "executed_gflop_per_step": conv_fl / n_prof / 1e9},
-                "elementwise_ms_per_step": prof["elementwise"][0] / n_prof,
-                "per_kernel": {k: dict(roof(v), ms_per_step=v[0] / n_prof, launches_per_step=v[1] // n_prof,
-                                       tflops=(v[2] / (v[0] * 1e-3) / 1e12) if v[0] > 0 else 0.0,
-                                       algorithmic_gb_per_step=v[3] / n_prof / 1e9) for k, v in prof.items() if v[1] > 0 and (v[2] > 0 or v[3] > 0)},
-                # [ms per step, TFLOP/s] inside dense block 1..4 (160^2, 80^2, 40^2, 20^2 planes at S=640)
-                "per_stage": {k: [[round(r[0] / n_prof, 4), round(r[2] / (r[0] * 1e-3) / 1e12, 2) if r[0] > 0 else 0.0] for r in rows]
-                              for k, rows in stages.items() if any(r[1] > 0 for r in rows)},
-            })
-            # whole step: the sum of the per-class roofline times against the measured step
-            floor_s = sum(max(v[2] * SPLIT_TERMS / (PEAK_BF16_MFMA_TFLOPS * 1e12), v[3] / (PEAK_HBM_GBS * 1e9)) for v in prof.values()) / n_prof
-            rl["step"] = dict(step_rl, roofline_ms=floor_s * 1e3, measured_ms=ms_per_step, frac=floor_s * 1e3 / ms_per_step)
-            out["roofline"] = rl
+            out["roofline"] = kernel_roofline(step, eng, dev, SPLIT_TERMS, ms_per_step, step_rl, pmc=True)
         if args.cpu_samples > 0:
             # threads = physical cores and two smaller settings; the best one is reported
             pc = physical_cores()

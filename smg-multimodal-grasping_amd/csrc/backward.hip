@@ -125,9 +125,9 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 a.xsum = fsum(e, e->st_X[b]); a.xsq = fsq(e, e->st_X[b]); a.xstride = Ct;
                 a.s1 = b1(e, e->bs_X[b]); a.s2 = b2(e, e->bs_X[b]); a.sstride = Ct; a.scoff = d.cin; a.gamma = nullptr; a.eps = kEps;
                 a.out = GSb; a.ldo = kGrowth;
-                BY(e, 4.0 * NS * pl.HW * 3 * kGrowth);
+                BY(e, ESZ(e) * NS * pl.HW * 3 * kGrowth);
                 ProfScope ps(e, st, K_OTHER, 0);
-                PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_bwd_apply_kernel<PREC>), dim3(pl.HWp / 64, NS), dim3(256), 0, st, a));
+                PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_bwd_apply_kernel<PREC>), dim3((pl.HWp + bn_apply_rows(PREC) - 1) / bn_apply_rows(PREC), NS), dim3(256), 0, st, a));
                 if (gs_mat) { gsrc = GradSrc{}; gsrc.g = GSb; gsrc.ldg = kGrowth; }
             }
             if (fork(e->ev_gs[db])) return -5;
@@ -138,7 +138,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 a.mbuf = bt;
                 a.dst = D2b; a.o1 = b1(e, e->bs_Bt[b][i]); a.o2 = b2(e, e->bs_Bt[b][i]); a.ostride = kBottleneck;
                 a.wu = e->packed_u + e->pk_hd[b][i]; a.bt = bn_table(e, e->sb_tab[b][i], e->max_streams, 0, kBottleneck, P + d.n2.w, P + d.n2.b);
-                BY(e, 4.0 * NS * pl.HW * (kGrowth + 2 * kBottleneck));      // gradient in, mask source in, dy out
+                BY(e, ESZ(e) * NS * pl.HW * (kGrowth + 2 * kBottleneck));      // gradient in, mask source in, dy out
                 ProfScope ps(e, st, K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
                 TraceScope ts(st, K_D3, halo_tile(pl, NS) == 16 ? dim3((pl.H / 16) * (pl.W / 16), NS) : dim3(((pl.H + 7) / 8) * ((pl.W + 7) / 8), NS, kBottleneck / 64));
                 if (halo_tile(pl, NS) == 16) {
@@ -167,7 +167,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                     p.dst = D2b; p.ldd = kBottleneck; p.dcoff = 0;
                     p.o1 = b1(e, e->bs_Bt[b][i]); p.o2 = b2(e, e->bs_Bt[b][i]); p.ostride = kBottleneck; p.ocoff = 0;
                     p.dbeta = Gr + d.n2.b; p.dgamma = Gr + d.n2.w; p.eps = kEps;
-                    BY(e, 4.0 * NS * pl.HW * (kGrowth + 2 * kBottleneck));
+                    BY(e, ESZ(e) * NS * pl.HW * (kGrowth + 2 * kBottleneck));
                     launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, kBottleneck / Cfg::BN), K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
                 };
                 if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
@@ -184,7 +184,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 const int groups = (a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
                 if ((int64_t)groups * NS * 9 * 32 * kBottleneck > e->part_floats) return fail(-12, "partial-gradient workspace too small");
                 {
-                    BY(e, 4.0 * NS * pl.HW * (kGrowth + kBottleneck));
+                    BY(e, ESZ(e) * NS * pl.HW * (kGrowth + kBottleneck));
                     ProfScope ps(e, s2, K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
                     if (ts == 16) {
                         PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_wgrad_kernel<16, PREC>), dim3(groups, kBottleneck / 32, NS), dim3(256),
@@ -209,7 +209,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 p.bgamma = P + d.n2.w; p.bbeta = P + d.n2.b; p.eps = kEps;
                 p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
                 p.dw = Gr + d.c2.w; p.ldw_out = kBottleneck * 9;
-                BY(e, 4.0 * NS * pl.HW * (kGrowth + kBottleneck));
+                BY(e, ESZ(e) * NS * pl.HW * (kGrowth + kBottleneck));
                 launch_wgrad(e, s2, p, dim3(1, 1, 9 * NS * cps), K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth, 9, C_3x3);
             }
             {   // norm2 backward applied once, in place: D2 <- gamma2*invstd*(dy - s1/n - xhat*s2/n)
@@ -219,9 +219,9 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 a.s1 = b1(e, e->bs_Bt[b][i]); a.s2 = b2(e, e->bs_Bt[b][i]); a.sstride = kBottleneck; a.scoff = 0;
                 a.gamma = P + d.n2.w; a.eps = kEps; a.out = D2b; a.ldo = kBottleneck;
                 if (!e->generic3x3) { a.dbeta = Gr + d.n2.b; a.dgamma = Gr + d.n2.w; }   // the halo dgrad leaves these to us
-                BY(e, 4.0 * NS * pl.HW * 3 * kBottleneck);
+                BY(e, ESZ(e) * NS * pl.HW * 3 * kBottleneck);
                 ProfScope ps(e, st, K_OTHER, 0);
-                PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_bwd_apply_kernel<PREC>), dim3(pl.HWp / 64, NS), dim3(256), 0, st, a));
+                PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_bwd_apply_kernel<PREC>), dim3((pl.HWp + bn_apply_rows(PREC) - 1) / bn_apply_rows(PREC), NS), dim3(256), 0, st, a));
             }
             if (fork(e->ev_d2[db])) return -5;
             // conv1 (1x1) data gradient -> relu1/norm1 backward accumulated into G'.  Layers are grouped (kGroup,
@@ -234,7 +234,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             const int cs = T.layers[b][g_lo].cin;                       // channels below the group
             if (d.cin > cs) {                                           // [cs, cin): per-layer accumulate
                 auto run = [&](auto tag, auto ptag) {
-                    using Cfg = decltype(tag);
+                    using Cfg = MC<decltype(tag), decltype(ptag)::value>;
                     BwdDataP<Cfg, false, E_ACCUM, false, decltype(ptag)::value> p{};
                     p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kBottleneck;
                     p.wp = e->packed_u + e->pk_d1[b][i]; p.K8tot = kBottleneck / 8; p.ldn = d.cin; p.wcol0 = cs; p.N = d.cin - cs;
@@ -244,14 +244,14 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                     p.dst = e->G[b]; p.ldd = Ct; p.dcoff = cs;
                     p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.ocoff = cs;
                     p.dbeta = Gr + d.n1.b + cs; p.dgamma = Gr + d.n1.w + cs; p.eps = kEps;
-                    BY(e, 4.0 * NS * pl.HW * (kBottleneck + 3.0 * p.N));          // dy in; x in, G' read + written
+                    BY(e, ESZ(e) * NS * pl.HW * (kBottleneck + 3.0 * p.N));          // dy in; x in, G' read + written
                     launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, (p.N + Cfg::BN - 1) / Cfg::BN), K_D1, 2.0 * NS * pl.HW * p.N * kBottleneck);
                 };
                 PREC_DISPATCH(e, if (pl.HWp % 128 == 0) run(CfgP128x64{}, PTAG); else run(CfgP64x64{}, PTAG));
             }
             if (i == g_lo) {                                            // [0, cs): the whole group at once
                 auto run = [&](auto tag, auto ptag) {
-                    using Cfg = decltype(tag);
+                    using Cfg = MC<decltype(tag), decltype(ptag)::value>;
                     BwdDataGroupP<Cfg, decltype(ptag)::value> p{};
                     const int g_hi = L - 1 - ((L - 1 - g_lo) / kGroup) * kGroup;      // top layer of this group
                     p.nseg = g_hi - g_lo + 1;
@@ -267,7 +267,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                     p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct;
                     p.dst = e->G[b]; p.ldd = Ct;
                     p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.eps = kEps;
-                    BY(e, 4.0 * NS * pl.HW * ((double)p.nseg * kBottleneck + 3.0 * cs));
+                    BY(e, ESZ(e) * NS * pl.HW * ((double)p.nseg * kBottleneck + 3.0 * cs));
                     launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, (cs + Cfg::BN - 1) / Cfg::BN), K_D1, 2.0 * NS * pl.HW * cs * kBottleneck * p.nseg);
                 };
                 PREC_DISPATCH(e, if (pl.HWp % 128 == 0) run(CfgP128x64{}, PTAG); else run(CfgP64x64{}, PTAG));
@@ -280,14 +280,14 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 static const int w1_target = getenv("SMG_W1_WGS") ? atoi(getenv("SMG_W1_WGS")) : 320;            // dev A/B
                 pick_chunk(pl, NS, nt, chunk, cps, w1_target);   // 256..384 measure the same (22.46 ms per step), 512: 22.6, 768: 22.8, 1024: 23.2
                 auto go = [&](auto ptag) {
-                BwdWeightP<Cfg, W_ONE, C_IDENT, SMG_PD_WGRAD, false, decltype(ptag)::value> p{};
+                BwdWeightP<MC<Cfg, decltype(ptag)::value>, W_ONE, C_IDENT, SMG_PD_WGRAD, false, decltype(ptag)::value> p{};
                 p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck;
                 p.bbuf = e->X[b]; p.ldb = Ct; p.pb = pl; p.NB = d.cin;
                 p.bsum = fsum(e, e->st_X[b]); p.bsq = fsq(e, e->st_X[b]); p.bstride = Ct;
                 p.bgamma = P + d.n1.w; p.bbeta = P + d.n1.b; p.eps = kEps;
                 p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
                 p.dw = Gr + d.c1.w; p.ldw_out = d.cin;
-                BY(e, 4.0 * NS * pl.HW * (kBottleneck + d.cin));
+                BY(e, ESZ(e) * NS * pl.HW * (kBottleneck + d.cin));
                 launch_wgrad(e, s2, p, dim3(1, nt, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck, 1, C_IDENT, e->deterministic);
                 };
                 PREC_DISPATCH(e, go(PTAG));
@@ -301,7 +301,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 int chunk, cps;
                 pick_chunk(pl, NS, (C0 / 128) * (Cp / 128), chunk, cps);
                 auto go = [&](auto ptag) -> int {
-                BwdWeightP<CfgW128x128, W_POOL, C_IDENT, 1, true, decltype(ptag)::value> p{};      // (one k-tile in flight: the pooling fetch holds 4 float4 per slot, three tiles of them leave one workgroup per CU)
+                BwdWeightP<MC<CfgW128x128, decltype(ptag)::value>, W_POOL, C_IDENT, 1, true, decltype(ptag)::value> p{};      // (one k-tile in flight: the pooling fetch holds 4 float4 per slot, three tiles of them leave one workgroup per CU)
                 p.gbuf = e->G[b]; p.ldg = Ct; p.gcoff = 0; p.xbuf = e->X[b]; p.ldx = Ct; p.xcoff = 0; p.pa = pl; p.MA = C0;
                 p.xsum = fsum(e, e->st_X[b]); p.xsq = fsq(e, e->st_X[b]); p.xstride = Ct;
                 p.s1 = b1(e, e->bs_X[b]); p.s2 = b2(e, e->bs_X[b]); p.sstride = Ct; p.scoff = 0; p.agamma = nullptr;
@@ -311,7 +311,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
                 p.dw = Gr + T.tconv[b - 1].w; p.ldw_out = Cp;
                 if (fork(e->ev_misc)) return -5;
-                BY(e, 4.0 * NS * (2.0 * pl.HW * C0 + (double)pp.HW * Cp));
+                BY(e, ESZ(e) * NS * (2.0 * pl.HW * C0 + (double)pp.HW * Cp));
                 launch_wgrad(e, s2, p, dim3(C0 / 128, Cp / 128, NS * cps), K_TW, 2.0 * NS * pl.HW * Cp * C0, 1, C_IDENT);
                 return 0;
                 };
@@ -323,7 +323,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             }
             {
                 auto run = [&](auto tag, auto ptag) {
-                using Cfg = decltype(tag);
+                using Cfg = MC<decltype(tag), decltype(ptag)::value>;
                 BwdDataP<Cfg, false, E_UNPOOL, true, decltype(ptag)::value> p{};
                 p.gbuf = e->G[b]; p.ldg = Ct; p.gcoff = 0; p.xbuf = e->X[b]; p.ldx = Ct; p.xcoff = 0; p.pa = pl; p.KA = C0;
                 p.xsum = fsum(e, e->st_X[b]); p.xsq = fsq(e, e->st_X[b]); p.xstride = Ct;
@@ -335,7 +335,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 p.dst = e->G[b - 1]; p.ldd = Cp; p.dcoff = 0;
                 p.o1 = b1(e, e->bs_X[b - 1]); p.o2 = b2(e, e->bs_X[b - 1]); p.ostride = Cp; p.ocoff = 0;
                 p.dbeta = Gr + T.tnorm[b - 1].b; p.dgamma = Gr + T.tnorm[b - 1].w; p.eps = kEps;
-                BY(e, 4.0 * NS * (2.0 * pl.HW * C0 + 2.0 * pp.HW * Cp));
+                BY(e, ESZ(e) * NS * (2.0 * pl.HW * C0 + 2.0 * pp.HW * Cp));
                 launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, Cp / Cfg::BN), K_TD, 2.0 * NS * pl.HW * Cp * C0);
             };
             PREC_DISPATCH(e, run(CfgP64x128{}, PTAG));   // the 128-row variant of the unpool epilogue spills registers

@@ -648,27 +648,32 @@ struct BnBwdApplyArgs {
                                                   // (one fp32 atomic per stream and channel instead of one per producer tile)
 };
 
+// rows of a plane per workgroup: the 16-bit modes move half the bytes per row, so a workgroup takes twice the rows
+constexpr int bn_apply_rows(int prec) { return prec ? 128 : 64; }
 template <int PREC>
 static __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApplyArgs a) {
     using XT = act_t<PREC>;
     using GT = grd_t<PREC>;
+    constexpr int E = 16 / GT::size;              // channels per 16-byte slot: 4 (fp32 storage) or 8 (16-bit storage)
+    constexpr int RPW = bn_apply_rows(PREC);      // rows per workgroup
+    static_assert(GT::size == XT::size, "one slot geometry");
     __shared__ float prm[4 * 128];
     const int n = blockIdx.y, t = threadIdx.x;
-    const int qpr = a.C / 4;                      // float4 per row
-    const int rows_per_pass = 256 / qpr;
-    const int cq = t % qpr;
-    const int r0 = blockIdx.x * 64 + t / qpr;
-    // 64 rows per workgroup: up to 8 row slots per thread.  The data loads go out FIRST (unconditional, clamped row) so that
+    const int spr = a.C / E;                      // slots per row
+    const int rows_per_pass = 256 / spr;
+    const int cs = t % spr;
+    const int r0 = blockIdx.x * RPW + t / spr;
+    // RPW rows per workgroup: up to 8 row slots per thread.  The data loads go out FIRST (unconditional, clamped row) so that
     // they share one memory round trip with the parameter prologue below; all loads before any store (the output may alias
     // the gradient input - it does for the in-place norm2 case).
     float4 gv[8], xv[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int r = r0 + k * rows_per_pass;
-        if (k * rows_per_pass >= 64) break;            // (workgroup-uniform: C = 32 uses two slots, C = 128 all eight)
+        if (k * rows_per_pass >= RPW) break;           // (workgroup-uniform: C = 32 uses two slots, C = 128 eight)
         const int64_t pix = (int64_t)n * a.pl.HWp + (r < a.pl.HW ? r : 0);
-        gv[k] = ldq<GT>(a.g, pix * a.ldg + a.gcoff + 4 * cq);
-        xv[k] = ldq<XT>(a.x, pix * a.ldx + a.xcoff + 4 * cq);
+        gv[k] = ld16(a.g, (int64_t)GT::size * (pix * a.ldg + a.gcoff + E * cs));
+        xv[k] = ld16(a.x, (int64_t)XT::size * (pix * a.ldx + a.xcoff + E * cs));
     }
     if (t < a.C) {
         const double inv = 1.0 / (double)a.pl.HW;
@@ -688,9 +693,15 @@ static __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApp
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int r = r0 + k * rows_per_pass;
-        if (k * rows_per_pass < 64 && r < a.pl.HW) {
+        if (k * rows_per_pass < RPW && r < a.pl.HW) {
             const int64_t pix = (int64_t)n * a.pl.HWp + r;
-            stq<GT>(a.out, pix * a.ldo + 4 * cq, affine2(gv[k], xv[k], prm + 4 * cq, a.C));
+            if constexpr (E == 4) {
+                stq<GT>(a.out, pix * a.ldo + 4 * cs, affine2(gv[k], xv[k], prm + 4 * cs, a.C));
+            } else {
+                const u32x4 u = pack_unit<1>(affine2(slot_quad<GT>(gv[k], 0), slot_quad<XT>(xv[k], 0), prm + 8 * cs, a.C),
+                                             affine2(slot_quad<GT>(gv[k], 1), slot_quad<XT>(xv[k], 1), prm + 8 * cs + 4, a.C));   // gradients: bf16
+                *reinterpret_cast<u32x4*>(static_cast<char*>(a.out) + (int64_t)GT::size * (pix * a.ldo + 8 * cs)) = u;
+            }
         }
     }
 }

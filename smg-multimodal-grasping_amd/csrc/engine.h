@@ -62,6 +62,11 @@ using CfgW128x128 = GemmCfg<128, 128, 16, 2, 2, 1, false>;   // transition wgrad
 using CfgW64x64 = GemmCfg<64, 64, 16, 2, 2, 1, false>;       // head conv0 wgrad
 using CfgW64x256 = GemmCfg<64, 256, 16, 2, 2, 1, false>;     // stem wgrad: all 196 (tap, channel) columns in one tile
 
+// 16-bit storage modes move half the bytes per k-tile with the same latency per k-tile (global load -> LDS -> barrier): their
+// k-tiles are MUL times deeper (the single-piece LDS images are a third of the fp32-class ones, so the tiles still fit).
+template <class C, int PREC, int MUL = 2>
+using MC = typename std::conditional<PREC == 0, C, GemmCfg<C::BM, C::BN, MUL * C::BK, C::WM, C::WN, C::WK, C::AT>>::type;
+
 enum Kind {
     K_STEM = 0, K_C1, K_C3, K_TRANS, K_HEAD0, K_D3, K_W3, K_D1, K_W1, K_TW, K_TD, K_SW, K_HW0, K_HD0, K_OTHER, K_COUNT
 };
@@ -194,6 +199,7 @@ static hipEvent_t prof_event(smg_engine* e) {
 // Algorithmic HBM bytes of the launch that follows: what the kernel must move once (inputs read once, outputs written
 // once, fp32), the yardstick of bench.py's HBM roofline.
 #define BY(e, x) ((e)->next_bytes = (double)(x))
+#define ESZ(e) ((e)->prec ? 2.0 : 4.0)      // bytes per element of the mode-typed buffers (X, Bt, G', GS, D2)
 struct ProfScope {
     smg_engine* e; hipStream_t st; int kind; double flops, bytes; hipEvent_t a{}, b{};
     ProfScope(smg_engine* e_, hipStream_t s, int k, double f) : e(e_), st(s), kind(k), flops(f), bytes(e_->next_bytes) {

@@ -138,7 +138,8 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                     const BnTab t1 = bn_table(e, e->sx_tab[b], e->max_streams, s0, Ct, P + d.n1.w, P + d.n1.b);
                     if (i == 0) bn_stat(cs, t1, ns, xsum, xsq, Ct, 0, d.cin, pl.HW);     // block input: from pool0 / the transition
                     auto run_p = [&](auto tag, auto ptag) {
-                        using Cfg = decltype(tag);
+                        using Cfg0 = decltype(tag);
+                        using Cfg = MC<Cfg0, decltype(ptag)::value, (Cfg0::BK < 32 ? 2 : 1)>;      // (cin is a multiple of 32 only)
                         FwdConvP<Cfg, F_ONE, decltype(ptag)::value> p{};
                         p.src = xs(b); p.lds_ = Ct; p.ps = pl; p.po = pl; p.K = d.cin;
                         p.bt = t1; p.fresh0 = i == 0 ? d.cin : d.cin - kGrowth; p.fsum = xsum; p.fsq = xsq; p.fstride = Ct; p.eps = kEps;
@@ -146,7 +147,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                         p.wp = e->packed_u + e->pk_c1[b][i]; p.K8tot = d.cin / 8; p.N = kBottleneck;
                         p.dst = bt; p.ldd = kBottleneck; p.dcoff = 0;
                         p.dsum = bsum; p.dsq = bsq; p.dstride = kBottleneck;
-                        BY(e, 4.0 * ns * pl.HW * (d.cin + kBottleneck));
+                        BY(e, ESZ(e) * ns * pl.HW * (d.cin + kBottleneck));
                         launch_gemm(e, cs, p, dim3(ns * pl.HWp / Cfg::BM, kBottleneck / Cfg::BN), K_C1, 2.0 * ns * pl.HW * d.cin * kBottleneck);
                     };
                     auto run = [&](auto tag) { PREC_DISPATCH(e, run_p(tag, PTAG)); };
@@ -168,7 +169,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                         a.dst = bt; a.ldd = kBottleneck; a.dsum = bsum; a.dsq = bsq; a.dstride = kBottleneck;
                         const int nM = ns * pl.HWp / 64, nN = kBottleneck / 64;
                         a.tm = TileMap{nM, nN, 0};
-                        BY(e, 4.0 * ns * pl.HW * (d.cin + kBottleneck));
+                        BY(e, ESZ(e) * ns * pl.HW * (d.cin + kBottleneck));
                         ProfScope ps(e, cs, K_C1, 2.0 * ns * pl.HW * d.cin * kBottleneck);
                         const size_t smem = WsGeo::smem_bytes(d.cin);
                         static bool raised[64] = {};
@@ -198,7 +199,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                     a.dst = xs(b); a.ldd = Ct; a.dcoff = d.cin;
                     a.dsum = xsum; a.dsq = xsq; a.dstride = Ct;
                     a.wu = e->packed_u + e->pk_hf[b][i];
-                    BY(e, 4.0 * ns * pl.HW * (kBottleneck + kGrowth));
+                    BY(e, ESZ(e) * ns * pl.HW * (kBottleneck + kGrowth));
                     ProfScope ps(e, cs, K_C3, 2.0 * ns * pl.HW * 9 * kBottleneck * kGrowth);
                     if (halo_tile(pl, ns) == 16) {
                         a.tiles_x = pl.W / 16;
@@ -219,7 +220,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                         p.wp = e->packed_u + e->pk_g3f[b][i]; p.K8tot = 9 * kBottleneck / 8; p.N = kGrowth;
                         p.dst = xs(b); p.ldd = Ct; p.dcoff = d.cin;
                         p.dsum = xsum; p.dsq = xsq; p.dstride = Ct;
-                        BY(e, 4.0 * ns * pl.HW * (kBottleneck + kGrowth));
+                        BY(e, ESZ(e) * ns * pl.HW * (kBottleneck + kGrowth));
                         launch_gemm(e, cs, p, dim3(ns * pl.HWp / Cfg::BM, 1), K_C3, 2.0 * ns * pl.HW * 9 * kBottleneck * kGrowth);
                     };
                     if (pl.HWp % 128 == 0) run(CfgP128x32{}); else run(CfgP64x32{});
@@ -230,7 +231,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                 const int Cn = kBlockCtot[b + 1];
                 const BnTab tt = bn_table(e, e->sx_tab[b], e->max_streams, s0, Ct, P + T.tnorm[b].w, P + T.tnorm[b].b);
                 auto run = [&](auto tag, auto ptag) {
-                    using Cfg = decltype(tag);
+                    using Cfg = MC<decltype(tag), decltype(ptag)::value>;
                     FwdConvP<Cfg, F_POOL, decltype(ptag)::value> p{};
                     p.src = xs(b); p.lds_ = Ct; p.ps = pl; p.po = pn; p.K = Ct;
                     p.bt = tt; p.fresh0 = Ct - kGrowth; p.fsum = xsum; p.fsq = xsq; p.fstride = Ct; p.eps = kEps;     // the block's last layer
@@ -238,7 +239,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                     p.wp = e->packed_u + e->pk_t[b]; p.K8tot = Ct / 8; p.N = Ct / 2;
                     p.dst = xs(b + 1); p.ldd = Cn; p.dcoff = 0;
                     p.dsum = st_off(fsum(e, e->st_X[b + 1]), Cn); p.dsq = st_off(fsq(e, e->st_X[b + 1]), Cn); p.dstride = Cn;
-                    BY(e, 4.0 * ns * ((double)pl.HW * Ct + (double)pn.HW * (Ct / 2)));
+                    BY(e, ESZ(e) * ns * ((double)pl.HW * Ct + (double)pn.HW * (Ct / 2)));
                     launch_gemm(e, cs, p, dim3(ns * pn.HWp / Cfg::BM, (Ct / 2) / Cfg::BN), K_TRANS, 2.0 * ns * pn.HW * Ct * (Ct / 2));
                 };
                 PREC_DISPATCH(e, if (pn.HWp % 128 == 0) run(CfgP128x128{}, PTAG); else run(CfgP64x128{}, PTAG));

@@ -230,6 +230,56 @@ __device__ __forceinline__ void mma_split(f32x16 (&acc)[TM][TN], const Frag (&a)
             for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].p[PA[t]], b[j].p[PB[t]], acc[i][j]);
 }
 
+// ------------------------------------------------------------------------------------
+// Accumulator tiles <-> memory in full-width accesses.  A 32x32 MFMA accumulator has lane = column (channel) and
+// register r = row (r & 3) + 8 (r >> 2) + 4 half: a group of four registers 4g .. 4g + 3 of the four lanes of a quad is a
+// 4 x 4 block of 4 consecutive rows x 4 consecutive channels.  Transposing it inside the quad (two DPP butterfly steps, 12
+// VALU per 16 values) leaves every lane with ONE row and four consecutive channels: the epilogues load / store 16 bytes
+// (fp32) or 8 bytes (16-bit storage) per lane and instruction instead of one element - a quarter of the memory
+// instructions (the epilogue of a 16-bit 1x1 data gradient issued three times the memory instructions of its k-loop).
+// in : v[k] = element (row k of the block, this lane's column);  out: v[k] = element (this lane's row = lane & 3, column k)
+// - the same call maps a loaded row segment back to the accumulator layout (the transpose is its own inverse).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_quad(float v, const int ctrl) {
+    // quad_perm exchange inside every 4 lanes (ctrl: 0xB1 = xor 1, 0x4E = xor 2)
+    return __int_as_float(ctrl == 0xB1 ? __builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)
+                                       : __builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void quad_transpose4(float& a0, float& a1, float& a2, float& a3) {
+    const int lane = threadIdx.x;
+    const bool o1 = lane & 1, o2 = lane & 2;
+    float t;
+    t = dpp_quad(o1 ? a0 : a1, 0xB1); if (o1) a0 = t; else a1 = t;
+    t = dpp_quad(o1 ? a2 : a3, 0xB1); if (o1) a2 = t; else a3 = t;
+    t = dpp_quad(o2 ? a0 : a2, 0x4E); if (o2) a0 = t; else a2 = t;
+    t = dpp_quad(o2 ? a1 : a3, 0x4E); if (o2) a1 = t; else a3 = t;
+}
+// Store the four accumulator rows 4g .. 4g + 3 (values in accumulator layout) of a 32x32 tile whose element (row 0, column 0)
+// sits at element index `at` of `base` with row pitch ld: one stq per lane.
+template <class T>
+__device__ __forceinline__ void store_acc_rows(void* base, int64_t at, int ld, int g, int half, int lane, float v0, float v1, float v2, float v3) {
+    quad_transpose4(v0, v1, v2, v3);
+    stq<T>(base, at + (int64_t)(8 * g + 4 * half + (lane & 3)) * ld + 4 * ((lane & 31) >> 2), make_float4(v0, v1, v2, v3));
+}
+// ... and the matching load in two halves, so that a workgroup can issue the loads at its start and leave them in flight across its
+// k-loop: fetch_acc_rows returns the row segment as loaded (no instruction depends on it), finish_acc_rows converts and
+// transposes it to accumulator layout (this lane's column, rows 4g .. 4g + 3) where the epilogue needs the values.
+template <class T> struct RawQ { using type = float4; };
+template <> struct RawQ<e_bf16> { using type = uint2; };
+template <> struct RawQ<e_f16> { using type = uint2; };
+template <class T> using rawq_t = typename RawQ<T>::type;
+template <class T>
+__device__ __forceinline__ rawq_t<T> fetch_acc_rows(const void* base, int64_t at, int ld, int g, int half, int lane) {
+    const int64_t idx = at + (int64_t)(8 * g + 4 * half + (lane & 3)) * ld + 4 * ((lane & 31) >> 2);
+    if constexpr (std::is_same<T, e_f32>::value) return *reinterpret_cast<const float4*>(static_cast<const float*>(base) + idx);
+    else return *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(base) + idx);
+}
+template <class T>
+__device__ __forceinline__ void finish_acc_rows(const rawq_t<T>& q, float (&v)[4]) {
+    if constexpr (std::is_same<T, e_f32>::value) { v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+    else { const float2 a = cvt2<T>(q.x), b = cvt2<T>(q.y); v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; }
+    quad_transpose4(v[0], v[1], v[2], v[3]);
+}
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int WK_, bool AT_>
 struct GemmCfg {
     static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, WK = WK_;
@@ -998,20 +1048,36 @@ struct FwdConvP {
                 for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
                     for (int j = 0; j < Cfg::TN; ++j) {
-                        // uniform tile base + one running 32-bit lane offset (saddr stores): 16 precomputed 64-bit
-                        // addresses per strip would cost a workgroup of occupancy
-                        char* tb = static_cast<char*>(dst) + (int64_t)DstT::size * ((int64_t)c.m0 * ldd + dcoff + c.n0);
-                        unsigned o = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + wn0 + j * 32 + l31);
-                        const float s = acc[i][j][0];
                         float s1 = 0.f, s2 = 0.f;
+                        const float s = acc[i][j][0];
+                        if constexpr (DstT::size == 2) {
+                            // 16-bit storage: rows 4g .. 4g + 3 of the strip leave as one quad-transposed 8-byte store per lane
+                            // (a 2-byte store per element issued four times the memory instructions)
+                            const int64_t at = (int64_t)(c.m0 + wm0 + i * 32) * ldd + dcoff + c.n0 + wn0 + j * 32;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {           // accumulator rows (r & 3) + 8 * (r >> 2)
-                            const float x = acc[i][j][r];
-                            st1<DstT>(tb, o, x);
-                            o += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
-                            const float dx = x - s;
-                            s1 += dx;
-                            s2 = fmaf(dx, dx, s2);
+                            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                                for (int r = 4 * g; r < 4 * g + 4; ++r) {
+                                    const float dx = acc[i][j][r] - s;
+                                    s1 += dx;
+                                    s2 = fmaf(dx, dx, s2);
+                                }
+                                store_acc_rows<DstT>(dst, at, ldd, g, half, lane, acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                            }
+                        } else {
+                            // uniform tile base + one running 32-bit lane offset (saddr stores): 16 precomputed 64-bit
+                            // addresses per strip would cost a workgroup of occupancy
+                            char* tb = static_cast<char*>(dst) + (int64_t)DstT::size * ((int64_t)c.m0 * ldd + dcoff + c.n0);
+                            unsigned o = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + wn0 + j * 32 + l31);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {           // accumulator rows (r & 3) + 8 * (r >> 2)
+                                const float x = acc[i][j][r];
+                                st1<DstT>(tb, o, x);
+                                o += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
+                                const float dx = x - s;
+                                s1 += dx;
+                                s2 = fmaf(dx, dx, s2);
+                            }
                         }
                         const double sd = (double)s, s1d = (double)s1;
                         v[0][j] += s1d + 16.0 * sd;
@@ -1104,9 +1170,17 @@ struct BwdDataP {
     // of the workgroup, into registers: the K loop of a 1x1 data gradient is 8 k-tiles, and an epilogue that only then starts
     // its loads costs more cycles than that loop (measured: 10k of 24k per workgroup).
     static constexpr bool kEarly = EMODE != E_UNPOOL;
+    // 16-bit storage: the epilogue's loads / stores go through quad transposes (8 bytes per lane instead of 2); fp32 storage
+    // keeps one element per lane and instruction (the transposes cost the fp32-class kernels registers they do not have)
+    static constexpr bool kWide = GT::size == 2;
     struct Ctx {
         int n, m0, n0; bool whole;
-        float xv[kEarly ? Cfg::TM : 1][kEarly ? Cfg::TN : 1][16], gold[(kEarly && EMODE == E_ACCUM) ? Cfg::TM : 1][(kEarly && EMODE == E_ACCUM) ? Cfg::TN : 1][16];
+        // mask source x and old G' of a whole tile, fetched at the start of the workgroup: per element in accumulator layout
+        // (fp32 storage), or as loaded row segments of four accumulator rows each (16-bit storage; fetch_acc_rows)
+        float xv[(kEarly && !kWide) ? Cfg::TM : 1][(kEarly && !kWide) ? Cfg::TN : 1][16];
+        float gold[(kEarly && !kWide && EMODE == E_ACCUM) ? Cfg::TM : 1][(kEarly && !kWide && EMODE == E_ACCUM) ? Cfg::TN : 1][16];
+        rawq_t<XT> xq[(kEarly && kWide) ? Cfg::TM : 1][(kEarly && kWide) ? Cfg::TN : 1][4];
+        rawq_t<GT> gq[(kEarly && kWide && EMODE == E_ACCUM) ? Cfg::TM : 1][(kEarly && kWide && EMODE == E_ACCUM) ? Cfg::TN : 1][4];
     };
     struct ARow { int y, x; bool valid; unsigned off; };
     struct DRow {};
@@ -1132,23 +1206,39 @@ struct BwdDataP {
             if (c.whole) {
                 const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
                 const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
-                const char* xb = static_cast<const char*>(mbuf) + (int64_t)XSZ * ((int64_t)c.m0 * ldm + mcoff + c.n0);
-                const char* gb = static_cast<const char*>(dst) + (int64_t)GSZ * ((int64_t)c.m0 * ldd + dcoff + c.n0);
-#pragma unroll
-                for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < Cfg::TN; ++j) {
-                        const int cj = wn0 + j * 32 + l31;
-                        unsigned ox = (unsigned)((wm0 + i * 32 + 4 * half) * ldm + cj);
-                        unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + cj);
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            c.xv[i][j][r] = ld1<XT>(xb, ox);
-                            if constexpr (EMODE == E_ACCUM) c.gold[i][j][r] = ld1<GT>(gb, og);
-                            ox += (r & 3) == 3 ? 5u * (unsigned)ldm : (unsigned)ldm;
-                            og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
+                if constexpr (kWide) {
+    #pragma unroll
+                    for (int i = 0; i < Cfg::TM; ++i)
+    #pragma unroll
+                        for (int j = 0; j < Cfg::TN; ++j) {
+                            // 16 / 8-byte loads, one per four accumulator rows (fetch_acc_rows, above GemmCfg); transposed in the epilogue
+                            const int64_t ax = (int64_t)(c.m0 + wm0 + i * 32) * ldm + mcoff + c.n0 + wn0 + j * 32;
+                            const int64_t ag = (int64_t)(c.m0 + wm0 + i * 32) * ldd + dcoff + c.n0 + wn0 + j * 32;
+    #pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                c.xq[i][j][g] = fetch_acc_rows<XT>(mbuf, ax, ldm, g, half, lane);
+                                if constexpr (EMODE == E_ACCUM) c.gq[i][j][g] = fetch_acc_rows<GT>(dst, ag, ldd, g, half, lane);
+                            }
                         }
-                    }
+                } else {
+                    const char* xb = static_cast<const char*>(mbuf) + (int64_t)XSZ * ((int64_t)c.m0 * ldm + mcoff + c.n0);
+                    const char* gb = static_cast<const char*>(dst) + (int64_t)GSZ * ((int64_t)c.m0 * ldd + dcoff + c.n0);
+    #pragma unroll
+                    for (int i = 0; i < Cfg::TM; ++i)
+    #pragma unroll
+                        for (int j = 0; j < Cfg::TN; ++j) {
+                            const int cj = wn0 + j * 32 + l31;
+                            unsigned ox = (unsigned)((wm0 + i * 32 + 4 * half) * ldm + cj);
+                            unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + cj);
+    #pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                c.xv[i][j][r] = ld1<XT>(xb, ox);
+                                if constexpr (EMODE == E_ACCUM) c.gold[i][j][r] = ld1<GT>(gb, og);
+                                ox += (r & 3) == 3 ? 5u * (unsigned)ldm : (unsigned)ldm;
+                                og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
+                            }
+                        }
+                }
             }
         }
         return true;
@@ -1259,19 +1349,43 @@ struct BwdDataP {
             if (kEarly && active && c.whole) {
                 // Whole tile inside the plane: no per-element predicates, operands already in registers (init_ctx), a uniform
                 // tile base + running 32-bit lane offset for the stores.
-                char* gb = static_cast<char*>(dst) + (int64_t)GSZ * ((int64_t)c.m0 * ldd + dcoff + c.n0);
-#pragma unroll
-                for (int i = 0; i < Cfg::TM; ++i) {
-                    unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + cj);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float xr = c.xv[kEarly ? i : 0][kEarly ? j : 0][r];
-                        const float dy = bn1(xr, mean, sc, sh) > 0.f ? acc[i][j][r] : 0.f;
-                        if constexpr (EMODE == E_STORE) st1<GT>(gb, og, dy);
-                        else st1<GT>(gb, og, c.gold[(kEarly && EMODE == E_ACCUM) ? i : 0][(kEarly && EMODE == E_ACCUM) ? j : 0][r] + gam * dy);
-                        og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
-                        v[0][j] += dy;
-                        v[1][j] += dy * ((xr - mean) * invstd);
+                if constexpr (kWide) {
+    #pragma unroll
+                    for (int i = 0; i < Cfg::TM; ++i) {
+                        const int64_t ag = (int64_t)(c.m0 + wm0 + i * 32) * ldd + dcoff + c.n0 + wn0 + j * 32;
+    #pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float o[4], xv4[4], go4[4] = {0.f, 0.f, 0.f, 0.f};
+                            finish_acc_rows<XT>(c.xq[(kEarly && kWide) ? i : 0][(kEarly && kWide) ? j : 0][g], xv4);
+                            if constexpr (EMODE == E_ACCUM) finish_acc_rows<GT>(c.gq[(kEarly && kWide && EMODE == E_ACCUM) ? i : 0][(kEarly && kWide && EMODE == E_ACCUM) ? j : 0][g], go4);
+    #pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const int r = 4 * g + k;
+                                const float xr = xv4[k];
+                                const float dy = bn1(xr, mean, sc, sh) > 0.f ? acc[i][j][r] : 0.f;
+                                if constexpr (EMODE == E_STORE) o[k] = dy;
+                                else o[k] = go4[k] + gam * dy;
+                                v[0][j] += dy;
+                                v[1][j] += dy * ((xr - mean) * invstd);
+                            }
+                            store_acc_rows<GT>(dst, ag, ldd, g, half, lane, o[0], o[1], o[2], o[3]);
+                        }
+                    }
+                } else {
+                    char* gb = static_cast<char*>(dst) + (int64_t)GSZ * ((int64_t)c.m0 * ldd + dcoff + c.n0);
+    #pragma unroll
+                    for (int i = 0; i < Cfg::TM; ++i) {
+                        unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + cj);
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float xr = c.xv[(kEarly && !kWide) ? i : 0][(kEarly && !kWide) ? j : 0][r];
+                            const float dy = bn1(xr, mean, sc, sh) > 0.f ? acc[i][j][r] : 0.f;
+                            if constexpr (EMODE == E_STORE) st1<GT>(gb, og, dy);
+                            else st1<GT>(gb, og, c.gold[(kEarly && !kWide && EMODE == E_ACCUM) ? i : 0][(kEarly && !kWide && EMODE == E_ACCUM) ? j : 0][r] + gam * dy);
+                            og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
+                            v[0][j] += dy;
+                            v[1][j] += dy * ((xr - mean) * invstd);
+                        }
                     }
                 }
             } else
@@ -1386,6 +1500,7 @@ struct BwdDataGroupP {
     using XT = act_t<PREC>;      // the block buffer X
     static constexpr int kOp = bwd_op(PREC), kAE = 16 / GT::size, kBE = 4, GSZ = GT::size;
     static constexpr bool kARawCopy = kAE == 8;
+    static constexpr bool kWide = GT::size == 2;        // 16-bit storage: quad-transposed 8-byte epilogue loads / stores (see BwdDataP)
     GroupSeg seg[GROUP_MAX]; int nseg;
     int ldg; Plane pa; int KA;
     int N;                                              // output channels [0, N)
@@ -1404,7 +1519,9 @@ struct BwdDataGroupP {
     struct Ctx {
         int n, m0, n0; bool whole;
         float x[Cfg::TM][Cfg::TN][16];                  // raw activation of this lane's accumulator elements
-        float gold[Cfg::TM][Cfg::TN][16];               // old G' of whole tiles, fetched with x at the start (the epilogue only adds and stores)
+                                                        // (16-bit storage, whole tiles: until the first k_hook the registers hold x AS FETCHED, row segments)
+        float gold[kWide ? 1 : Cfg::TM][kWide ? 1 : Cfg::TN][16];               // fp32 storage: old G' of whole tiles, fetched with x at the start
+        rawq_t<GT> gq[kWide ? Cfg::TM : 1][kWide ? Cfg::TN : 1][4];             // 16-bit storage: the same as fetched row segments
         float run[Cfg::TM][Cfg::TN][16];                // sum_i gamma_i * dy_i
         float ls[GROUP_MAX][2][Cfg::TN];                // per-segment column partials (sum dy, sum dy*(x-mean))
     };
@@ -1446,38 +1563,83 @@ struct BwdDataGroupP {
         const int pbase = c.m0 - c.n * pa.HWp;
         if (pbase >= pa.HW) return false;
         c.whole = pbase + Cfg::BM <= pa.HW && c.n0 + Cfg::BN <= N;
-        // this lane's x elements: in flight under the first K segment
-        const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
-        const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
-#pragma unroll
-        for (int j = 0; j < Cfg::TN; ++j) {
-            const int col = c.n0 + wn0 + j * 32 + l31;
-#pragma unroll
-            for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = SMG_ACC_ROW(wm0, i, r, half);
-                    const bool ok = pbase + row < pa.HW && col < N;
-                    // unconditional load from a clamped address (a branch around it would serialise the loads)
-                    const float v = ld1<XT>(mbuf, (int64_t)(c.m0 + (ok ? row : 0)) * ldm + (ok ? col : 0));
-                    c.x[i][j][r] = ok ? v : 0.f;
-                    c.run[i][j][r] = 0.f;
-                    c.gold[i][j][r] = 0.f;
-                }
-        }
-        if (c.whole) {
-            const char* gb = static_cast<const char*>(dst) + (int64_t)GSZ * ((int64_t)c.m0 * ldd + c.n0);
-#pragma unroll
+        if constexpr (kWide) {
+            // this lane's x elements (and, for whole tiles, the old G'): in flight under the first K segment.  Whole tiles fetch
+            // row segments (16 / 8 bytes per lane, fetch_acc_rows); x is transposed to accumulator layout by the first segment's
+            // k_hook, the old G' by the epilogue.
+            const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
+            const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
+    #pragma unroll
             for (int j = 0; j < Cfg::TN; ++j)
-#pragma unroll
-                for (int i = 0; i < Cfg::TM; ++i) {
-                    unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + wn0 + j * 32 + l31);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        c.gold[i][j][r] = ld1<GT>(gb, og);
-                        og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
+    #pragma unroll
+                for (int i = 0; i < Cfg::TM; ++i)
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) c.run[i][j][r] = 0.f;
+            if (c.whole) {
+    #pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j)
+    #pragma unroll
+                    for (int i = 0; i < Cfg::TM; ++i) {
+                        const int64_t ax = (int64_t)(c.m0 + wm0 + i * 32) * ldm + c.n0 + wn0 + j * 32;
+                        const int64_t ag = (int64_t)(c.m0 + wm0 + i * 32) * ldd + c.n0 + wn0 + j * 32;
+    #pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const rawq_t<XT> xr = fetch_acc_rows<XT>(mbuf, ax, ldm, g, half, lane);
+                            if constexpr (std::is_same<XT, e_f32>::value) { c.x[i][j][4 * g] = xr.x; c.x[i][j][4 * g + 1] = xr.y; c.x[i][j][4 * g + 2] = xr.z; c.x[i][j][4 * g + 3] = xr.w; }
+                            else { c.x[i][j][4 * g] = __uint_as_float(xr.x); c.x[i][j][4 * g + 1] = __uint_as_float(xr.y); }
+                            c.gq[i][j][g] = fetch_acc_rows<GT>(dst, ag, ldd, g, half, lane);
+                        }
                     }
+            } else {
+    #pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j) {
+                    const int col = c.n0 + wn0 + j * 32 + l31;
+    #pragma unroll
+                    for (int i = 0; i < Cfg::TM; ++i)
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = SMG_ACC_ROW(wm0, i, r, half);
+                            const bool ok = pbase + row < pa.HW && col < N;
+                            // unconditional load from a clamped address (a branch around it would serialise the loads)
+                            const float v = ld1<XT>(mbuf, (int64_t)(c.m0 + (ok ? row : 0)) * ldm + (ok ? col : 0));
+                            c.x[i][j][r] = ok ? v : 0.f;
+                        }
                 }
+            }
+        } else {
+            // this lane's x elements: in flight under the first K segment
+            const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
+            const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
+    #pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) {
+                const int col = c.n0 + wn0 + j * 32 + l31;
+    #pragma unroll
+                for (int i = 0; i < Cfg::TM; ++i)
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = SMG_ACC_ROW(wm0, i, r, half);
+                        const bool ok = pbase + row < pa.HW && col < N;
+                        // unconditional load from a clamped address (a branch around it would serialise the loads)
+                        const float v = ld1<XT>(mbuf, (int64_t)(c.m0 + (ok ? row : 0)) * ldm + (ok ? col : 0));
+                        c.x[i][j][r] = ok ? v : 0.f;
+                        c.run[i][j][r] = 0.f;
+                        c.gold[i][j][r] = 0.f;
+                    }
+            }
+            if (c.whole) {
+                const char* gb = static_cast<const char*>(dst) + (int64_t)GSZ * ((int64_t)c.m0 * ldd + c.n0);
+    #pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j)
+    #pragma unroll
+                    for (int i = 0; i < Cfg::TM; ++i) {
+                        unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + wn0 + j * 32 + l31);
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            c.gold[i][j][r] = ld1<GT>(gb, og);
+                            og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
+                        }
+                    }
+            }
         }
 #pragma unroll
         for (int s = 0; s < GROUP_MAX; ++s)
@@ -1517,6 +1679,22 @@ struct BwdDataGroupP {
         const int s = kt / per;
         const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31;
         const int wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
+        if (kWide && s == 0 && c.whole) {                 // (workgroup-uniform)
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+                for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v4[4];
+                        rawq_t<XT> xr;
+                        if constexpr (std::is_same<XT, e_f32>::value) xr = make_float4(c.x[i][j][4 * g], c.x[i][j][4 * g + 1], c.x[i][j][4 * g + 2], c.x[i][j][4 * g + 3]);
+                        else xr = make_uint2(__float_as_uint(c.x[i][j][4 * g]), __float_as_uint(c.x[i][j][4 * g + 1]));
+                        finish_acc_rows<XT>(xr, v4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) c.x[i][j][4 * g + k] = v4[k];
+                    }
+        }
         const float* q = sp + (2 + 3 * s) * Cfg::BN;
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) {
@@ -1554,17 +1732,37 @@ struct BwdDataGroupP {
             const float mean = sp[cj], invstd = sp[Cfg::BN + cj];
             float a0 = 0.f, a1 = 0.f;
             if (c.whole) {        // whole tile inside the plane: see E_ACCUM
-                char* gb = static_cast<char*>(dst) + (int64_t)GSZ * ((int64_t)c.m0 * ldd + c.n0);
-#pragma unroll
-                for (int i = 0; i < Cfg::TM; ++i) {
-                    unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + cj);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float run = c.run[i][j][r];
-                        st1<GT>(gb, og, c.gold[i][j][r] + run);
-                        og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
-                        a0 += run;
-                        a1 = fmaf(run, (c.x[i][j][r] - mean) * invstd, a1);
+                if constexpr (kWide) {
+    #pragma unroll
+                    for (int i = 0; i < Cfg::TM; ++i) {
+                        const int64_t ag = (int64_t)(c.m0 + wm0 + i * 32) * ldd + c.n0 + wn0 + j * 32;
+    #pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float go4[4], o[4];
+                            finish_acc_rows<GT>(c.gq[kWide ? i : 0][kWide ? j : 0][g], go4);
+    #pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float run = c.run[i][j][4 * g + k];
+                                o[k] = go4[k] + run;
+                                a0 += run;
+                                a1 = fmaf(run, (c.x[i][j][4 * g + k] - mean) * invstd, a1);
+                            }
+                            store_acc_rows<GT>(dst, ag, ldd, g, half, lane, o[0], o[1], o[2], o[3]);
+                        }
+                    }
+                } else {
+                    char* gb = static_cast<char*>(dst) + (int64_t)GSZ * ((int64_t)c.m0 * ldd + c.n0);
+    #pragma unroll
+                    for (int i = 0; i < Cfg::TM; ++i) {
+                        unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + cj);
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float run = c.run[i][j][r];
+                            st1<GT>(gb, og, c.gold[kWide ? 0 : i][kWide ? 0 : j][r] + run);
+                            og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
+                            a0 += run;
+                            a1 = fmaf(run, (c.x[i][j][r] - mean) * invstd, a1);
+                        }
                     }
                 }
             } else

@@ -249,16 +249,25 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const H
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
-                if (TS == 16 || (py < a.pl.H && px < a.pl.W)) {      // TS == 8 tiles may hang over the edge
-                    const float x = acc[m][r];
-                    st1<ST>(a.dst, ((int64_t)n * a.pl.HWp + py * a.pl.W + px) * a.ldd + a.dcoff + l31, x);
-                    const double xd = (double)x;
-                    s += xd;
-                    ss += xd * xd;
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = 4 * g + k, i = k + 8 * g + 4 * half;
+                    const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
+                    v[k] = acc[m][r];
+                    if (TS == 16 || (py < a.pl.H && px < a.pl.W)) {      // TS == 8 tiles may hang over the edge
+                        const double xd = (double)v[k];
+                        s += xd;
+                        ss += xd * xd;
+                    }
                 }
+                // four pixels x four channels of the quad, transposed: this lane stores ONE pixel's four consecutive channels
+                quad_transpose4(v[0], v[1], v[2], v[3]);
+                const int i = (lane & 3) + 8 * g + 4 * half;
+                const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
+                if (TS == 16 || (py < a.pl.H && px < a.pl.W))
+                    stq<ST>(a.dst, ((int64_t)n * a.pl.HWp + py * a.pl.W + px) * a.ldd + a.dcoff + 4 * (l31 >> 2), make_float4(v[0], v[1], v[2], v[3]));
             }
     }
     s += __shfl_xor(s, 32);
@@ -438,16 +447,20 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
     __syncthreads();
     if (trace) trace[1] = __builtin_amdgcn_s_memtime();
     f32x16 acc[MT];
-    float xvp[MT][16];                        // TS == 8: prefetched one stage ahead
-    auto load_mask = [&](int c, float (&xv)[MT][16]) {   // mask / xhat source of this wave's output tile
+    rawq_t<XT> xvp[MT][4];                    // TS == 8: prefetched one stage ahead
+    // mask / xhat source of this wave's output tile (32 output channels from c0): one row segment (a pixel's four consecutive
+    // channels, 16 / 8 bytes) per lane and four accumulator rows; finish_acc_rows turns it into accumulator layout
+    auto load_mask = [&](int c0, rawq_t<XT> (&xq)[MT][4]) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+            for (int g = 0; g < 4; ++g) {
+                const int i = (lane & 3) + 8 * g + 4 * half;
                 const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
-                const bool ok = TS == 16 || (py < a.pl.H && px < a.pl.W);     // TS == 8 tiles may hang over the edge
-                xv[m][r] = ok ? ld1<XT>(a.mbuf, ((int64_t)n * a.pl.HWp + py * a.pl.W + px) * C + c) : 0.f;
+                const bool ok = TS == 16 || (py < a.pl.H && px < a.pl.W);     // TS == 8 tiles may hang over the edge: clamped address
+                const int64_t idx = ((int64_t)n * a.pl.HWp + (ok ? py * a.pl.W + px : 0)) * C + c0 + 4 * (l31 >> 2);
+                if constexpr (std::is_same<XT, e_f32>::value) xq[m][g] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.mbuf) + idx);
+                else xq[m][g] = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(a.mbuf) + idx);
             }
     };
     for (int s3 = 0; s3 < NSTAGE; s3 += 3) {           // NSTAGE is a multiple of 9: three stages (one kernel row) per trip
@@ -463,7 +476,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
         const int stage = s3 + dx, buf = dx, tap = 3 * dy + dx;
         g_load(stage + 2 < NSTAGE ? stage + 2 : NSTAGE - 1, rb[(dx + 2) % 3]);
         if constexpr (TS == 8) {
-            if (tap == 8) load_mask(((cg0 + stage / 9) * NCW + wc) * 32 + l31, xvp);   // in flight under the last MFMA block
+            if (tap == 8) load_mask(((cg0 + stage / 9) * NCW + wc) * 32, xvp);   // in flight under the last MFMA block
         }
         // output pixel (ry, rx), tap (dy, dx) reads g at halo (ry + 2 - dy, rx + 2 - dx)
         const int toff = (2 - dy) * G::W + (2 - dx);
@@ -514,24 +527,34 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
             const int c = ((cg0 + stage / 9) * NCW + wc) * 32 + l31;
             const float sc = prm[c], be = prm[C + c], mean = prm[2 * C + c], invstd = prm[3 * C + c];
             float s1 = 0.f, s2 = 0.f;
-            auto finish = [&](float (&xv)[MT][16]) {
+            auto finish = [&](rawq_t<XT> (&xq)[MT][4]) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    for (int g = 0; g < 4; ++g) {
+                        float xv[4], o[4];
+                        finish_acc_rows<XT>(xq[m][g], xv);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int i = k + 8 * g + 4 * half;
+                            const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
+                            const bool in = TS == 16 || (py < a.pl.H && px < a.pl.W);
+                            const float dyv = (in && bn1(xv[k], mean, sc, be) > 0.f) ? acc[m][4 * g + k] : 0.f;
+                            o[k] = dyv;
+                            s1 += dyv;
+                            s2 += dyv * ((xv[k] - mean) * invstd);
+                        }
+                        quad_transpose4(o[0], o[1], o[2], o[3]);
+                        const int i = (lane & 3) + 8 * g + 4 * half;
                         const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
-                        if (TS == 8 && (py >= a.pl.H || px >= a.pl.W)) continue;
-                        const float dyv = bn1(xv[m][r], mean, sc, be) > 0.f ? acc[m][r] : 0.f;
-                        st1<GT>(a.dst, ((int64_t)n * a.pl.HWp + py * a.pl.W + px) * C + c, dyv);
-                        s1 += dyv;
-                        s2 += dyv * ((xv[m][r] - mean) * invstd);
+                        if (TS == 16 || (py < a.pl.H && px < a.pl.W))
+                            stq<GT>(a.dst, ((int64_t)n * a.pl.HWp + py * a.pl.W + px) * C + c - l31 + 4 * (l31 >> 2), make_float4(o[0], o[1], o[2], o[3]));
                     }
             };
             if constexpr (TS == 16) {
-                float xv[MT][16];
-                load_mask(c, xv);             // all loads before the stores (which may alias them)
-                finish(xv);
+                rawq_t<XT> xq[MT][4];
+                load_mask(c - l31, xq);       // all loads before the stores (which may alias them)
+                finish(xq);
             } else {
                 finish(xvp);
             }
