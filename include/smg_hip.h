@@ -156,8 +156,9 @@ int smg_backward(smg_engine* e, const smg_net* net, const float* dq_dev, void* s
 int smg_engine_set_precision(smg_engine* e, int precision);
 
 /* Engine switches by name.  "deterministic" (0 / 1): the 1x1-convolution weight gradients (conv1 of every dense layer,
- * the largest gradient tensors) are reduced from partial tiles in a fixed order instead of fp32 atomics, so the convolution
- * weight gradients of two identical calls are bit-identical like the reference's (code/trainer.py:350-351 on one device).
+ * the largest gradient tensors) are reduced from partial tiles in a fixed order instead of fp32 atomics, so the trunk's
+ * convolution weight gradients of two identical calls are bit-identical like the reference's (code/trainer.py:350-351 on one
+ * device); BatchNorm affine gradients and the head's value convolution keep their fp32 atomics.
  * "serialize" (0 / 1): every kernel on the caller's stream in issue order instead of two concurrent chains (profiling). */
 int smg_engine_set_option(smg_engine* e, const char* name, int value);
 

@@ -447,36 +447,37 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
     __syncthreads();
     if (trace) trace[1] = __builtin_amdgcn_s_memtime();
     f32x16 acc[MT];
-    rawq_t<XT> xvp[MT][4];                    // TS == 8: prefetched one stage ahead
-    // mask / xhat source of this wave's output tile (32 output channels from c0): one row segment (a pixel's four consecutive
-    // channels, 16 / 8 bytes) per lane and four accumulator rows; finish_acc_rows turns it into accumulator layout
-    auto load_mask = [&](int c0, rawq_t<XT> (&xq)[MT][4]) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int i = (lane & 3) + 8 * g + 4 * half;
-                const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
-                const bool ok = TS == 16 || (py < a.pl.H && px < a.pl.W);     // TS == 8 tiles may hang over the edge: clamped address
-                const int64_t idx = ((int64_t)n * a.pl.HWp + (ok ? py * a.pl.W + px : 0)) * C + c0 + 4 * (l31 >> 2);
-                if constexpr (std::is_same<XT, e_f32>::value) xq[m][g] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.mbuf) + idx);
-                else xq[m][g] = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(a.mbuf) + idx);
-            }
+    // Mask / xhat source of this wave's output tile (32 output channels from c0), prefetched: one row segment (a pixel's four
+    // consecutive channels, 16 / 8 bytes per lane; finish_acc_rows turns it into accumulator layout) per four accumulator rows,
+    // MT x 4 of them per output-channel group - issued ONE PER STAGE through the first eight stages of the group (statically
+    // unrolled: every path issues the same loads, the exact vmcnt waits of the weight ring survive), consumed by the epilogue
+    // at the ninth.  (Fetching them only in the epilogue cost 5.5 - 6k of a group's 21k cycles.)
+    rawq_t<XT> xq[MT][4];
+    auto load_mask_seg = [&](int c0, int m, int g) {
+        const int i = (lane & 3) + 8 * g + 4 * half;
+        const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
+        const bool ok = TS == 16 || (py < a.pl.H && px < a.pl.W);     // TS == 8 tiles may hang over the edge: clamped address
+        const int64_t idx = ((int64_t)n * a.pl.HWp + (ok ? py * a.pl.W + px : 0)) * C + c0 + 4 * (l31 >> 2);
+        if constexpr (std::is_same<XT, e_f32>::value) xq[m][g] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.mbuf) + idx);
+        else xq[m][g] = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(a.mbuf) + idx);
     };
-    for (int s3 = 0; s3 < NSTAGE; s3 += 3) {           // NSTAGE is a multiple of 9: three stages (one kernel row) per trip
-      const int dy = (s3 / 3) % 3;
-      if (dy == 0) {
+    for (int s9 = 0; s9 < NSTAGE; s9 += 9) {           // NSTAGE is a multiple of 9: one output-channel group (nine taps) per trip
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-      }
+          for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+      const int cmask0 = ((cg0 + s9 / 9) * NCW + wc) * 32;
+#pragma unroll
+     for (int dy = 0; dy < 3; ++dy) {
+      const int s3 = s9 + 3 * dy;
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         const int stage = s3 + dx, buf = dx, tap = 3 * dy + dx;
         g_load(stage + 2 < NSTAGE ? stage + 2 : NSTAGE - 1, rb[(dx + 2) % 3]);
-        if constexpr (TS == 8) {
-            if (tap == 8) load_mask(((cg0 + stage / 9) * NCW + wc) * 32, xvp);   // in flight under the last MFMA block
+        if (tap < 8) {                                    // (compile-time after unrolling)
+            constexpr int SEGS = MT * 4;
+            const int sg = tap - (8 - SEGS);              // TS == 16: stages 0..7 load segments 0..7; TS == 8: stages 4..7 load 0..3
+            if (sg >= 0) load_mask_seg(cmask0, sg / 4, sg % 4);
         }
         // output pixel (ry, rx), tap (dy, dx) reads g at halo (ry + 2 - dy, rx + 2 - dx)
         const int toff = (2 - dy) * G::W + (2 - dx);
@@ -522,7 +523,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
         }
         s_store((dx + 1) % 3, rb[(dx + 1) % 3]);        // that buffer was last read two stages ago (at the very end: a dead store)
         if (tap == 8) {
-            if (trace && s3 == 6) trace[2] = __builtin_amdgcn_s_memtime();
+            if (trace && s9 == 0) trace[2] = __builtin_amdgcn_s_memtime();
             // epilogue of this wave's output-channel chunk: ReLU mask, store dy, BN(norm2) backward sums
             const int c = ((cg0 + stage / 9) * NCW + wc) * 32 + l31;
             const float sc = prm[c], be = prm[C + c], mean = prm[2 * C + c], invstd = prm[3 * C + c];
@@ -551,13 +552,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
                             stq<GT>(a.dst, ((int64_t)n * a.pl.HWp + py * a.pl.W + px) * C + c - l31 + 4 * (l31 >> 2), make_float4(o[0], o[1], o[2], o[3]));
                     }
             };
-            if constexpr (TS == 16) {
-                rawq_t<XT> xq[MT][4];
-                load_mask(c - l31, xq);       // all loads before the stores (which may alias them)
-                finish(xq);
-            } else {
-                finish(xvp);
-            }
+            finish(xq);
             s1 += __shfl_xor(s1, 32);
             s2 += __shfl_xor(s2, 32);
             float* red = prm + 4 * C;                 // [2][4][32]
@@ -571,10 +566,11 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
                 const int ch = ((cg0 + stage / 9) * NCW + j) * 32 + cc;
                 atomicAdd((q ? a.o2 : a.o1) + (int64_t)n * a.ostride + ch, (double)tot);
             }
-            if (trace && s3 == 6) trace[3] = __builtin_amdgcn_s_memtime();
+            if (trace && s9 == 0) trace[3] = __builtin_amdgcn_s_memtime();
         }
         __syncthreads();
       }
+     }
     }
     if (trace) { trace[4] = __builtin_amdgcn_s_memtime(); trace[6] = __builtin_amdgcn_s_memrealtime(); }
 }

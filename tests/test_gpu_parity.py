@@ -992,9 +992,9 @@ def test_layer_products_within_fp32_chain_error(gpu, block, layer):
 def test_deterministic_option_gives_bit_identical_conv_weight_gradients(gpu):
     """smg_engine_set_option("deterministic", 1): the 1x1 weight gradients are reduced from partial tiles in a fixed order
     instead of fp32 atomics.  Two identical training calls then give bit-identical gradients for every convolution weight
-    (the reference's backward on one device is deterministic, code/trainer.py:350-351); without the switch the 1x1 weight
-    gradients differ in the last bits.  (BatchNorm affine gradients are still summed over workgroups with fp32 atomics in
-    either mode: equal to 1e-5.)"""
+    of the trunk and the head's conv0 (the reference's backward on one device is deterministic, code/trainer.py:350-351);
+    without the switch the 1x1 weight gradients differ in the last bits.  (BatchNorm affine gradients and the head's 20x20 value
+    convolution are still summed with fp32 atomics in either mode: equal to 1e-5.)"""
     from trainer import Trainer
     import synthetic
     import models
@@ -1007,7 +1007,11 @@ def test_deterministic_option_gives_bit_identical_conv_weight_gradients(gpu):
     rots, labels = [0, 3, 7, 12], [0.2, 1.7, 0.6, 0.9]
     tr.train_batch(depth, depth * masks[0], 0, rots, labels)
     eng = engine_of(tr.model)
-    conv = [(n, p) for n, p in tr.model.named_parameters() if p.dim() == 4 and n.startswith(("grasp_depth_trunk", "graspnet_val"))]
+    # every convolution of the trunk (120 tensors, 6.9 M of the 7.1 M gradient elements) and the head's 1x1 conv0; the head's 20x20
+    # value convolution sums its (pair, pixel) terms with fp32 atomics like the BN affine gradients
+    conv = [(n, p) for n, p in tr.model.named_parameters()
+            if p.dim() == 4 and n.startswith(("grasp_depth_trunk", "graspnet_val")) and not n.endswith("val-conv1.weight")]
+    assert len(conv) == 121
 
     def run():
         tr.train_batch(depth, depth * masks[0], 0, rots, labels)
