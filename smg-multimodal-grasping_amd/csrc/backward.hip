@@ -363,20 +363,23 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         const Plane ps_ = e->p_stem;
         int chunk, cps;
         pick_chunk(ps_, NS, 1, chunk, cps);
-        auto go = [&](auto ptag) -> int {
-        BwdWeightP<CfgW64x256, W_STEM, C_STEM, SMG_PD_WGRAD, true, decltype(ptag)::value> p{};      // (fp32 image / stem plane in every mode)
+        auto go = [&](auto ptag, auto mtag) -> int {
+        constexpr int SM = decltype(mtag)::value;      // W_STEM (3-channel image, 196 columns) or W_STEM1 (one channel, 49 taps, replicated x3 at the flush)
+        using WCfg = typename std::conditional<SM == W_STEM1, CfgW64x64, CfgW64x256>::type;
+        BwdWeightP<WCfg, SM, SM == W_STEM1 ? C_STEM1 : C_STEM, SMG_PD_WGRAD, true, decltype(ptag)::value> p{};      // (fp32 image / stem plane in every mode)
         p.gbuf = e->DY0; p.ldg = 64; p.gcoff = 0; p.xbuf = e->stem; p.ldx = 64; p.xcoff = 0; p.pa = ps_; p.MA = 64;
         p.xsum = fsum(e, e->st_stem); p.xsq = fsq(e, e->st_stem); p.xstride = 64;
         p.s1 = b1(e, e->bs_stem); p.s2 = b2(e, e->bs_stem); p.sstride = 64; p.scoff = 0; p.agamma = P + T.norm0.w;
-        p.bbuf = e->img4; p.ldb = 4; p.pb = e->p_img; p.NB = 196;
+        p.bbuf = e->img4; p.ldb = 4; p.pb = e->p_img; p.NB = SM == W_STEM1 ? 64 : 196;
         p.eps = kEps; p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
         p.dw = Gr + T.conv0.w; p.ldw_out = 147;
         if (fork(e->ev_misc)) return -5;
-        BY(e, 4.0 * NS * (2.0 * ps_.HW * 64 + (double)e->p_img.HW * 4));
-        launch_wgrad(e, s2, p, dim3(1, 1, NS * cps), K_SW, 2.0 * NS * ps_.HW * 64 * 147, 1, C_STEM);
+        BY(e, 4.0 * NS * (2.0 * ps_.HW * 64 + (double)e->p_img.HW * (SM == W_STEM1 ? 1 : 4)));
+        launch_wgrad(e, s2, p, dim3(1, 1, NS * cps), K_SW, 2.0 * NS * ps_.HW * 64 * 147, 1, SM == W_STEM1 ? C_STEM1 : C_STEM);
         return 0;
         };
-        PREC_DISPATCH(e, if (go(PTAG)) return -5);
+        if (e->f_stem1) { PREC_DISPATCH(e, if (go(PTAG, std::integral_constant<int, W_STEM1>{})) return -5); }
+        else { PREC_DISPATCH(e, if (go(PTAG, std::integral_constant<int, W_STEM>{})) return -5); }
     }
     HIP_OK(hipEventRecord(e->ev_end, s2));          // join: everything after the backward sees every gradient
     HIP_OK(hipStreamWaitEvent(st, e->ev_end, 0));

@@ -25,6 +25,7 @@ struct PrepArgs {
     const float* stream_affine;
     const int* stream_rotated;
     float* img4;                // [streams][HWp][4]
+    float* img1;                // if set (heightmap form): ONE channel per pixel [streams][HWp] instead - the three are identical
     int HWp;
     const double* masks;        // [n_masks][hm][hm] or null: object masks applied here (code/main.py:160,187)
     const int* stream_mask_a;   // per stream: mask index or -1
@@ -82,7 +83,8 @@ static __global__ void prep_rotate_kernel(const PrepArgs a) {
             out.x = out.y = out.z = f;
         }
     }
-    *reinterpret_cast<float4*>(a.img4 + ((int64_t)s * a.HWp + p) * 4) = out;
+    if (a.img1) a.img1[(int64_t)s * a.HWp + p] = out.x;
+    else *reinterpret_cast<float4*>(a.img4 + ((int64_t)s * a.HWp + p) * 4) = out;
 }
 
 // ------------------------------------------------------------------------------------
@@ -92,7 +94,7 @@ static __global__ void prep_rotate_kernel(const PrepArgs a) {
 //   output column n, already split into the three bf16 pieces (gemm.cuh) - staging them is a plain copy;
 //   PK_HF / PK_HD: the per-stage LDS images of the LDS-halo 3x3 kernels; PK_HEAD: the value convolution's fp32 layout.
 // ------------------------------------------------------------------------------------
-enum { PK_T1 = 0, PK_D1 = 1, PK_3F = 2, PK_3D = 3, PK_STEM = 4, PK_HEAD = 5, PK_HF = 6, PK_HD = 7 };
+enum { PK_T1 = 0, PK_D1 = 1, PK_3F = 2, PK_3D = 3, PK_STEM = 4, PK_HEAD = 5, PK_HF = 6, PK_HD = 7, PK_STEM1 = 8 };
 struct PackDesc { int64_t src, dst; int cout, cin, mode, K8tot, N, count; };   // dst: unit offset (split modes) / float offset (fp32 modes)
 
 // prec: the engine's precision mode.  Operand kind of a pack: the forward packs (PK_T1, PK_STEM, PK_3F, PK_HF) take the
@@ -165,6 +167,8 @@ static __global__ void pack_weights_kernel(const PackDesc* descs, const float* p
             } else if (d.mode == PK_3D) {          // B(k = tap*cout + nn, n = c) = src[nn][c][tap]
                 const int tap = k / d.cout, nn = k - tap * d.cout;
                 v[j] = s[((int64_t)nn * d.cin + n) * 9 + tap];
+            } else if (d.mode == PK_STEM1) {       // k = tap (49 padded to 64): the weights summed over the 3 (identical) input channels
+                v[j] = k < 49 ? (float)((double)s[((int64_t)n * 3 + 0) * 49 + k] + (double)s[((int64_t)n * 3 + 1) * 49 + k] + (double)s[((int64_t)n * 3 + 2) * 49 + k]) : 0.f;
             } else {                               // PK_STEM: k = tap*4 + c (K padded to 224), src[n][c][tap]
                 const int tap = k >> 2, c = k & 3;
                 v[j] = (c < 3 && tap < 49) ? s[((int64_t)n * 3 + c) * 49 + tap] : 0.f;

@@ -115,7 +115,7 @@ struct smg_engine {
     float* packed_f = nullptr; int64_t packed_floats = 0;
     PackDesc* d_pack = nullptr; std::vector<PackDesc> h_pack[3]; std::vector<PackDesc> h_pack_head[3];
     int pack_stride = 0, bnupd_stride = 0, n_bnupd = 0;   // d_pack / d_bnupd hold one table per (trunk, head)
-    int64_t pk_conv0 = 0, pk_head0 = 0, pk_hd0 = 0, pk_head1 = 0;
+    int64_t pk_conv0 = 0, pk_conv0_1 = 0, pk_head0 = 0, pk_hd0 = 0, pk_head1 = 0;
     std::vector<int64_t> pk_c1[4], pk_d1[4], pk_g3f[4], pk_g3d[4], pk_hf[4], pk_hd[4]; int64_t pk_t[3] = {}, pk_td[3] = {};
     int max_pack = 0;
     // BN statistics as fp32 tables (mean | invstd, [rows][C] each): one per dense-block buffer, one per bottleneck, one
@@ -126,6 +126,7 @@ struct smg_engine {
     BnUpdDesc* d_bnupd = nullptr;
     // last forward
     bool have_fwd = false; int f_trunk = 0, f_head = 0, f_streams = 0, f_pairs = 0;
+    bool f_stem1 = false;      // the last forward ran the one-channel stem (heightmap input form): img4 holds [streams][HWp] single floats
     int* d_stream_image = nullptr; int* d_stream_rot = nullptr; int* d_pair_a = nullptr; int* d_pair_b = nullptr;
     int* d_seq_t = nullptr; int* d_seq_h = nullptr; int* d_user_ptr = nullptr; int* d_user_pair = nullptr; int* d_user_slot = nullptr;
     float* d_affine = nullptr;

@@ -109,6 +109,7 @@ static int engine_build(smg_engine* e) {
         const TrunkRef& T = L.trunk[t];
         std::vector<PackDesc>& v = e->h_pack[t];
         e->pk_conv0 = add_units(v, T.conv0.w, 64, 3, PK_STEM, 224, 64);
+        e->pk_conv0_1 = add_units(v, T.conv0.w, 64, 3, PK_STEM1, 64, 64);      // one-channel stem: weights summed over the 3 input channels
         for (int b = 0; b < 4; ++b) {
             if (t == 0) { e->pk_c1[b].clear(); e->pk_d1[b].clear(); e->pk_g3f[b].clear(); e->pk_g3d[b].clear(); e->pk_hf[b].clear(); e->pk_hd[b].clear(); }
             for (size_t i = 0; i < T.layers[b].size(); ++i) {
@@ -394,7 +395,18 @@ int64_t smg_debug_read(smg_engine* e, const char* name, float* host_out, int64_t
     const int NS = e->max_streams, NP = e->max_pairs;
     const float* src = nullptr; int64_t n = 0;
     std::string s(name);
-    if (s == "img") { src = e->img4; n = (int64_t)NS * e->p_img.HWp * 4; }
+    if (s == "img") {
+        src = e->img4; n = (int64_t)NS * e->p_img.HWp * 4;
+        if (e->f_stem1 && host_out) {          // one-channel stem: the buffer holds [streams][HWp] floats; present it as the 4-channel image
+            if (cap < n) return fail(-22, "img: buffer too small");
+            HIP_OK(hipSetDevice(e->device));
+            HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+            std::vector<float> one((size_t)(n / 4));
+            HIP_OK(hipMemcpy(one.data(), src, one.size() * sizeof(float), hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < n / 4; ++i) { host_out[4 * i] = host_out[4 * i + 1] = host_out[4 * i + 2] = one[(size_t)i]; host_out[4 * i + 3] = 0.f; }
+            return n;
+        }
+    }
     else if (s == "stem") { src = e->stem; n = (int64_t)NS * e->p_stem.HWp * 64; }
     else if (s == "dy0") { src = e->DY0; n = (int64_t)NS * e->p_stem.HWp * 64; }
     else if (s == "feat") { src = e->F; n = (int64_t)NP * e->p_blk[3].HWp * 2 * kFeat; }

@@ -88,7 +88,9 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
         auto on = [&]() { const bool r = unit >= u_lo && unit < u_hi; ++unit; return r; };
         auto xs = [&](int b) { return el(e, e->X[b], (int64_t)s0 * e->p_blk[b].HWp * kBlockCtot[b]); };
         auto st_off = [&](double* base, int stride) { return base + (int64_t)s0 * stride; };
-        float* img4 = e->img4 + (int64_t)s0 * e->p_img.HWp * 4;
+        static const bool stem3_env = getenv("SMG_STEM3") != nullptr;          // dev A/B: the 3-channel stem for every input form
+        const bool stem1 = B->heightmaps_dev && !stem3_env;                   // heightmap form: the three channels are identical by construction
+        float* img4 = stem1 ? e->img4 + (int64_t)s0 * e->p_img.HWp : e->img4 + (int64_t)s0 * e->p_img.HWp * 4;
         float* stem = e->stem + (int64_t)s0 * e->p_stem.HWp * 64;
         const bool head_unit = on();
         if (head_unit) {   // K1 input preparation
@@ -96,23 +98,25 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
             a.images_nchw = B->images_nchw_dev; a.heightmaps = B->heightmaps_dev; a.hm = B->hm_size; a.pad = pad; a.S = e->S;
             a.mean = B->image_mean; a.stdv = B->image_std;
             a.stream_image = e->d_stream_image + s0; a.stream_affine = e->d_affine + 6 * s0; a.stream_rotated = e->d_stream_rot + s0;
-            a.img4 = img4; a.HWp = e->p_img.HWp;
+            a.img4 = img4; a.img1 = stem1 ? img4 : nullptr; a.HWp = e->p_img.HWp;
             a.masks = B->masks_dev; a.stream_mask_a = e->d_stage + e->so_ma + s0; a.stream_mask_b = e->d_stage + e->so_mb + s0;
             ProfScope ps(e, cs, K_OTHER, 0);
             hipLaunchKernelGGL(prep_rotate_kernel, dim3((e->S * e->S + 255) / 256, ns), dim3(256), 0, cs, a);
         }
         if (head_unit) {   // stem conv0 7x7/2
-            auto run = [&](auto tag, auto ptag) {
+            auto run = [&](auto tag, auto ptag, auto mtag) {
                 using Cfg = decltype(tag);
-                FwdConvP<Cfg, F_STEM, decltype(ptag)::value> p{};
+                constexpr int SM = decltype(mtag)::value;          // F_STEM (3-channel image) or F_STEM1 (one channel, 49 taps)
+                FwdConvP<Cfg, SM, decltype(ptag)::value> p{};
                 p.src = img4; p.lds_ = 4; p.ps = e->p_img; p.po = e->p_stem; p.K = 0;
-                p.wp = e->packed_u + e->pk_conv0; p.K8tot = 224 / 8; p.N = 64;
+                p.wp = e->packed_u + (SM == F_STEM1 ? e->pk_conv0_1 : e->pk_conv0); p.K8tot = (SM == F_STEM1 ? 64 : 224) / 8; p.N = 64;
                 p.dst = stem; p.ldd = 64; p.dcoff = 0;
                 p.dsum = st_off(fsum(e, e->st_stem), 64); p.dsq = st_off(fsq(e, e->st_stem), 64); p.dstride = 64;
-                BY(e, 4.0 * ns * ((double)e->p_img.HW * 4 + (double)e->p_stem.HW * 64));
+                BY(e, 4.0 * ns * ((double)e->p_img.HW * (SM == F_STEM1 ? 1 : 4) + (double)e->p_stem.HW * 64));
                 launch_gemm(e, cs, p, dim3(ns * e->p_stem.HWp / Cfg::BM, 1), K_STEM, 2.0 * ns * e->p_stem.HW * 64 * 147);
             };
-            PREC_DISPATCH(e, if (e->p_stem.HWp % 128 == 0) run(CfgP128x64{}, PTAG); else run(CfgP64x64{}, PTAG));
+            if (stem1) { PREC_DISPATCH(e, if (e->p_stem.HWp % 128 == 0) run(CfgP128x64{}, PTAG, std::integral_constant<int, F_STEM1>{}); else run(CfgP64x64{}, PTAG, std::integral_constant<int, F_STEM1>{})); }
+            else { PREC_DISPATCH(e, if (e->p_stem.HWp % 128 == 0) run(CfgP128x64{}, PTAG, std::integral_constant<int, F_STEM>{}); else run(CfgP64x64{}, PTAG, std::integral_constant<int, F_STEM>{})); }
         }
         if (head_unit) {   // norm0 + relu0 + pool0
             Pool0Args a;
@@ -306,6 +310,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                            e->fstat, e->fstat + e->fstat_span, net->bufs, net->nbt, e->d_seq_t, n_seq_t, e->d_seq_h, n_seq_h);
     }
     HIP_OK(hipGetLastError());
+    e->f_stem1 = B->heightmaps_dev && getenv("SMG_STEM3") == nullptr;
     e->have_fwd = true; e->f_trunk = trunk_id; e->f_head = head_id; e->f_streams = NS; e->f_pairs = NP;
     return 0;
 }

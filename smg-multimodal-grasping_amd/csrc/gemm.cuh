@@ -850,9 +850,11 @@ static __global__ __launch_bounds__(256, P::kMinWaves) void gemm_kernel(const P 
 //   F_POOL  1x1 conv over avgpool2x2(BN+ReLU(src))          (transition; pool commutes
 //           with the pointwise conv, so it is applied first: 4x fewer MACs)
 //   F_STEM  7x7 stride-2 pad-3 conv over the NHWC4 input image (no BN)
+//   F_STEM1 the same over a ONE-channel image plane with the weights summed over the three input channels (K = 49 taps,
+//           padded to 64): the reference feeds the stem three identical channels (code/trainer.py:178-181)
 // Epilogue: store raw output + per-(stream, channel) sum / sum-of-squares (fp64 atomics).
 // ------------------------------------------------------------------------------------
-enum { F_ONE = 0, F_THREE = 1, F_POOL = 2, F_STEM = 3 };
+enum { F_ONE = 0, F_THREE = 1, F_POOL = 2, F_STEM = 3, F_STEM1 = 4 };
 
 // PREC: the engine's precision mode (storage of src / dst, operand kind).  F32IO: src and dst are fp32 buffers whatever the
 // mode (the head's feature buffers; the stem reads the fp32 image and writes the fp32 stem plane).
@@ -860,7 +862,7 @@ template <class Cfg_, int MODE, int PREC = 0, bool F32IO_ = false>
 struct FwdConvP {
     using Cfg = Cfg_;
     static_assert(Cfg::AT, "forward form");
-    static constexpr bool F32IO = F32IO_ || MODE == 3;      // F_STEM
+    static constexpr bool F32IO = F32IO_ || MODE == 3 || MODE == 4;      // F_STEM, F_STEM1
     using SrcT = typename std::conditional<F32IO, e_f32, act_t<PREC>>::type;
     using DstT = SrcT;
     static constexpr int kOp = fwd_op(PREC), kAE = 16 / SrcT::size, kBE = 4, ESZ = SrcT::size;
@@ -883,7 +885,8 @@ struct FwdConvP {
     static constexpr bool kDeep = Cfg::BN == 128 && Cfg::BK == 32;      // one workgroup per CU: its own loads must cover the latency
     static constexpr int kPrefetch = kDeep ? SMG_PD_FWD_DEEP : (Cfg::TM * Cfg::TN == 1) ? SMG_PD_FWD_SMALL : SMG_PD_FWD_BIG;
     static constexpr bool kSegmented = false;
-    static constexpr bool kHasPrologue = MODE != F_STEM;
+    static constexpr bool kStem = MODE == F_STEM || MODE == F_STEM1;
+    static constexpr bool kHasPrologue = !kStem;
     static constexpr int kFresh = 32;       // growth rate: at most this many fresh channels
     // waves per SIMD the register allocator is held to: the 128x128 tile (64 accumulator registers) must stay at 3
     static constexpr int kMinWaves = (Cfg::TM * Cfg::TN == 4 && MODE != F_POOL && !kDeep) ? SMG_FWD_BIG_MINWAVES : 1;    // (the pooling fetch holds 4 float4 per row)
@@ -892,9 +895,9 @@ struct FwdConvP {
     struct ARow { int y, x; bool valid; unsigned off; };     // off: element offset of the row inside its stream (F_ONE)
     struct DRow {};
     using KPrm = KPrm0;
-    using KFin = typename std::conditional<MODE == F_STEM, KPrm0, KPrm3>::type;
+    using KFin = typename std::conditional<kStem, KPrm0, KPrm3>::type;
 
-    __host__ __device__ int param_floats() const { return MODE == F_STEM ? 0 : 3 * K; }       // mean | gamma*invstd | beta of all K channels
+    __host__ __device__ int param_floats() const { return kStem ? 0 : 3 * K; }       // mean | gamma*invstd | beta of all K channels
 
     __device__ bool init_ctx(Ctx& c, const VBlock& vb) const {
         int mt = vb.x, nt = vb.y;
@@ -909,7 +912,7 @@ struct FwdConvP {
     // The staging threads then read their channel quad's parameters from LDS per k-tile (reading them from the tables per
     // k-tile was 16 KB of L1 traffic per workgroup and k-tile, twice the A operand).
     __device__ void init_params(const Ctx& c, float* sp) const {
-        if constexpr (MODE != F_STEM) {
+        if constexpr (!kStem) {
             const int t = threadIdx.x;
             const float* tmean = tab_mean(bt, c.n);
             const float* tinv = tab_invstd(bt, c.n);
@@ -938,6 +941,7 @@ struct FwdConvP {
     __device__ int ktiles(const Ctx&) const {
         if constexpr (MODE == F_THREE) return 9 * (K / Cfg::BK);
         else if constexpr (MODE == F_STEM) return 224 / Cfg::BK;
+        else if constexpr (MODE == F_STEM1) return 64 / Cfg::BK;
         else return K / Cfg::BK;
     }
     __device__ void a_row_init(const Ctx& c, ARow& r, int line) const {
@@ -947,7 +951,8 @@ struct FwdConvP {
         r.x = p - r.y * po.W;
         r.off = (unsigned)ESZ * (unsigned)(p * lds_);    // byte offset of the row inside its stream
     }
-    using ARaw = RawT<(MODE == F_POOL) ? 4 : 1>;
+    struct RawTaps { float4 v[1]; bool ok; unsigned m; };      // F_STEM1: four gathered taps + which of them exist
+    using ARaw = typename std::conditional<MODE == F_STEM1, RawTaps, RawT<(MODE == F_POOL) ? 4 : 1>>::type;
     using BRaw = u32x4;
     // first channel of k-tile kt (workgroup-uniform: the per-thread part of every address below is loop-invariant, so the
     // loads are scalar base + 32-bit lane offset with no address arithmetic per k-tile)
@@ -960,7 +965,7 @@ struct FwdConvP {
     // quad h of a fetched slot as a slot of fp32 values (16-bit storage: the staging code transforms the two quads of a slot
     // one after the other)
     __device__ ARaw a_quad(const ARaw& o, int h) const {
-        ARaw r; r.ok = o.ok;
+        ARaw r = o;
 #pragma unroll
         for (int j = 0; j < (MODE == F_POOL ? 4 : 1); ++j) r.v[j] = slot_quad<SrcT>(o.v[j], h);
         return r;
@@ -969,7 +974,7 @@ struct FwdConvP {
     // BN parameters of this thread's channel quad for k-tile kt, from the workgroup's LDS copy
     __device__ KFin k_finish(const Ctx&, const KPrm&, int kt, int q, const float* sp) const {
         KFin f;
-        if constexpr (MODE != F_STEM) {
+        if constexpr (!kStem) {
             const int ch = a_chan(kt, q);
             f.mean = ldv4(sp + ch);
             f.scale = ldv4(sp + K + ch);
@@ -997,6 +1002,21 @@ struct FwdConvP {
             o.v[1] = ld16(src, b + (int64_t)ESZ * lds_);
             o.v[2] = ld16(src, b + (int64_t)ESZ * ps.W * lds_);
             o.v[3] = ld16(src, b + (int64_t)ESZ * (ps.W + 1) * lds_);
+        } else if constexpr (MODE == F_STEM1) {
+            // slot q of the k-tile = taps 4 q' .. 4 q' + 3 of the 7x7 window: four unconditional scalar loads from clamped
+            // addresses of the one-channel plane; which taps exist (inside the window and the image) travels as a bit mask
+            const float* img = static_cast<const float*>(src) + (int64_t)c.n * ps.HWp;
+            float tv[4];
+            o.ok = true; o.m = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tap = kt * Cfg::BK + 4 * q + j;
+                const int yy = 2 * r.y + tap / 7 - 3, xx = 2 * r.x + tap % 7 - 3;
+                const bool in = r.valid && tap < 49 && (unsigned)yy < (unsigned)ps.H && (unsigned)xx < (unsigned)ps.W;
+                tv[j] = img[in ? yy * ps.W + xx : 0];
+                o.m |= in ? (1u << j) : 0u;
+            }
+            o.v[0] = make_float4(tv[0], tv[1], tv[2], tv[3]);
         } else {
             const int tap = kt * (Cfg::BK / 4) + q;
             const int yy = 2 * r.y + tap / 7 - 3, xx = 2 * r.x + tap % 7 - 3;
@@ -1006,7 +1026,9 @@ struct FwdConvP {
         return o;
     }
     __device__ float4 a_xform(const Ctx&, const ARaw& o, const KFin& k, int, int, const float*) const {
-        if constexpr (MODE == F_STEM) {
+        if constexpr (MODE == F_STEM1) {
+            return make_float4((o.m & 1u) ? o.v[0].x : 0.f, (o.m & 2u) ? o.v[0].y : 0.f, (o.m & 4u) ? o.v[0].z : 0.f, (o.m & 8u) ? o.v[0].w : 0.f);
+        } else if constexpr (MODE == F_STEM) {
             return o.ok ? o.v[0] : zero4();
         } else {
             if constexpr (MODE == F_ONE) return bnrelu4(o.v[0], k);
@@ -1388,6 +1410,48 @@ struct BwdDataP {
                         }
                     }
                 }
+            } else if (EMODE == E_UNPOOL && kWide && active && pbase + Cfg::BM <= pa.HW && c.n0 + Cfg::BN <= N) {
+                // 16-bit storage, whole tile: every 4 x 4 block of (pooled pixel, channel) is transposed inside its quad, so a lane
+                // owns ONE pooled pixel and four consecutive channels - four 8-byte mask loads and four 8-byte G' stores (its 2 x 2
+                // source pixels) instead of sixteen 2-byte ones each; the per-channel sums are transposed back.
+                const int cq0 = wn0 + j * 32 + 4 * (l31 >> 2);
+                float pm_[4], ps_[4], ph_[4], pi_[4], pg_[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ps_[k] = ep[cq0 + k]; ph_[k] = ep[Cfg::BN + cq0 + k]; pm_[k] = ep[2 * Cfg::BN + cq0 + k];
+                    pi_[k] = ep[3 * Cfg::BN + cq0 + k]; pg_[k] = ep[4 * Cfg::BN + cq0 + k];
+                }
+#pragma unroll
+                for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float a4[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        quad_transpose4(a4[0], a4[1], a4[2], a4[3]);
+                        const int p = pbase + wm0 + i * 32 + 8 * g + 4 * half + (lane & 3);
+                        const int y = p / pa.W, x = p - y * pa.W;
+                        const int64_t pix0 = (int64_t)c.n * pm.HWp + (2 * y) * pm.W + 2 * x;
+                        float4 xq[4];
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) xq[d] = ldq<XT>(mbuf, (pix0 + (d >> 1) * pm.W + (d & 1)) * ldm + mcoff + c.n0 + cq0);
+                        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const float xv4[4] = {xq[d].x, xq[d].y, xq[d].z, xq[d].w};
+                            float o[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float dy = bn1(xv4[k], pm_[k], ps_[k], ph_[k]) > 0.f ? 0.25f * a4[k] : 0.f;
+                                o[k] = pg_[k] * dy;
+                                s0[k] += dy;
+                                s1[k] += dy * ((xv4[k] - pm_[k]) * pi_[k]);
+                            }
+                            stq<GT>(dst, (pix0 + (d >> 1) * pm.W + (d & 1)) * ldd + dcoff + c.n0 + cq0, make_float4(o[0], o[1], o[2], o[3]));
+                        }
+                        quad_transpose4(s0[0], s0[1], s0[2], s0[3]);
+                        quad_transpose4(s1[0], s1[1], s1[2], s1[3]);
+                        v[0][j] += (s0[0] + s0[1]) + (s0[2] + s0[3]);
+                        v[1][j] += (s1[0] + s1[1]) + (s1[2] + s1[3]);
+                    }
             } else
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i) {
@@ -1818,15 +1882,15 @@ struct BwdDataGroupP {
 //   Epilogue: fp32 atomicAdd into the gradient array in the reference's native
 //   [cout][cin][kh][kw] layout (C_IDENT / C_3x3 / C_STEM index maps).
 // ------------------------------------------------------------------------------------
-enum { W_ONE = 0, W_THREE = 1, W_POOL = 2, W_STEM = 3 };
-enum { C_IDENT = 0, C_3x3 = 1, C_STEM = 2 };
+enum { W_ONE = 0, W_THREE = 1, W_POOL = 2, W_STEM = 3, W_STEM1 = 4 };      // W_STEM1: one-channel image plane, 49 taps (see F_STEM1)
+enum { C_IDENT = 0, C_3x3 = 1, C_STEM = 2, C_STEM1 = 3 };                  // C_STEM1: column = tap, written to all three input channels
 
 // PREC: the engine's precision mode; F32IO: every buffer is fp32 whatever the mode (head conv0; the stem's image / plane).
 template <class Cfg_, int BMODE, int CMAP, int PD_ = SMG_PD_WGRAD, bool AFF = true, int PREC = 0, bool F32IO_ = false>
 struct BwdWeightP {
     using Cfg = Cfg_;
     static_assert(!Cfg::AT, "weight-gradient form");
-    static constexpr bool F32IO = F32IO_ || BMODE == 3;      // W_STEM
+    static constexpr bool F32IO = F32IO_ || BMODE == 3 || BMODE == 4;      // W_STEM, W_STEM1
     using GT = typename std::conditional<F32IO, e_f32, grd_t<PREC>>::type;      // output gradient (gbuf)
     using XT = typename std::conditional<F32IO, e_f32, act_t<PREC>>::type;      // activations (xbuf, bbuf)
     static_assert(GT::size == XT::size, "one slot geometry");
@@ -1918,7 +1982,7 @@ struct BwdWeightP {
             sp[2 * Cfg::BM + k] = mean;
             sp[3 * Cfg::BM + k] = kk;
         }
-        if constexpr (BMODE != W_STEM) {
+        if constexpr (BMODE != W_STEM && BMODE != W_STEM1) {
             float* bp = sp + 4 * Cfg::BM;
             const double binv = 1.0 / (double)pb.HW;
             for (int j = threadIdx.x; j < Cfg::BN; j += 256) {
@@ -1938,7 +2002,8 @@ struct BwdWeightP {
     __device__ int ktiles(const Ctx& c) const { return c.kt; }
     __device__ void a_row_init(const Ctx&, ARow&, int) const {}
     using ARaw = RawT<2>;
-    using BRaw = RawT<(BMODE == W_POOL) ? 4 : 1>;
+    struct RawTaps { float4 v[1]; bool ok; unsigned m; };      // W_STEM1: four gathered taps + which of them exist
+    using BRaw = typename std::conditional<BMODE == W_STEM1, RawTaps, RawT<(BMODE == W_POOL) ? 4 : 1>>::type;
     __device__ ARaw a_fetch(const Ctx&, const ARow&, int, int) const { return ARaw{}; }
     // Unconditional loads from clamped addresses (pixel 0 / channel 0 of the stream where the slot lies outside the plane or
     // the matrix; zeroed at the LDS store): a branch around a staged load makes hipcc drain vmcnt(0) between load groups.
@@ -1967,7 +2032,7 @@ struct BwdWeightP {
         return r;
     }
     __device__ BRaw b_quad(const BRaw& o, int h) const {
-        BRaw r; r.ok = o.ok;
+        BRaw r = o;
 #pragma unroll
         for (int j = 0; j < (BMODE == W_POOL ? 4 : 1); ++j) r.v[j] = slot_quad<XT>(o.v[j], h);
         return r;
@@ -1998,6 +2063,20 @@ struct BwdWeightP {
             o.v[1] = ld16(bbuf, b + (int64_t)XSZ * ldb);
             o.v[2] = ld16(bbuf, b + (int64_t)XSZ * pb.W * ldb);
             o.v[3] = ld16(bbuf, b + (int64_t)XSZ * (pb.W + 1) * ldb);
+        } else if constexpr (BMODE == W_STEM1) {
+            const float* img = static_cast<const float*>(bbuf) + (int64_t)c.n * pb.HWp;
+            float tv[4];
+            const bool pin = r.p < pa.HW;
+            o.ok = true; o.m = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tap = ch + j;
+                const int yy = 2 * r.y + tap / 7 - 3, xx = 2 * r.x + tap % 7 - 3;
+                const bool in = pin && tap < 49 && (unsigned)yy < (unsigned)pb.H && (unsigned)xx < (unsigned)pb.W;
+                tv[j] = img[in ? yy * pb.W + xx : 0];
+                o.m |= in ? (1u << j) : 0u;
+            }
+            o.v[0] = make_float4(tv[0], tv[1], tv[2], tv[3]);
         } else {
             const int tap = ch >> 2;
             const int yy = 2 * r.y + tap / 7 - 3, xx = 2 * r.x + tap % 7 - 3;
@@ -2009,7 +2088,7 @@ struct BwdWeightP {
     // mean | gamma*invstd | beta of the B channel quad this thread stages in every k-tile (loop-invariant: one LDS read)
     __device__ KPrm3 b_fix(const Ctx&, int q, const float* sp) const {
         KPrm3 f{};
-        if constexpr (BMODE != W_STEM) {
+        if constexpr (BMODE != W_STEM && BMODE != W_STEM1) {
             const float* pr = sp + 4 * Cfg::BM + 4 * q;
             f.mean = ldv4(pr);
             f.scale = ldv4(pr + Cfg::BN);
@@ -2018,7 +2097,9 @@ struct BwdWeightP {
         return f;
     }
     __device__ float4 b_xform(const Ctx&, const BRaw& o, int, int, const float*, const KPrm3& f) const {
-        if constexpr (BMODE == W_STEM) {
+        if constexpr (BMODE == W_STEM1) {
+            return make_float4((o.m & 1u) ? o.v[0].x : 0.f, (o.m & 2u) ? o.v[0].y : 0.f, (o.m & 4u) ? o.v[0].z : 0.f, (o.m & 8u) ? o.v[0].w : 0.f);
+        } else if constexpr (BMODE == W_STEM) {
             return o.ok ? o.v[0] : zero4();
         } else {
             if constexpr (BMODE == W_ONE) return bnrelu4(o.v[0], f);
@@ -2072,7 +2153,11 @@ struct BwdWeightP {
                         int64_t idx;
                         if constexpr (CMAP == C_IDENT) idx = (int64_t)row * ldw_out + col;
                         else if constexpr (CMAP == C_3x3) idx = (int64_t)row * ldw_out + col * 9 + c.tap;
-                        else {
+                        else if constexpr (CMAP == C_STEM1) {
+                            if (col >= 49) continue;
+                            for (int cc = 0; cc < 3; ++cc) atomicAdd(dw + (int64_t)row * ldw_out + cc * 49 + col, acc[i][j][r]);
+                            continue;
+                        } else {
                             const int tap = col >> 2, cc = col & 3;
                             if (cc == 3 || tap >= 49) continue;
                             idx = (int64_t)row * ldw_out + cc * 49 + tap;
@@ -2110,7 +2195,12 @@ static __global__ void reduce_partials_kernel(const ReduceArgs a) {
         int64_t idx;
         if (a.cmap == C_IDENT) idx = (int64_t)row * a.ldw_out + col;
         else if (a.cmap == C_3x3) idx = (int64_t)row * a.ldw_out + col * 9 + tap;
-        else {
+        else if (a.cmap == C_STEM1) {         // one-channel stem: the three input channels were identical, so are their gradients
+            if (col >= 49) continue;
+            const float v = (s0 + s1) + (s2 + s3);
+            for (int cc = 0; cc < 3; ++cc) a.dw[(int64_t)row * a.ldw_out + cc * 49 + col] += v;
+            continue;
+        } else {
             const int t7 = col >> 2, cc = col & 3;
             if (cc == 3 || t7 >= 49) continue;
             idx = (int64_t)row * a.ldw_out + cc * 49 + t7;
