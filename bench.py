@@ -265,6 +265,7 @@ def main():
                          "32 rotations per GPU in fp16")
     ap.add_argument("--scenes-per-rank", type=int, default=8, help="--leg config4: scenes per GPU per step")
     ap.add_argument("--train-only", action="store_true", help="only the timed training steps (profiling runs: every kernel in the trace belongs to a step)")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: blocking gradient all-reduce after the backward instead of the one hidden under its second half")
     ap.add_argument("--serialize", action="store_true", help="one HIP stream, launches in issue order (per-kernel durations of a rocprofv3 trace stay per kernel)")
     args = ap.parse_args()
     if args.train_only:
@@ -305,18 +306,27 @@ def main():
     labels = synthetic.uniform(rank, "bench/labels", R, 0.0, 1.5)    # both Huber branches occur
     rots = list(range(R))
 
-    # gradient all-reduce between backward and Adam, timed with events on the launch stream (the collective's own stream
-    # joins it before Adam is enqueued)
+    # Gradient all-reduce between backward and Adam.  Default under N > 1: hidden under the second half of the backward
+    # (parallel.OverlappedGradSync over smg_backward_phase); --no-overlap: one blocking collective per range after the backward.
+    # Events on the launch stream bracket every hook call: with the overlap they measure the EXPOSED part only.
     ar_events = []
 
-    def sync(model, trunk_id, head_id):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        parallel.allreduce_grads(model, trunk_id, head_id)
-        e1.record()
-        ar_events.append((e0, e1))
-    if not distributed:
-        sync = None
+    def bracket(fn):
+        def wrapped(*a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(*a)
+            e1.record()
+            ar_events.append((e0, e1))
+        return wrapped
+
+    class BenchSync(parallel.OverlappedGradSync):
+        pass
+    BenchSync.start = bracket(parallel.OverlappedGradSync.start)
+    BenchSync.finish = bracket(parallel.OverlappedGradSync.finish)
+    sync = None
+    if distributed:
+        sync = bracket(parallel.allreduce_grads) if args.no_overlap else BenchSync()
 
     # inputs resident in HBM before the timed region (the heightmaps as float64, the labels as float32): the numpy form
     # of the same call costs a pageable host-to-device copy per step, which also stalls the host behind the previous step
@@ -416,11 +426,23 @@ def main():
     step_rl = {"algorithmic_tflops": out["pass_tflops_algorithmic"], "mfma_roof_tflops": mfma_roof * world,
                "frac_of_mfma_roof": out["pass_tflops_algorithmic"] / (mfma_roof * world),
                "frac_of_fp32_mfma_peak": out["pass_tflops_algorithmic"] / (PEAK_F32_MFMA_TFLOPS * world)}
-    if ar_events:
+    if distributed:
         torch.cuda.synchronize(dev)
         ar = [a.elapsed_time(b) for a, b in ar_events]
-        out["allreduce_ms"] = float(np.mean(ar))                  # per collective call (trunk + head ranges), hipEvents on the launch stream
-        out["allreduce_ms_per_step"] = float(np.sum(ar)) / args.steps
+        out["allreduce_overlapped"] = not args.no_overlap
+        out["allreduce_exposed_ms_per_step"] = float(np.sum(ar)) / args.steps      # launch-stream time inside the sync hooks (hipEvents)
+        # the collective itself: blocking all-reduce of the (trunk, head) gradient ranges of the last step, hipEvents around it
+        tid, hid = tr.model._saved[2], tr.model._saved[3]
+        t_ar = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            parallel.allreduce_grads(tr.model, tid, hid)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            t_ar.append(e0.elapsed_time(e1))
+        out["allreduce_ms"] = float(np.min(t_ar))
+        out["allreduce_bytes"] = 4 * sum(n for _, n in parallel.grad_segments(tr.model.HEAD_OUT, tid, hid))
         out["allreduce_backend"] = torch.distributed.get_backend()
     out["roofline"] = {"step": step_rl}
 

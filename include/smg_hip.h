@@ -148,11 +148,25 @@ int smg_loss(smg_engine* e, int mode, const float* q_dev, const float* labels_de
  * code/trainer.py:350-351. */
 int smg_backward(smg_engine* e, const smg_net* net, const float* dq_dev, void* stream);
 
-/* Operand precision of every matrix product of the engine:
- *   0  fp32-class (default): each fp32 operand as three bf16 pieces, six MFMA terms per product - what the reference's
- *      apex O0 arithmetic (code/trainer.py:101) is gated against;
- *   1  bf16 operands, 2  fp16 operands: one MFMA term per product (BASELINE.json configs 3 and 5).
- * Activations, gradients, BN statistics and every accumulation stay fp32.  Takes effect with the next smg_forward. */
+/* The same backward in two halves, for a data-parallel caller that hides its gradient all-reduce under compute:
+ * phase 0 runs the head and dense blocks 4, 3, 2; when it returns (in stream order) every gradient of the parameters from
+ * smg_layout_trunk_split() to the end of the trunk range, and of the head range, is final - their all-reduce can start while
+ * phase 1 (dense block 1, pool0, the stem: about a third of the backward) computes the rest, [trunk begin, split).
+ * smg_backward == phase 0 followed by phase 1. */
+int smg_backward_phase(smg_engine* e, const smg_net* net, const float* dq_dev, void* stream, int phase);
+/* Element offset (params / grads) of the first parameter behind dense block 1 of trunk `trunk_id` (transition1.norm.weight). */
+int smg_layout_trunk_split(int head_out, int trunk_id, int64_t* offset);
+
+/* Precision mode of the engine (the reference runs apex O0 = fp32, code/trainer.py:101; modes 1 and 2 are BASELINE.json configs 3
+ * and 5):
+ *   0  (default) fp32 storage; every product as three bf16 pieces per fp32 operand, six MFMA terms - fp32-class accuracy,
+ *      what the parity suite gates;
+ *   1  bf16 STORAGE of activations and gradients (dense-block buffers, bottlenecks, G', the backward ring), one bf16 MFMA term
+ *      per product;
+ *   2  fp16 storage of activations with fp16 forward products; gradients stored and multiplied in bf16 (fp32 exponent range:
+ *      no loss scaling).
+ * In every mode parameters, their gradients, Adam, BN statistics, every accumulation, the input image, the stem plane and the
+ * head's feature buffers stay fp32.  Takes effect with the next smg_forward (a saved forward of another mode is dropped). */
 int smg_engine_set_precision(smg_engine* e, int precision);
 
 /* Engine switches by name.  "deterministic" (0 / 1): the 1x1-convolution weight gradients (conv1 of every dense layer,
@@ -185,7 +199,7 @@ int smg_layout_trunk_range(int head_out, int trunk_id, int64_t* offset, int64_t*
 int smg_layout_head_range(int head_out, int head_id, int64_t* offset, int64_t* count);
 
 /* ---- debug / test access (used by tests/ only) ------------------------------------ */
-/* Copies an internal float32 buffer to host.  name: "img", "stem", "x1".."x4",
+/* Copies an internal buffer to host as float32 (16-bit storage is widened).  name: "img", "stem", "x1".."x4",
  * "feat", "g1".."g4" ...; returns the element count or a negative error. */
 int64_t smg_debug_read(smg_engine* e, const char* name, float* host_out, int64_t cap, void* stream);
 /* Geometry of the engine: fills H (per block spatial size), HWp (padded rows). */

@@ -14,7 +14,10 @@ static void pick_chunk(const Plane& pl, int n_planes, int tiles_per_chunk, int& 
     cps = (pl.HWp + chunk - 1) / chunk;
 }
 
-int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t st) {
+// phases: bit 0 = the head and dense blocks 4, 3, 2 (down to the gradient of block 1's buffer), bit 1 = dense block 1, pool0 and
+// the stem.  Between the two halves every gradient of [transition1 .. norm5] and of the head is final on `st`: a data-parallel
+// caller starts their all-reduce there and hides it under the second half (smg_backward_phase).
+int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t st, int phases) {
     if (!e->have_fwd) return fail(-22, "smg_backward without a preceding smg_forward");
     if (!net->grads) return fail(-22, "net.grads is NULL");
     const Layout& L = *e->L;
@@ -24,7 +27,8 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
     const float* P = net->params;
     float* Gr = net->grads;
     const Plane p4 = e->p_blk[3];
-    HIP_OK(hipMemsetAsync(e->bstat, 0, 2 * e->bstat_span * sizeof(double), st));
+    const bool ph_a = phases & 1, ph_b = phases & 2;
+    if (ph_a) HIP_OK(hipMemsetAsync(e->bstat, 0, 2 * e->bstat_span * sizeof(double), st));
     // Weight-gradient kernels only read what the data-gradient chain produces and write disjoint
     // gradient ranges, so they run on a second stream beside it (their MFMA/L2-bound phases overlap the
     // HBM-bound epilogues of the data-gradient kernels).  While profiling everything is serialised on
@@ -37,8 +41,10 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         HIP_OK(hipStreamWaitEvent(s2, ev, 0));
         return 0;
     };
-    int layer_no = 0;
+    if (ph_a) e->bw_layer_no = 0;
+    int layer_no = e->bw_layer_no;
 
+    if (ph_a) {
     {   // value conv backward + relu1 + norm1 sums
         ValueBwdArgs a;
         a.h1 = e->H1; a.p4 = p4; a.hsum = fsum(e, e->st_H1); a.hsq = fsq(e, e->st_H1);
@@ -96,7 +102,8 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         ProfScope ps(e, st, K_OTHER, 0);
         PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(norm5_bwd_kernel<PREC>), dim3(1, NS, (p4.HW + 15) / 16), dim3(256), 0, st, a));
     }
-    for (int b = 3; b >= 0; --b) {
+    }   // ph_a: head
+    for (int b = ph_a ? 3 : 0; b >= (ph_b ? 0 : 1); --b) {
         e->prof_stage = b;
         const Plane pl = e->p_blk[b];
         const int Ct = kBlockCtot[b];
@@ -278,7 +285,8 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 const int nt = (d.cin + Cfg::BN - 1) / Cfg::BN;
                 int chunk, cps;
                 static const int w1_target = getenv("SMG_W1_WGS") ? atoi(getenv("SMG_W1_WGS")) : 320;            // dev A/B
-                pick_chunk(pl, NS, nt, chunk, cps, w1_target);   // 256..384 measure the same (22.46 ms per step), 512: 22.6, 768: 22.8, 1024: 23.2
+                static const int w1_small = getenv("SMG_W1_WGS_SMALL") ? atoi(getenv("SMG_W1_WGS_SMALL")) : w1_target;      // dev A/B: planes of <= 1600 pixels
+                pick_chunk(pl, NS, nt, chunk, cps, pl.HW <= 1600 ? w1_small : w1_target);   // 256..384 measure the same (22.46 ms per step), 512: 22.6, 768: 22.8, 1024: 23.2
                 auto go = [&](auto ptag) {
                 BwdWeightP<MC<Cfg, decltype(ptag)::value>, W_ONE, C_IDENT, SMG_PD_WGRAD, false, decltype(ptag)::value> p{};
                 p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck;
@@ -343,6 +351,8 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         }
     }
     e->prof_stage = -1;
+    e->bw_layer_no = layer_no;
+    if (ph_b) {
     {   // pool0 / relu0 backward + norm0 sums
         Pool0BwdArgs a;
         a.G1 = e->G[0]; a.X1 = e->X[0]; a.ld1 = kBlockCtot[0]; a.p1 = e->p_blk[0];
@@ -381,7 +391,8 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         if (e->f_stem1) { PREC_DISPATCH(e, if (go(PTAG, std::integral_constant<int, W_STEM1>{})) return -5); }
         else { PREC_DISPATCH(e, if (go(PTAG, std::integral_constant<int, W_STEM>{})) return -5); }
     }
-    HIP_OK(hipEventRecord(e->ev_end, s2));          // join: everything after the backward sees every gradient
+    }   // ph_b: pool0 + stem
+    HIP_OK(hipEventRecord(e->ev_end, s2));          // join: everything after the backward (or this half of it) sees every gradient
     HIP_OK(hipStreamWaitEvent(st, e->ev_end, 0));
     HIP_OK(hipGetLastError());
     return 0;

@@ -126,6 +126,7 @@ struct smg_engine {
     BnUpdDesc* d_bnupd = nullptr;
     // last forward
     bool have_fwd = false; int f_trunk = 0, f_head = 0, f_streams = 0, f_pairs = 0;
+    int bw_layer_no = 0;       // backward ring position, carried from the first half of a two-phase backward to the second
     bool f_stem1 = false;      // the last forward ran the one-channel stem (heightmap input form): img4 holds [streams][HWp] single floats
     int* d_stream_image = nullptr; int* d_stream_rot = nullptr; int* d_pair_a = nullptr; int* d_pair_b = nullptr;
     int* d_seq_t = nullptr; int* d_seq_h = nullptr; int* d_user_ptr = nullptr; int* d_user_pair = nullptr; int* d_user_slot = nullptr;
@@ -333,4 +334,4 @@ static BnTab bn_table(smg_engine* e, int64_t at, int rows_max, int r0, int C, co
 
 
 int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, const smg_batch* B, float* q_out, hipStream_t st);
-int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t st);
+int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t st, int phases = 3);

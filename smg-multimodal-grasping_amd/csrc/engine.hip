@@ -325,6 +325,19 @@ int smg_backward(smg_engine* e, const smg_net* net, const float* dq_dev, void* s
     return do_backward(e, net, dq_dev, (hipStream_t)stream);
 }
 
+int smg_backward_phase(smg_engine* e, const smg_net* net, const float* dq_dev, void* stream, int phase) {
+    if (!e || !net || !dq_dev) return fail(-22, "NULL argument");
+    if (phase != 0 && phase != 1) return fail(-22, "phase must be 0 or 1");
+    HIP_OK(hipSetDevice(e->device));
+    return do_backward(e, net, dq_dev, (hipStream_t)stream, phase == 0 ? 1 : 2);
+}
+
+int smg_layout_trunk_split(int head_out, int trunk_id, int64_t* offset) {
+    if (trunk_id < 0 || trunk_id > 2 || !offset) return fail(-22, "trunk_id");
+    *offset = layout_for(head_out).trunk[trunk_id].tnorm[0].w;       // first parameter behind dense block 1 (transition1.norm.weight)
+    return 0;
+}
+
 int smg_engine_set_precision(smg_engine* e, int precision) {
     if (!e) return fail(-22, "engine is NULL");
     if (precision < 0 || precision > 2) return fail(-22, "precision must be 0 (fp32 storage, fp32-class split products), 1 (bf16 storage) or 2 (fp16 activations, bf16 gradients)");

@@ -161,10 +161,11 @@ class _AffordanceNet(nn.Module):
                 node._buffers[leaf] = self._flat_nbt[off:off + 1].view(())
 
     def set_precision(self, name):
-        """Operand precision of the matrix products: 'fp32' (default - every fp32 operand as three bf16 pieces, six MFMA
-        terms per product: the accuracy of the reference's apex O0 arithmetic, code/trainer.py:101), 'bf16' or 'fp16'
-        (one MFMA term per product; BASELINE.json configs 3 and 5).  Parameters, activations, gradients, BN statistics
-        and Adam stay fp32 in every mode."""
+        """Precision mode of the engine calls of this model: 'fp32' (default - fp32 storage, every fp32 operand as three bf16
+        pieces, six MFMA terms per product: the accuracy of the reference's apex O0 arithmetic, code/trainer.py:101), 'bf16'
+        (activations and gradients STORED in bf16, one bf16 MFMA term per product; BASELINE.json config 3) or 'fp16' (activations
+        stored in fp16 with fp16 forward products, gradients stored and multiplied in bf16; config 5).  Parameters, their
+        gradients, BN statistics, every accumulation and Adam stay fp32 in every mode."""
         name = str(name).replace("torch.", "")
         if name not in smg_hip.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(smg_hip.PRECISIONS))
@@ -333,7 +334,9 @@ class _AffordanceNet(nn.Module):
         self._saved = None
         return q
 
-    def _engine_backward(self, token, dq):
+    def _engine_backward(self, token, dq, phase=None):
+        """phase None: the whole backward; 0 / 1: its two halves (a data-parallel caller all-reduces the gradients the first half
+        finished while the second runs, parallel.OverlappedGradSync)."""
         if self._saved is None or self._saved[1] != token or not self._saved[0].h or self._saved[0].forward_id != token:
             raise RuntimeError("backward: the activations of that forward are gone (another forward ran on the engine)")
         eng, _, trunk_id, head_id = self._saved
@@ -344,13 +347,15 @@ class _AffordanceNet(nn.Module):
         # zero_grad(set_to_none=True) only drops p.grad and never sees that buffer, so a range whose parameters
         # have no .grad is started from zero here; a range that still has its .grad keeps accumulating.
         g = self.flat_grads()
-        for (off, n), probe in ((smg_hip.trunk_range(self.HEAD_OUT, trunk_id), self._range_probe[("t", trunk_id)]),
-                                (smg_hip.head_range(self.HEAD_OUT, head_id), self._range_probe[("h", head_id)])):
-            if probe.grad is None and not self._grads_clean:
-                g[off:off + n].zero_()
-        self._grads_clean = False
-        eng.backward(self._net_struct(True), dq.data_ptr(), stream)
-        self.expose_grads(trunk_id, head_id)
+        if phase in (None, 0):
+            for (off, n), probe in ((smg_hip.trunk_range(self.HEAD_OUT, trunk_id), self._range_probe[("t", trunk_id)]),
+                                    (smg_hip.head_range(self.HEAD_OUT, head_id), self._range_probe[("h", head_id)])):
+                if probe.grad is None and not self._grads_clean:
+                    g[off:off + n].zero_()
+            self._grads_clean = False
+        eng.backward(self._net_struct(True), dq.data_ptr(), stream, phase)
+        if phase in (None, 1):
+            self.expose_grads(trunk_id, head_id)
 
     # ---- the reference interface -------------------------------------------------------------
     def forward(self, input_depth_data, m_input_depth_data, style=0, is_volatile=False, specific_rotation=-1):

@@ -72,6 +72,8 @@ def lib():
     L.smg_forward.argtypes = [C.c_void_p, C.POINTER(SmgNet), C.c_int, C.c_int, C.POINTER(SmgBatch), C.c_void_p, C.c_void_p]
     L.smg_loss.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.smg_backward.argtypes = [C.c_void_p, C.POINTER(SmgNet), C.c_void_p, C.c_void_p]
+    L.smg_backward_phase.argtypes = [C.c_void_p, C.POINTER(SmgNet), C.c_void_p, C.c_void_p, C.c_int]
+    L.smg_layout_trunk_split.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int64)]
     L.smg_engine_set_precision.argtypes = [C.c_void_p, C.c_int]
     L.smg_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.smg_heightmap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -95,7 +97,7 @@ EXPORTS = (
     "smg_last_error", "smg_version", "smg_abi_struct_bytes", "smg_engine_set_option", "smg_layout_count", "smg_layout_param_floats", "smg_layout_buffer_floats",
     "smg_layout_nbt_count", "smg_layout_entry", "smg_layout_trunk_range", "smg_layout_head_range",
     "smg_engine_create", "smg_engine_destroy", "smg_engine_workspace_bytes", "smg_engine_geometry",
-    "smg_forward", "smg_loss", "smg_backward", "smg_adam_step", "smg_argmax", "smg_heightmap", "smg_engine_set_precision", "smg_debug_read",
+    "smg_forward", "smg_loss", "smg_backward", "smg_backward_phase", "smg_layout_trunk_split", "smg_adam_step", "smg_argmax", "smg_heightmap", "smg_engine_set_precision", "smg_debug_read",
     "smg_profile_enable", "smg_profile_kinds", "smg_profile_kind_name", "smg_profile_read", "smg_profile_read_bytes",
 )
 
@@ -122,6 +124,13 @@ def trunk_range(head_out, trunk_id):
     o, n = C.c_int64(), C.c_int64()
     check(lib().smg_layout_trunk_range(head_out, trunk_id, C.byref(o), C.byref(n)))
     return o.value, n.value
+
+
+def trunk_split(head_out, trunk_id):
+    """Element offset of the first parameter behind dense block 1 (smg_layout_trunk_split)."""
+    o = C.c_int64()
+    check(lib().smg_layout_trunk_split(head_out, trunk_id, C.byref(o)))
+    return o.value
 
 
 def head_range(head_out, head_id):
@@ -162,8 +171,8 @@ class Engine(object):
             pass
 
     def set_precision(self, name):
-        """Operand precision of the matrix products: 'fp32' (3-piece bf16 split, fp32-class; default), 'bf16' or
-        'fp16' (single-piece operands; fp32 storage and accumulation)."""
+        """Precision mode: 'fp32' (fp32 storage, 3-piece bf16 split products: fp32-class; default), 'bf16' (bf16 storage of
+        activations and gradients) or 'fp16' (fp16 activations, bf16 gradients); include/smg_hip.h."""
         code = PRECISIONS[str(name).replace("torch.", "")]
         check(lib().smg_engine_set_precision(self.h, code))
         self.precision = PRECISION_NAMES[code]          # canonical name: callers compare against 'fp32' / 'bf16' / 'fp16'
@@ -210,8 +219,12 @@ class Engine(object):
     def loss(self, mode, q, labels, n_pairs, loss_out, dq_out, stream):
         check(lib().smg_loss(self.h, mode, q, labels, n_pairs, loss_out, dq_out, stream))
 
-    def backward(self, net, dq, stream):
-        check(lib().smg_backward(self.h, C.byref(net), dq, stream))
+    def backward(self, net, dq, stream, phase=None):
+        """phase None: the whole backward; 0 / 1: its two halves (smg_backward_phase)."""
+        if phase is None:
+            check(lib().smg_backward(self.h, C.byref(net), dq, stream))
+        else:
+            check(lib().smg_backward_phase(self.h, C.byref(net), dq, stream, int(phase)))
 
     def debug_read(self, name, stream=None):
         n = lib().smg_debug_read(self.h, name.encode(), None, 0, stream)

@@ -358,7 +358,8 @@ class Trainer(object):
         One scene: 2-D heightmaps, `rotations` a list of rotation indices.  Several scenes
         (SURVEY.md config 4): heightmaps [n_scenes, H, H], `rotations` a list of lists; labels are
         flat, scene-major.  `grad_sync(model, trunk_id, head_id)` is the data-parallel hook
-        (parallel.allreduce_grads) called between backward and Adam.  Returns the loss vector."""
+        (parallel.allreduce_grads) called between backward and Adam; a hook with `.overlapped` set (parallel.OverlappedGradSync)
+        gets `.start()` after the first half of the backward and `.finish()` after the second.  Returns the loss vector."""
         model = self.model
         self.optimizer.zero_grad()
         model._require_gpu()
@@ -399,9 +400,16 @@ class Trainer(object):
         loss = torch.empty(n, dtype=torch.float32, device=dev)
         dq = torch.empty_like(q)
         eng.loss(0 if self.method == 'reinforcement' else 1, q.data_ptr(), lab.data_ptr(), n, loss.data_ptr(), dq.data_ptr(), stream)
-        model._engine_backward(token, dq)
-        if grad_sync is not None:
-            grad_sync(model, trunk_id, head_id)
+        if grad_sync is not None and getattr(grad_sync, "overlapped", False):
+            # the all-reduce of everything behind dense block 1 (most of the parameters) runs under the second half of the backward
+            model._engine_backward(token, dq, phase=0)
+            grad_sync.start(model, trunk_id, head_id)
+            model._engine_backward(token, dq, phase=1)
+            grad_sync.finish(model, trunk_id, head_id)
+        else:
+            model._engine_backward(token, dq)
+            if grad_sync is not None:
+                grad_sync(model, trunk_id, head_id)
         self.optimizer.step()
         return (loss, q) if return_q else loss
 

@@ -877,6 +877,10 @@ def _dp_worker(rank, world, port, out_q):
         # rank r trains on scene r; one all-reduce of the (trunk, head) gradient ranges between backward and Adam
         tr.train_batch(depth, depth * masks[1], 0, rots[rank], labels[rank], grad_sync=parallel.allreduce_grads)
         g = tr.model.flat_grads().cpu()
+        # the same step with the all-reduce split around the two halves of the backward (smg_backward_phase)
+        tr.train_batch(depth, depth * masks[1], 0, rots[rank], labels[rank], grad_sync=parallel.OverlappedGradSync())
+        g2 = tr.model.flat_grads().cpu()
+        assert float((g - g2).double().norm()) <= 1e-5 * float(g.double().norm())
         # sharded forward sweep of scene 5: 8 rotations per rank, 16 scalars gathered, argmax on every rank
         d5, m5 = synthetic.heightmap_scene(5)
         q, best = parallel.sweep_sharded(tr, d5, d5 * m5[1], style=0)
@@ -920,6 +924,56 @@ def test_data_parallel_two_ranks_equal_single_process_batch(gpu):
     assert q_dp.shape == (16,)
     np.testing.assert_allclose(q_dp, q_one, rtol=0, atol=3e-5)
     assert best_dp == int(np.argmax(q_one))
+
+
+def test_two_phase_backward_equals_single_call(gpu):
+    """smg_backward_phase(0) + (1) = smg_backward: with the deterministic option every convolution weight gradient bit for bit,
+    everything to 1e-5 (the atomics' order); the ranges a data-parallel caller all-reduces after phase 0 are final then."""
+    from trainer import Trainer
+    import parallel
+    import smg_hip
+    import synthetic
+    tr = Trainer('reinforcement', 0.5, False, None, False)
+    sd = synthetic.make_state_dict(orc.state_layout(1), 7)
+    tr.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    tr.model.gnum_rotations = tr.model.snum_rotations = 16
+    tr.optimizer.lr = 0.0
+    depth, masks = synthetic.heightmap_scene(9)
+    rots, labels = [1, 6, 11], [0.4, 1.6, 0.8]
+    tr.train_batch(depth, depth * masks[0], 0, rots, labels)
+    eng = engine_of(tr.model)
+    snap = {}
+
+    class Probe(object):                     # stands where the all-reduce would: records what phase 0 has finished
+        overlapped = True
+
+        def start(self, model, trunk_id, head_id):
+            early, late = parallel.OverlappedGradSync()._ranges(model, trunk_id, head_id)
+            snap["early"] = [(o, n, model.flat_grads()[o:o + n].clone()) for o, n in early]
+            snap["late_before"] = [float(model.flat_grads()[o:o + n].abs().sum()) for o, n in late]
+
+        def finish(self, model, trunk_id, head_id):
+            pass
+    try:
+        eng.set_option("deterministic", 1)
+        tr.train_batch(depth, depth * masks[0], 0, rots, labels)
+        g_one = tr.model.flat_grads().clone()
+        tr.train_batch(depth, depth * masks[0], 0, rots, labels, grad_sync=Probe())
+        g_two = tr.model.flat_grads().clone()
+    finally:
+        eng.set_option("deterministic", 0)
+    assert float((g_one - g_two).double().norm()) <= 1e-5 * float(g_one.double().norm())
+    for n_, p in tr.model.named_parameters():
+        if p.dim() == 4 and n_.startswith("grasp_depth_trunk.features"):
+            off = p.data_ptr() - tr.model._flat_params.data_ptr()
+            assert torch.equal(g_one[off // 4: off // 4 + p.numel()], g_two[off // 4: off // 4 + p.numel()]), n_
+    # after phase 0 the early ranges already held their final values, the late range (conv0 .. dense block 1) was still zero
+    for o, n, early in snap["early"]:
+        assert float((early - g_two[o:o + n]).double().norm()) <= 1e-5 * float(g_two[o:o + n].double().norm())
+    assert snap["late_before"] == [0.0]
+    t0, tn = smg_hip.trunk_range(1, 1)
+    split = smg_hip.trunk_split(1, 1)
+    assert t0 < split < t0 + tn and float(g_two[t0:split].abs().sum()) > 0
 
 
 def _fp32_chain(a32, w32):
@@ -1080,7 +1134,8 @@ def test_bench_two_ranks_config4_leg_on_one_gpu(gpu):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["leg"] == "config4" and out["scaling"] == "weak"
-    assert out["allreduce_ms"] > 0 and out["allreduce_backend"] == "gloo"
+    assert out["allreduce_ms"] > 0 and out["allreduce_backend"] == "gloo" and out["allreduce_overlapped"] is True
+    assert out["allreduce_exposed_ms_per_step"] > 0 and out["allreduce_bytes"] == 4 * (6953856 + 160896)
     st = out["roofline"]["step"]
     assert 0 < st["frac_of_mfma_roof"] < 1 and st["mfma_roof_tflops"] > 800          # 2 x 416.7
     assert abs(out["value"] - 2 * 2 * 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]    # passes/s of the whole job

@@ -59,8 +59,26 @@ def _worker(rank, world, port, out):
             def _heightmaps_to_device(self, a, b):
                 return None
         q, best = parallel.sweep_sharded(_Trainer(), None, None, style=0)
+        # overlapped form: the ranges behind dense block 1 (+ the head) first, the rest after the second half of the backward
+
+        class _Net(object):
+            HEAD_OUT = 1
+
+            def __init__(self):
+                self.g = torch.full((n,), float(rank + 1))
+
+            def flat_grads(self):
+                return self.g
+        net, ov = _Net(), parallel.OverlappedGradSync()
+        early, late = ov._ranges(net, 1, 1)
+        ov.start(net, 1, 1)
+        for w, _ in ov.pending:
+            w.wait()
+        after_start = (sum(float(net.g[o:o + c].sum()) for o, c in early), sum(float(net.g[o:o + c].sum()) for o, c in late))
+        ov.finish(net, 1, 1)
+        after_finish = sum(float(net.g[o:o + c].sum()) for o, c in early + late)
         if rank == 0:
-            out.put((gathered, segs, inside, total, n, q, best))
+            out.put((gathered, segs, inside, total, n, q, best, early, late, after_start, after_finish, float(net.g.sum())))
     finally:
         dist.destroy_process_group()
 
@@ -73,7 +91,7 @@ def test_shard_and_allreduce_world2():
     procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
     for p in procs:
         p.start()
-    gathered, segs, inside, total, n, q, best = out.get(timeout=120)
+    gathered, segs, inside, total, n, q, best, early, late, after_start, after_finish, ov_total = out.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -85,6 +103,11 @@ def test_shard_and_allreduce_world2():
     assert total == pytest.approx(3.0 * seg_elems + 1.0 * (n - seg_elems))          # untouched elsewhere (rank 0 holds 1.0)
     assert q.shape == (16,) and q.dtype == np.float64 and abs(q[13] - 0.69) < 1e-6    # rank order = rotation order
     assert best == 2                                                                  # tie 0.7 / 0.7: lowest index, like np.argmax
+    # OverlappedGradSync: early + late ranges tile the same (trunk, head) segments; start() reduces the early ones only
+    n_early, n_late = sum(c for _, c in early), sum(c for _, c in late)
+    assert n_early + n_late == seg_elems and n_late < n_early and late[0][0] == segs[0][0]
+    assert after_start[0] == pytest.approx(3.0 * n_early) and after_start[1] == pytest.approx(1.0 * n_late)
+    assert after_finish == pytest.approx(3.0 * seg_elems) and ov_total == pytest.approx(total)
 
 
 def test_shard_uneven():
