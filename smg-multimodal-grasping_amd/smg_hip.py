@@ -72,8 +72,9 @@ def lib():
     L.smg_forward.argtypes = [C.c_void_p, C.POINTER(SmgNet), C.c_int, C.c_int, C.POINTER(SmgBatch), C.c_void_p, C.c_void_p]
     L.smg_loss.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.smg_backward.argtypes = [C.c_void_p, C.POINTER(SmgNet), C.c_void_p, C.c_void_p]
-    L.smg_backward_phase.argtypes = [C.c_void_p, C.POINTER(SmgNet), C.c_void_p, C.c_void_p, C.c_int]
-    L.smg_layout_trunk_split.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int64)]
+    if hasattr(L, "smg_backward_phase"):          # (absent from the dev builds tools/ab_kernels.sh compares against)
+        L.smg_backward_phase.argtypes = [C.c_void_p, C.POINTER(SmgNet), C.c_void_p, C.c_void_p, C.c_int]
+        L.smg_layout_trunk_split.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int64)]
     L.smg_engine_set_precision.argtypes = [C.c_void_p, C.c_int]
     L.smg_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.smg_heightmap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
