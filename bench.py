@@ -47,13 +47,16 @@ PMC_FILE = "pmc_r03_hbm_traffic.json"                     # tools/profile_round.
 SERIAL_CSV = "rocprof_r03_kernel_stats_serialized.csv"    # rocprofv3 --kernel-trace --stats of `bench.py --train-only --serialize`
 PASS5_GFLOP = 36767.6                 # S=1824, R=32 fwd+bwd pass, masked stream de-duplicated
 # rocprofv3 kernel-name fragments that make up each class of roofline.per_kernel (profiles/*kernel_stats*.csv)
-CLASS_SYMBOLS = {
-    "stem7x7_fwd": ["FwdConvP<", ", 3>"], "conv1x1_fwd": ["FwdConvP<*, 0>", "conv1x1_fwd_ws_kernel"],
-    "conv3x3_fwd": ["conv3x3_halo_fwd_kernel"], "transition_fwd": ["FwdConvP<*, 2>"],
+CLASS_SYMBOLS = {      # fnmatch patterns; template arguments: FwdConvP<Cfg, MODE, PREC, F32IO>, BwdDataP<Cfg, SHIFT3, EMODE, AFF, PREC, F32IO>,
+                       # BwdDataGroupP<Cfg, PREC>, BwdWeightP<Cfg, BMODE, CMAP, PD, AFF, PREC, F32IO>, conv3x3_halo_*_kernel<tile, PREC>
+    "stem7x7_fwd": ["FwdConvP<*>, 3, ?, false>", "FwdConvP<*>, 4, ?, false>"],
+    "conv1x1_fwd": ["FwdConvP<*>, 0, ?, false>", "conv1x1_fwd_ws_kernel"], "head_conv0_fwd": ["FwdConvP<*>, 0, ?, true>"],
+    "conv3x3_fwd": ["conv3x3_halo_fwd_kernel"], "transition_fwd": ["FwdConvP<*>, 2, ?, false>"],
     "conv3x3_dgrad": ["conv3x3_halo_dgrad_kernel"], "conv3x3_wgrad": ["conv3x3_halo_wgrad_kernel", "reduce_partials_kernel"],
-    "conv1x1_dgrad": ["BwdDataGroupP<", "BwdDataP<*, false, 1, false>"], "conv1x1_wgrad": ["BwdWeightP<*, 0, 0, 3, false>"],
-    "transition_wgrad": ["BwdWeightP<*, 2, 0, 1, true>"], "transition_dgrad": ["BwdDataP<*, false, 2, true>"],
-    "stem_wgrad": ["BwdWeightP<*, 3, 2, 3, true>", "stem_wgrad_kernel"],
+    "conv1x1_dgrad": ["BwdDataGroupP<", "BwdDataP<*>, false, 1, false, ?, false>"], "conv1x1_wgrad": ["BwdWeightP<*>, 0, 0, 3, false, ?, false>"],
+    "transition_wgrad": ["BwdWeightP<*>, 2, 0, 1, true, ?, false>"], "transition_dgrad": ["BwdDataP<*>, false, 2, true, ?, false>"],
+    "stem_wgrad": ["BwdWeightP<*>, 3, 2, 3, true, ?, false>", "BwdWeightP<*>, 4, 3, 3, true, ?, false>"],
+    "head_conv0_wgrad": ["BwdWeightP<*>, 0, 0, 3, true, ?, true>"], "head_conv0_dgrad": ["BwdDataP<*>, false, 0, true, ?, true>"],
 }
 
 
@@ -71,6 +74,7 @@ def csv_class_avg_ms(symbols):
     calls = tot = 0.0
     for r in rows:
         nm = r["Name"]
+        nm = nm.split("(")[0]                    # kernel name without its argument list (which repeats the policy type)
         if any(fnmatch.fnmatchcase(nm, "*" + frag + "*") for frag in symbols):
             calls += float(r["Calls"]); tot += float(r["TotalDurationNs"])
     if calls == 0:
@@ -270,6 +274,8 @@ def main():
     args = ap.parse_args()
     if args.train_only:
         args.cpu_samples, args.batched_scenes, args.no_configs, args.no_roofline = 0, 0, True, True
+    if args.serialize:
+        os.environ["SMG_SERIALIZE"] = "1"        # read by the engine at creation: every launch of the run on one stream
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
@@ -389,11 +395,8 @@ def main():
         torch.cuda.synchronize(dev)
 
     import models
-    for _ in range(max(1, args.warmup) if args.serialize else args.warmup):
+    for _ in range(args.warmup):
         step()
-    if args.serialize:
-        for eng_ in models._ENGINES.values():
-            eng_.set_option("serialize", 1)
     barrier()
     del ar_events[:]
     t0 = time.perf_counter()

@@ -25,6 +25,7 @@ static int engine_build(smg_engine* e) {
     e->OH = e->OW = e->p_blk[3].H - kHeadKernel + 1;
     if (e->OH < 1) return fail(-22, "input_size too small for the 20x20 value head");
 
+    if (getenv("SMG_SERIALIZE")) e->serialize = true;        // profiling runs: serialised from the first launch (bench.py --serialize)
     const char* g3 = getenv("SMG_GENERIC_3X3");
     e->generic3x3 = g3 && g3[0] == '1';
 

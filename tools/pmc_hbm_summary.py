@@ -16,22 +16,38 @@ FORWARDS = 9
 FWD_ONLY = ("prep_rotate", "pack_weights", "pool0_kernel", "feat_kernel", "value_conv", "bn_update", "bn_stat", "FwdConvP<", "conv3x3_halo_fwd", "conv1x1_fwd_ws")
 
 
+def targs(name, tmpl):
+    """Template arguments of `tmpl<GemmCfg<...>, a, b, ...>` behind the tile configuration."""
+    tail = name.split(tmpl + "<", 1)[1]
+    tail = tail.split(">", 1)[1]              # behind GemmCfg<...>
+    depth, out = 0, ""
+    for ch in tail:
+        if ch == "<": depth += 1
+        if ch == ">":
+            if depth == 0: break
+            depth -= 1
+        out += ch
+    return [a.strip() for a in out.split(",") if a.strip()]
+
+
 def kclass(name):
     if "conv1x1_fwd_ws_kernel" in name: return "conv1x1_fwd"
     if "conv3x3_halo_fwd" in name: return "conv3x3_fwd"
     if "conv3x3_halo_dgrad" in name: return "conv3x3_dgrad"
     if "conv3x3_halo_wgrad" in name or "reduce_partials" in name: return "conv3x3_wgrad"
     if "FwdConvP<" in name:
-        tail = name.split("FwdConvP<", 1)[1].split(">", 2)[1]
-        return {" 0": "conv1x1_fwd", " 1": "conv3x3_fwd", " 2": "transition_fwd", " 3": "stem7x7_fwd"}.get(tail.replace(",", ""), "conv1x1_fwd")
+        a = targs(name, "FwdConvP")           # MODE, PREC, F32IO
+        if a[0] == "0" and len(a) > 2 and a[2] == "true": return "head_conv0_fwd"
+        return {"0": "conv1x1_fwd", "1": "conv3x3_fwd", "2": "transition_fwd", "3": "stem7x7_fwd", "4": "stem7x7_fwd"}.get(a[0], "conv1x1_fwd")
     if "BwdDataGroupP" in name: return "conv1x1_dgrad"
     if "BwdDataP<" in name:
-        args = [a.strip() for a in name.split("BwdDataP<", 1)[1].split(">", 2)[1].split(",") if a.strip()]     # SHIFT3, EMODE, AFF
-        if args[0] == "true": return "conv3x3_dgrad"
-        return {"0": "head_conv0_dgrad", "1": "conv1x1_dgrad", "2": "transition_dgrad"}.get(args[1], "conv1x1_dgrad")
+        a = targs(name, "BwdDataP")           # SHIFT3, EMODE, AFF, PREC, F32IO
+        if a[0] == "true": return "conv3x3_dgrad"
+        return {"0": "head_conv0_dgrad", "1": "conv1x1_dgrad", "2": "transition_dgrad"}.get(a[1], "conv1x1_dgrad")
     if "BwdWeightP<" in name:
-        args = [a.strip() for a in name.split("BwdWeightP<", 1)[1].split(">", 2)[1].split(",") if a.strip()]
-        return {"0": "conv1x1_wgrad", "1": "conv3x3_wgrad", "2": "transition_wgrad", "3": "stem_wgrad"}.get(args[0], "conv1x1_wgrad")
+        a = targs(name, "BwdWeightP")         # BMODE, CMAP, PD, AFF, PREC, F32IO
+        if a[0] == "0" and len(a) > 5 and a[5] == "true": return "head_conv0_wgrad"
+        return {"0": "conv1x1_wgrad", "1": "conv3x3_wgrad", "2": "transition_wgrad", "3": "stem_wgrad", "4": "stem_wgrad"}.get(a[0], "conv1x1_wgrad")
     if "smg::" in name: return "elementwise"
     return None
 
