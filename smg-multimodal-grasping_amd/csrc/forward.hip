@@ -164,6 +164,24 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                     static const int mid = getenv("SMG_C1_MID") ? atoi(getenv("SMG_C1_MID")) : 0;                     // dev A/B
                     static const int deep_min = getenv("SMG_C1_DEEP") ? atoi(getenv("SMG_C1_DEEP")) : 1 << 30;       // dev A/B
                     static const bool ws_on = !(getenv("SMG_C1_WS") && atoi(getenv("SMG_C1_WS")) == 0);      // wave-specialised 64x64x32 (ws.cuh); SMG_C1_WS=0: the generic kernel (A/B, cross-check)
+                    static const int rs_on = getenv("SMG_C1_RS") ? atoi(getenv("SMG_C1_RS")) : 0;       // 1: row-streaming 1x1 forward (gemm_tile_rs) where it measured ahead - off by default: the step is the same within noise; cross-checked in test_alternative_kernel_paths_agree
+                    static const int rs_mink = getenv("SMG_C1_RS_MINK") ? atoi(getenv("SMG_C1_RS_MINK")) : 256;   // measured: the row-streaming loop wins on long K
+                    static const int rs_minhw = getenv("SMG_C1_RS_MINHW") ? atoi(getenv("SMG_C1_RS_MINHW")) : 1600;  // (blocks 2-3: -4 % / -10 %), loses on K < 256 (block 1: +10 %, 2 instead of 3 workgroups per CU under a store-heavy epilogue) and on the 20^2 planes (too few workgroups)
+                    if (rs_on && e->prec == 0 && pl.HWp % 64 == 0 && d.cin >= rs_mink && pl.HW >= rs_minhw) {
+                        auto run_rs = [&](auto tag) {
+                            using Cfg = decltype(tag);
+                            FwdConvP<Cfg, F_ONE, 0> p{};
+                            p.src = xs(b); p.lds_ = Ct; p.ps = pl; p.po = pl; p.K = d.cin;
+                            p.bt = t1; p.fresh0 = i == 0 ? d.cin : d.cin - kGrowth; p.fsum = xsum; p.fsq = xsq; p.fstride = Ct; p.eps = kEps;
+                            p.tw_mean = const_cast<float*>(t1.mean); p.tw_invstd = const_cast<float*>(t1.invstd);
+                            p.wp = e->packed_u + e->pk_c1[b][i]; p.K8tot = d.cin / 8; p.N = kBottleneck;
+                            p.dst = bt; p.ldd = kBottleneck; p.dcoff = 0;
+                            p.dsum = bsum; p.dsq = bsq; p.dstride = kBottleneck;
+                            BY(e, ESZ(e) * ns * pl.HW * (d.cin + kBottleneck));
+                            launch_gemm_rs(e, cs, p, dim3(ns * pl.HWp / Cfg::BM, 1), K_C1, 2.0 * ns * pl.HW * d.cin * kBottleneck);
+                        };
+                        if (pl.HWp % 128 == 0) run_rs(CfgR128x128{}); else run_rs(CfgR64x128{});
+                    } else
                     if (ws_on && e->prec == 0 && !(pl.HWp % 128 == 0 && wg128 >= small_wgs) && wg64 >= small_wgs && d.cin % 32 == 0 && pl.HWp % 64 == 0) {
                         Fwd1x1WsArgs a{};
                         a.src = xs(b); a.lds_ = Ct; a.pl = pl; a.K = d.cin;

@@ -827,18 +827,20 @@ def test_alternative_kernel_paths_agree(gpu):
     """The same sweep + one backward through three independent implementations of the 3x3 layers: the LDS-halo kernels
     (default), the generic implicit GEMM (SMG_GENERIC_3X3=1) and the halo kernels with the BN-backward apply fused
     into their loads (SMG_GS_FUSED=1) - and with the 1x1 forward of the small planes through the generic kernel instead of
-    the wave-specialised one (SMG_C1_WS=0).  Separate child processes: the switches are read at engine creation."""
+    the wave-specialised one (SMG_C1_WS=0), or of every plane through the row-streaming k-loop (gemm_tile_rs: A fragments loaded,
+    transformed and split in registers per wave, SMG_C1_RS=1 with its K / plane thresholds at 0).  Separate child processes: the
+    switches are read at engine creation."""
     import json
     import os
     import subprocess
     import sys
     tests_dir = os.path.dirname(os.path.abspath(__file__))
     res = {}
-    for tag, env in (("halo", {}), ("generic", {"SMG_GENERIC_3X3": "1"}), ("fused", {"SMG_GS_FUSED": "1"}), ("c1_generic", {"SMG_C1_WS": "0"})):
+    for tag, env in (("halo", {}), ("generic", {"SMG_GENERIC_3X3": "1"}), ("fused", {"SMG_GS_FUSED": "1"}), ("c1_generic", {"SMG_C1_WS": "0"}),
+                     ("c1_rowstream", {"SMG_C1_RS": "1", "SMG_C1_RS_MINK": "0", "SMG_C1_RS_MINHW": "0"})):
         e = dict(os.environ)
-        e.pop("SMG_GENERIC_3X3", None)
-        e.pop("SMG_GS_FUSED", None)
-        e.pop("SMG_C1_WS", None)
+        for k in ("SMG_GENERIC_3X3", "SMG_GS_FUSED", "SMG_C1_WS", "SMG_C1_RS", "SMG_C1_RS_MINK", "SMG_C1_RS_MINHW"):
+            e.pop(k, None)
         e.update(env)
         out = subprocess.run([sys.executable, "-c", _VARIANT_SCRIPT % {"tests": tests_dir}], env=e, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
@@ -846,7 +848,7 @@ def test_alternative_kernel_paths_agree(gpu):
         res[tag] = json.loads(line[7:])
     ref = res["halo"]
     qs = np.abs(np.asarray(ref["q"])).max()
-    for tag in ("generic", "fused", "c1_generic"):
+    for tag in ("generic", "fused", "c1_generic", "c1_rowstream"):
         r = res[tag]
         assert np.abs(np.asarray(r["q"]) - np.asarray(ref["q"])).max() <= 2e-5 * max(qs, 1e-2), tag     # fp32 summation order only
         assert int(np.argmax(r["q"])) == int(np.argmax(ref["q"])), tag
