@@ -231,9 +231,10 @@ struct ProfScope {
 // Dev instrumentation: per-workgroup phase stamps of ONE launch (SMG_TRACE_KIND = kernel class, SMG_TRACE_SKIP = how many
 // launches of that class to skip).  The kernels store s_memtime at up to five points (slots 0..4) and the device-wide
 // 100 MHz counter at start / end (slots 5, 6) through g_smg_trace; the scope prints the mean phase lengths.
+namespace {   // per translation unit: the scope writes THIS unit's g_smg_trace (a shared inline copy would write another unit's)
 struct TraceScope {
-    hipStream_t st; int kind; dim3 grid; unsigned long long* tbuf = nullptr; size_t n_wg = 0;
-    TraceScope(hipStream_t s, int k, dim3 g) : st(s), kind(k), grid(g) {
+    hipStream_t st; int kind; dim3 grid; const char* what; unsigned long long* tbuf = nullptr; size_t n_wg = 0;
+    TraceScope(hipStream_t s, int k, dim3 g, const char* w = "") : st(s), kind(k), grid(g), what(w) {
         static const int tr_kind = getenv("SMG_TRACE_KIND") ? atoi(getenv("SMG_TRACE_KIND")) : -1;
         static const int tr_skip = getenv("SMG_TRACE_SKIP") ? atoi(getenv("SMG_TRACE_SKIP")) : 0;
         static int tr_seen = 0;
@@ -262,10 +263,11 @@ struct TraceScope {
             life += (double)(r[6] - r[5]);
         }
         const double span = (double)(t_max - t_min) * 0.01, resid = life / (double)(t_max - t_min) / 256.0;
-        fprintf(stderr, "[smg trace] kind %d grid %ux%ux%u live %zu: init %.0f | first tile %.0f | k-loop %.0f | epilogue %.0f cycles/WG (mean); span %.1f us, %.2f workgroups resident per CU, mean life %.1f us\n",
-                kind, grid.x, grid.y, grid.z, live, sum[0] / live, sum[1] / live, sum[2] / live, sum[3] / live, span, resid, life / live * 0.01);
+        fprintf(stderr, "[smg trace] kind %d grid %ux%ux%u live %zu: init %.0f | first tile %.0f | k-loop %.0f | epilogue %.0f cycles/WG (mean); span %.1f us, %.2f workgroups resident per CU, mean life %.1f us  %.160s\n",
+                kind, grid.x, grid.y, grid.z, live, sum[0] / live, sum[1] / live, sum[2] / live, sum[3] / live, span, resid, life / live * 0.01, strstr(what, "[P = ") ? strstr(what, "[P = ") : what);
     }
 };
+}  // namespace
 
 template <class P>
 static void launch_gemm(smg_engine* e, hipStream_t st, P p, dim3 grid, int kind, double flops) {
@@ -291,7 +293,7 @@ static void launch_gemm(smg_engine* e, hipStream_t st, P p, dim3 grid, int kind,
             grid = dim3(8 * ((grid.z + 7) / 8) * tiles, 1, 1);
         }
     }
-    TraceScope ts(st, kind, grid);
+    TraceScope ts(st, kind, grid, __PRETTY_FUNCTION__);
     {
         ProfScope ps(e, st, kind, flops);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_kernel<P>), dim3((unsigned)(grid.x * grid.y * grid.z)), dim3(256), smem, st, p, (int)grid.x, (int)grid.y);

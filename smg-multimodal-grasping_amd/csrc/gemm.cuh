@@ -75,6 +75,9 @@
 // The order of fragment reads and MFMAs inside a k-tile is left to hipcc (with two k-tiles of loads in flight it interleaves
 // the next tile's split / LDS stores with the MFMAs: k-loop of the 64x64 forward -17 %, of the 1x1 data gradient -27 %);
 // SMG_PIN_ORDER restores round 2's early pinned order for A/B.
+#ifndef SMG_ABL_EPI
+#define SMG_ABL_EPI 0      // dev ablation of the grouped data gradient's epilogue (1: no stores, 2: no column sums)
+#endif
 #ifdef SMG_PIN_ORDER
 #define SMG_PIN() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -476,11 +479,18 @@ __device__ __forceinline__ void block_col_reduce(T (&v)[NQ][C::TN], T* red, T (&
 
 // Dev instrumentation (SMG_TRACE_* in engine.hip): when set, thread 0 of every workgroup of a gemm_kernel launch
 // stores s_memtime at five points: start | parameters ready | first tile staged | k-loop done | epilogue done.
+// a cycle stamp the scheduler may not move: hipcc otherwise hoists s_memtime over whole phases
+static __device__ __forceinline__ unsigned long long smg_stamp() {
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
 static __device__ unsigned long long* g_smg_trace = nullptr;      // (one copy per translation unit; TraceScope sets its own)
 #if defined(SMG_TRACE_ITER) || defined(SMG_TRACE_EPI)
 #define SMG_TRACE(slot) do {} while (0)
 #else
-#define SMG_TRACE(slot) do { if (trace) trace[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SMG_TRACE(slot) do { if (trace) trace[slot] = smg_stamp(); } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------
@@ -740,23 +750,26 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
             constexpr int buf = decltype(BUF)::value;
 #ifdef SMG_TRACE_ITER   // dev: sub-phase stamps of k-tile 4 instead of the whole-kernel phases (compute | load wait | store | barrier)
             const bool tr = trace && kt == 4;
-            if (tr) trace[0] = __builtin_amdgcn_s_memtime();
+            if (tr) trace[0] = smg_stamp();
 #endif
             if (more) g_load(kt + 1, ra[0], rb[0], kp[0]);
+#ifdef SMG_PIN_LOADS     // dev A/B: keep the loads at the head of the k-tile (hipcc sinks them under the first MFMA groups)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             compute(buf);
             if constexpr (P::kSegmented) p.k_hook(ctx, kt, acc, sp);   // end of a K segment: fold acc away
 #ifdef SMG_TRACE_ITER
-            if (tr) trace[1] = __builtin_amdgcn_s_memtime();
+            if (tr) trace[1] = smg_stamp();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (tr) trace[2] = __builtin_amdgcn_s_memtime();
+            if (tr) trace[2] = smg_stamp();
 #endif
             if (more) s_store(buf ^ 1, kt + 1, ra[0], rb[0], kp[0]);
 #ifdef SMG_TRACE_ITER
-            if (tr) trace[3] = __builtin_amdgcn_s_memtime();
+            if (tr) trace[3] = smg_stamp();
 #endif
             __syncthreads();
 #ifdef SMG_TRACE_ITER
-            if (tr) trace[4] = __builtin_amdgcn_s_memtime();
+            if (tr) trace[4] = smg_stamp();
 #endif
         };
         int kt = 0;
@@ -774,11 +787,24 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
 #pragma unroll
             for (int u = 0; u < PD; ++u) {
                 const int kt = kt0 + u, buf = kt & 1;
+#ifdef SMG_TRACE_ITER
+                const bool tr = trace && kt == 4;
+                if (tr) trace[0] = smg_stamp();
+#endif
                 g_load(kt + PD < KT ? kt + PD : KT - 1, ra[u], rb[u], kp[u]);   // slot u went to LDS one step ago
                 compute(buf);
                 if constexpr (P::kSegmented) p.k_hook(ctx, kt, acc, sp);
+#ifdef SMG_TRACE_ITER
+                if (tr) { trace[1] = smg_stamp(); trace[2] = trace[1]; }
+#endif
                 s_store(buf ^ 1, kt + 1 < KT ? kt + 1 : KT - 1, ra[(u + 1) % PD], rb[(u + 1) % PD], kp[(u + 1) % PD]);   // at kt + 1 == KT: a dead store of the clamped re-load
+#ifdef SMG_TRACE_ITER
+                if (tr) trace[3] = smg_stamp();
+#endif
                 __syncthreads();
+#ifdef SMG_TRACE_ITER
+                if (tr) trace[4] = smg_stamp();
+#endif
             }
         }
 #pragma unroll
@@ -1403,7 +1429,10 @@ struct BwdDataP {
         c.n = sgpr(c.m0 / pa.HWp);
         const int pbase = c.m0 - c.n * pa.HWp;
         if (pbase >= pa.HW) return false;
-        c.whole = kEarly && pbase + Cfg::BM <= pa.HW && c.n0 + Cfg::BN <= N;
+        // whole = every ROW of the tile inside the plane; a last column tile may be partial as long as it ends on a 32-column
+        // boundary: an accumulator tile (wave, j) is then entirely inside or entirely outside [0, N) - a wave-uniform test (jok),
+        // no per-element predicate.  (The narrow per-layer launches of a layer group have N = 32 / 64 / 96.)
+        c.whole = kEarly && pbase + Cfg::BM <= pa.HW && (c.n0 + Cfg::BN <= N || (N & 31) == 0);
         if constexpr (kEarly) {
             if (c.whole) {
                 const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
@@ -1413,6 +1442,7 @@ struct BwdDataP {
                     for (int i = 0; i < Cfg::TM; ++i)
     #pragma unroll
                         for (int j = 0; j < Cfg::TN; ++j) {
+                            if (c.n0 + wn0 + j * 32 + 32 > N) continue;      // (wave-uniform) tile outside [0, N): never read
                             // 16 / 8-byte loads, one per four accumulator rows (fetch_acc_rows, above GemmCfg); transposed in the epilogue
                             const int64_t ax = (int64_t)(c.m0 + wm0 + i * 32) * ldm + mcoff + c.n0 + wn0 + j * 32;
                             const int64_t ag = (int64_t)(c.m0 + wm0 + i * 32) * ldd + dcoff + c.n0 + wn0 + j * 32;
@@ -1429,6 +1459,7 @@ struct BwdDataP {
                     for (int i = 0; i < Cfg::TM; ++i)
     #pragma unroll
                         for (int j = 0; j < Cfg::TN; ++j) {
+                            if (c.n0 + wn0 + j * 32 + 32 > N) continue;      // (wave-uniform) tile outside [0, N): never read
                             const int cj = wn0 + j * 32 + l31;
                             unsigned ox = (unsigned)((wm0 + i * 32 + 4 * half) * ldm + cj);
                             unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + cj);
@@ -1535,7 +1566,7 @@ struct BwdDataP {
         const float* ep = sp + 4 * KA;
 #ifdef SMG_TRACE_EPI    // dev: stamps inside the epilogue (start | stores issued | column sums reduced | atomics issued)
         unsigned long long* etr = (g_smg_trace && threadIdx.x == 0) ? g_smg_trace + 8 * (size_t)blockIdx.x : nullptr;
-        if (etr) etr[0] = __builtin_amdgcn_s_memtime();
+        if (etr) etr[0] = smg_stamp();
 #endif
         float v[2][Cfg::TN];
 #pragma unroll
@@ -1551,6 +1582,7 @@ struct BwdDataP {
             if (kEarly && active && c.whole) {
                 // Whole tile inside the plane: no per-element predicates, operands already in registers (init_ctx), a uniform
                 // tile base + running 32-bit lane offset for the stores.
+                if (c.n0 + wn0 + j * 32 + 32 > N) continue;      // (wave-uniform) accumulator tile outside [0, N)
                 if constexpr (kWide) {
     #pragma unroll
                     for (int i = 0; i < Cfg::TM; ++i) {
@@ -1691,11 +1723,11 @@ struct BwdDataP {
         }
         float tot[2];
 #ifdef SMG_TRACE_EPI
-        if (etr) etr[1] = __builtin_amdgcn_s_memtime();
+        if (etr) etr[1] = smg_stamp();
 #endif
         block_col_reduce<Cfg, 2, float>(v, smem, tot);
 #ifdef SMG_TRACE_EPI
-        if (etr) etr[2] = __builtin_amdgcn_s_memtime();
+        if (etr) etr[2] = smg_stamp();
 #endif
         if (t < Cfg::BN && c.n0 + t < N) {
             const int col = c.n0 + t;
@@ -1707,7 +1739,7 @@ struct BwdDataP {
             atomicAdd(dgamma + col, tot[1]);
         }
 #ifdef SMG_TRACE_EPI
-        if (etr) { etr[3] = __builtin_amdgcn_s_memtime(); etr[4] = etr[3] + 1; }
+        if (etr) { etr[3] = smg_stamp(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); etr[4] = smg_stamp(); }
 #endif
     }
 };
@@ -1969,6 +2001,10 @@ struct BwdDataGroupP {
         const int pbase = c.m0 - c.n * pa.HWp;
         constexpr int NQ = 2 + 2 * GROUP_MAX;
         float v[NQ][Cfg::TN];
+#ifdef SMG_TRACE_EPI    // dev: stamps inside the epilogue (start | stores issued | column sums reduced | atomics issued)
+        unsigned long long* etr = (g_smg_trace && threadIdx.x == 0) ? g_smg_trace + 8 * (size_t)blockIdx.x : nullptr;
+        if (etr) etr[0] = smg_stamp();
+#endif
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) {
             const int cj = wn0 + j * 32 + l31;
@@ -2002,10 +2038,16 @@ struct BwdDataGroupP {
     #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const float run = c.run[i][j][r];
+#if SMG_ABL_EPI == 1
+                            a0 += c.gold[kWide ? 0 : i][kWide ? 0 : j][r];
+#else
                             st1<GT>(gb, og, c.gold[kWide ? 0 : i][kWide ? 0 : j][r] + run);
+#endif
                             og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
+#if SMG_ABL_EPI != 2
                             a0 += run;
                             a1 = fmaf(run, (c.x[i][j][r] - mean) * invstd, a1);
+#endif
                         }
                     }
                 }
@@ -2036,7 +2078,13 @@ struct BwdDataGroupP {
             for (int z = 0; z < GROUP_MAX; ++z) { v[2 + 2 * z][j] = c.ls[z][0][j]; v[3 + 2 * z][j] = c.ls[z][1][j] * invstd; }
         }
         float tot[NQ];
+#ifdef SMG_TRACE_EPI
+        if (etr) etr[1] = smg_stamp();
+#endif
         block_col_reduce<Cfg, NQ, float>(v, smem, tot);
+#ifdef SMG_TRACE_EPI
+        if (etr) etr[2] = smg_stamp();
+#endif
         if (t < Cfg::BN && c.n0 + t < N) {
             const int col = c.n0 + t;
             const int64_t oi = (int64_t)c.n * ostride + col;
@@ -2049,6 +2097,9 @@ struct BwdDataGroupP {
                     atomicAdd(seg[z].dgamma + col, tot[3 + 2 * z]);
                 }
         }
+#ifdef SMG_TRACE_EPI
+        if (etr) { etr[3] = smg_stamp(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); etr[4] = smg_stamp(); }
+#endif
     }
 };
 
