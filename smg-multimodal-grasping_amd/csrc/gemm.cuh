@@ -75,9 +75,6 @@
 // The order of fragment reads and MFMAs inside a k-tile is left to hipcc (with two k-tiles of loads in flight it interleaves
 // the next tile's split / LDS stores with the MFMAs: k-loop of the 64x64 forward -17 %, of the 1x1 data gradient -27 %);
 // SMG_PIN_ORDER restores round 2's early pinned order for A/B.
-#ifndef SMG_ABL_EPI
-#define SMG_ABL_EPI 0      // dev ablation of the grouped data gradient's epilogue (1: no stores, 2: no column sums)
-#endif
 #ifdef SMG_PIN_ORDER
 #define SMG_PIN() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -735,6 +732,10 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
         else if (u < KT) g_load(u, ra[u], rb[u], kp[u]);
     }
     p.init_params(ctx, sp);
+    // The epilogue's operands (mask source, old G') go out BEHIND the first k-tiles' loads and the parameter loads: vmcnt is
+    // in-order, so issued first they would have to land before the first k-tile could be staged (measured: 15-17k of a
+    // workgroup's 98k cycles); now the k-loop runs PD tiles before its waits reach them.
+    if constexpr (P::kEarlyFetch) p.early_fetch(ctx);
     if constexpr (P::kHasPrologue) __syncthreads();
     if constexpr (!C::AT) {
 #pragma unroll
@@ -753,9 +754,6 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
             if (tr) trace[0] = smg_stamp();
 #endif
             if (more) g_load(kt + 1, ra[0], rb[0], kp[0]);
-#ifdef SMG_PIN_LOADS     // dev A/B: keep the loads at the head of the k-tile (hipcc sinks them under the first MFMA groups)
-            __builtin_amdgcn_sched_barrier(0);
-#endif
             compute(buf);
             if constexpr (P::kSegmented) p.k_hook(ctx, kt, acc, sp);   // end of a K segment: fold acc away
 #ifdef SMG_TRACE_ITER
@@ -1093,6 +1091,7 @@ struct FwdConvP {
     static constexpr bool kSegmented = false;
     static constexpr bool kStem = MODE == F_STEM || MODE == F_STEM1;
     static constexpr bool kHasPrologue = !kStem;
+    static constexpr bool kEarlyFetch = false;
     static constexpr int kFresh = 32;       // growth rate: at most this many fresh channels
     // waves per SIMD the register allocator is held to: the 128x128 tile (64 accumulator registers) must stay at 3
     static constexpr int kMinWaves = (Cfg::TM * Cfg::TN == 4 && MODE != F_POOL && !kDeep) ? SMG_FWD_BIG_MINWAVES : 1;    // (the pooling fetch holds 4 float4 per row)
@@ -1389,6 +1388,7 @@ struct BwdDataP {
     static constexpr int kPrefetch = (Cfg::TM * Cfg::TN <= 2) ? SMG_PD_DGRAD : SMG_PD_DGRAD_BIG;
     static constexpr bool kSegmented = false;
     static constexpr bool kHasPrologue = true;
+    static constexpr bool kEarlyFetch = EMODE != E_UNPOOL;     // early_fetch(): the epilogue's operands, issued behind the first k-tiles' loads
     static constexpr int kMinWaves = 1;
 
     // AFF = false: the gradient operand is finished (xbuf unused).  Pointwise and finished -> descriptor loads, rows outside
@@ -1433,6 +1433,9 @@ struct BwdDataP {
         // boundary: an accumulator tile (wave, j) is then entirely inside or entirely outside [0, N) - a wave-uniform test (jok),
         // no per-element predicate.  (The narrow per-layer launches of a layer group have N = 32 / 64 / 96.)
         c.whole = kEarly && pbase + Cfg::BM <= pa.HW && (c.n0 + Cfg::BN <= N || (N & 31) == 0);
+        return true;
+    }
+    __device__ void early_fetch(Ctx& c) const {
         if constexpr (kEarly) {
             if (c.whole) {
                 const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
@@ -1474,7 +1477,6 @@ struct BwdDataP {
                 }
             }
         }
-        return true;
     }
     __device__ void init_params(const Ctx& c, float* sp) const {
         const double inv = 1.0 / (double)pa.HW;
@@ -1790,6 +1792,7 @@ struct BwdDataGroupP {
     static constexpr int kPrefetch = (Cfg::TM * Cfg::TN <= 1) ? SMG_PD_DGRAD : SMG_PD_DGRAD_BIG;
     static constexpr bool kSegmented = true;
     static constexpr bool kHasPrologue = true;
+    static constexpr bool kEarlyFetch = true;
     static constexpr int kMinWaves = 2;       // (x, the running sum and the old G' of the tile live in registers)
 
     struct Ctx {
@@ -1818,15 +1821,23 @@ struct BwdDataGroupP {
         for (int j = threadIdx.x; j < Cfg::BN; j += 256) {
             const int col = c.n0 + j;
             float mean = 0.f, invstd = 0.f;
+            // every segment's gamma / beta first (one memory round trip; a loop that loads and stores per segment waits per load)
+            float g[GROUP_MAX], be[GROUP_MAX];
+#pragma unroll
+            for (int s = 0; s < GROUP_MAX; ++s) {
+                const bool on = s < nseg && col < N;
+                g[s] = on ? seg[s].gamma[col] : 0.f;
+                be[s] = on ? seg[s].beta[col] : 0.f;
+            }
             if (col < N) bn_moments(msum, msq, (int64_t)c.n * mstride + col, minv, eps, mean, invstd);
             sp[j] = mean;
             sp[Cfg::BN + j] = invstd;
-            for (int s = 0; s < nseg; ++s) {
-                const float g = col < N ? seg[s].gamma[col] : 0.f;
+#pragma unroll
+            for (int s = 0; s < GROUP_MAX; ++s) {
                 float* q = sp + (2 + 3 * s) * Cfg::BN;
-                q[j] = g * invstd;
-                q[Cfg::BN + j] = col < N ? seg[s].beta[col] : 0.f;
-                q[2 * Cfg::BN + j] = g;
+                q[j] = g[s] * invstd;
+                q[Cfg::BN + j] = be[s];
+                q[2 * Cfg::BN + j] = g[s];
             }
         }
     }
@@ -1839,6 +1850,14 @@ struct BwdDataGroupP {
         const int pbase = c.m0 - c.n * pa.HWp;
         if (pbase >= pa.HW) return false;
         c.whole = pbase + Cfg::BM <= pa.HW && c.n0 + Cfg::BN <= N;
+#pragma unroll
+        for (int s = 0; s < GROUP_MAX; ++s)
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) c.ls[s][0][j] = c.ls[s][1][j] = 0.f;
+        return true;
+    }
+    __device__ void early_fetch(Ctx& c) const {
+        const int pbase = c.m0 - c.n * pa.HWp;
         if constexpr (kWide) {
             // this lane's x elements (and, for whole tiles, the old G'): in flight under the first K segment.  Whole tiles fetch
             // row segments (16 / 8 bytes per lane, fetch_acc_rows); x is transposed to accumulator layout by the first segment's
@@ -1883,45 +1902,47 @@ struct BwdDataGroupP {
                 }
             }
         } else {
-            // this lane's x elements: in flight under the first K segment
+            // this lane's x elements (and, for whole tiles, the old G'): in flight under the first K segment.  Whole tiles load
+            // without a predicate - a select on the loaded value would make the workgroup wait for it here.
             const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
             const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
-    #pragma unroll
-            for (int j = 0; j < Cfg::TN; ++j) {
-                const int col = c.n0 + wn0 + j * 32 + l31;
-    #pragma unroll
-                for (int i = 0; i < Cfg::TM; ++i)
-    #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = SMG_ACC_ROW(wm0, i, r, half);
-                        const bool ok = pbase + row < pa.HW && col < N;
-                        // unconditional load from a clamped address (a branch around it would serialise the loads)
-                        const float v = ld1<XT>(mbuf, (int64_t)(c.m0 + (ok ? row : 0)) * ldm + (ok ? col : 0));
-                        c.x[i][j][r] = ok ? v : 0.f;
-                        c.run[i][j][r] = 0.f;
-                        c.gold[i][j][r] = 0.f;
-                    }
-            }
             if (c.whole) {
+                const char* xb = static_cast<const char*>(mbuf) + (int64_t)XT::size * ((int64_t)c.m0 * ldm + c.n0);
                 const char* gb = static_cast<const char*>(dst) + (int64_t)GSZ * ((int64_t)c.m0 * ldd + c.n0);
     #pragma unroll
                 for (int j = 0; j < Cfg::TN; ++j)
     #pragma unroll
                     for (int i = 0; i < Cfg::TM; ++i) {
+                        unsigned ox = (unsigned)((wm0 + i * 32 + 4 * half) * ldm + wn0 + j * 32 + l31);
                         unsigned og = (unsigned)((wm0 + i * 32 + 4 * half) * ldd + wn0 + j * 32 + l31);
     #pragma unroll
                         for (int r = 0; r < 16; ++r) {
+                            c.x[i][j][r] = ld1<XT>(xb, ox);
                             c.gold[i][j][r] = ld1<GT>(gb, og);
+                            ox += (r & 3) == 3 ? 5u * (unsigned)ldm : (unsigned)ldm;
                             og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
+                            c.run[i][j][r] = 0.f;
                         }
                     }
+            } else {
+    #pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j) {
+                    const int col = c.n0 + wn0 + j * 32 + l31;
+    #pragma unroll
+                    for (int i = 0; i < Cfg::TM; ++i)
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = SMG_ACC_ROW(wm0, i, r, half);
+                            const bool ok = pbase + row < pa.HW && col < N;
+                            // unconditional load from a clamped address (a branch around it would serialise the loads)
+                            const float v = ld1<XT>(mbuf, (int64_t)(c.m0 + (ok ? row : 0)) * ldm + (ok ? col : 0));
+                            c.x[i][j][r] = ok ? v : 0.f;
+                            c.run[i][j][r] = 0.f;
+                            c.gold[i][j][r] = 0.f;
+                        }
+                }
             }
         }
-#pragma unroll
-        for (int s = 0; s < GROUP_MAX; ++s)
-#pragma unroll
-            for (int j = 0; j < Cfg::TN; ++j) c.ls[s][0][j] = c.ls[s][1][j] = 0.f;
-        return true;
     }
     __device__ int kps() const { return KA / Cfg::BK; }                   // k-tiles per segment
     __device__ int ktiles(const Ctx&) const { return nseg * kps(); }
@@ -2038,16 +2059,10 @@ struct BwdDataGroupP {
     #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const float run = c.run[i][j][r];
-#if SMG_ABL_EPI == 1
-                            a0 += c.gold[kWide ? 0 : i][kWide ? 0 : j][r];
-#else
                             st1<GT>(gb, og, c.gold[kWide ? 0 : i][kWide ? 0 : j][r] + run);
-#endif
                             og += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
-#if SMG_ABL_EPI != 2
                             a0 += run;
                             a1 = fmaf(run, (c.x[i][j][r] - mean) * invstd, a1);
-#endif
                         }
                     }
                 }
@@ -2147,6 +2162,7 @@ struct BwdWeightP {
     static constexpr int kPrefetch = PD_;     // k-tiles of global loads in flight per thread
     static constexpr bool kSegmented = false;
     static constexpr bool kHasPrologue = true;
+    static constexpr bool kEarlyFetch = false;
     static constexpr int kMinWaves = 1;
 
     struct Ctx { int n, p0, m0, n0, tap, kt, z; };
