@@ -286,7 +286,10 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 int chunk, cps;
                 static const int w1_target = getenv("SMG_W1_WGS") ? atoi(getenv("SMG_W1_WGS")) : 320;            // dev A/B
                 static const int w1_small = getenv("SMG_W1_WGS_SMALL") ? atoi(getenv("SMG_W1_WGS_SMALL")) : w1_target;      // dev A/B: planes of <= 1600 pixels
-                pick_chunk(pl, NS, nt, chunk, cps, pl.HW <= 1600 ? w1_small : w1_target);   // 256..384 measure the same (22.46 ms per step), 512: 22.6, 768: 22.8, 1024: 23.2
+                // 16-bit storage: the k-loop is a third as long, the 128 x 64 atomics per workgroup are not - half as many workgroups
+                // on many-stream batches (config 3: 28.9 -> 28.5 ms at 160; 120 / 80: 28.6 / 28.8; S = 1824 with 5 streams: 320 stays)
+                const int w1_prec = (e->prec && NS >= 16 && !getenv("SMG_W1_WGS")) ? 160 : w1_target;
+                pick_chunk(pl, NS, nt, chunk, cps, pl.HW <= 1600 ? (getenv("SMG_W1_WGS_SMALL") ? w1_small : w1_prec) : w1_prec);   // 256..384 measure the same (22.46 ms per step), 512: 22.6, 768: 22.8, 1024: 23.2
                 auto go = [&](auto ptag) {
                 BwdWeightP<MC<Cfg, decltype(ptag)::value>, W_ONE, C_IDENT, SMG_PD_WGRAD, false, decltype(ptag)::value> p{};
                 p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck;

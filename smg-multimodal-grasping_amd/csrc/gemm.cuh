@@ -735,7 +735,13 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
     // The epilogue's operands (mask source, old G') go out BEHIND the first k-tiles' loads and the parameter loads: vmcnt is
     // in-order, so issued first they would have to land before the first k-tile could be staged (measured: 15-17k of a
     // workgroup's 98k cycles); now the k-loop runs PD tiles before its waits reach them.
-    if constexpr (P::kEarlyFetch) p.early_fetch(ctx);
+    // The explicit vmcnt(0) in front of them costs nothing (the parameter threads have just waited for younger loads) and tells
+    // hipcc that the first tiles ARE in registers on every path: behind the divergent parameter branch and the conditional
+    // early fetch it otherwise drains everything - the early fetch included - before the first tile's LDS store.
+    if constexpr (P::kEarlyFetch) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) only
+        p.early_fetch(ctx);
+    }
     if constexpr (P::kHasPrologue) __syncthreads();
     if constexpr (!C::AT) {
 #pragma unroll
