@@ -1795,7 +1795,7 @@ struct BwdDataGroupP {
     float eps;
     TileMap tm;
     static constexpr int kSwizzle = 1;
-    static constexpr int kPrefetch = (Cfg::TM * Cfg::TN <= 1) ? SMG_PD_DGRAD : SMG_PD_DGRAD_BIG;
+    static constexpr int kPrefetch = (PREC == 0 && Cfg::BK >= 32 && Cfg::TM * Cfg::TN >= 2) ? 1 : (Cfg::TM * Cfg::TN <= 1) ? SMG_PD_DGRAD : SMG_PD_DGRAD_BIG;
     static constexpr bool kSegmented = true;
     static constexpr bool kHasPrologue = true;
     static constexpr bool kEarlyFetch = true;
