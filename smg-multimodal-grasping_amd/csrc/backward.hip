@@ -279,8 +279,8 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 };
                 // mode 0, 128-row tiles: 32-deep k-tiles with ONE tile of loads in flight - the staging registers of two 16-deep
                 // tiles, half the barriers (k-loop 65k -> 50k cycles per workgroup, launches -7 %; same k16 order, same bits)
-                PREC_DISPATCH(e, if (pl.HWp % 128 == 0) { if constexpr (PREC == 0) run(GemmCfg<128, 64, 32, 2, 2, 1, true>{}, PTAG); else run(CfgP128x64{}, PTAG); }
-                                 else run(CfgP64x64{}, PTAG));
+                // (MC doubles the depth in the 16-bit modes: 128 x 64 x 64 / 64 x 64 x 64)
+                PREC_DISPATCH(e, if (pl.HWp % 128 == 0) run(GemmCfg<128, 64, 32, 2, 2, 1, true>{}, PTAG); else run(CfgP64x64{}, PTAG));
             }
             {   // conv1 weight gradient.  ~320 workgroups: it shares the chip with the data-gradient chain on the other
                 // stream, and every workgroup ends with 128 x 64 fp32 atomics (measured: atomics beat partial tiles here)

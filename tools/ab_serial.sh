@@ -1,13 +1,14 @@
 #!/bin/bash
 # dev helper: serialised per-kernel totals (rocprofv3 --stats of bench.py --train-only --serialize) per library variant.
-# usage: ab_serial.sh "grep pattern" lib1.so lib2.so ...   ("-" = the default build)
+# usage: [LEG=config3] ab_serial.sh "grep pattern" lib1.so lib2.so ...   ("-" = the default build)
 pat=$1; shift
+LEGARG=${LEG:+--leg $LEG}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 for L in "$@"; do
   d=gpurun_out/abs_$(basename $L .so); rm -rf $d
   if [ "$L" != "-" ]; then export SMG_HIP_LIB=$GRAFT_REPO_ROOT/$L; else unset SMG_HIP_LIB; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py --train-only --steps 4 --warmup 1 --serialize > $d.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py --train-only --steps 4 --warmup 1 --serialize $LEGARG > $d.log 2>&1
   f=$(find $d -name "*kernel_stats.csv" | head -1)
   echo "== $L"
   python3 - "$f" "$pat" <<'PY'
