@@ -206,7 +206,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 r.z_stride = (int64_t)9 * kGrowth * kBottleneck; r.tap_stride = (int64_t)kGrowth * kBottleneck;
                 r.dw = Gr + d.c2.w; r.ldw_out = kBottleneck * 9; r.cmap = C_3x3;
                 ProfScope ps(e, s2, K_W3, 0);
-                hipLaunchKernelGGL(reduce_partials_kernel, dim3((9 * kGrowth * kBottleneck + 255) / 256), dim3(256), 0, s2, r);
+                hipLaunchKernelGGL(reduce_partials_kernel, dim3((9 * kGrowth * kBottleneck + 63) / 64), dim3(256), 0, s2, r);
             } else {   // conv2 weight gradient (generic implicit GEMM, one launch slice per tap)
                 const int chunk = 512, cps = (pl.HWp + chunk - 1) / chunk;   // latency-bound: many short workgroups
                 BwdWeightP<CfgW32x128, W_THREE, C_3x3, SMG_PD_WGRAD, false> p{};

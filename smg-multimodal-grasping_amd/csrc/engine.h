@@ -336,7 +336,7 @@ static void launch_wgrad(smg_engine* e, hipStream_t st, P& p, dim3 grid, int kin
         r.dw = p.dw; r.ldw_out = p.ldw_out; r.cmap = cmap;
         const int total = taps * p.MA * p.NB;
         ProfScope ps(e, st, kind, 0);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((total + 255) / 256), dim3(256), 0, st, r);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((total + 63) / 64), dim3(256), 0, st, r);
     }
 }
 

@@ -2433,36 +2433,48 @@ struct ReduceArgs {
     const float* part; int Z, taps, rows, cols, ldp; int64_t z_stride, tap_stride;
     float* dw; int ldw_out, cmap;
 };
+// A workgroup sums 64 elements: its four waves take every fourth partial tile each (coalesced 256-byte reads, four loads in
+// flight per lane) and meet in LDS - a fixed order, so the result is reproducible.  (One thread per element over all Z partials
+// was a serial chain of Z / 4 memory round trips on a grid of 144 workgroups: 10-12 us per launch, 189 launches per step.)
 static __global__ void reduce_partials_kernel(const ReduceArgs a) {
+    __shared__ float red[3][64];
     const int total = a.taps * a.rows * a.cols;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const int tap = e / (a.rows * a.cols);
-        const int rc = e - tap * a.rows * a.cols;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int e0 = blockIdx.x * 64; e0 < total; e0 += gridDim.x * 64) {      // (block-uniform trip count)
+        const int e = e0 + lane;
+        const bool on = e < total;
+        const int ec = on ? e : 0;
+        const int tap = ec / (a.rows * a.cols);
+        const int rc = ec - tap * a.rows * a.cols;
         const int row = rc / a.cols, col = rc - row * a.cols;
         const float* p = a.part + tap * a.tap_stride + (int64_t)row * a.ldp + col;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int z = 0;
-        for (; z + 3 < a.Z; z += 4) {
+        int z = w;
+        for (; z + 12 < a.Z; z += 16) {
             s0 += p[(int64_t)z * a.z_stride];
-            s1 += p[(int64_t)(z + 1) * a.z_stride];
-            s2 += p[(int64_t)(z + 2) * a.z_stride];
-            s3 += p[(int64_t)(z + 3) * a.z_stride];
+            s1 += p[(int64_t)(z + 4) * a.z_stride];
+            s2 += p[(int64_t)(z + 8) * a.z_stride];
+            s3 += p[(int64_t)(z + 12) * a.z_stride];
         }
-        for (; z < a.Z; ++z) s0 += p[(int64_t)z * a.z_stride];
-        int64_t idx;
-        if (a.cmap == C_IDENT) idx = (int64_t)row * a.ldw_out + col;
-        else if (a.cmap == C_3x3) idx = (int64_t)row * a.ldw_out + col * 9 + tap;
-        else if (a.cmap == C_STEM1) {         // one-channel stem: the three input channels were identical, so are their gradients
-            if (col >= 49) continue;
-            const float v = (s0 + s1) + (s2 + s3);
-            for (int cc = 0; cc < 3; ++cc) a.dw[(int64_t)row * a.ldw_out + cc * 49 + col] += v;
-            continue;
-        } else {
-            const int t7 = col >> 2, cc = col & 3;
-            if (cc == 3 || t7 >= 49) continue;
-            idx = (int64_t)row * a.ldw_out + cc * 49 + t7;
+        for (; z < a.Z; z += 4) s0 += p[(int64_t)z * a.z_stride];
+        float v = (s0 + s1) + (s2 + s3);
+        if (w) red[w - 1][lane] = v;
+        __syncthreads();
+        if (w == 0 && on) {
+            v = (v + red[0][lane]) + (red[1][lane] + red[2][lane]);
+            int64_t idx = -1;
+            if (a.cmap == C_IDENT) idx = (int64_t)row * a.ldw_out + col;
+            else if (a.cmap == C_3x3) idx = (int64_t)row * a.ldw_out + col * 9 + tap;
+            else if (a.cmap == C_STEM1) {         // one-channel stem: the three input channels were identical, so are their gradients
+                if (col < 49)
+                    for (int cc = 0; cc < 3; ++cc) a.dw[(int64_t)row * a.ldw_out + cc * 49 + col] += v;
+            } else {
+                const int t7 = col >> 2, cc = col & 3;
+                if (cc != 3 && t7 < 49) idx = (int64_t)row * a.ldw_out + cc * 49 + t7;
+            }
+            if (idx >= 0) a.dw[idx] += v;
         }
-        a.dw[idx] += (s0 + s1) + (s2 + s3);
+        __syncthreads();
     }
 }
 
