@@ -100,7 +100,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         a.G4 = e->G[3]; a.SA = b1(e, e->bs_X[3]); a.SB = b2(e, e->bs_X[3]);
         a.dbeta5 = Gr + T.norm5.b; a.dgamma5 = Gr + T.norm5.w; a.chunk = 16;
         ProfScope ps(e, st, K_OTHER, 0);
-        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(norm5_bwd_kernel<PREC>), dim3(1, NS, (p4.HW + 15) / 16), dim3(256), 0, st, a));
+        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(norm5_bwd_kernel<PREC>), dim3(4, NS, (p4.HW + 15) / 16), dim3(256), 0, st, a));
     }
     }   // ph_a: head
     for (int b = ph_a ? 3 : 0; b >= (ph_b ? 0 : 1); --b) {

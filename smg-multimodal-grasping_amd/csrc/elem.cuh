@@ -449,8 +449,23 @@ template <int PREC>
 static __global__ __launch_bounds__(256) void norm5_bwd_kernel(const Norm5BwdArgs a) {
     using XT = act_t<PREC>;
     using GT = grd_t<PREC>;
-    const int s = blockIdx.y, c5 = 4 * threadIdx.x;      // 256 threads x 4 = 1024 channels
-    const int p0 = blockIdx.z * a.chunk, p1 = min(p0 + a.chunk, a.p4.HW);
+    // Workgroup = (256 channels, one stream, 16 pixels): 64 channel quads x 4 user phases.  A stream with several users (the masked
+    // stream feeds every pair) is a serial chain of parameter + pixel round trips per user; its users are dealt round-robin to the
+    // four phases, which meet in LDS in a fixed order (one thread per quad over all users: 175 us, a 16x longer tail than the
+    // single-user streams).
+    constexpr int CH = 16;                               // pixels per workgroup (= a.chunk, checked at the launch)
+    __shared__ float4 red[3][CH][64];
+    __shared__ float reds[3][8][64];
+    const int s = blockIdx.y, cq = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c5 = 4 * (blockIdx.x * 64 + cq);
+    const int u0 = a.user_ptr[s], u1 = a.user_ptr[s + 1];
+    const bool multi = u1 - u0 > 1;                      // (workgroup-uniform)
+    // single-user streams: kSpan chunks per workgroup, so that the per-channel dbeta / dgamma (one address for every stream and
+    // chunk) see a fifth of the atomics - 425 same-address atomics per channel were 38 of the kernel's 110 us
+    constexpr int kSpan = 5;
+    const int n_sub = multi ? 1 : kSpan;
+    const int z0 = multi ? blockIdx.z : blockIdx.z * kSpan;
+    if (z0 * a.chunk >= a.p4.HW) return;
     const double inv = 1.0 / (double)a.p4.HW;
     float mean5[4], inv5[4], g5[4];
 #pragma unroll
@@ -459,14 +474,15 @@ static __global__ __launch_bounds__(256) void norm5_bwd_kernel(const Norm5BwdArg
         g5[c] = a.gamma5[c5 + c];
     }
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-    const int u0 = a.user_ptr[s], u1 = a.user_ptr[s + 1];
-    // G4 of the chunk's pixels accumulates in registers over the users of the stream (the masked stream feeds all 16 pairs: a
-    // read-modify-write of G4 per user was a chain of 16 dependent global round trips per pixel, 187 us for this kernel)
-    constexpr int CH = 16;                               // pixels per workgroup (= a.chunk, checked at the launch)
+    for (int sub = 0; sub < n_sub; ++sub) {
+    const int p0 = (z0 + sub) * a.chunk, p1 = min(p0 + a.chunk, a.p4.HW);
+    if (p0 >= p1) break;
+    // G4 of the chunk's pixels accumulates in registers over the users of the stream (a read-modify-write of G4 per user was a
+    // chain of dependent global round trips per pixel)
     float4 gacc[CH];
 #pragma unroll
     for (int q = 0; q < CH; ++q) gacc[q] = zero4();
-    for (int u = u0; u < u1; ++u) {
+    for (int u = u0 + ph; u < u1; u += 4) {
         const int j = a.user_pair[u], ch = a.user_slot[u] * 1024 + c5;
         float cf[16];   // a[4], q1[4], mean[4], k[4]
 #pragma unroll
@@ -494,10 +510,35 @@ static __global__ __launch_bounds__(256) void norm5_bwd_kernel(const Norm5BwdArg
             }
         }
     }
+    if (multi) {
+        if (ph) {
 #pragma unroll
-    for (int q = 0; q < CH; ++q)
-        if (p0 + q < p1) stq<GT>(a.G4, ((int64_t)s * a.p4.HWp + p0 + q) * 1024 + c5, gacc[q]);
-    if (u0 == u1) return;
+            for (int q = 0; q < CH; ++q) red[ph - 1][q][cq] = gacc[q];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { reds[ph - 1][c][cq] = s1[c]; reds[ph - 1][4 + c][cq] = s2[c]; }
+        }
+        __syncthreads();
+        if (ph == 0) {
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const float4 r0 = red[0][q][cq], r1 = red[1][q][cq], r2 = red[2][q][cq];
+                gacc[q].x = (gacc[q].x + r0.x) + (r1.x + r2.x); gacc[q].y = (gacc[q].y + r0.y) + (r1.y + r2.y);
+                gacc[q].z = (gacc[q].z + r0.z) + (r1.z + r2.z); gacc[q].w = (gacc[q].w + r0.w) + (r1.w + r2.w);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s1[c] = (s1[c] + reds[0][c][cq]) + (reds[1][c][cq] + reds[2][c][cq]);
+                s2[c] = (s2[c] + reds[0][4 + c][cq]) + (reds[1][4 + c][cq] + reds[2][4 + c][cq]);
+            }
+        }
+    }
+    if (ph == 0) {
+#pragma unroll
+        for (int q = 0; q < CH; ++q)
+            if (p0 + q < p1) stq<GT>(a.G4, ((int64_t)s * a.p4.HWp + p0 + q) * 1024 + c5, gacc[q]);
+    }
+    }   // sub-chunks
+    if (ph || u0 == u1) return;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         atomicAdd(a.SA + (int64_t)s * 1024 + c5 + c, (double)(g5[c] * s1[c]));
