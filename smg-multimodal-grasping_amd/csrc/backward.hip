@@ -85,7 +85,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         p.msum = fsum(e, e->st_F); p.msq = fsq(e, e->st_F); p.mstride = 2 * kFeat; p.egamma = P + Hd.n0.w; p.ebeta = P + Hd.n0.b;
         p.dst = e->DF; p.ldd = 2 * kFeat; p.dcoff = 0;
         p.o1 = b1(e, e->bs_F); p.o2 = b2(e, e->bs_F); p.ostride = 2 * kFeat; p.ocoff = 0;
-        p.dbeta = Gr + Hd.n0.b; p.dgamma = Gr + Hd.n0.w; p.eps = kEps;
+        p.dbeta = Gr + Hd.n0.b; p.dgamma = Gr + Hd.n0.w; p.rep_stride = 0; p.eps = kEps;
         BY(e, 4.0 * NP * p4.HW * (2 * kHeadMid + 2 * 2 * kFeat));
         launch_gemm(e, st, p, dim3(NP * p4.HWp / Cfg::BM, 2 * kFeat / Cfg::BN), K_HD0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid);
             };
@@ -250,7 +250,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                     p.egamma = P + d.n1.w + cs; p.ebeta = P + d.n1.b + cs;
                     p.dst = e->G[b]; p.ldd = Ct; p.dcoff = cs;
                     p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.ocoff = cs;
-                    p.dbeta = Gr + d.n1.b + cs; p.dgamma = Gr + d.n1.w + cs; p.eps = kEps;
+                    p.dbeta = e->dbscr + e->db_off[b][i] + cs; p.dgamma = e->dbscr + e->db_off[b][i] + d.cin + cs; p.rep_stride = e->db_total; p.eps = kEps;
                     BY(e, ESZ(e) * NS * pl.HW * (kBottleneck + 3.0 * p.N));          // dy in; x in, G' read + written
                     launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, (p.N + Cfg::BN - 1) / Cfg::BN), K_D1, 2.0 * NS * pl.HW * p.N * kBottleneck);
                 };
@@ -267,13 +267,13 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                         const int slot = (layer_no - 1 - k + kRing * 4) % kRing;
                         p.seg[k].g = e->D2[slot]; p.seg[k].wp = e->packed_u + e->pk_d1[b][g_lo + k]; p.seg[k].ldn = dk.cin;
                         p.seg[k].gamma = P + dk.n1.w; p.seg[k].beta = P + dk.n1.b;
-                        p.seg[k].dbeta = Gr + dk.n1.b; p.seg[k].dgamma = Gr + dk.n1.w;
+                        p.seg[k].dbeta = e->dbscr + e->db_off[b][g_lo + k]; p.seg[k].dgamma = e->dbscr + e->db_off[b][g_lo + k] + dk.cin;
                     }
                     p.ldg = kBottleneck; p.pa = pl; p.KA = kBottleneck; p.N = cs;
                     p.mbuf = e->X[b]; p.ldm = Ct;
                     p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct;
                     p.dst = e->G[b]; p.ldd = Ct;
-                    p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.eps = kEps;
+                    p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.rep_stride = e->db_total; p.eps = kEps;
                     BY(e, ESZ(e) * NS * pl.HW * ((double)p.nseg * kBottleneck + 3.0 * cs));
                     launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, (cs + Cfg::BN - 1) / Cfg::BN), K_D1, 2.0 * NS * pl.HW * cs * kBottleneck * p.nseg);
                 };
@@ -348,7 +348,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 p.egamma = P + T.tnorm[b - 1].w; p.ebeta = P + T.tnorm[b - 1].b;
                 p.dst = e->G[b - 1]; p.ldd = Cp; p.dcoff = 0;
                 p.o1 = b1(e, e->bs_X[b - 1]); p.o2 = b2(e, e->bs_X[b - 1]); p.ostride = Cp; p.ocoff = 0;
-                p.dbeta = Gr + T.tnorm[b - 1].b; p.dgamma = Gr + T.tnorm[b - 1].w; p.eps = kEps;
+                p.dbeta = e->dbscr + e->db_toff[b - 1]; p.dgamma = e->dbscr + e->db_toff[b - 1] + Cp; p.rep_stride = e->db_total; p.eps = kEps;
                 BY(e, ESZ(e) * NS * (2.0 * pl.HW * C0 + 2.0 * pp.HW * Cp));
                 launch_gemm(e, st, p, dim3(NS * pl.HWp / Cfg::BM, Cp / Cfg::BN), K_TD, 2.0 * NS * pl.HW * Cp * C0);
             };
@@ -398,6 +398,11 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         else { PREC_DISPATCH(e, if (go(PTAG, std::integral_constant<int, W_STEM>{})) return -5); }
     }
     }   // ph_b: pool0 + stem
+    {   // the trunk's dbeta / dgamma: replicas -> gradient array (and zeroed for the next call)
+        ProfScope ps(e, st, K_OTHER, 0);
+        hipLaunchKernelGGL(db_flush_kernel, dim3(4, e->n_dbseg), dim3(256), 0, st, reinterpret_cast<const DbSegD*>(e->d_dbseg + (size_t)e->f_trunk * e->n_dbseg),
+                           e->dbscr, e->db_total, kDbRep, Gr);
+    }
     HIP_OK(hipEventRecord(e->ev_end, s2));          // join: everything after the backward (or this half of it) sees every gradient
     HIP_OK(hipStreamWaitEvent(st, e->ev_end, 0));
     HIP_OK(hipGetLastError());

@@ -751,6 +751,21 @@ static __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApp
     }
 }
 
+// Sum the replicas of the dbeta / dgamma scratch (engine.h) into the gradient array and leave the scratch zeroed for the next call.
+struct DbSegD { int64_t grad_off; int scr_off; int n; };
+static __global__ void db_flush_kernel(const DbSegD* segs, float* scr, int rep_stride, int reps, float* grads) {
+    const DbSegD sg = segs[blockIdx.y];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < sg.n; k += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int r = 0; r < reps; ++r) {
+            float* q = scr + (int64_t)r * rep_stride + sg.scr_off + k;
+            v += *q;
+            *q = 0.f;
+        }
+        grads[sg.grad_off + k] += v;
+    }
+}
+
 // Zero the rows/columns of a gradient plane that an odd-sized 2x2/stride-2 average
 // pool never reads (they receive no gradient from the transition).
 template <int PREC>

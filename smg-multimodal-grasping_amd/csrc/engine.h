@@ -85,6 +85,9 @@ static const char* kKindNames[K_COUNT] = {"stem7x7_fwd", "conv1x1_fwd", "conv3x3
 constexpr int kGroup = GROUP_MAX;          // dense layers per 1x1-dgrad group
 constexpr int kRing = kGroup + 2;
 
+constexpr int kDbRep = 8;
+struct DbSeg { int64_t grad_off; int scr_off; int n; };      // n floats at scr_off (per replica) -> grads[grad_off ..]
+
 struct ProfRec { hipEvent_t a, b; int kind; double flops; int stage; double bytes; };
 
 struct StatArr { int64_t off; int stride; };   // into a double arena: sum at off, sumsq at off + span
@@ -112,6 +115,11 @@ struct smg_engine {
     // statistics arenas (doubles). fwd: [sum | sumsq] halves; bwd: [s1 | s2] halves
     double* fstat = nullptr; int64_t fstat_span = 0;
     double* bstat = nullptr; int64_t bstat_span = 0;
+    // dbeta / dgamma of the trunk's norm1 / transition norms: the data-gradient GEMMs add one value per (workgroup, column) to ONE
+    // address per channel - thousands of same-address atomics per launch, which the L2 serialises (about 50-90 ns each: the
+    // kernels' tails).  They go to kDbRep replicas of a compact scratch instead (replica = workgroup index mod kDbRep);
+    // db_flush_kernel sums the replicas into the gradient array at the end of the backward (half) and re-zeroes them.
+    float* dbscr = nullptr; int db_total = 0; int db_off[4][24] = {}; int db_toff[3] = {}; struct DbSeg* d_dbseg = nullptr; int n_dbseg = 0;
     StatArr st_stem, st_X[4], st_F, st_H1; std::vector<StatArr> st_Bt[4];
     StatArr bs_stem, bs_X[4], bs_F, bs_H1; std::vector<StatArr> bs_Bt[4];
     // packed weights: split bf16 units for the MFMA GEMMs (packed_u) and fp32 K-major layouts for the halo 3x3

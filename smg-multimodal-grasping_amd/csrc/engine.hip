@@ -83,6 +83,33 @@ static int engine_build(smg_engine* e) {
     for (int b = 0; b < 4; ++b) { e->bs_X[b] = e->st_X[b]; e->bs_Bt[b] = e->st_Bt[b]; }
     ALLOC(e->fstat, 2 * off);
     ALLOC(e->bstat, 2 * off);
+    {   // dbeta / dgamma scratch (engine.h): per dense layer [beta cin | gamma cin], per transition [beta Cp | gamma Cp]
+        int at = 0;
+        for (int b = 0; b < 4; ++b)
+            for (int i = 0; i < kBlockLayers[b]; ++i) { e->db_off[b][i] = at; at += 2 * (kBlockCin[b] + i * kGrowth); }
+        for (int b = 0; b < 3; ++b) { e->db_toff[b] = at; at += 2 * kBlockCtot[b]; }
+        e->db_total = at;
+        ALLOC(e->dbscr, (int64_t)kDbRep * at);
+        HIP_OK(hipMemset(e->dbscr, 0, (size_t)kDbRep * at * sizeof(float)));
+        e->n_dbseg = 2 * (6 + 12 + 24 + 16 + 3);
+        HIP_OK(hipMalloc((void**)&e->d_dbseg, (size_t)3 * e->n_dbseg * sizeof(DbSeg)));
+        for (int t = 0; t < 3; ++t) {
+            const TrunkRef& T = L.trunk[t];
+            if ((int)T.layers[0].size() != kBlockLayers[0]) continue;      // trunk slot not used by this net
+            std::vector<DbSeg> v;
+            for (int b = 0; b < 4; ++b)
+                for (int i = 0; i < kBlockLayers[b]; ++i) {
+                    const DenseLayerRef& d = T.layers[b][i];
+                    v.push_back(DbSeg{d.n1.b, e->db_off[b][i], d.cin});
+                    v.push_back(DbSeg{d.n1.w, e->db_off[b][i] + d.cin, d.cin});
+                }
+            for (int b = 0; b < 3; ++b) {
+                v.push_back(DbSeg{T.tnorm[b].b, e->db_toff[b], kBlockCtot[b]});
+                v.push_back(DbSeg{T.tnorm[b].w, e->db_toff[b] + kBlockCtot[b], kBlockCtot[b]});
+            }
+            HIP_OK(hipMemcpy(e->d_dbseg + (size_t)t * e->n_dbseg, v.data(), v.size() * sizeof(DbSeg), hipMemcpyHostToDevice));
+        }
+    }
     {   // BN statistic tables: mean | invstd, [rows][C] each
         int64_t po = 0;
         auto carve_t = [&](int rows, int C) { int64_t at = po; po += (int64_t)2 * rows * C; return at; };
@@ -274,7 +301,7 @@ void smg_engine_destroy(smg_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     void* ptrs[] = {e->img4, e->stem, e->DY0, e->argmax, e->X[0], e->X[1], e->X[2], e->X[3], e->G[0], e->G[1], e->G[2], e->G[3],
-                    e->Bt, e->part, e->F, e->DF, e->H1, e->DH1, e->fstat, e->bstat, e->packed_u, e->packed_f, e->stab, e->d_pack, e->d_bnupd,
+                    e->Bt, e->part, e->F, e->DF, e->H1, e->DH1, e->fstat, e->bstat, e->dbscr, e->d_dbseg, e->packed_u, e->packed_f, e->stab, e->d_pack, e->d_bnupd,
                     e->d_stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) { if (e->h_stage[k]) (void)hipHostFree(e->h_stage[k]); if (e->ev_stage[k]) (void)hipEventDestroy(e->ev_stage[k]); }

@@ -1387,7 +1387,7 @@ struct BwdDataP {
     const float* egamma; const float* ebeta;
     void* dst; int ldd; int dcoff;
     double* o1; double* o2; int ostride; int ocoff;
-    float* dbeta; float* dgamma;
+    float* dbeta; float* dgamma; int rep_stride;      // rep_stride != 0: kDbRep replicas of a scratch (engine.h), this workgroup's = index mod 8
     float eps;
     TileMap tm;
     static constexpr int kSwizzle = 1;
@@ -1743,8 +1743,9 @@ struct BwdDataP {
             const int64_t oi = (int64_t)c.n * ostride + ocoff + col;
             atomicAdd(o1 + oi, (double)(wgt * tot[0]));
             atomicAdd(o2 + oi, (double)(wgt * tot[1]));
-            atomicAdd(dbeta + col, tot[0]);
-            atomicAdd(dgamma + col, tot[1]);
+            const int64_t rep = (int64_t)(blockIdx.x & 7) * rep_stride;
+            atomicAdd(dbeta + rep + col, tot[0]);
+            atomicAdd(dgamma + rep + col, tot[1]);
         }
 #ifdef SMG_TRACE_EPI
         if (etr) { etr[3] = smg_stamp(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); etr[4] = smg_stamp(); }
@@ -1792,6 +1793,7 @@ struct BwdDataGroupP {
     const double* msum; const double* msq; int mstride;
     void* dst; int ldd;                                 // G'
     double* o1; double* o2; int ostride;                // SA / SB [n][C]
+    int rep_stride;                                     // replicas of the dbeta / dgamma scratch (see BwdDataP)
     float eps;
     TileMap tm;
     static constexpr int kSwizzle = 1;
@@ -2115,11 +2117,12 @@ struct BwdDataGroupP {
             const int64_t oi = (int64_t)c.n * ostride + col;
             atomicAdd(o1 + oi, (double)tot[0]);
             atomicAdd(o2 + oi, (double)tot[1]);
+            const int64_t rep = (int64_t)(blockIdx.x & 7) * rep_stride;
 #pragma unroll
             for (int z = 0; z < GROUP_MAX; ++z)
                 if (z < nseg) {
-                    atomicAdd(seg[z].dbeta + col, tot[2 + 2 * z]);
-                    atomicAdd(seg[z].dgamma + col, tot[3 + 2 * z]);
+                    atomicAdd(seg[z].dbeta + rep + col, tot[2 + 2 * z]);
+                    atomicAdd(seg[z].dgamma + rep + col, tot[3 + 2 * z]);
                 }
         }
 #ifdef SMG_TRACE_EPI
