@@ -400,8 +400,9 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
     }   // ph_b: pool0 + stem
     {   // the trunk's dbeta / dgamma: replicas -> gradient array (and zeroed for the next call)
         ProfScope ps(e, st, K_OTHER, 0);
-        hipLaunchKernelGGL(db_flush_kernel, dim3(4, e->n_dbseg), dim3(256), 0, st, reinterpret_cast<const DbSegD*>(e->d_dbseg + (size_t)e->f_trunk * e->n_dbseg),
-                           e->dbscr, e->db_total, kDbRep, Gr);
+        hipLaunchKernelGGL(db_flush_kernel, dim3(4, e->n_dbseg + 1), dim3(256), 0, st, reinterpret_cast<const DbSegD*>(e->d_dbseg + (size_t)e->f_trunk * e->n_dbseg),
+                           e->dbscr, e->db_total, kDbRep, Gr,
+                           ph_b ? b1(e, e->bs_stem) : nullptr, ph_b ? b2(e, e->bs_stem) : nullptr, NS, Gr + T.norm0.b, Gr + T.norm0.w);
     }
     HIP_OK(hipEventRecord(e->ev_end, s2));          // join: everything after the backward (or this half of it) sees every gradient
     HIP_OK(hipStreamWaitEvent(st, e->ev_end, 0));

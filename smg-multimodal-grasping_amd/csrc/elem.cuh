@@ -671,7 +671,8 @@ static __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArg
         float tot = 0.f;
         for (int k = 0; k < 16; ++k) tot += red[q][k][c];
         atomicAdd((q ? a.o2 : a.o1) + (int64_t)n * 64 + c, (double)tot);
-        atomicAdd((q ? a.dgamma : a.dbeta) + c, tot);
+        // (norm0's dbeta / dgamma are these sums over the streams: db_flush_kernel adds them - 3400 workgroups on one address per
+        // channel here were the tail of this kernel)
     }
 }
 
@@ -753,7 +754,17 @@ static __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApp
 
 // Sum the replicas of the dbeta / dgamma scratch (engine.h) into the gradient array and leave the scratch zeroed for the next call.
 struct DbSegD { int64_t grad_off; int scr_off; int n; };
-static __global__ void db_flush_kernel(const DbSegD* segs, float* scr, int rep_stride, int reps, float* grads) {
+static __global__ void db_flush_kernel(const DbSegD* segs, float* scr, int rep_stride, int reps, float* grads,
+                                       const double* stem1, const double* stem2, int ns, float* dbeta0, float* dgamma0) {
+    if (blockIdx.y == gridDim.y - 1) {       // norm0: dbeta / dgamma = pool0_bwd's per-stream sums, summed over the streams
+        if (blockIdx.x == 0 && threadIdx.x < 128 && stem1) {
+            const int q = threadIdx.x >> 6, c = threadIdx.x & 63;
+            double v = 0.0;
+            for (int n = 0; n < ns; ++n) v += (q ? stem2 : stem1)[(int64_t)n * 64 + c];
+            (q ? dgamma0 : dbeta0)[c] += (float)v;
+        }
+        return;
+    }
     const DbSegD sg = segs[blockIdx.y];
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < sg.n; k += gridDim.x * blockDim.x) {
         float v = 0.f;
