@@ -28,7 +28,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
     float* Gr = net->grads;
     const Plane p4 = e->p_blk[3];
     const bool ph_a = phases & 1, ph_b = phases & 2;
-    if (ph_a) HIP_OK(hipMemsetAsync(e->bstat, 0, 2 * e->bstat_span * sizeof(double), st));
+    if (ph_a) HIP_OK(hipMemset2DAsync(e->bstat, kStatRepStride * sizeof(double), 0, 2 * e->bstat_span * sizeof(double), kStatRep, st));      // every replica
     // Weight-gradient kernels only read what the data-gradient chain produces and write disjoint
     // gradient ranges, so they run on a second stream beside it (their MFMA/L2-bound phases overlap the
     // HBM-bound epilogues of the data-gradient kernels).  While profiling everything is serialised on

@@ -420,7 +420,7 @@ static __global__ __launch_bounds__(256) void value_bwd_kernel(const ValueBwdArg
         const int q = t >> 6, c = t & 63;
         float tot = 0.f;
         for (int k = 0; k < 16; ++k) tot += red[q][k][c];
-        atomicAdd((q ? a.o2 : a.o1) + (int64_t)j * 64 + c, (double)tot);
+        atomicAdd((q ? a.o2 : a.o1) + (int64_t)j * 64 + c + stat_rep(), (double)tot);
         atomicAdd((q ? a.dgamma : a.dbeta) + c, tot);
     }
 }
@@ -489,9 +489,9 @@ static __global__ __launch_bounds__(256) void norm5_bwd_kernel(const Norm5BwdArg
         for (int c = 0; c < 4; ++c) {
             float mean, invstd;
             bn_moments(a.fsum, a.fsq, (int64_t)j * 2048 + ch + c, inv, a.eps, mean, invstd);
-            const float q2 = (float)(a.f2[(int64_t)j * 2048 + ch + c] * inv);
+            const float q2 = (float)(stat_get(a.f2, (int64_t)j * 2048 + ch + c) * inv);
             cf[c] = a.hgamma[ch + c] * invstd;
-            cf[4 + c] = (float)(a.f1[(int64_t)j * 2048 + ch + c] * inv);
+            cf[4 + c] = (float)(stat_get(a.f1, (int64_t)j * 2048 + ch + c) * inv);
             cf[8 + c] = mean;
             cf[12 + c] = invstd * q2;
         }
@@ -541,8 +541,8 @@ static __global__ __launch_bounds__(256) void norm5_bwd_kernel(const Norm5BwdArg
     if (ph || u0 == u1) return;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        atomicAdd(a.SA + (int64_t)s * 1024 + c5 + c, (double)(g5[c] * s1[c]));
-        atomicAdd(a.SB + (int64_t)s * 1024 + c5 + c, (double)(g5[c] * s2[c]));
+        atomicAdd(a.SA + (int64_t)s * 1024 + c5 + c + stat_rep(), (double)(g5[c] * s1[c]));
+        atomicAdd(a.SB + (int64_t)s * 1024 + c5 + c + stat_rep(), (double)(g5[c] * s2[c]));
         atomicAdd(a.dbeta5 + c5 + c, s1[c]);
         atomicAdd(a.dgamma5 + c5 + c, s2[c]);
     }
@@ -591,8 +591,8 @@ static __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArg
         const double inv = 1.0 / (double)a.p1.HW;
         float m1, i1;
         bn_moments(a.xsum, a.xsq, (int64_t)n * a.xstride + t, inv, a.eps, m1, i1);
-        const float q1 = (float)(a.SA[(int64_t)n * a.sstride + t] * inv);
-        const float q2 = (float)(a.SB[(int64_t)n * a.sstride + t] * inv);
+        const float q1 = (float)(stat_get(a.SA, (int64_t)n * a.sstride + t) * inv);
+        const float q2 = (float)(stat_get(a.SB, (int64_t)n * a.sstride + t) * inv);
         prm[256 + t] = i1; prm[320 + t] = q1; prm[384 + t] = m1; prm[448 + t] = i1 * q2;
     }
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
@@ -670,7 +670,7 @@ static __global__ __launch_bounds__(256) void pool0_bwd_kernel(const Pool0BwdArg
         const int q = t >> 6, c = t & 63;
         float tot = 0.f;
         for (int k = 0; k < 16; ++k) tot += red[q][k][c];
-        atomicAdd((q ? a.o2 : a.o1) + (int64_t)n * 64 + c, (double)tot);
+        atomicAdd((q ? a.o2 : a.o1) + (int64_t)n * 64 + c + stat_rep(), (double)tot);
         // (norm0's dbeta / dgamma are these sums over the streams: db_flush_kernel adds them - 3400 workgroups on one address per
         // channel here were the tail of this kernel)
     }
@@ -725,14 +725,14 @@ static __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApp
         const double inv = 1.0 / (double)a.pl.HW;
         float mean, invstd;
         bn_moments(a.xsum, a.xsq, (int64_t)n * a.xstride + a.xcoff + t, inv, a.eps, mean, invstd);
-        const float q2 = (float)(a.s2[(int64_t)n * a.sstride + a.scoff + t] * inv);
+        const float q2 = (float)(stat_get(a.s2, (int64_t)n * a.sstride + a.scoff + t) * inv);
         prm[t] = (a.gamma ? a.gamma[t] : 1.f) * invstd;
-        prm[a.C + t] = (float)(a.s1[(int64_t)n * a.sstride + a.scoff + t] * inv);
+        prm[a.C + t] = (float)(stat_get(a.s1, (int64_t)n * a.sstride + a.scoff + t) * inv);
         prm[2 * a.C + t] = mean;
         prm[3 * a.C + t] = invstd * q2;
         if (a.dbeta && blockIdx.x == 0) {
-            atomicAdd(a.dbeta + t, (float)a.s1[(int64_t)n * a.sstride + a.scoff + t]);
-            atomicAdd(a.dgamma + t, (float)a.s2[(int64_t)n * a.sstride + a.scoff + t]);
+            atomicAdd(a.dbeta + t, (float)stat_get(a.s1, (int64_t)n * a.sstride + a.scoff + t));
+            atomicAdd(a.dgamma + t, (float)stat_get(a.s2, (int64_t)n * a.sstride + a.scoff + t));
         }
     }
     __syncthreads();
@@ -760,7 +760,7 @@ static __global__ void db_flush_kernel(const DbSegD* segs, float* scr, int rep_s
         if (blockIdx.x == 0 && threadIdx.x < 128 && stem1) {
             const int q = threadIdx.x >> 6, c = threadIdx.x & 63;
             double v = 0.0;
-            for (int n = 0; n < ns; ++n) v += (q ? stem2 : stem1)[(int64_t)n * 64 + c];
+            for (int n = 0; n < ns; ++n) v += stat_get(q ? stem2 : stem1, (int64_t)n * 64 + c);
             (q ? dgamma0 : dbeta0)[c] += (float)v;
         }
         return;

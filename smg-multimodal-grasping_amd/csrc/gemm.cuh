@@ -364,9 +364,23 @@ __device__ __forceinline__ f32x4 bloadv4(const void* ubase, unsigned bytes, unsi
 }
 
 
+// The BACKWARD fp64 statistic arena (s1 / s2 sums) exists in kStatRep replicas kStatRepStride doubles apart: a producer's workgroup
+// adds to replica (workgroup index mod kStatRep) - hundreds of same-address fp64 atomics per (stream, channel) and launch serialise
+// in the L2 - and every reader sums the replicas (stat_get).  The forward arena stays single: its readers (every workgroup's
+// parameter prologue, 32-128 channels each) outnumber its writers, and eight loads per value cost them more than the spread saves.  The stride is a compile-time constant so that no kernel needs another argument; the engine
+// checks that its arenas fit.
+constexpr int kStatRep = 8;
+constexpr int64_t kStatRepStride = (int64_t)1 << 23;
+__device__ __forceinline__ double stat_get(const double* p, int64_t idx) {
+    double v = p[idx];
+#pragma unroll
+    for (int r = 1; r < kStatRep; ++r) v += p[idx + r * kStatRepStride];
+    return v;
+}
+__device__ __forceinline__ int64_t stat_rep() { return (int64_t)((blockIdx.x + blockIdx.y + blockIdx.z) % kStatRep) * kStatRepStride; }
 __device__ __forceinline__ void bn_moments(const double* sum, const double* sq, int64_t idx, double inv_cnt, float eps,
                                            float& mean, float& invstd) {
-    const double m = sum[idx] * inv_cnt;
+    const double m = sum[idx] * inv_cnt;              // (forward sums: one copy)
     double var = sq[idx] * inv_cnt - m * m;
     var = var < 0.0 ? 0.0 : var;
     mean = (float)m;
@@ -1490,8 +1504,8 @@ struct BwdDataP {
             float mean, invstd;
             bn_moments(xsum, xsq, (int64_t)c.n * xstride + xcoff + k, inv, eps, mean, invstd);
             const float g = agamma ? agamma[k] : 1.f;
-            const float q1 = (float)(s1[(int64_t)c.n * sstride + scoff + k] * inv);
-            const float q2 = (float)(s2[(int64_t)c.n * sstride + scoff + k] * inv);
+            const float q1 = (float)(stat_get(s1, (int64_t)c.n * sstride + scoff + k) * inv);
+            const float q2 = (float)(stat_get(s2, (int64_t)c.n * sstride + scoff + k) * inv);
             sp[k] = g * invstd;
             sp[KA + k] = q1;
             sp[2 * KA + k] = mean;
@@ -1741,8 +1755,8 @@ struct BwdDataP {
             const int col = c.n0 + t;
             const float wgt = (EMODE == E_STORE) ? 1.f : ep[4 * Cfg::BN + t];
             const int64_t oi = (int64_t)c.n * ostride + ocoff + col;
-            atomicAdd(o1 + oi, (double)(wgt * tot[0]));
-            atomicAdd(o2 + oi, (double)(wgt * tot[1]));
+            atomicAdd(o1 + oi + stat_rep(), (double)(wgt * tot[0]));
+            atomicAdd(o2 + oi + stat_rep(), (double)(wgt * tot[1]));
             const int64_t rep = (int64_t)(blockIdx.x & 7) * rep_stride;
             atomicAdd(dbeta + rep + col, tot[0]);
             atomicAdd(dgamma + rep + col, tot[1]);
@@ -2115,8 +2129,8 @@ struct BwdDataGroupP {
         if (t < Cfg::BN && c.n0 + t < N) {
             const int col = c.n0 + t;
             const int64_t oi = (int64_t)c.n * ostride + col;
-            atomicAdd(o1 + oi, (double)tot[0]);
-            atomicAdd(o2 + oi, (double)tot[1]);
+            atomicAdd(o1 + oi + stat_rep(), (double)tot[0]);
+            atomicAdd(o2 + oi + stat_rep(), (double)tot[1]);
             const int64_t rep = (int64_t)(blockIdx.x & 7) * rep_stride;
 #pragma unroll
             for (int z = 0; z < GROUP_MAX; ++z)
@@ -2232,8 +2246,8 @@ struct BwdWeightP {
                 float invstd;
                 bn_moments(xsum, xsq, (int64_t)c.n * xstride + xcoff + ch, inv, eps, mean, invstd);
                 const float g = agamma ? agamma[ch] : 1.f;
-                q1 = (float)(s1[(int64_t)c.n * sstride + scoff + ch] * inv);
-                const float q2 = (float)(s2[(int64_t)c.n * sstride + scoff + ch] * inv);
+                q1 = (float)(stat_get(s1, (int64_t)c.n * sstride + scoff + ch) * inv);
+                const float q2 = (float)(stat_get(s2, (int64_t)c.n * sstride + scoff + ch) * inv);
                 a = g * invstd;
                 kk = invstd * q2;
             }

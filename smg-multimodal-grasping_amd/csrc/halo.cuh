@@ -303,9 +303,9 @@ __device__ __forceinline__ void grad_src_params(const GradSrc& s, int n, int hw,
         float mean, invstd;
         bn_moments(s.xsum, s.xsq, (int64_t)n * s.sstride + t, inv, s.eps, mean, invstd);
         gp[t] = invstd;
-        gp[32 + t] = (float)(s.s1[(int64_t)n * s.sstride + t] * inv);
+        gp[32 + t] = (float)(stat_get(s.s1, (int64_t)n * s.sstride + t) * inv);
         gp[64 + t] = mean;
-        gp[96 + t] = invstd * (float)(s.s2[(int64_t)n * s.sstride + t] * inv);
+        gp[96 + t] = invstd * (float)(stat_get(s.s2, (int64_t)n * s.sstride + t) * inv);
     }
 }
 
@@ -564,7 +564,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
 #pragma unroll
                 for (int w = 0; w < G::WQ; ++w) tot += red[q * 128 + (j * G::WQ + w) * 32 + cc];
                 const int ch = ((cg0 + stage / 9) * NCW + j) * 32 + cc;
-                atomicAdd((q ? a.o2 : a.o1) + (int64_t)n * a.ostride + ch, (double)tot);
+                atomicAdd((q ? a.o2 : a.o1) + (int64_t)n * a.ostride + ch + stat_rep(), (double)tot);
             }
             if (trace && s9 == 0) trace[3] = __builtin_amdgcn_s_memtime();
         }
