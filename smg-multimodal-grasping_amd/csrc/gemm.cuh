@@ -366,10 +366,15 @@ __device__ __forceinline__ f32x4 bloadv4(const void* ubase, unsigned bytes, unsi
 
 // The BACKWARD fp64 statistic arena (s1 / s2 sums) exists in kStatRep replicas kStatRepStride doubles apart: a producer's workgroup
 // adds to replica (workgroup index mod kStatRep) - hundreds of same-address fp64 atomics per (stream, channel) and launch serialise
-// in the L2 - and every reader sums the replicas (stat_get).  The forward arena stays single: its readers (every workgroup's
-// parameter prologue, 32-128 channels each) outnumber its writers, and eight loads per value cost them more than the spread saves.  The stride is a compile-time constant so that no kernel needs another argument; the engine
-// checks that its arenas fit.
-constexpr int kStatRep = 8;
+// in the L2 - and every reader sums the replicas (stat_get).  Same box, ms per step, replicas 1 / 2 / 4 / 8: headline (17 streams,
+// 160^2 planes) 21.64 / 21.71 / 21.74 / 21.88 - the readers pay; config 5's share (5 streams, 456^2 planes: 800-1600 row tiles per
+// stream) 27.2 / 25.7 / 25.4 / 25.6; config 3 27.2 / - / 27.2 / 27.5.  Two it is.  The forward arena stays single: its readers (every
+// workgroup's parameter prologue, 32-128 channels each) outnumber its writers (replicated eightfold: headline + 0.6 ms).
+// The stride is a compile-time constant so that no kernel needs another argument; the engine checks that its arena fits.
+#ifndef SMG_STAT_REP
+#define SMG_STAT_REP 2
+#endif
+constexpr int kStatRep = SMG_STAT_REP;
 constexpr int64_t kStatRepStride = (int64_t)1 << 23;
 __device__ __forceinline__ double stat_get(const double* p, int64_t idx) {
     double v = p[idx];
