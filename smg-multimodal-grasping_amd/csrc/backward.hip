@@ -282,8 +282,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 // (MC doubles the depth in the 16-bit modes: 128 x 64 x 64 / 64 x 64 x 64)
                 PREC_DISPATCH(e, if (pl.HWp % 128 == 0) run(GemmCfg<128, 64, 32, 2, 2, 1, true>{}, PTAG); else run(CfgP64x64{}, PTAG));
             }
-            {   // conv1 weight gradient.  ~320 workgroups: it shares the chip with the data-gradient chain on the other
-                // stream, and every workgroup ends with 128 x 64 fp32 atomics (measured: atomics beat partial tiles here)
+            {   // conv1 weight gradient.  ~320 workgroups: it shares the chip with the data-gradient chain on the other stream
                 using Cfg = CfgW128x64;
                 const int nt = (d.cin + Cfg::BN - 1) / Cfg::BN;
                 int chunk, cps;
@@ -302,7 +301,12 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
                 p.dw = Gr + d.c1.w; p.ldw_out = d.cin;
                 BY(e, ESZ(e) * NS * pl.HW * (kBottleneck + d.cin));
-                launch_wgrad(e, s2, p, dim3(1, nt, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck, 1, C_IDENT, e->deterministic);
+                // partial tiles + the fixed-order reduce (reproducible) - since reduce_partials splits the partials over four waves this beats
+                // 128 x 64 fp32 atomics per workgroup everywhere (same box: headline 20.99 -> 20.84 ms, config 3 27.36 -> 27.16, config 5
+                // share 25.68 -> 25.49); SMG_W1_PART=0: the atomics, for A/B (the "deterministic" option overrides it)
+                static const bool w1_atomics = getenv("SMG_W1_PART") && atoi(getenv("SMG_W1_PART")) == 0;
+                const bool w1_part = e->deterministic || !w1_atomics;
+                launch_wgrad(e, s2, p, dim3(1, nt, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck, 1, C_IDENT, w1_part);
                 };
                 PREC_DISPATCH(e, go(PTAG));
                 HIP_OK(hipEventRecord(e->ev_side[db], s2));
