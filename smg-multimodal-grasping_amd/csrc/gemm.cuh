@@ -503,7 +503,7 @@ static __device__ __forceinline__ unsigned long long smg_stamp() {
     return t;
 }
 static __device__ unsigned long long* g_smg_trace = nullptr;      // (one copy per translation unit; TraceScope sets its own)
-#if defined(SMG_TRACE_ITER) || defined(SMG_TRACE_EPI)
+#if defined(SMG_TRACE_ITER) || defined(SMG_TRACE_EPI) || defined(SMG_TRACE_PRO)
 #define SMG_TRACE(slot) do {} while (0)
 #else
 #define SMG_TRACE(slot) do { if (trace) trace[slot] = smg_stamp(); } while (0)
@@ -535,6 +535,9 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
 
     unsigned long long* trace = (g_smg_trace && t == 0) ? g_smg_trace + 8 * (size_t)vb.linear : nullptr;
     SMG_TRACE(0);
+#ifdef SMG_TRACE_PRO
+    if (trace) trace[0] = smg_stamp();
+#endif
     if (trace) trace[5] = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one base for the whole device
     typename P::Ctx ctx;
     if (!p.init_ctx(ctx, vb)) return;      // tile made of padding rows only (block-uniform)
@@ -750,7 +753,13 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
         if constexpr (PD > 1) g_load(u < KT ? u : KT - 1, ra[u], rb[u], kp[u]);   // same load count on every path: exact vmcnt
         else if (u < KT) g_load(u, ra[u], rb[u], kp[u]);
     }
+#ifdef SMG_TRACE_PRO     // dev: prologue stamps (start | first loads issued | parameters in LDS | early fetch issued | barrier passed)
+    if (trace) trace[1] = smg_stamp();
+#endif
     p.init_params(ctx, sp);
+#ifdef SMG_TRACE_PRO
+    if (trace) trace[2] = smg_stamp();
+#endif
     // The epilogue's operands (mask source, old G') go out BEHIND the first k-tiles' loads and the parameter loads: vmcnt is
     // in-order, so issued first they would have to land before the first k-tile could be staged (measured: 15-17k of a
     // workgroup's 98k cycles); now the k-loop runs PD tiles before its waits reach them.
@@ -761,7 +770,13 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) only
         p.early_fetch(ctx);
     }
+#ifdef SMG_TRACE_PRO
+    if (trace) trace[3] = smg_stamp();
+#endif
     if constexpr (P::kHasPrologue) __syncthreads();
+#ifdef SMG_TRACE_PRO
+    if (trace) trace[4] = smg_stamp();
+#endif
     if constexpr (!C::AT) {
 #pragma unroll
         for (int h = 0; h < BE / 4; ++h) bfix[h] = p.b_fix(ctx, (BE / 4) * bq + h, sp);
