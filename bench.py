@@ -47,6 +47,9 @@ PMC_FILE = "pmc_r03_hbm_traffic.json"                     # tools/profile_round.
 SERIAL_CSV = "rocprof_r03_kernel_stats_serialized.csv"    # rocprofv3 --kernel-trace --stats of `bench.py --train-only --serialize`
 PASS5_GFLOP = 36767.6                 # S=1824, R=32 fwd+bwd pass, masked stream de-duplicated
 # rocprofv3 kernel-name fragments that make up each class of roofline.per_kernel (profiles/*kernel_stats*.csv)
+# (reduce_partials_kernel serves every weight gradient that goes through partial tiles - the 3x3 ones, since round 3 the 1x1 ones too,
+# the transitions, the stem - and carries no policy in its name: the CSV lists it once; it is filed under conv3x3_wgrad here, while the
+# live hipEvent classes of roofline.per_kernel charge each reduce to the class that launched it)
 CLASS_SYMBOLS = {      # fnmatch patterns; template arguments: FwdConvP<Cfg, MODE, PREC, F32IO>, BwdDataP<Cfg, SHIFT3, EMODE, AFF, PREC, F32IO>,
                        # BwdDataGroupP<Cfg, PREC>, BwdWeightP<Cfg, BMODE, CMAP, PD, AFF, PREC, F32IO>, conv3x3_halo_*_kernel<tile, PREC>
     "stem7x7_fwd": ["FwdConvP<*>, 3, ?, false>", "FwdConvP<*>, 4, ?, false>"],
