@@ -256,7 +256,7 @@ static __global__ __launch_bounds__(256) void pool0_kernel(const Pool0Args a) {
         const int q = t >> 6, c = t & 63;
         double tot = 0.0;
         for (int k = 0; k < 16; ++k) tot += red[q][k][c];
-        atomicAdd((q ? a.dsq : a.dsum) + (int64_t)n * a.dstride + c, tot);
+        atomicAdd((q ? a.dsq : a.dsum) + (int64_t)n * a.dstride + c + fstat_rep(), tot);
     }
 }
 
@@ -304,8 +304,8 @@ static __global__ __launch_bounds__(256) void feat_kernel(const FeatArgs a) {
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        atomicAdd(a.fsum + (int64_t)j * 2048 + ch + c, sm[c]);
-        atomicAdd(a.fsq + (int64_t)j * 2048 + ch + c, sq[c]);
+        atomicAdd(a.fsum + (int64_t)j * 2048 + ch + c + fstat_rep(), sm[c]);
+        atomicAdd(a.fsq + (int64_t)j * 2048 + ch + c + fstat_rep(), sq[c]);
     }
 }
 
@@ -911,8 +911,8 @@ static __global__ void bn_update_kernel(const BnUpdDesc* descs, const double* st
     const double inv = 1.0 / (double)d.count;
     for (int i = 0; i < ns; ++i) {
         const int64_t idx = d.stat_off + (int64_t)seq[i] * d.stride + d.coff + c;
-        const double m = stats_sum[idx] * inv;
-        double var = stats_sq[idx] * inv - m * m;
+        const double m = fstat_get(stats_sum, idx) * inv;
+        double var = fstat_get(stats_sq, idx) * inv - m * m;
         var = var < 0 ? 0 : var;
         const double unb = var * (double)d.count / (double)(d.count - 1);
         rm = (double)(float)(0.1 * m + 0.9 * rm);

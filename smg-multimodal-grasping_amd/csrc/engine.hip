@@ -82,7 +82,7 @@ static int engine_build(smg_engine* e) {
     e->bs_stem = e->st_stem; e->bs_F = e->st_F; e->bs_H1 = e->st_H1;
     for (int b = 0; b < 4; ++b) { e->bs_X[b] = e->st_X[b]; e->bs_Bt[b] = e->st_Bt[b]; }
     if (2 * off > kStatRepStride) return fail(-22, "batch too large for the statistic arenas (kStatRepStride in gemm.cuh)");
-    ALLOC(e->fstat, 2 * off);
+    ALLOC(e->fstat, kFStatRep > 1 ? (int64_t)kFStatRep * kStatRepStride : 2 * off);
     ALLOC(e->bstat, (int64_t)kStatRep * kStatRepStride);      // kStatRep replicas (gemm.cuh: stat_get / stat_rep), 2 * off doubles used of each
     {   // dbeta / dgamma scratch (engine.h): per dense layer [beta cin | gamma cin], per transition [beta Cp | gamma Cp]
         int at = 0;

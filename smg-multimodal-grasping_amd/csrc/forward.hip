@@ -57,7 +57,8 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
         HIP_OK(hipMemcpyAsync(e->d_stage, h, (size_t)e->stage_ints * sizeof(int), hipMemcpyHostToDevice, st));
         HIP_OK(hipEventRecord(e->ev_stage[turn], st));
     }
-    HIP_OK(hipMemsetAsync(e->fstat, 0, 2 * e->fstat_span * sizeof(double), st));
+    if (kFStatRep > 1) HIP_OK(hipMemset2DAsync(e->fstat, kStatRepStride * sizeof(double), 0, 2 * e->fstat_span * sizeof(double), kFStatRep, st));
+    else HIP_OK(hipMemsetAsync(e->fstat, 0, 2 * e->fstat_span * sizeof(double), st));
 
     // weights -> K-major packs
     {

@@ -382,11 +382,24 @@ __device__ __forceinline__ double stat_get(const double* p, int64_t idx) {
     for (int r = 1; r < kStatRep; ++r) v += p[idx + r * kStatRepStride];
     return v;
 }
+#ifndef SMG_FSTAT_REP
+#define SMG_FSTAT_REP 1      // dev knob: replicas of the FORWARD statistic arena (readers: every parameter prologue).  Same box, 1 / 2 / 4:
+                             // headline 21.40 / 21.52 / 21.58 ms, config 5 share 25.4 / 24.5 / 24.7, config 3 27.0 / 27.1 / - : stays 1 until the
+                             // backward prologues read the fp32 tables instead of these sums
+#endif
+constexpr int kFStatRep = SMG_FSTAT_REP;
+__device__ __forceinline__ double fstat_get(const double* p, int64_t idx) {
+    double v = p[idx];
+#pragma unroll
+    for (int r = 1; r < kFStatRep; ++r) v += p[idx + r * kStatRepStride];
+    return v;
+}
+__device__ __forceinline__ int64_t fstat_rep() { return (int64_t)((blockIdx.x + blockIdx.y + blockIdx.z) % kFStatRep) * kStatRepStride; }
 __device__ __forceinline__ int64_t stat_rep() { return (int64_t)((blockIdx.x + blockIdx.y + blockIdx.z) % kStatRep) * kStatRepStride; }
 __device__ __forceinline__ void bn_moments(const double* sum, const double* sq, int64_t idx, double inv_cnt, float eps,
                                            float& mean, float& invstd) {
-    const double m = sum[idx] * inv_cnt;              // (forward sums: one copy)
-    double var = sq[idx] * inv_cnt - m * m;
+    const double m = fstat_get(sum, idx) * inv_cnt;
+    double var = fstat_get(sq, idx) * inv_cnt - m * m;
     var = var < 0.0 ? 0.0 : var;
     mean = (float)m;
     invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -1375,8 +1388,8 @@ struct FwdConvP {
         block_col_reduce<Cfg, 2, double>(v, reinterpret_cast<double*>(smem), tot);
         if (t < Cfg::BN && c.n0 + t < N) {
             const int64_t si = (int64_t)c.n * dstride + dcoff + c.n0 + t;
-            atomicAdd(dsum + si, tot[0]);
-            atomicAdd(dsq + si, tot[1]);
+            atomicAdd(dsum + si + fstat_rep(), tot[0]);
+            atomicAdd(dsq + si + fstat_rep(), tot[1]);
         }
     }
 };

@@ -279,7 +279,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const H
     if (t < 64) {
         const int q = t >> 5, c = t & 31;
         const double tot = red[q * 128 + c] + red[q * 128 + 32 + c] + red[q * 128 + 64 + c] + red[q * 128 + 96 + c];
-        atomicAdd((q ? a.dsq : a.dsum) + (int64_t)n * a.dstride + a.dcoff + c, tot);
+        atomicAdd((q ? a.dsq : a.dsum) + (int64_t)n * a.dstride + a.dcoff + c + fstat_rep(), tot);
     }
 }
 

@@ -223,7 +223,7 @@ static __global__ __launch_bounds__(512, 1) void conv1x1_fwd_ws_kernel(const Fwd
     if (t < 128) {
         const int q = t >> 6, c = t & 63;
         const double tot = red[(q * 2) * 64 + c] + red[(q * 2 + 1) * 64 + c];
-        atomicAdd((q ? a.dsq : a.dsum) + (int64_t)n * a.dstride + n0 + c, tot);
+        atomicAdd((q ? a.dsq : a.dsum) + (int64_t)n * a.dstride + n0 + c + fstat_rep(), tot);
     }
 }
 
