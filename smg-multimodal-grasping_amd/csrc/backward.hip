@@ -36,6 +36,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
     // (a lowest-priority stream for the weight gradients gains 0.2 ms per step with one engine alive, and LOSES 10 ms as soon
     // as a second engine - two more streams - exists in the process: the streams then share hardware queues and serialise)
     const hipStream_t s2 = (e->prof || e->serialize) ? st : e->side;
+    static const bool use_tabs = !(getenv("SMG_BWD_TABS") && atoi(getenv("SMG_BWD_TABS")) == 0);      // dev A/B: 0 = the fp64 sums, as before
     auto fork = [&](hipEvent_t ev) -> int {      // side stream continues after everything enqueued on st so far
         HIP_OK(hipEventRecord(ev, st));
         HIP_OK(hipStreamWaitEvent(s2, ev, 0));
@@ -129,7 +130,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             if (e->generic3x3 || gs_mat) {
                 BnBwdApplyArgs a{};
                 a.g = e->G[b]; a.ldg = Ct; a.gcoff = d.cin; a.x = e->X[b]; a.ldx = Ct; a.xcoff = d.cin; a.pl = pl; a.C = kGrowth;
-                a.xsum = fsum(e, e->st_X[b]); a.xsq = fsq(e, e->st_X[b]); a.xstride = Ct;
+                a.xsum = fsum(e, e->st_X[b]); a.xsq = fsq(e, e->st_X[b]); a.xstride = Ct; a.xtab = use_tabs ? stat_table(e, e->sx_tab[b], e->max_streams, Ct) : StatTab{};
                 a.s1 = b1(e, e->bs_X[b]); a.s2 = b2(e, e->bs_X[b]); a.sstride = Ct; a.scoff = d.cin; a.gamma = nullptr; a.eps = kEps;
                 a.out = GSb; a.ldo = kGrowth;
                 BY(e, ESZ(e) * NS * pl.HW * 3 * kGrowth);
@@ -222,7 +223,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             {   // norm2 backward applied once, in place: D2 <- gamma2*invstd*(dy - s1/n - xhat*s2/n)
                 BnBwdApplyArgs a{};
                 a.g = D2b; a.ldg = kBottleneck; a.gcoff = 0; a.x = bt; a.ldx = kBottleneck; a.xcoff = 0; a.pl = pl; a.C = kBottleneck;
-                a.xsum = fsum(e, e->st_Bt[b][i]); a.xsq = fsq(e, e->st_Bt[b][i]); a.xstride = kBottleneck;
+                a.xsum = fsum(e, e->st_Bt[b][i]); a.xsq = fsq(e, e->st_Bt[b][i]); a.xstride = kBottleneck; a.xtab = (use_tabs && !e->generic3x3) ? stat_table(e, e->sb_tab[b][i], e->max_streams, kBottleneck) : StatTab{};
                 a.s1 = b1(e, e->bs_Bt[b][i]); a.s2 = b2(e, e->bs_Bt[b][i]); a.sstride = kBottleneck; a.scoff = 0;
                 a.gamma = P + d.n2.w; a.eps = kEps; a.out = D2b; a.ldo = kBottleneck;
                 if (!e->generic3x3) { a.dbeta = Gr + d.n2.b; a.dgamma = Gr + d.n2.w; }   // the halo dgrad leaves these to us
@@ -246,7 +247,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                     p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kBottleneck;
                     p.wp = e->packed_u + e->pk_d1[b][i]; p.K8tot = kBottleneck / 8; p.ldn = d.cin; p.wcol0 = cs; p.N = d.cin - cs;
                     p.mbuf = e->X[b]; p.ldm = Ct; p.mcoff = cs; p.pm = pl;
-                    p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct;
+                    p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct; p.mtab = use_tabs ? stat_table(e, e->sx_tab[b], e->max_streams, Ct) : StatTab{};
                     p.egamma = P + d.n1.w + cs; p.ebeta = P + d.n1.b + cs;
                     p.dst = e->G[b]; p.ldd = Ct; p.dcoff = cs;
                     p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.ocoff = cs;
@@ -271,7 +272,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                     }
                     p.ldg = kBottleneck; p.pa = pl; p.KA = kBottleneck; p.N = cs;
                     p.mbuf = e->X[b]; p.ldm = Ct;
-                    p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct;
+                    p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct; p.mtab = use_tabs ? stat_table(e, e->sx_tab[b], e->max_streams, Ct) : StatTab{};
                     p.dst = e->G[b]; p.ldd = Ct;
                     p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.rep_stride = e->db_total; p.eps = kEps;
                     BY(e, ESZ(e) * NS * pl.HW * ((double)p.nseg * kBottleneck + 3.0 * cs));
@@ -296,7 +297,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 BwdWeightP<MC<Cfg, decltype(ptag)::value>, W_ONE, C_IDENT, SMG_PD_WGRAD, false, decltype(ptag)::value> p{};
                 p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck;
                 p.bbuf = e->X[b]; p.ldb = Ct; p.pb = pl; p.NB = d.cin;
-                p.bsum = fsum(e, e->st_X[b]); p.bsq = fsq(e, e->st_X[b]); p.bstride = Ct;
+                p.bsum = fsum(e, e->st_X[b]); p.bsq = fsq(e, e->st_X[b]); p.bstride = Ct; p.btab = use_tabs ? stat_table(e, e->sx_tab[b], e->max_streams, Ct) : StatTab{};
                 p.bgamma = P + d.n1.w; p.bbeta = P + d.n1.b; p.eps = kEps;
                 p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
                 p.dw = Gr + d.c1.w; p.ldw_out = d.cin;

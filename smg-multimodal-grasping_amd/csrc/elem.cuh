@@ -686,7 +686,7 @@ struct BnBwdApplyArgs {
     const void* g; int ldg, gcoff;                // gradient storage of the mode
     const void* x; int ldx, xcoff;                // activation storage of the mode
     Plane pl; int C;
-    const double* xsum; const double* xsq; int xstride;
+    const double* xsum; const double* xsq; int xstride; StatTab xtab;      // xtab: table of the same activation (columns as xcoff + t), or none
     const double* s1; const double* s2; int sstride, scoff;
     const float* gamma; float eps;
     void* out; int ldo;
@@ -724,7 +724,7 @@ static __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApp
     if (t < a.C) {
         const double inv = 1.0 / (double)a.pl.HW;
         float mean, invstd;
-        bn_moments(a.xsum, a.xsq, (int64_t)n * a.xstride + a.xcoff + t, inv, a.eps, mean, invstd);
+        tab_or_moments(a.xtab, n, a.xcoff + t, a.xsum, a.xsq, (int64_t)n * a.xstride + a.xcoff + t, inv, a.eps, mean, invstd);
         const float q2 = (float)(stat_get(a.s2, (int64_t)n * a.sstride + a.scoff + t) * inv);
         prm[t] = (a.gamma ? a.gamma[t] : 1.f) * invstd;
         prm[a.C + t] = (float)(stat_get(a.s1, (int64_t)n * a.sstride + a.scoff + t) * inv);

@@ -361,6 +361,9 @@ static const float kEps = 1e-5f;
 
 // BN statistics table at float offset `at` of the table arena ([rows_max][C] mean, then invstd), from row r0 on, with the
 // affine parameters of the consuming BatchNorm
+static StatTab stat_table(smg_engine* e, int64_t at, int rows_max, int C) {      // the same table, read-only view for the backward
+    StatTab t; t.mean = e->stab + at; t.invstd = t.mean + (int64_t)rows_max * C; t.ld = C; return t;
+}
 static BnTab bn_table(smg_engine* e, int64_t at, int rows_max, int r0, int C, const float* gamma, const float* beta) {
     BnTab t;
     t.mean = e->stab + at + (int64_t)r0 * C; t.invstd = t.mean + (int64_t)rows_max * C; t.ld = C; t.gamma = gamma; t.beta = beta;

@@ -248,6 +248,12 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                     };
                     if (pl.HWp % 128 == 0) run(CfgP128x32{}); else run(CfgP64x32{});
                 }
+                if (b == 3 && i + 1 == T.layers[b].size()) {
+                    // the last layer's 32 channels have no dense-layer or transition consumer to finish their table entries (norm5 reads
+                    // the sums); the backward reads the table (backward.hip: use_tabs), so finish them here
+                    const BnTab t5 = bn_table(e, e->sx_tab[b], e->max_streams, s0, Ct, nullptr, nullptr);
+                    bn_stat(cs, t5, ns, xsum, xsq, Ct, Ct - kGrowth, kGrowth, pl.HW);
+                }
             }
             if (b < 3 && on()) {   // transition: norm + relu + (avgpool2 commuted in front of) conv 1x1
                 const Plane pn = e->p_blk[b + 1];

@@ -384,8 +384,9 @@ __device__ __forceinline__ double stat_get(const double* p, int64_t idx) {
 }
 #ifndef SMG_FSTAT_REP
 #define SMG_FSTAT_REP 1      // dev knob: replicas of the FORWARD statistic arena (readers: every parameter prologue).  Same box, 1 / 2 / 4:
-                             // headline 21.40 / 21.52 / 21.58 ms, config 5 share 25.4 / 24.5 / 24.7, config 3 27.0 / 27.1 / - : stays 1 until the
-                             // backward prologues read the fp32 tables instead of these sums
+                             // headline 21.40 / 21.52 / 21.58 ms, config 5 share 25.4 / 24.5 / 24.7, config 3 27.0 / 27.1 / - ; with the backward's
+                             // per-layer prologues on the fp32 tables (StatTab) 2 replicas still cost the headline 0.15 ms (21.59 -> 21.75; config 5
+                             // 25.7 -> 24.8; serialised kernel total 24.11 -> 23.99): the forward's own first-consumer prologues pay.  Stays 1.
 #endif
 constexpr int kFStatRep = SMG_FSTAT_REP;
 __device__ __forceinline__ double fstat_get(const double* p, int64_t idx) {
@@ -396,6 +397,10 @@ __device__ __forceinline__ double fstat_get(const double* p, int64_t idx) {
 }
 __device__ __forceinline__ int64_t fstat_rep() { return (int64_t)((blockIdx.x + blockIdx.y + blockIdx.z) % kFStatRep) * kStatRepStride; }
 __device__ __forceinline__ int64_t stat_rep() { return (int64_t)((blockIdx.x + blockIdx.y + blockIdx.z) % kStatRep) * kStatRepStride; }
+// The backward's per-layer kernels take (mean, invstd) of a forward activation from the fp32 table the forward finished (the very
+// floats bn_moments would produce from the fp64 sums) when the caller hands one over: two float loads instead of fp64 loads,
+// a divide and a square root per channel and workgroup - and no reader of the forward sums left on the per-layer path.
+struct StatTab { const float* mean; const float* invstd; int ld; };       // mean == nullptr: no table, use the sums
 __device__ __forceinline__ void bn_moments(const double* sum, const double* sq, int64_t idx, double inv_cnt, float eps,
                                            float& mean, float& invstd) {
     const double m = fstat_get(sum, idx) * inv_cnt;
@@ -403,6 +408,11 @@ __device__ __forceinline__ void bn_moments(const double* sum, const double* sq, 
     var = var < 0.0 ? 0.0 : var;
     mean = (float)m;
     invstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+__device__ __forceinline__ void tab_or_moments(const StatTab& t, int n, int col, const double* sum, const double* sq, int64_t idx,
+                                               double inv_cnt, float eps, float& mean, float& invstd) {
+    if (t.mean) { mean = t.mean[(int64_t)n * t.ld + col]; invstd = t.invstd[(int64_t)n * t.ld + col]; }
+    else bn_moments(sum, sq, idx, inv_cnt, eps, mean, invstd);
 }
 
 // BatchNorm statistics of one activation buffer as fp32, finished ONCE per (stream, channel): mean | invstd tables of
@@ -1430,7 +1440,7 @@ struct BwdDataP {
     const u32x4* wp; int K8tot; int ldn; int wcol0;    // packed weight units [piece][K8tot][ldn], first output column wcol0
     int N;
     const void* mbuf; int ldm; int mcoff; Plane pm;
-    const double* msum; const double* msq; int mstride;
+    const double* msum; const double* msq; int mstride; StatTab mtab;
     const float* egamma; const float* ebeta;
     void* dst; int ldd; int dcoff;
     double* o1; double* o2; int ostride; int ocoff;
@@ -1550,7 +1560,7 @@ struct BwdDataP {
             const int col = c.n0 + j;
             float mean = 0.f, invstd = 0.f, g = 0.f, b = 0.f;
             if (col < N) {
-                bn_moments(msum, msq, (int64_t)c.n * mstride + mcoff + col, minv, eps, mean, invstd);
+                tab_or_moments(mtab, c.n, mcoff + col, msum, msq, (int64_t)c.n * mstride + mcoff + col, minv, eps, mean, invstd);
                 g = egamma[col];
                 b = ebeta[col];
             }
@@ -1837,7 +1847,7 @@ struct BwdDataGroupP {
     int ldg; Plane pa; int KA;
     int N;                                              // output channels [0, N)
     const void* mbuf; int ldm;                          // block buffer X (mask / xhat source)
-    const double* msum; const double* msq; int mstride;
+    const double* msum; const double* msq; int mstride; StatTab mtab;
     void* dst; int ldd;                                 // G'
     double* o1; double* o2; int ostride;                // SA / SB [n][C]
     int rep_stride;                                     // replicas of the dbeta / dgamma scratch (see BwdDataP)
@@ -1888,7 +1898,7 @@ struct BwdDataGroupP {
                 g[s] = on ? seg[s].gamma[col] : 0.f;
                 be[s] = on ? seg[s].beta[col] : 0.f;
             }
-            if (col < N) bn_moments(msum, msq, (int64_t)c.n * mstride + col, minv, eps, mean, invstd);
+            if (col < N) tab_or_moments(mtab, c.n, col, msum, msq, (int64_t)c.n * mstride + col, minv, eps, mean, invstd);
             sp[j] = mean;
             sp[Cfg::BN + j] = invstd;
 #pragma unroll
@@ -2209,7 +2219,7 @@ struct BwdWeightP {
     const double* s1; const double* s2; int sstride; int scoff;
     const float* agamma;
     const void* bbuf; int ldb; Plane pb; int NB;
-    const double* bsum; const double* bsq; int bstride;
+    const double* bsum; const double* bsq; int bstride; StatTab btab;
     const float* bgamma; const float* bbeta;
     float eps;
     int chunk, chunks_per_stream, n_chunks;   // virtual block z = tap * n_chunks + chunk index
@@ -2296,7 +2306,7 @@ struct BwdWeightP {
                 const int ch = c.n0 + j;
                 float mean = 0.f, invstd = 0.f, sc = 0.f, be = 0.f;
                 if (ch < NB) {
-                    bn_moments(bsum, bsq, (int64_t)c.n * bstride + ch, binv, eps, mean, invstd);
+                    tab_or_moments(btab, c.n, ch, bsum, bsq, (int64_t)c.n * bstride + ch, binv, eps, mean, invstd);
                     sc = bgamma[ch] * invstd;
                     be = bbeta[ch];
                 }
