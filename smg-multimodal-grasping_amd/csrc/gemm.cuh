@@ -1866,11 +1866,16 @@ struct BwdDataGroupP {
 
     struct Ctx {
         int n, m0, n0; bool whole;
-        float x[Cfg::TM][Cfg::TN][16];                  // raw activation of this lane's accumulator elements
+        // 16-bit modes: 16-register vectors like the accumulators they shadow (256 -> 206 registers for the 128-row tile); in mode 0
+        // hipcc sends whole vectors to scratch instead (any of the three, 128-192 bytes), so plain arrays there - two of their 96 scalars
+        // still end up in scratch at any register budget, with a vmcnt(0) in front of the fold that uses one
+        typedef float farr16[16];
+        using V16 = typename std::conditional<kWide, f32x16, farr16>::type;
+        V16 x[Cfg::TM][Cfg::TN];                        // raw activation of this lane's accumulator elements
                                                         // (16-bit storage, whole tiles: until the first k_hook the registers hold x AS FETCHED, row segments)
-        float gold[kWide ? 1 : Cfg::TM][kWide ? 1 : Cfg::TN][16];               // fp32 storage: old G' of whole tiles, fetched with x at the start
+        V16 gold[kWide ? 1 : Cfg::TM][kWide ? 1 : Cfg::TN];                     // fp32 storage: old G' of whole tiles, fetched with x at the start
         rawq_t<GT> gq[kWide ? Cfg::TM : 1][kWide ? Cfg::TN : 1][4];             // 16-bit storage: the same as fetched row segments
-        float run[Cfg::TM][Cfg::TN][16];                // sum_i gamma_i * dy_i
+        V16 run[Cfg::TM][Cfg::TN];                      // sum_i gamma_i * dy_i
         float ls[GROUP_MAX][2][Cfg::TN];                // per-segment column partials (sum dy, sum dy*(x-mean))
     };
     struct ARow { unsigned off; };      // byte offset of the row inside the tile; rows outside the plane: kOOB (read as zero)
