@@ -277,7 +277,12 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
         return 0;
     };
     static const bool one_chain = getenv("SMG_FWD_ONE_CHAIN") != nullptr;      // dev: A/B switch
-    if (NS >= 2 && !e->prof && !e->serialize && !one_chain) {
+    // (two chains pay once a chain has work to overlap: a single-sample pass - 2 streams of 160^2 - is bound by the host's launch
+    //  rate, and two chains launch every kernel twice: 6.2 -> 5.1 ms for config 3's enveloping-then-sucking head on one chain; 5 streams
+    //  of 456^2 want two: 30.1 against 28.9 ms on one)
+    static const bool force_two = getenv("SMG_FWD_TWO_CHAINS") != nullptr;      // dev: A/B switch
+    const bool two_chains = NS >= 2 && (force_two || (int64_t)NS * e->p_blk[0].HW >= 200000);
+    if (two_chains && !e->prof && !e->serialize && !one_chain) {
         const int h = NS / 2;
         HIP_OK(hipEventRecord(e->ev_misc, st));                 // packed weights + batch description are ready
         HIP_OK(hipStreamWaitEvent(e->side, e->ev_misc, 0));
