@@ -306,7 +306,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 // 128 x 64 fp32 atomics per workgroup everywhere (same box: headline 20.99 -> 20.84 ms, config 3 27.36 -> 27.16, config 5
                 // share 25.68 -> 25.49); SMG_W1_PART=0: the atomics, for A/B (the "deterministic" option overrides it)
                 static const bool w1_atomics = getenv("SMG_W1_PART") && atoi(getenv("SMG_W1_PART")) == 0;
-                const bool w1_part = e->deterministic || !w1_atomics;
+                const bool w1_part = e->deterministic || (!w1_atomics && NS > 4);      // (a few streams: host-launch-bound - atomics save the 58 reduce launches)
                 launch_wgrad(e, s2, p, dim3(1, nt, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck, 1, C_IDENT, w1_part);
                 };
                 PREC_DISPATCH(e, go(PTAG));
