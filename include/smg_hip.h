@@ -173,7 +173,8 @@ int smg_engine_set_precision(smg_engine* e, int precision);
  * the largest gradient tensors) are reduced from partial tiles in a fixed order instead of fp32 atomics, so the trunk's
  * convolution weight gradients of two identical calls are bit-identical like the reference's (code/trainer.py:350-351 on one
  * device); BatchNorm affine gradients and the head's value convolution keep their fp32 atomics.  (Since round 3 the fixed-order
- * path is also the default whenever the partial tiles fit the workspace - it is the faster one; the option guarantees it.)
+ * path is also the default for batches of more than four streams whenever the partial tiles fit the workspace - it is the
+ * faster one there; the option guarantees it for every batch.)
  * "serialize" (0 / 1): every kernel on the caller's stream in issue order instead of two concurrent chains (profiling). */
 int smg_engine_set_option(smg_engine* e, const char* name, int value);
 
