@@ -212,6 +212,7 @@ def kernel_roofline(step_fn, eng, dev, terms, ms_per_step, step_rl, n_prof=3, pm
                              "frac_of_fp32_mfma_peak": conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                              "ms_per_step": conv_ms / n_prof, "executed_gflop_per_step": conv_fl / n_prof / 1e9},
         "elementwise_ms_per_step": prof["elementwise"][0] / n_prof,
+        "launches_per_step_all": sum(v[1] for v in prof.values()) // n_prof,
         "per_kernel": {k: dict(roof(v), ms_per_step=v[0] / n_prof, launches_per_step=v[1] // n_prof,
                                tflops=(v[2] / (v[0] * 1e-3) / 1e12) if v[0] > 0 else 0.0,
                                algorithmic_gb_per_step=v[3] / n_prof / 1e9) for k, v in prof.items() if v[1] > 0 and (v[2] > 0 or v[3] > 0)},
@@ -223,6 +224,85 @@ def kernel_roofline(step_fn, eng, dev, terms, ms_per_step, step_rl, n_prof=3, pm
     floor_s = sum(max(v[2] * terms / (PEAK_BF16_MFMA_TFLOPS * 1e12), v[3] / (PEAK_HBM_GBS * 1e9)) for v in prof.values()) / n_prof
     rl["step"] = dict(step_rl or {}, roofline_ms=floor_s * 1e3, measured_ms=ms_per_step, frac=floor_s * 1e3 / ms_per_step)
     return rl
+
+
+DETAIL_FILE = "bench_detail.json"
+LINE_LIMIT = 1900          # the driver keeps a 2000-character tail of stdout and parses the last line: the whole line must fit in it
+
+
+def _r(x, nd=4):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def compact_line(out):
+    """The ONE stdout line of the bench contract, < LINE_LIMIT characters: headline fields, the dominant kernel's roofline,
+    the CPU baseline and one scalar per side measurement.  Everything else (per-kernel tables, per-stage, config rooflines)
+    goes to bench_detail.json (emit)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    c = {k: _r(out[k]) for k in keep if k in out}
+    cfgd = out.get("config", {})
+    c["config"] = {"workload": cfgd.get("workload", "")[:120], **{k: v for k, v in cfgd.items() if k != "workload"}}
+    rl = out.get("roofline") or {}
+    if "bound" in rl:
+        crl = {k: _r(rl[k]) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                                       "avg_launch_ms", "launches_per_step", "kernel_symbols") if k in rl}
+        rs = rl.get("rocprof_serialized")
+        if rs:
+            crl["rocprof_avg_launch_ms"] = _r(rs.get("avg_launch_ms"))
+            crl["rocprof_file"] = rs.get("file")
+        if "launches_per_step_all" in rl:
+            c["launches_per_step"] = rl["launches_per_step_all"]
+        if rl.get("mfma_terms"):
+            crl["mfma_terms"] = rl["mfma_terms"]
+        ack = rl.get("all_conv_kernels")
+        if ack:
+            crl["all_conv"] = {"tflops": _r(ack["achieved"], 2), "frac_of_mfma_roof": _r(ack["frac_of_mfma_roof"]), "ms_per_step": _r(ack["ms_per_step"], 3)}
+        pk = rl.get("per_kernel")
+        if pk:       # class -> [ms per step, frac of its roof]
+            crl["classes"] = {k: [_r(v["ms_per_step"], 3), _r(v["frac"], 3)] for k, v in pk.items() if v["ms_per_step"] >= 1.0}
+        c["roofline"] = crl
+    st = rl.get("step")
+    if st:
+        c.setdefault("roofline", {})["step"] = {k: _r(v) for k, v in st.items()}
+    cb = out.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {k: _r(cb[k]) for k in ("value", "unit", "cores", "kind", "seconds_per_pass", "physical_cores",
+                                                    "value_physical_cores", "seconds_per_pass_physical_cores", "sweep_fwd_seconds") if k in cb}
+        c["cpu_baseline"]["sample"] = cb.get("sample", "")[:100]
+    for k in ("pass_tflops_algorithmic", "host_enqueue_ms_per_step", "ms_per_step_host_inputs", "sweep_fwd_ms", "train_step_ms",
+              "train_step_kernel_ms", "train_step_launches", "forward_1rot_ms", "launches_per_step", "allreduce_overlapped", "allreduce_exposed_ms_per_step",
+              "allreduce_ms", "allreduce_bytes", "allreduce_backend", "rccl_world", "device_count", "devices_seen"):
+        if k in out:
+            c[k] = _r(out[k])
+    if "batched" in out:
+        c["batched4_ms"] = _r(out["batched"]["ms_per_step"], 3)
+    cf = out.get("configs") or {}
+    for name, key in (("config3_three_heads_bf16", "ms"), ("config4_share_8_scenes", "ms_per_step"), ("config5_share_1824_fp16", "ms_per_step")):
+        if name in cf:
+            c[name.split("_")[0] + "_ms"] = _r(cf[name][key], 3)
+    c["detail"] = DETAIL_FILE
+    line = json.dumps(c, separators=(",", ":"))
+    for k in ("classes", "all_conv", "kernel_symbols", "step"):   # never let the side fields cost the headline its parse
+        if len(line) <= LINE_LIMIT:
+            break
+        c.get("roofline", {}).pop(k, None)
+        line = json.dumps(c, separators=(",", ":"))
+    return line
+
+
+def emit(out):
+    """Full detail -> bench_detail.json (repo root; also gpurun_out/ when it exists, so it comes back from a GPU box);
+    the compact line -> stdout, last."""
+    for d in (REPO, os.path.join(REPO, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, DETAIL_FILE), "w") as f:
+                    json.dump(out, f, indent=1)
+            except OSError:
+                pass
+    sys.stdout.flush()
+    print(compact_line(out), flush=True)
 
 
 def physical_cores():
@@ -270,6 +350,9 @@ def main():
                     help="what a timed step is (under any --gpus N): the headline 1 scene x 16 rotations per GPU; config3 = E + S + ES "
                          "heads in bf16 per GPU; config4 = 8 scenes x 16 rotations per GPU + all-reduce; config5 = S=1824, 4 of the "
                          "32 rotations per GPU in fp16")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="headline leg under N > 1: weak = one scene x 16 rotations per GPU (default); strong = ONE scene per step, its 16 "
+                         "rotations dealt contiguously to the ranks (16 / N each + the masked stream on every rank), one all-reduce")
     ap.add_argument("--scenes-per-rank", type=int, default=8, help="--leg config4: scenes per GPU per step")
     ap.add_argument("--train-only", action="store_true", help="only the timed training steps (profiling runs: every kernel in the trace belongs to a step)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: blocking gradient all-reduce after the backward instead of the one hidden under its second half")
@@ -350,6 +433,18 @@ def main():
         workload = ("reinforcement_net style 0 (grasp trunk + graspnet_val head): 1 scene x 1 mask x 16 rotations per GPU per "
                     "step, fwd + 16 Huber losses + bwd + Adam, S=640 (224^2 heightmap), masked stream de-duplicated (17 trunk passes)")
 
+        if args.scaling == "strong" and world > 1:
+            # total work fixed: every rank holds the SAME scene and trains on its contiguous share of the 16 rotations; the masked
+            # stream's trunk pass is repeated on every rank (its gradient is the sum over the rank's rotations: exact, linear)
+            depth, masks = synthetic.heightmap_scene(0)
+            labels = synthetic.uniform(0, "bench/labels", R, 0.0, 1.5)
+            rots = parallel.shard(list(range(R)), rank, world)
+            lo, hi = rots[0], rots[-1] + 1
+            depth_d, mdepth_d, labels_d = on_dev(depth), on_dev(depth * masks[0]), on_dev(labels[lo:hi], np.float32)
+            units_per_step = 1.0 / world
+            workload = ("strong scaling: ONE scene x 1 mask x 16 rotations per step over all GPUs (%d rotations + the masked stream per GPU), "
+                        "fwd + Huber + bwd + all-reduce + Adam, S=640" % len(rots))
+
         def step():
             return tr.train_batch(depth_d, mdepth_d, 0, rots, labels_d, grad_sync=sync)
     elif leg == "config4":
@@ -420,7 +515,7 @@ def main():
     out = {
         "metric": "affordance fwd+bwd passes/sec (16-rot 224^2 RGB-D)",
         "value": passes_per_s, "unit": "passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling if leg == "headline" else "weak", "vs_baseline": None,
         "dtype": dtype, "data": "synthetic", "dtype_note": dtype_note,
         "config": {"workload": workload, "leg": leg, "rotations": 32 if leg == "config5" else R, "input_size": input_size,
                    "passes_per_step_per_gpu": units_per_step, "parallelism": "dp%d" % world},
@@ -450,6 +545,11 @@ def main():
         out["allreduce_ms"] = float(np.min(t_ar))
         out["allreduce_bytes"] = 4 * sum(n for _, n in parallel.grad_segments(tr.model.HEAD_OUT, tid, hid))
         out["allreduce_backend"] = torch.distributed.get_backend()
+        out["rccl_world"] = torch.distributed.get_world_size()         # what the process group saw, not what WORLD_SIZE asked for
+        out["device_count"] = torch.cuda.device_count()
+        devs = [None] * world
+        torch.distributed.all_gather_object(devs, "%s:%d" % (os.uname().nodename, torch.cuda.current_device()))
+        out["devices_seen"] = len(set(devs))
     out["roofline"] = {"step": step_rl}
 
     if rank == 0 and world == 1 and leg in ("config3", "config5") and not args.no_roofline:
@@ -471,6 +571,36 @@ def main():
         out["ms_per_step_host_inputs"] = (time.perf_counter() - t_h) / n_h * 1e3
         import models
         eng = models._ENGINES[(local_rank, 640, 1)]
+        # the reference's REAL call pattern (code/main.py:338, code/trainer.py:334-384): one (mask, rotation) sample per
+        # Trainer.backprop - host numpy inputs, the loss read back every call (a latency, not a throughput), 2 trunk streams
+        mk3 = masks.copy()
+        with contextlib.redirect_stdout(sys.stderr):
+            def one_backprop(i):
+                return tr.backprop(depth, 'grasp', (0, i % R), (0, 0), (0, 0), (0, 0), float(labels[i % R]), mk3.reshape(mk3.shape[:3]), None, None, None)
+            for i in range(3):
+                one_backprop(i)
+            torch.cuda.synchronize(dev)
+            n_1 = max(5, args.steps // 2)
+            t_h = time.perf_counter()
+            for i in range(n_1):
+                one_backprop(i)
+            torch.cuda.synchronize(dev)
+            out["train_step_ms"] = (time.perf_counter() - t_h) / n_1 * 1e3
+            # the same step's kernels serialised on one stream with hipEvents around every launch: what the GPU needs for it
+            eng.profile_enable(True)
+            for i in range(3):
+                one_backprop(i)
+            torch.cuda.synchronize(dev)
+            p1 = eng.profile_read()
+            eng.profile_enable(False)
+            out["train_step_kernel_ms"] = sum(v[0] for v in p1.values()) / 3.0
+            out["train_step_launches"] = sum(v[1] for v in p1.values()) // 3
+            for i in range(2):
+                tr.forward(depth, mdepth, 0, True, False, i)
+            t_h = time.perf_counter()
+            for i in range(n_1):
+                tr.forward(depth, mdepth, 0, True, False, i % R)          # one rotation, Q read back (trainer.py:205-207)
+            out["forward_1rot_ms"] = (time.perf_counter() - t_h) / n_1 * 1e3
         # forward-only sweep (BASELINE.json configs[1]), reported beside the headline number
         x_d = tr._heightmaps_to_device(depth, mdepth)
         for _ in range(2):
@@ -593,11 +723,13 @@ def main():
                           "stream recomputed per sample, fwd + Huber + bwd + Adam per sample, PyTorch CPU fp32), extrapolated x%g; best of "
                           "the thread settings tried" % (args.cpu_samples, R / args.cpu_samples),
                 "seconds_per_pass": secs[best], "physical_cores": pc, "logical_cpus": os.cpu_count(),
+                # n = physical cores - reported beside the best setting, not instead of it
+                "value_physical_cores": 1.0 / secs[pc], "seconds_per_pass_physical_cores": secs[pc],
                 "seconds_per_pass_by_threads": {str(k): v for k, v in secs.items()},
                 "sweep_fwd_seconds": cpu_sweep,       # 16-rotation forward-only sweep (2 rotations timed, x8), same thread setting
             }
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if distributed:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -20,6 +20,11 @@ static void pick_chunk(const Plane& pl, int n_planes, int tiles_per_chunk, int& 
 int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t st, int phases) {
     if (!e->have_fwd) return fail(-22, "smg_backward without a preceding smg_forward");
     if (!net->grads) return fail(-22, "net.grads is NULL");
+    // phase bookkeeping: the second half continues the first half of the SAME forward (statistic arenas, ring position, G' buffers)
+    if (phases == 2 && !e->bw_phase0_done)
+        return fail(-22, "smg_backward_phase(1) must follow smg_backward_phase(0) of the same forward");
+    if ((phases & 1) && e->bw_phase0_done)
+        return fail(-22, "smg_backward / smg_backward_phase(0) while the second half of a two-phase backward is still due (run phase 1 or a new forward)");
     const Layout& L = *e->L;
     const TrunkRef& T = L.trunk[e->f_trunk];
     const HeadRef& Hd = L.head[e->f_head];
@@ -69,10 +74,9 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         p.dw = Gr + Hd.c0.w; p.ldw_out = 2 * kFeat;
         if (fork(e->ev_misc)) return -5;
         BY(e, 4.0 * NP * p4.HW * (2 * kHeadMid + 2 * kFeat));
-        launch_wgrad(e, s2, p, dim3(1, 2 * kFeat / 64, NP * cps4), K_HW0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid, 1, C_IDENT);
-        return 0;
+        return launch_wgrad(e, s2, p, dim3(1, 2 * kFeat / 64, NP * cps4), K_HW0, 2.0 * NP * p4.HW * 2 * kFeat * kHeadMid, 1, C_IDENT);
         };
-        PREC_DISPATCH(e, if (go(PTAG)) return -5);
+        PREC_DISPATCH(e, if (int rc = go(PTAG)) return rc);
     }
     {   // head conv0 data gradient + relu0 + norm0 sums
         auto run = [&](auto tag, auto ptag) {
@@ -218,7 +222,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
                 p.dw = Gr + d.c2.w; p.ldw_out = kBottleneck * 9;
                 BY(e, ESZ(e) * NS * pl.HW * (kGrowth + kBottleneck));
-                launch_wgrad(e, s2, p, dim3(1, 1, 9 * NS * cps), K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth, 9, C_3x3);
+                if (int rc = launch_wgrad(e, s2, p, dim3(1, 1, 9 * NS * cps), K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth, 9, C_3x3)) return rc;
             }
             {   // norm2 backward applied once, in place: D2 <- gamma2*invstd*(dy - s1/n - xhat*s2/n)
                 BnBwdApplyArgs a{};
@@ -293,7 +297,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 // on many-stream batches (config 3: 28.9 -> 28.5 ms at 160; 120 / 80: 28.6 / 28.8; S = 1824 with 5 streams: 320 stays)
                 const int w1_prec = (e->prec && NS >= 16 && !getenv("SMG_W1_WGS")) ? 160 : w1_target;
                 pick_chunk(pl, NS, nt, chunk, cps, pl.HW <= 1600 ? (getenv("SMG_W1_WGS_SMALL") ? w1_small : w1_prec) : w1_prec);   // 256..384 measure the same (22.46 ms per step), 512: 22.6, 768: 22.8, 1024: 23.2
-                auto go = [&](auto ptag) {
+                auto go = [&](auto ptag) -> int {
                 BwdWeightP<MC<Cfg, decltype(ptag)::value>, W_ONE, C_IDENT, SMG_PD_WGRAD, false, decltype(ptag)::value> p{};
                 p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck;
                 p.bbuf = e->X[b]; p.ldb = Ct; p.pb = pl; p.NB = d.cin;
@@ -307,9 +311,9 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 // share 25.68 -> 25.49); SMG_W1_PART=0: the atomics, for A/B (the "deterministic" option overrides it)
                 static const bool w1_atomics = getenv("SMG_W1_PART") && atoi(getenv("SMG_W1_PART")) == 0;
                 const bool w1_part = e->deterministic || (!w1_atomics && NS > 4);      // (a few streams: host-launch-bound - atomics save the 58 reduce launches)
-                launch_wgrad(e, s2, p, dim3(1, nt, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck, 1, C_IDENT, w1_part);
+                return launch_wgrad(e, s2, p, dim3(1, nt, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck, 1, C_IDENT, w1_part);
                 };
-                PREC_DISPATCH(e, go(PTAG));
+                PREC_DISPATCH(e, if (int rc = go(PTAG)) return rc);
                 HIP_OK(hipEventRecord(e->ev_side[db], s2));
             }
         }
@@ -331,10 +335,9 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 p.dw = Gr + T.tconv[b - 1].w; p.ldw_out = Cp;
                 if (fork(e->ev_misc)) return -5;
                 BY(e, ESZ(e) * NS * (2.0 * pl.HW * C0 + (double)pp.HW * Cp));
-                launch_wgrad(e, s2, p, dim3(C0 / 128, Cp / 128, NS * cps), K_TW, 2.0 * NS * pl.HW * Cp * C0, 1, C_IDENT);
-                return 0;
+                return launch_wgrad(e, s2, p, dim3(C0 / 128, Cp / 128, NS * cps), K_TW, 2.0 * NS * pl.HW * Cp * C0, 1, C_IDENT);
                 };
-                PREC_DISPATCH(e, if (go(PTAG)) return -5);
+                PREC_DISPATCH(e, if (int rc = go(PTAG)) return rc);
             }
             if (pp.H != 2 * pl.H || pp.W != 2 * pl.W) {
                 ProfScope ps(e, st, K_OTHER, 0);
@@ -396,22 +399,29 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         p.dw = Gr + T.conv0.w; p.ldw_out = 147;
         if (fork(e->ev_misc)) return -5;
         BY(e, 4.0 * NS * (2.0 * ps_.HW * 64 + (double)e->p_img.HW * (SM == W_STEM1 ? 1 : 4)));
-        launch_wgrad(e, s2, p, dim3(1, 1, NS * cps), K_SW, 2.0 * NS * ps_.HW * 64 * 147, 1, SM == W_STEM1 ? C_STEM1 : C_STEM);
-        return 0;
+        return launch_wgrad(e, s2, p, dim3(1, 1, NS * cps), K_SW, 2.0 * NS * ps_.HW * 64 * 147, 1, SM == W_STEM1 ? C_STEM1 : C_STEM);
         };
-        if (e->f_stem1) { PREC_DISPATCH(e, if (go(PTAG, std::integral_constant<int, W_STEM1>{})) return -5); }
-        else { PREC_DISPATCH(e, if (go(PTAG, std::integral_constant<int, W_STEM>{})) return -5); }
+        if (e->f_stem1) { PREC_DISPATCH(e, if (int rc = go(PTAG, std::integral_constant<int, W_STEM1>{})) return rc); }
+        else { PREC_DISPATCH(e, if (int rc = go(PTAG, std::integral_constant<int, W_STEM>{})) return rc); }
     }
     }   // ph_b: pool0 + stem
-    {   // the trunk's dbeta / dgamma: replicas -> gradient array (and zeroed for the next call)
+    {   // the trunk's dbeta / dgamma: replicas -> gradient array (and zeroed for the next call).  Each half flushes ONLY the segments
+        // it produced - the table holds dense block 1's 2 x 6 segments first, then blocks 2-4 and the transitions - because the
+        // flush is a non-atomic read-modify-write of the gradient array: between the halves of a two-phase backward the ranges
+        // [trunk split, end) + head are being all-reduced IN PLACE on another stream (parallel.OverlappedGradSync), and the second
+        // half must not touch a single element of them (it would re-write a stale local value over the reduced one).
+        const int first_b = 2 * kBlockLayers[0];
+        const int seg0 = ph_b ? 0 : first_b, seg1 = ph_a ? e->n_dbseg : first_b;
         ProfScope ps(e, st, K_OTHER, 0);
-        hipLaunchKernelGGL(db_flush_kernel, dim3(4, e->n_dbseg + 1), dim3(256), 0, st, reinterpret_cast<const DbSegD*>(e->d_dbseg + (size_t)e->f_trunk * e->n_dbseg),
+        hipLaunchKernelGGL(db_flush_kernel, dim3(4, seg1 - seg0 + 1), dim3(256), 0, st,
+                           reinterpret_cast<const DbSegD*>(e->d_dbseg + (size_t)e->f_trunk * e->n_dbseg) + seg0,
                            e->dbscr, e->db_total, kDbRep, Gr,
                            ph_b ? b1(e, e->bs_stem) : nullptr, ph_b ? b2(e, e->bs_stem) : nullptr, NS, Gr + T.norm0.b, Gr + T.norm0.w);
     }
     HIP_OK(hipEventRecord(e->ev_end, s2));          // join: everything after the backward (or this half of it) sees every gradient
     HIP_OK(hipStreamWaitEvent(st, e->ev_end, 0));
     HIP_OK(hipGetLastError());
+    e->bw_phase0_done = phases == 1;
     return 0;
 }
 

@@ -900,7 +900,8 @@ struct BnUpdDesc { int64_t rm, rv, nbt; int64_t stat_off; int stride, coff, C, c
 
 static __global__ void bn_update_kernel(const BnUpdDesc* descs, const double* stats_sum, const double* stats_sq,
                                  float* bufs, int64_t* nbt, const int* seq_trunk, int n_trunk,
-                                 const int* seq_head, int n_head) {
+                                 const int* seq_head, int n_head,
+                                 const int* pair_a, const int* pair_b, int n_pairs, int per_pair, float* q_out) {
     const BnUpdDesc d = descs[blockIdx.y];
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int* seq = d.head ? seq_head : seq_trunk;
@@ -917,6 +918,18 @@ static __global__ void bn_update_kernel(const BnUpdDesc* descs, const double* st
         const double unb = var * (double)d.count / (double)(d.count - 1);
         rm = (double)(float)(0.1 * m + 0.9 * rm);
         rv = (double)(float)(0.1 * unb + 0.9 * rv);
+        // A non-finite batch statistic (NaN / inf anywhere in that channel of that sample) makes every later activation of the
+        // sample NaN in the reference: BN turns the whole channel into NaN, torch's relu / max_pool keep NaN, the next convolution
+        // sums over the channel.  The kernels' v_max_f32 ReLU returns the non-NaN operand instead, so the NaN would die at the
+        // first ReLU and a valid-looking Q come out - a diverged network, or the released mean = std = 0 constants
+        // (code/trainer.py:176-185, golden G2), would go unnoticed.  Restore the reference's result here: Q of every sample that
+        // used the stream (trunk statistics) / of the pair (head statistics) becomes NaN.
+        if (!(m - m == 0.0) || !(var - var == 0.0)) {
+            const int s = seq[i];
+            for (int p = 0; p < n_pairs; ++p)
+                if (d.head ? p == s : (pair_a[p] == s || pair_b[p] == s))
+                    for (int j = 0; j < per_pair; ++j) q_out[(int64_t)p * per_pair + j] = __builtin_nanf("");
+        }
     }
     bufs[d.rm + c] = (float)rm;
     bufs[d.rv + c] = (float)rv;

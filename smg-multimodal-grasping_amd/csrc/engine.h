@@ -140,6 +140,7 @@ struct smg_engine {
     // last forward
     bool have_fwd = false; int f_trunk = 0, f_head = 0, f_streams = 0, f_pairs = 0;
     int bw_layer_no = 0;       // backward ring position, carried from the first half of a two-phase backward to the second
+    bool bw_phase0_done = false;   // smg_backward_phase(0) ran on the last forward and its second half is still due (reset by every forward / precision change)
     bool f_stem1 = false;      // the last forward ran the one-channel stem (heightmap input form): img4 holds [streams][HWp] single floats
     int* d_stream_image = nullptr; int* d_stream_rot = nullptr; int* d_pair_a = nullptr; int* d_pair_b = nullptr;
     int* d_seq_t = nullptr; int* d_seq_h = nullptr; int* d_user_ptr = nullptr; int* d_user_pair = nullptr; int* d_user_slot = nullptr;
@@ -331,11 +332,14 @@ static void launch_gemm_rs(smg_engine* e, hipStream_t st, P p, dim3 grid, int ki
 // Weight-gradient launch: partial tiles to the workspace + one reduce kernel (falls back to
 // atomics if the workspace is too small for this launch).
 template <class P>
-static void launch_wgrad(smg_engine* e, hipStream_t st, P& p, dim3 grid, int kind, double flops, int taps, int cmap, bool use_part = true) {
+static int launch_wgrad(smg_engine* e, hipStream_t st, P& p, dim3 grid, int kind, double flops, int taps, int cmap, bool use_part = true) {
     using C = typename P::Cfg;
     const int64_t ldp = (int64_t)grid.y * C::BN, rowsp = (int64_t)grid.x * C::BM;
     const int64_t need = (int64_t)grid.z * rowsp * ldp;
     p.part = (use_part && need <= e->part_floats) ? e->part : nullptr;
+    if (use_part && !p.part && e->deterministic)      // never a silent loss of the bit-reproducibility the option promises
+        return fail(-12, "deterministic: a weight-gradient launch needs " + std::to_string(need) + " partial-tile floats, the workspace holds " +
+                             std::to_string(e->part_floats) + " (smaller batch per call, or a larger engine)");
     launch_gemm(e, st, p, grid, kind, flops);
     if (p.part) {
         ReduceArgs r;
@@ -346,6 +350,7 @@ static void launch_wgrad(smg_engine* e, hipStream_t st, P& p, dim3 grid, int kin
         ProfScope ps(e, st, kind, 0);
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((total + 63) / 64), dim3(256), 0, st, r);
     }
+    return 0;
 }
 
 // element `elems` of a mode-typed buffer (X, Bt, G, GS, D2): 4-byte elements in mode 0, 2-byte elements in modes 1 / 2

@@ -373,6 +373,7 @@ int smg_engine_set_precision(smg_engine* e, int precision) {
     if (precision && e->generic3x3) return fail(-22, "SMG_GENERIC_3X3 (the generic implicit-GEMM 3x3 path) exists in the fp32-class mode only");
     e->prec = precision;
     e->have_fwd = false;        // activations saved by a forward of another precision are not backward-compatible
+    e->bw_phase0_done = false;
     return 0;
 }
 
@@ -461,7 +462,7 @@ int64_t smg_debug_read(smg_engine* e, const char* name, float* host_out, int64_t
     } else if (s.size() >= 4 && s.substr(0, 2) == "bt") {   // "bt<block>_<layer>" 1-based
         int b = 0, i = 0;
         if (std::sscanf(name, "bt%d_%d", &b, &i) != 2 || b < 1 || b > 4 || i < 1 || i > kBlockLayers[b - 1]) return fail(-22, "bad bt name");
-        src = e->Bt + e->bt_off[b - 1][i - 1]; n = (int64_t)NS * e->p_blk[b - 1].HWp * kBottleneck;
+        src = el(e, e->Bt, e->bt_off[b - 1][i - 1]); n = (int64_t)NS * e->p_blk[b - 1].HWp * kBottleneck;      // bt_off counts ELEMENTS of the mode
     } else return fail(-22, "unknown debug buffer");
     if (!host_out) return n;
     if (cap < n) n = cap;

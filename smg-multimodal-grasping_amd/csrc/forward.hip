@@ -337,10 +337,12 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
         ProfScope ps(e, st, K_OTHER, 0);
         hipLaunchKernelGGL(bn_update_kernel, dim3(8, (unsigned)e->n_bnupd), dim3(256), 0, st,
                            e->d_bnupd + (trunk_id * 3 + head_id) * e->bnupd_stride,
-                           e->fstat, e->fstat + e->fstat_span, net->bufs, net->nbt, e->d_seq_t, n_seq_t, e->d_seq_h, n_seq_h);
+                           e->fstat, e->fstat + e->fstat_span, net->bufs, net->nbt, e->d_seq_t, n_seq_t, e->d_seq_h, n_seq_h,
+                           e->d_pair_a, e->d_pair_b, NP, e->head_out * e->OH * e->OW, q_out);
     }
     HIP_OK(hipGetLastError());
     e->f_stem1 = B->heightmaps_dev && getenv("SMG_STEM3") == nullptr;
+    e->bw_phase0_done = false;
     e->have_fwd = true; e->f_trunk = trunk_id; e->f_head = head_id; e->f_streams = NS; e->f_pairs = NP;
     return 0;
 }

@@ -127,6 +127,7 @@ class _AffordanceNet(nn.Module):
         self._autograd_hook = None
         self._grads_clean = False
         self.precision = "fp32"     # operand precision of the matrix products (set_precision)
+        self._prec_from_cast = False
 
     # ---- initialisation ------------------------------------------------------------------
     def _init_weights(self):
@@ -170,6 +171,7 @@ class _AffordanceNet(nn.Module):
         if name not in smg_hip.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(smg_hip.PRECISIONS))
         self.precision = {0: "fp32", 1: "bf16", 2: "fp16"}[smg_hip.PRECISIONS[name]]
+        self._prec_from_cast = False       # an explicit choice: a later .float() does not undo it (only .half() / .bfloat16() casts are undone)
         self._saved = None
         return self
 
@@ -179,13 +181,16 @@ class _AffordanceNet(nn.Module):
             # model.half() / .bfloat16(): the master copy stays fp32 (like apex O1/O2 keep fp32 weights); only the
             # matrix products change their operand precision
             self.set_precision("bf16" if probe.dtype == torch.bfloat16 else "fp16")
+            self._prec_from_cast = True
             dev = probe.device
             fn = lambda t: t.to(dev)                                     # noqa: E731
         elif probe.dtype != torch.float32:
             raise TypeError("the affordance engine stores fp32 and computes in fp32 / bf16 / fp16 operands; got %s" % probe.dtype)
-        elif self.precision != "fp32" and fn(torch.zeros(1, dtype=torch.float16, device=self._flat_params.device)).dtype == torch.float32:
+        elif (self.precision != "fp32" and self._prec_from_cast
+              and fn(torch.zeros(1, dtype=torch.float16, device=self._flat_params.device)).dtype == torch.float32):
             # model.float() / .to(torch.float32) after a .half(): a dtype cast (it turns a half probe into fp32; a device
-            # move leaves it half) - back to the fp32-class products
+            # move leaves it half) - back to the fp32-class products.  A precision chosen with set_precision() stays: the
+            # common `model.float().cuda()` idiom must not silently change the numerics and speed of configs 3 / 5.
             self.set_precision("fp32")
         self._flat_params = fn(self._flat_params)
         self._flat_bufs = fn(self._flat_bufs)
@@ -202,7 +207,7 @@ class _AffordanceNet(nn.Module):
         new._flat_nbt = self._flat_nbt.clone()
         new._rebind()
         new.gnum_rotations, new.snum_rotations = self.gnum_rotations, self.snum_rotations
-        new.precision = self.precision
+        new.precision, new._prec_from_cast = self.precision, self._prec_from_cast
         return new
 
     def train(self, mode=True):

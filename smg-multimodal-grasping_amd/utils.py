@@ -5,12 +5,54 @@ Same signature and return tuple; the two DEPTH outputs (the 224x224 heightmap Tr
 outputs only feed the reference's Mask R-CNN (code/masks.py, out of scope) and are warped with the
 same inverse map in numpy, nearest to cv2's 8-bit bilinear path (not bit-pinned: OpenCV is not available to pin it).
 
-The rest of the reference's utils.py (grasp-angle heuristics, rotation helpers) is robot-side code and out of scope.
+The rest of the reference's utils.py (grasp-angle heuristics, rotation helpers, CrossEntropyLoss2d) is robot-side / host code
+and is NOT restated here - but this module sits in front of the reference's `utils` on the module path (INTEGRATION.md
+section 1), and the reference's callers need those names from `import utils` (code/robot.py:4,97 `utils.euler2rotm`,
+code/main.py:253,264 `utils.get_best_grasp_angle / get_best_suction_angle`, code/trainer.py:9 `from utils import
+CrossEntropyLoss2d`).  Every attribute this module does not define is therefore FORWARDED to the next `utils` module on
+sys.path (PEP 562 module __getattr__, resolved lazily on first use), so the drop-in shadows `get_heightmap` only.
 """
+import importlib.util
+import os
+import sys
+
 import numpy as np
 import torch
 
 import smg_hip
+
+_NEXT_UTILS = None
+
+
+def _next_utils():
+    """The `utils` module that `import utils` would have found had this directory not been in front of it on sys.path (the
+    reference's code/utils.py in the INTEGRATION.md set-up), loaded under a private name; None if there is none."""
+    global _NEXT_UTILS
+    if _NEXT_UTILS is None:
+        here = os.path.dirname(os.path.abspath(__file__))
+        for d in sys.path:
+            d = os.path.abspath(d or os.getcwd())
+            if d == here:
+                continue
+            for cand in (os.path.join(d, "utils.py"), os.path.join(d, "utils", "__init__.py")):
+                if os.path.isfile(cand):
+                    spec = importlib.util.spec_from_file_location("_smg_forwarded_utils", cand)
+                    mod = importlib.util.module_from_spec(spec)
+                    spec.loader.exec_module(mod)
+                    _NEXT_UTILS = mod
+                    return mod
+        _NEXT_UTILS = False
+    return _NEXT_UTILS or None
+
+
+def __getattr__(name):
+    if name.startswith("__") and name.endswith("__"):
+        raise AttributeError(name)
+    nxt = _next_utils()
+    if nxt is None or not hasattr(nxt, name):
+        raise AttributeError("module 'utils' (MI355X drop-in: get_heightmap) has no attribute %r, and no other `utils` module on "
+                             "sys.path provides it" % name)
+    return getattr(nxt, name)
 
 HEIGHTMAP_SIZE = (224, 224)      # code/utils.py:41-42
 COLORMASK_SIZE = (448, 448)
