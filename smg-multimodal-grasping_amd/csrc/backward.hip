@@ -34,6 +34,8 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
     const Plane p4 = e->p_blk[3];
     const bool ph_a = phases & 1, ph_b = phases & 2;
     if (ph_a) HIP_OK(hipMemset2DAsync(e->bstat, kStatRepStride * sizeof(double), 0, 2 * e->bstat_span * sizeof(double), kStatRep, st));      // every replica
+    const bool split16 = e->prec == 0 && kSplitOp == 3;      // the hot classes run on fp16-split operands scaled by recorded maxima
+    if (ph_a && split16) HIP_OK(hipMemsetAsync(e->gamax, 0, (size_t)e->gamax_words * sizeof(unsigned), st));
     // Weight-gradient kernels only read what the data-gradient chain produces and write disjoint
     // gradient ranges, so they run on a second stream beside it (their MFMA/L2-bound phases overlap the
     // HBM-bound epilogues of the data-gradient kernels).  While profiling everything is serialised on
@@ -130,17 +132,18 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             gsrc.s1 = b1(e, e->bs_X[b]) + d.cin; gsrc.s2 = b2(e, e->bs_X[b]) + d.cin; gsrc.sstride = Ct; gsrc.eps = kEps;
             static const bool gs_env_fused = getenv("SMG_GS_FUSED") != nullptr;
             static const int gs_fused_hw = getenv("SMG_GS_FUSED_HW") ? atoi(getenv("SMG_GS_FUSED_HW")) : 0;   // dev A/B: fuse on planes up to this many pixels
-            const bool gs_mat = !gs_env_fused && NS > 4 && pl.HW > gs_fused_hw;      // few streams: launch-bound, the fused form wins (8.78 -> 8.56 ms per sample)
+            // (operand kind 3 needs the finished gradient's recorded maximum: always materialised there)
+            const bool gs_mat = split16 || (!gs_env_fused && NS > 4 && pl.HW > gs_fused_hw);      // few streams: launch-bound, the fused form wins (8.78 -> 8.56 ms per sample)
             if (e->generic3x3 || gs_mat) {
                 BnBwdApplyArgs a{};
                 a.g = e->G[b]; a.ldg = Ct; a.gcoff = d.cin; a.x = e->X[b]; a.ldx = Ct; a.xcoff = d.cin; a.pl = pl; a.C = kGrowth;
                 a.xsum = fsum(e, e->st_X[b]); a.xsq = fsq(e, e->st_X[b]); a.xstride = Ct; a.xtab = use_tabs ? stat_table(e, e->sx_tab[b], e->max_streams, Ct) : StatTab{};
                 a.s1 = b1(e, e->bs_X[b]); a.s2 = b2(e, e->bs_X[b]); a.sstride = Ct; a.scoff = d.cin; a.gamma = nullptr; a.eps = kEps;
-                a.out = GSb; a.ldo = kGrowth;
+                a.out = GSb; a.ldo = kGrowth; a.amax = split16 ? gamax_of(e, b, i, 0) : nullptr;
                 BY(e, ESZ(e) * NS * pl.HW * 3 * kGrowth);
                 ProfScope ps(e, st, K_OTHER, 0);
                 PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_bwd_apply_kernel<PREC>), dim3((pl.HWp + bn_apply_rows(PREC) - 1) / bn_apply_rows(PREC), NS), dim3(256), 0, st, a));
-                if (gs_mat) { gsrc = GradSrc{}; gsrc.g = GSb; gsrc.ldg = kGrowth; }
+                if (gs_mat) { gsrc = GradSrc{}; gsrc.g = GSb; gsrc.ldg = kGrowth; gsrc.amax = gamax_of(e, b, i, 0); }
             }
             if (fork(e->ev_gs[db])) return -5;
             if (!e->generic3x3) {
@@ -191,6 +194,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 a.g = gsrc; a.pl = pl; a.src = bt; a.C = kBottleneck;
                 const int th = 8;                              // tiles are ts x 8 pixels
                 a.bt = bn_table(e, e->sb_tab[b][i], e->max_streams, 0, kBottleneck, P + d.n2.w, P + d.n2.b);
+                a.asc = asc_n2(e, b, i);
                 a.part = e->part; a.tiles_x = (pl.W + ts - 1) / ts; a.n_tiles = ((pl.H + th - 1) / th) * a.tiles_x;
                 a.tiles_per_wg = w3_tiles_per_wg(a.n_tiles, ts, NS, e->part_floats, (double)ts / th);
                 const int groups = (a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
@@ -229,7 +233,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 a.g = D2b; a.ldg = kBottleneck; a.gcoff = 0; a.x = bt; a.ldx = kBottleneck; a.xcoff = 0; a.pl = pl; a.C = kBottleneck;
                 a.xsum = fsum(e, e->st_Bt[b][i]); a.xsq = fsq(e, e->st_Bt[b][i]); a.xstride = kBottleneck; a.xtab = (use_tabs && !e->generic3x3) ? stat_table(e, e->sb_tab[b][i], e->max_streams, kBottleneck) : StatTab{};
                 a.s1 = b1(e, e->bs_Bt[b][i]); a.s2 = b2(e, e->bs_Bt[b][i]); a.sstride = kBottleneck; a.scoff = 0;
-                a.gamma = P + d.n2.w; a.eps = kEps; a.out = D2b; a.ldo = kBottleneck;
+                a.gamma = P + d.n2.w; a.eps = kEps; a.out = D2b; a.ldo = kBottleneck; a.amax = split16 ? gamax_of(e, b, i, 1) : nullptr;
                 if (!e->generic3x3) { a.dbeta = Gr + d.n2.b; a.dgamma = Gr + d.n2.w; }   // the halo dgrad leaves these to us
                 BY(e, ESZ(e) * NS * pl.HW * 3 * kBottleneck);
                 ProfScope ps(e, st, K_OTHER, 0);
@@ -248,7 +252,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 auto run = [&](auto tag, auto ptag) {
                     using Cfg = MC<decltype(tag), decltype(ptag)::value>;
                     BwdDataP<Cfg, false, E_ACCUM, false, decltype(ptag)::value> p{};
-                    p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kBottleneck;
+                    p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kBottleneck; p.gamax = gamax_of(e, b, i, 1);
                     p.wp = e->packed_u + e->pk_d1[b][i]; p.K8tot = kBottleneck / 8; p.ldn = d.cin; p.wcol0 = cs; p.N = d.cin - cs;
                     p.mbuf = e->X[b]; p.ldm = Ct; p.mcoff = cs; p.pm = pl;
                     p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct; p.mtab = use_tabs ? stat_table(e, e->sx_tab[b], e->max_streams, Ct) : StatTab{};
@@ -270,7 +274,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                     for (int k = 0; k < p.nseg; ++k) {                  // layer g_lo + k ran (k layers) before this one
                         const DenseLayerRef& dk = T.layers[b][g_lo + k];
                         const int slot = (layer_no - 1 - k + kRing * 4) % kRing;
-                        p.seg[k].g = e->D2[slot]; p.seg[k].wp = e->packed_u + e->pk_d1[b][g_lo + k]; p.seg[k].ldn = dk.cin;
+                        p.seg[k].g = e->D2[slot]; p.seg[k].wp = e->packed_u + e->pk_d1[b][g_lo + k]; p.seg[k].ldn = dk.cin; p.seg[k].amax = gamax_of(e, b, g_lo + k, 1);
                         p.seg[k].gamma = P + dk.n1.w; p.seg[k].beta = P + dk.n1.b;
                         p.seg[k].dbeta = e->dbscr + e->db_off[b][g_lo + k]; p.seg[k].dgamma = e->dbscr + e->db_off[b][g_lo + k] + dk.cin;
                     }
@@ -299,7 +303,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 pick_chunk(pl, NS, nt, chunk, cps, pl.HW <= 1600 ? (getenv("SMG_W1_WGS_SMALL") ? w1_small : w1_prec) : w1_prec);   // 256..384 measure the same (22.46 ms per step), 512: 22.6, 768: 22.8, 1024: 23.2
                 auto go = [&](auto ptag) -> int {
                 BwdWeightP<MC<Cfg, decltype(ptag)::value>, W_ONE, C_IDENT, SMG_PD_WGRAD, false, decltype(ptag)::value> p{};
-                p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck;
+                p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck; p.gamax = gamax_of(e, b, i, 1); p.basc = asc_n1(e, b, i);
                 p.bbuf = e->X[b]; p.ldb = Ct; p.pb = pl; p.NB = d.cin;
                 p.bsum = fsum(e, e->st_X[b]); p.bsq = fsq(e, e->st_X[b]); p.bstride = Ct; p.btab = use_tabs ? stat_table(e, e->sx_tab[b], e->max_streams, Ct) : StatTab{};
                 p.bgamma = P + d.n1.w; p.bbeta = P + d.n1.b; p.eps = kEps;

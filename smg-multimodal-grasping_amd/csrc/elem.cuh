@@ -95,7 +95,51 @@ static __global__ void prep_rotate_kernel(const PrepArgs a) {
 //   PK_HF / PK_HD: the per-stage LDS images of the LDS-halo 3x3 kernels; PK_HEAD: the value convolution's fp32 layout.
 // ------------------------------------------------------------------------------------
 enum { PK_T1 = 0, PK_D1 = 1, PK_3F = 2, PK_3D = 3, PK_STEM = 4, PK_HEAD = 5, PK_HF = 6, PK_HD = 7, PK_STEM1 = 8 };
-struct PackDesc { int64_t src, dst; int cout, cin, mode, K8tot, N, count; };   // dst: unit offset (split modes) / float offset (fp32 modes)
+struct PackDesc { int64_t src, dst; int cout, cin, mode, K8tot, N, count, op0; };   // dst: unit offset (split modes) / float offset (fp32 modes); op0: operand kind of the pack in precision mode 0 (0 = 3-piece bf16 split, 3 = 2-piece fp16 split with a header unit at dst - 1)
+
+// Scales of operand kind 3 (gemm.cuh), one launch per forward in front of pack_weights_kernel:
+//   blockIdx.y <  n_pack: the weight tensor of pack descriptor y (kind-3 packs only): s = 2^(13 - floor(log2 max|w|)) -> header
+//                         unit {s, 1 / s, 0, 0} in front of the pack
+//   blockIdx.y >= n_pack: BatchNorm + ReLU operand y - n_pack: m = max_c hypot(gamma_c, beta_c), s = 2^(4 - floor(log2 m))
+//                         (m * s in [16, 32)) -> asc[2 * (y - n_pack)] = {s, 1 / s}
+struct ActScaleDesc { int64_t gamma, beta; int C; };
+static __global__ void scale_kernel(const PackDesc* descs, int n_pack, const ActScaleDesc* adescs, const float* params, u32x4* packed_u,
+                                    float* asc, int prec) {
+    __shared__ float red[4];
+    const int t = threadIdx.x, y = blockIdx.y;
+    float m = 0.f;
+    int target;
+    if (y < n_pack) {
+        const PackDesc d = descs[y];
+        if (prec != 0 || d.op0 != 3) return;               // (workgroup-uniform)
+        const int taps = (d.mode == PK_3F || d.mode == PK_3D || d.mode == PK_HF || d.mode == PK_HD) ? 9 : 1;
+        const int64_t count = (int64_t)d.cout * d.cin * taps;
+        const float* w = params + d.src;
+        for (int64_t i = t; i < count; i += 256) m = fmaxf(m, fabsf(w[i]));
+        target = 13;
+    } else {
+        const ActScaleDesc d = adescs[y - n_pack];
+        for (int c = t; c < d.C; c += 256) { const float g = params[d.gamma + c], b = params[d.beta + c]; m = fmaxf(m, g * g + b * b); }
+        m = sqrtf(m);
+        target = 4;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((t & 63) == 0) red[t >> 6] = m;
+    __syncthreads();
+    if (t == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        int e = (int)(__float_as_uint(m) >> 23) - 127;     // floor(log2 m); 0, subnormal or non-finite maxima: scale 1
+        float sc = 1.f, inv = 1.f;
+        if (m > 0.f && e > -100 && e < 100) { sc = __uint_as_float((unsigned)(127 + target - e) << 23); inv = __uint_as_float((unsigned)(127 - target + e) << 23); }
+        if (y < n_pack) {
+            float* h = reinterpret_cast<float*>(packed_u + descs[y].dst - 1);
+            h[0] = sc; h[1] = inv; h[2] = 0.f; h[3] = 0.f;
+        } else {
+            asc[2 * (y - n_pack)] = sc; asc[2 * (y - n_pack) + 1] = inv;
+        }
+    }
+}
 
 // prec: the engine's precision mode.  Operand kind of a pack: the forward packs (PK_T1, PK_STEM, PK_3F, PK_HF) take the
 // forward kind (3-piece split / bf16 / fp16), the data-gradient packs (PK_D1, PK_3D, PK_HD) the backward kind (split / bf16).
@@ -115,14 +159,15 @@ static __global__ void pack_weights_kernel(const PackDesc* descs, const float* p
         return;
     }
     const bool bwd = d.mode == PK_D1 || d.mode == PK_3D || d.mode == PK_HD;
-    const int op = bwd ? (prec ? 1 : 0) : prec;    // 0 split, 1 bf16, 2 fp16
-    const int np = op ? 1 : NPIECE;
+    const int op = prec == 0 ? d.op0 : (bwd ? 1 : prec);    // 0 bf16 split (3 pieces), 1 bf16, 2 fp16, 3 fp16 split (2 pieces, scaled)
+    const int np = np_of(op);
     const int total = d.K8tot * d.N;               // units per piece
     u32x4* o = packed_u + d.dst;
+    const float wsc = op == 3 ? reinterpret_cast<const float*>(o - 1)[0] : 1.f;      // header written by scale_kernel
     auto put = [&](const float (&v)[8], int64_t base, int64_t pstride) {
-        const float4 v0 = make_float4(v[0], v[1], v[2], v[3]), v1 = make_float4(v[4], v[5], v[6], v[7]);
-        const Split4 lo = op == 0 ? split4<0>(v0) : op == 1 ? split4<1>(v0) : split4<2>(v0);
-        const Split4 hi = op == 0 ? split4<0>(v1) : op == 1 ? split4<1>(v1) : split4<2>(v1);
+        const float4 v0 = make_float4(v[0] * wsc, v[1] * wsc, v[2] * wsc, v[3] * wsc), v1 = make_float4(v[4] * wsc, v[5] * wsc, v[6] * wsc, v[7] * wsc);
+        const Split4 lo = op == 0 ? split4<0>(v0) : op == 1 ? split4<1>(v0) : op == 2 ? split4<2>(v0) : split4<3>(v0);
+        const Split4 hi = op == 0 ? split4<0>(v1) : op == 1 ? split4<1>(v1) : op == 2 ? split4<2>(v1) : split4<3>(v1);
 #pragma unroll
         for (int pc = 0; pc < NPIECE; ++pc)
             if (pc < np) o[base + pc * pstride] = u32x4{lo.p[pc].x, lo.p[pc].y, hi.p[pc].x, hi.p[pc].y};
@@ -692,6 +737,8 @@ struct BnBwdApplyArgs {
     void* out; int ldo;
     float* dbeta; float* dgamma;                  // if set: the affine gradients, dbeta += sum_n s1[n], dgamma += sum_n s2[n]
                                                   // (one fp32 atomic per stream and channel instead of one per producer tile)
+    unsigned* amax;                               // if set: [streams][kAmaxRep] - the largest |out| of each stream as float bits (atomicMax per
+                                                  // workgroup): the scale of the consumers' fp16-split operand (gemm.cuh, operand kind 3)
 };
 
 // rows of a plane per workgroup: the 16-bit modes move half the bytes per row, so a workgroup takes twice the rows
@@ -736,17 +783,33 @@ static __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApp
         }
     }
     __syncthreads();
+    float vmax = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int r = r0 + k * rows_per_pass;
         if (k * rows_per_pass < RPW && r < a.pl.HW) {
             const int64_t pix = (int64_t)n * a.pl.HWp + r;
             if constexpr (E == 4) {
-                stq<GT>(a.out, pix * a.ldo + 4 * cs, affine2(gv[k], xv[k], prm + 4 * cs, a.C));
+                const float4 o = affine2(gv[k], xv[k], prm + 4 * cs, a.C);
+                stq<GT>(a.out, pix * a.ldo + 4 * cs, o);
+                vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
             } else {
                 const u32x4 u = pack_unit<1>(affine2(slot_quad<GT>(gv[k], 0), slot_quad<XT>(xv[k], 0), prm + 8 * cs, a.C),
                                              affine2(slot_quad<GT>(gv[k], 1), slot_quad<XT>(xv[k], 1), prm + 8 * cs + 4, a.C));   // gradients: bf16
                 *reinterpret_cast<u32x4*>(static_cast<char*>(a.out) + (int64_t)GT::size * (pix * a.ldo + 8 * cs)) = u;
+            }
+        }
+    }
+    if constexpr (E == 4) {
+        if (a.amax) {                             // (launch-uniform) largest |out| of the workgroup -> this stream's replica
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+            __syncthreads();                      // prm is free again
+            if ((t & 63) == 0) prm[t >> 6] = vmax;
+            __syncthreads();
+            if (t == 0) {
+                vmax = fmaxf(fmaxf(prm[0], prm[1]), fmaxf(prm[2], prm[3]));
+                if (vmax > 0.f) atomicMax(a.amax + (int64_t)n * kAmaxRep + (blockIdx.x % kAmaxRep), __float_as_uint(vmax));
             }
         }
     }

@@ -131,6 +131,11 @@ struct smg_engine {
     int64_t pk_conv0 = 0, pk_conv0_1 = 0, pk_head0 = 0, pk_hd0 = 0, pk_head1 = 0;
     std::vector<int64_t> pk_c1[4], pk_d1[4], pk_g3f[4], pk_g3d[4], pk_hf[4], pk_hd[4]; int64_t pk_t[3] = {}, pk_td[3] = {};
     int max_pack = 0;
+    // operand kind 3 (gemm.cuh): activation scales {s, 1 / s} per BatchNorm + ReLU operand (norm1 / norm2 of every dense layer, the
+    // transition norms, the head's norm0), written by scale_kernel at the start of every forward from the descriptor table of
+    // the (trunk, head) in use; recorded gradient maxima per (dense layer, GS | D2, stream), zeroed at the start of a backward
+    float* asc = nullptr; ActScaleDesc* d_asc = nullptr; int n_asc = 0;
+    unsigned* gamax = nullptr; int64_t gamax_words = 0;
     // BN statistics as fp32 tables (mean | invstd, [rows][C] each): one per dense-block buffer, one per bottleneck, one
     // for the head's features; written by the first consumer of a channel (BnTab, gemm.cuh), kept until the backward
     float* stab = nullptr; int64_t stab_floats = 0;
@@ -363,6 +368,18 @@ static inline double* b1(smg_engine* e, const StatArr& s) { return e->bstat + s.
 static inline double* b2(smg_engine* e, const StatArr& s) { return e->bstat + e->bstat_span + s.off; }
 
 static const float kEps = 1e-5f;
+
+// indices into the activation-scale table / the gradient-maximum buffer
+static inline int layer_seq(int b, int i) { static const int first[4] = {0, 6, 18, 42}; return first[b] + i; }
+constexpr int kDenseLayers = 58;
+static inline const float* asc_n1(const smg_engine* e, int b, int i) { return e->asc + 2 * (2 * layer_seq(b, i)); }
+static inline const float* asc_n2(const smg_engine* e, int b, int i) { return e->asc + 2 * (2 * layer_seq(b, i) + 1); }
+static inline const float* asc_trans(const smg_engine* e, int b) { return e->asc + 2 * (2 * kDenseLayers + b); }
+static inline const float* asc_head0(const smg_engine* e) { return e->asc + 2 * (2 * kDenseLayers + 3); }
+// kind 0: GS (finished gradient of the layer's 32 output channels), 1: D2 (finished bottleneck gradient)
+static inline unsigned* gamax_of(const smg_engine* e, int b, int i, int kind) {
+    return e->gamax + ((int64_t)(2 * layer_seq(b, i) + kind) * e->max_streams) * kAmaxRep;
+}
 
 // BN statistics table at float offset `at` of the table arena ([rows_max][C] mean, then invstd), from row r0 on, with the
 // affine parameters of the consuming BatchNorm

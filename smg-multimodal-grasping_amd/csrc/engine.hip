@@ -125,8 +125,11 @@ static int engine_build(smg_engine* e) {
 
     // packed weights + descriptor tables (one table per trunk, one per head)
     int64_t pku = 0, pkf = 0;
-    auto add_units = [&](std::vector<PackDesc>& v, int64_t src, int cout, int cin, int mode, int K, int N) {
-        PackDesc d{}; d.src = src; d.dst = pku; d.cout = cout; d.cin = cin; d.mode = mode; d.K8tot = K / 8; d.N = N; d.count = 0;
+    // op0: operand kind of the pack in precision mode 0 (kSplitOp for the hot classes' operands, 0 otherwise).  Every pack is
+    // preceded by one header unit (the kind-3 scale of the tensor, scale_kernel); the returned offset is the first data unit.
+    auto add_units = [&](std::vector<PackDesc>& v, int64_t src, int cout, int cin, int mode, int K, int N, int op0 = 0) {
+        pku += 1;
+        PackDesc d{}; d.src = src; d.dst = pku; d.cout = cout; d.cin = cin; d.mode = mode; d.K8tot = K / 8; d.N = N; d.count = 0; d.op0 = op0;
         v.push_back(d); int64_t at = pku; pku += (int64_t)NPIECE * (K / 8) * N; return at;
     };
     auto add_f32 = [&](std::vector<PackDesc>& v, int64_t src, int cout, int cin, int mode, int64_t count) {
@@ -143,13 +146,13 @@ static int engine_build(smg_engine* e) {
             if (t == 0) { e->pk_c1[b].clear(); e->pk_d1[b].clear(); e->pk_g3f[b].clear(); e->pk_g3d[b].clear(); e->pk_hf[b].clear(); e->pk_hd[b].clear(); }
             for (size_t i = 0; i < T.layers[b].size(); ++i) {
                 const DenseLayerRef& d = T.layers[b][i];
-                int64_t a1 = add_units(v, d.c1.w, kBottleneck, d.cin, PK_T1, d.cin, kBottleneck);
-                int64_t a1d = add_units(v, d.c1.w, kBottleneck, d.cin, PK_D1, kBottleneck, d.cin);
+                int64_t a1 = add_units(v, d.c1.w, kBottleneck, d.cin, PK_T1, d.cin, kBottleneck, kSplitOp);
+                int64_t a1d = add_units(v, d.c1.w, kBottleneck, d.cin, PK_D1, kBottleneck, d.cin, kSplitOp);
                 int64_t g2 = 0, g3 = 0;
-                const int64_t hf = add_units(v, d.c2.w, kGrowth, kBottleneck, PK_HF, 9 * kBottleneck, kGrowth);
-                const int64_t hd = add_units(v, d.c2.w, kGrowth, kBottleneck, PK_HD, 9 * kGrowth, kBottleneck);
+                const int64_t hf = add_units(v, d.c2.w, kGrowth, kBottleneck, PK_HF, 9 * kBottleneck, kGrowth, kSplitOp);
+                const int64_t hd = add_units(v, d.c2.w, kGrowth, kBottleneck, PK_HD, 9 * kGrowth, kBottleneck, kSplitOp);
                 if (e->generic3x3) {
-                    g2 = add_units(v, d.c2.w, kGrowth, kBottleneck, PK_3F, 9 * kBottleneck, kGrowth);
+                    g2 = add_units(v, d.c2.w, kGrowth, kBottleneck, PK_3F, 9 * kBottleneck, kGrowth, kSplitOp);      // (FwdConvP F_THREE: a forward policy)
                     g3 = add_units(v, d.c2.w, kGrowth, kBottleneck, PK_3D, 9 * kGrowth, kBottleneck);
                 }
                 if (t == 0) {
@@ -158,7 +161,7 @@ static int engine_build(smg_engine* e) {
                 }
             }
             if (b < 3) {
-                e->pk_t[b] = add_units(v, T.tconv[b].w, T.tconv[b].cout, T.tconv[b].cin, PK_T1, T.tconv[b].cin, T.tconv[b].cout);
+                e->pk_t[b] = add_units(v, T.tconv[b].w, T.tconv[b].cout, T.tconv[b].cin, PK_T1, T.tconv[b].cin, T.tconv[b].cout, kSplitOp);
                 e->pk_td[b] = add_units(v, T.tconv[b].w, T.tconv[b].cout, T.tconv[b].cin, PK_D1, T.tconv[b].cout, T.tconv[b].cin);
             }
         }
@@ -168,7 +171,7 @@ static int engine_build(smg_engine* e) {
         pku = trunk_pku; pkf = trunk_pkf;
         const HeadRef& H = L.head[hd];
         std::vector<PackDesc>& v = e->h_pack_head[hd];
-        e->pk_head0 = add_units(v, H.c0.w, kHeadMid, 2 * kFeat, PK_T1, 2 * kFeat, kHeadMid);
+        e->pk_head0 = add_units(v, H.c0.w, kHeadMid, 2 * kFeat, PK_T1, 2 * kFeat, kHeadMid, kSplitOp);
         e->pk_hd0 = add_units(v, H.c0.w, kHeadMid, 2 * kFeat, PK_D1, kHeadMid, 2 * kFeat);
         e->pk_head1 = add_f32(v, H.c1.w, e->head_out, kHeadMid, PK_HEAD, H.c1.count());
     }
@@ -188,6 +191,32 @@ static int engine_build(smg_engine* e) {
             v.insert(v.end(), e->h_pack_head[hd].begin(), e->h_pack_head[hd].end());
             HIP_OK(hipMemcpy(e->d_pack + (t * 3 + hd) * e->pack_stride, v.data(), v.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
         }
+    {   // activation-scale descriptors (gamma / beta of every BN + ReLU operand of a matrix product), one table per (trunk, head)
+        e->n_asc = 2 * kDenseLayers + 4;
+        ALLOC(e->asc, 2 * e->n_asc);
+        ALLOC(e->d_asc, 9 * e->n_asc);
+        std::vector<float> ones(2 * e->n_asc, 1.f);
+        HIP_OK(hipMemcpy(e->asc, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
+        for (int t = 0; t < 3; ++t)
+            for (int hd = 0; hd < 3; ++hd) {
+                const TrunkRef& T = L.trunk[t];
+                const HeadRef& Hd = L.head[hd];
+                if ((int)T.layers[0].size() != kBlockLayers[0]) continue;      // trunk slot not used by this net
+                std::vector<ActScaleDesc> v;
+                for (int b = 0; b < 4; ++b)
+                    for (size_t i = 0; i < T.layers[b].size(); ++i) {
+                        v.push_back(ActScaleDesc{T.layers[b][i].n1.w, T.layers[b][i].n1.b, T.layers[b][i].cin});
+                        v.push_back(ActScaleDesc{T.layers[b][i].n2.w, T.layers[b][i].n2.b, kBottleneck});
+                    }
+                for (int b = 0; b < 3; ++b) v.push_back(ActScaleDesc{T.tnorm[b].w, T.tnorm[b].b, kBlockCtot[b]});
+                v.push_back(ActScaleDesc{Hd.n0.w, Hd.n0.b, 2 * kFeat});
+                if ((int)v.size() != e->n_asc) return fail(-22, "activation-scale table size");
+                HIP_OK(hipMemcpy(e->d_asc + (t * 3 + hd) * e->n_asc, v.data(), v.size() * sizeof(ActScaleDesc), hipMemcpyHostToDevice));
+            }
+        e->gamax_words = (int64_t)2 * kDenseLayers * NS * kAmaxRep;
+        ALLOC(e->gamax, e->gamax_words);
+        HIP_OK(hipMemset(e->gamax, 0, (size_t)e->gamax_words * sizeof(unsigned)));
+    }
     e->bnupd_stride = 128;
     ALLOC(e->d_bnupd, 9 * e->bnupd_stride);
     for (int t = 0; t < 3; ++t)
@@ -302,7 +331,7 @@ void smg_engine_destroy(smg_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     void* ptrs[] = {e->img4, e->stem, e->DY0, e->argmax, e->X[0], e->X[1], e->X[2], e->X[3], e->G[0], e->G[1], e->G[2], e->G[3],
-                    e->Bt, e->part, e->F, e->DF, e->H1, e->DH1, e->fstat, e->bstat, e->dbscr, e->d_dbseg, e->packed_u, e->packed_f, e->stab, e->d_pack, e->d_bnupd,
+                    e->Bt, e->part, e->F, e->DF, e->H1, e->DH1, e->fstat, e->bstat, e->dbscr, e->d_dbseg, e->asc, e->d_asc, e->gamax, e->packed_u, e->packed_f, e->stab, e->d_pack, e->d_bnupd,
                     e->d_stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) { if (e->h_stage[k]) (void)hipHostFree(e->h_stage[k]); if (e->ev_stage[k]) (void)hipEventDestroy(e->ev_stage[k]); }
@@ -463,6 +492,17 @@ int64_t smg_debug_read(smg_engine* e, const char* name, float* host_out, int64_t
         int b = 0, i = 0;
         if (std::sscanf(name, "bt%d_%d", &b, &i) != 2 || b < 1 || b > 4 || i < 1 || i > kBlockLayers[b - 1]) return fail(-22, "bad bt name");
         src = el(e, e->Bt, e->bt_off[b - 1][i - 1]); n = (int64_t)NS * e->p_blk[b - 1].HWp * kBottleneck;      // bt_off counts ELEMENTS of the mode
+    } else if (s.size() >= 6 && s.substr(0, 5) == "fs_bt") {   // "fs_bt<block>_<layer>": the fp64 forward sums of that bottleneck, raw doubles [sum | sumsq][streams][128] in the float buffer
+        int b = 0, i = 0;
+        if (std::sscanf(name, "fs_bt%d_%d", &b, &i) != 2 || b < 1 || b > 4 || i < 1 || i > kBlockLayers[b - 1]) return fail(-22, "bad fs_bt name");
+        n = (int64_t)4 * NS * kBottleneck;                     // floats = 2 x doubles
+        if (!host_out) return n;
+        if (cap < n) return fail(-22, "fs_bt: buffer too small");
+        HIP_OK(hipSetDevice(e->device));
+        HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+        HIP_OK(hipMemcpy(host_out, fsum(e, e->st_Bt[b - 1][i - 1]), (size_t)NS * kBottleneck * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(host_out + 2 * NS * kBottleneck, fsq(e, e->st_Bt[b - 1][i - 1]), (size_t)NS * kBottleneck * sizeof(double), hipMemcpyDeviceToHost));
+        return n;
     } else return fail(-22, "unknown debug buffer");
     if (!host_out) return n;
     if (cap < n) n = cap;

@@ -63,6 +63,12 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
     // weights -> K-major packs
     {
         const unsigned n_pack = (unsigned)(e->h_pack[trunk_id].size() + e->h_pack_head[head_id].size());
+        if (e->prec == 0 && kSplitOp == 3) {       // scales of the fp16-split operands: weight headers + activation scales (gemm.cuh, operand kind 3)
+            ProfScope ps(e, st, K_OTHER, 0);
+            hipLaunchKernelGGL(scale_kernel, dim3(1, n_pack + (unsigned)e->n_asc), dim3(256), 0, st,
+                               e->d_pack + (trunk_id * 3 + head_id) * e->pack_stride, (int)n_pack, e->d_asc + (trunk_id * 3 + head_id) * e->n_asc,
+                               net->params, e->packed_u, e->asc, e->prec);
+        }
         ProfScope ps(e, st, K_OTHER, 0);
         hipLaunchKernelGGL(pack_weights_kernel, dim3(64, n_pack), dim3(256), 0, st,
                            e->d_pack + (trunk_id * 3 + head_id) * e->pack_stride, net->params, e->packed_u, e->packed_f, e->prec);
@@ -146,7 +152,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                         using Cfg0 = decltype(tag);
                         using Cfg = MC<Cfg0, decltype(ptag)::value, (Cfg0::BK < 32 ? 2 : 1)>;      // (cin is a multiple of 32 only)
                         FwdConvP<Cfg, F_ONE, decltype(ptag)::value> p{};
-                        p.src = xs(b); p.lds_ = Ct; p.ps = pl; p.po = pl; p.K = d.cin;
+                        p.src = xs(b); p.lds_ = Ct; p.ps = pl; p.po = pl; p.K = d.cin; p.asc = asc_n1(e, b, (int)i);
                         p.bt = t1; p.fresh0 = i == 0 ? d.cin : d.cin - kGrowth; p.fsum = xsum; p.fsq = xsq; p.fstride = Ct; p.eps = kEps;
                         p.tw_mean = const_cast<float*>(t1.mean); p.tw_invstd = const_cast<float*>(t1.invstd);
                         p.wp = e->packed_u + e->pk_c1[b][i]; p.K8tot = d.cin / 8; p.N = kBottleneck;
@@ -165,30 +171,12 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                     static const int mid = getenv("SMG_C1_MID") ? atoi(getenv("SMG_C1_MID")) : 0;                     // dev A/B
                     static const int deep_min = getenv("SMG_C1_DEEP") ? atoi(getenv("SMG_C1_DEEP")) : 1 << 30;       // dev A/B
                     static const bool ws_on = !(getenv("SMG_C1_WS") && atoi(getenv("SMG_C1_WS")) == 0);      // wave-specialised 64x64x32 (ws.cuh); SMG_C1_WS=0: the generic kernel (A/B, cross-check)
-                    static const int rs_on = getenv("SMG_C1_RS") ? atoi(getenv("SMG_C1_RS")) : 0;       // 1: row-streaming 1x1 forward (gemm_tile_rs) where it measured ahead - off by default: the step is the same within noise; cross-checked in test_alternative_kernel_paths_agree
-                    static const int rs_mink = getenv("SMG_C1_RS_MINK") ? atoi(getenv("SMG_C1_RS_MINK")) : 256;   // measured: the row-streaming loop wins on long K
-                    static const int rs_minhw = getenv("SMG_C1_RS_MINHW") ? atoi(getenv("SMG_C1_RS_MINHW")) : 1600;  // (blocks 2-3: -4 % / -10 %), loses on K < 256 (block 1: +10 %, 2 instead of 3 workgroups per CU under a store-heavy epilogue) and on the 20^2 planes (too few workgroups)
-                    if (rs_on && e->prec == 0 && pl.HWp % 64 == 0 && d.cin >= rs_mink && pl.HW >= rs_minhw) {
-                        auto run_rs = [&](auto tag) {
-                            using Cfg = decltype(tag);
-                            FwdConvP<Cfg, F_ONE, 0> p{};
-                            p.src = xs(b); p.lds_ = Ct; p.ps = pl; p.po = pl; p.K = d.cin;
-                            p.bt = t1; p.fresh0 = i == 0 ? d.cin : d.cin - kGrowth; p.fsum = xsum; p.fsq = xsq; p.fstride = Ct; p.eps = kEps;
-                            p.tw_mean = const_cast<float*>(t1.mean); p.tw_invstd = const_cast<float*>(t1.invstd);
-                            p.wp = e->packed_u + e->pk_c1[b][i]; p.K8tot = d.cin / 8; p.N = kBottleneck;
-                            p.dst = bt; p.ldd = kBottleneck; p.dcoff = 0;
-                            p.dsum = bsum; p.dsq = bsq; p.dstride = kBottleneck;
-                            BY(e, ESZ(e) * ns * pl.HW * (d.cin + kBottleneck));
-                            launch_gemm_rs(e, cs, p, dim3(ns * pl.HWp / Cfg::BM, 1), K_C1, 2.0 * ns * pl.HW * d.cin * kBottleneck);
-                        };
-                        if (pl.HWp % 128 == 0) run_rs(CfgR128x128{}); else run_rs(CfgR64x128{});
-                    } else
                     if (ws_on && e->prec == 0 && !(pl.HWp % 128 == 0 && wg128 >= small_wgs) && wg64 >= small_wgs && d.cin % 32 == 0 && pl.HWp % 64 == 0) {
                         Fwd1x1WsArgs a{};
                         a.src = xs(b); a.lds_ = Ct; a.pl = pl; a.K = d.cin;
                         a.bt = t1; a.fresh0 = i == 0 ? d.cin : d.cin - kGrowth; a.fsum = xsum; a.fsq = xsq; a.fstride = Ct; a.eps = kEps;
                         a.tw_mean = const_cast<float*>(t1.mean); a.tw_invstd = const_cast<float*>(t1.invstd);
-                        a.wp = e->packed_u + e->pk_c1[b][i]; a.N = kBottleneck;
+                        a.wp = e->packed_u + e->pk_c1[b][i]; a.N = kBottleneck; a.asc = asc_n1(e, b, (int)i);
                         a.dst = bt; a.ldd = kBottleneck; a.dsum = bsum; a.dsq = bsq; a.dstride = kBottleneck;
                         const int nM = ns * pl.HWp / 64, nN = kBottleneck / 64;
                         a.tm = TileMap{nM, nN, 0};
@@ -221,7 +209,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                     a.tw_mean = const_cast<float*>(t2.mean); a.tw_invstd = const_cast<float*>(t2.invstd);
                     a.dst = xs(b); a.ldd = Ct; a.dcoff = d.cin;
                     a.dsum = xsum; a.dsq = xsq; a.dstride = Ct;
-                    a.wu = e->packed_u + e->pk_hf[b][i];
+                    a.wu = e->packed_u + e->pk_hf[b][i]; a.asc = asc_n2(e, b, (int)i);
                     BY(e, ESZ(e) * ns * pl.HW * (kBottleneck + kGrowth));
                     ProfScope ps(e, cs, K_C3, 2.0 * ns * pl.HW * 9 * kBottleneck * kGrowth);
                     if (halo_tile(pl, ns) == 16) {
@@ -237,7 +225,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                     auto run = [&](auto tag) {
                         using Cfg = decltype(tag);
                         FwdConvP<Cfg, F_THREE> p{};
-                        p.src = bt; p.lds_ = kBottleneck; p.ps = pl; p.po = pl; p.K = kBottleneck;
+                        p.src = bt; p.lds_ = kBottleneck; p.ps = pl; p.po = pl; p.K = kBottleneck; p.asc = asc_n2(e, b, (int)i);
                         p.bt = t2; p.fresh0 = kBottleneck; p.fsum = bsum; p.fsq = bsq; p.fstride = kBottleneck; p.eps = kEps;
                         p.tw_mean = const_cast<float*>(t2.mean); p.tw_invstd = const_cast<float*>(t2.invstd);
                         p.wp = e->packed_u + e->pk_g3f[b][i]; p.K8tot = 9 * kBottleneck / 8; p.N = kGrowth;
@@ -262,7 +250,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                 auto run = [&](auto tag, auto ptag) {
                     using Cfg = MC<decltype(tag), decltype(ptag)::value>;
                     FwdConvP<Cfg, F_POOL, decltype(ptag)::value> p{};
-                    p.src = xs(b); p.lds_ = Ct; p.ps = pl; p.po = pn; p.K = Ct;
+                    p.src = xs(b); p.lds_ = Ct; p.ps = pl; p.po = pn; p.K = Ct; p.asc = asc_trans(e, b);
                     p.bt = tt; p.fresh0 = Ct - kGrowth; p.fsum = xsum; p.fsq = xsq; p.fstride = Ct; p.eps = kEps;     // the block's last layer
                     p.tw_mean = const_cast<float*>(tt.mean); p.tw_invstd = const_cast<float*>(tt.invstd);
                     p.wp = e->packed_u + e->pk_t[b]; p.K8tot = Ct / 8; p.N = Ct / 2;
@@ -314,7 +302,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
         auto run = [&](auto tag, auto ptag) {
                 using Cfg = decltype(tag);
                 FwdConvP<Cfg, F_ONE, decltype(ptag)::value, true> p{};      // fp32 feature buffers in every mode
-        p.src = e->F; p.lds_ = 2 * kFeat; p.ps = p4; p.po = p4; p.K = 2 * kFeat;
+        p.src = e->F; p.lds_ = 2 * kFeat; p.ps = p4; p.po = p4; p.K = 2 * kFeat; p.asc = asc_head0(e);
         p.bt = th; p.fresh0 = 2 * kFeat; p.fsum = fsum(e, e->st_F); p.fsq = fsq(e, e->st_F); p.fstride = 2 * kFeat; p.eps = kEps;
         p.tw_mean = const_cast<float*>(th.mean); p.tw_invstd = const_cast<float*>(th.invstd);
         p.wp = e->packed_u + e->pk_head0; p.K8tot = 2 * kFeat / 8; p.N = kHeadMid;

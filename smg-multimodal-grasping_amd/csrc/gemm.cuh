@@ -116,8 +116,24 @@ template <> struct GrdT<1> { using type = e_bf16; };
 template <> struct GrdT<2> { using type = e_bf16; };
 template <int PREC> using act_t = typename ActT<PREC>::type;
 template <int PREC> using grd_t = typename GrdT<PREC>::type;
-constexpr int fwd_op(int prec) { return prec; }                   // operand kind of the forward kernels
-constexpr int bwd_op(int prec) { return prec ? 1 : 0; }           // ... of the backward kernels (gradients are bf16 in both 16-bit modes)
+// Operand kind 3: the fp32-class products of the HOT classes (dense-layer 1x1 / 3x3 forward, data and weight gradients) as a
+// TWO-piece fp16 split  x * s = h + l  (round-to-nearest pieces, v_cvt_pk_f16_f32; s a power of two that places the operand in
+// fp16's range: 2 x 11 significand bits) and THREE v_mfma_f32_32x32x16_f16 terms  h*l + l*h + h*h  - half the matrix work, two
+// thirds of the LDS bytes and half the split arithmetic of kind 0.  Measured against fp64 (tools/split16_probe.hip): error /
+// sum|a*b| 1.03-1.09x the exact fp32 FMA chain at K = 64 / 128, 0.87x at K = 288 (kind 0: 1.06-1.11x), provided the operand's
+// typical magnitude sits well above fp16's subnormal floor - which is what the scales are for (the fp16 MFMA honours subnormal
+// inputs, measured): activations by a per-BN-layer scale from gamma / beta (scale_kernel), weights per tensor from their
+// maximum (header unit in front of every pack), gradients per (tensor, stream) from the maximum their producer recorded
+// (amax_scale).  The accumulator is multiplied by the inverse scales (exact powers of two) in the epilogue.
+#ifndef SMG_SPLIT16
+#define SMG_SPLIT16 1        // 0: every fp32-class product on the 3-piece bf16 split (kind 0), as in rounds 2-3 (A/B)
+#endif
+constexpr int kSplitOp = SMG_SPLIT16 ? 3 : 0;
+constexpr int np_of(int op) { return op == 0 ? NPIECE : (op == 3 ? 2 : 1); }      // pieces per operand
+constexpr int fwd_op(int prec) { return prec ? prec : kSplitOp; }         // operand kind of the hot forward kernels
+constexpr int bwd_op(int prec) { return prec ? 1 : kSplitOp; }            // ... of the hot backward kernels (gradients are bf16 in both 16-bit modes)
+constexpr int fwd_op_plain(int prec) { return prec; }                     // policies that keep kind 0 in mode 0 (stem: unscaled image operand)
+constexpr int bwd_op_plain(int prec) { return prec ? 1 : 0; }             // ... (gradient operands transformed on the fly: no recorded maximum)
 // bf16 pieces of 4 floats (element 0 in the low half of .x): 8 bytes per piece
 struct Split4 { uint2 p[NPIECE]; };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -136,12 +152,21 @@ __device__ __forceinline__ unsigned pack_f16(float lo_elem, float hi_elem) {
     const f32x2 v = {lo_elem, hi_elem};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
+__device__ __forceinline__ float f16_lo(unsigned u) { return (float)__builtin_bit_cast(f16x2, u).x; }
+__device__ __forceinline__ float f16_hi(unsigned u) { return (float)__builtin_bit_cast(f16x2, u).y; }
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
 // x = hi + mid + lo: the residuals x - hi and (x - hi) - mid are exact in fp32, the last one has <= 9 significant bits
 template <int OP = 0>
 __device__ __forceinline__ Split4 split4(float4 v) {
     Split4 o;
+    if constexpr (OP == 3) {                             // two fp16 pieces of an operand the caller has scaled into range
+        const unsigned h01 = pack_f16(v.x, v.y), h23 = pack_f16(v.z, v.w);
+        o.p[0] = make_uint2(h01, h23);
+        o.p[1] = make_uint2(pack_f16(v.x - f16_lo(h01), v.y - f16_hi(h01)), pack_f16(v.z - f16_lo(h23), v.w - f16_hi(h23)));
+        o.p[2] = make_uint2(0u, 0u);
+        return o;
+    } else
     if constexpr (OP != 0) {                             // single-piece operands
         o.p[0] = OP == 1 ? make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)) : make_uint2(pack_f16(v.x, v.y), pack_f16(v.z, v.w));
         o.p[1] = o.p[2] = make_uint2(0u, 0u);
@@ -167,11 +192,9 @@ __device__ __forceinline__ f32x16 mfma_f16(const u32x4& a, const u32x4& b, f32x1
 // one term of a single-piece operand kind
 template <int OP>
 __device__ __forceinline__ f32x16 mfma_1p(const u32x4& a, const u32x4& b, f32x16 c) {
-    if constexpr (OP == 2) return mfma_f16(a, b, c); else return mfma_bf16(a, b, c);
+    if constexpr (OP == 2 || OP == 3) return mfma_f16(a, b, c); else return mfma_bf16(a, b, c);
 }
 // ---- typed element access: `base` + element index -> fp32 values, whatever the array stores ---------------------------
-__device__ __forceinline__ float f16_lo(unsigned u) { return (float)__builtin_bit_cast(f16x2, u).x; }
-__device__ __forceinline__ float f16_hi(unsigned u) { return (float)__builtin_bit_cast(f16x2, u).y; }
 template <class T> __device__ __forceinline__ float2 cvt2(unsigned u) {          // two packed 16-bit elements -> fp32
     if constexpr (std::is_same<T, e_bf16>::value) return make_float2(bf16_lo(u), bf16_hi(u));
     else return make_float2(f16_lo(u), f16_hi(u));
@@ -325,7 +348,7 @@ struct GemmCfg {
     };
 };
 // LDS geometry of policy P's kernel
-template <class P> using GeoOf = typename P::Cfg::template G<(P::kOp ? 1 : NPIECE), P::kAE, P::kBE>;
+template <class P> using GeoOf = typename P::Cfg::template G<np_of(P::kOp), P::kAE, P::kBE>;
 
 // What a fetch leaves in registers: the untouched global loads (NV of them) and whether the
 // element exists at all (conv zero padding / padded pixel rows).  The BN transform is applied later,
@@ -414,6 +437,32 @@ __device__ __forceinline__ void tab_or_moments(const StatTab& t, int n, int col,
     if (t.mean) { mean = t.mean[(int64_t)n * t.ld + col]; invstd = t.invstd[(int64_t)n * t.ld + col]; }
     else bn_moments(sum, sq, idx, inv_cnt, eps, mean, invstd);
 }
+
+// ---- scales of operand kind 3 ---------------------------------------------------------------------------------------
+// Weight packs carry a header unit in FRONT of their first unit: floats {s, 1 / s, 0, 0}, s the power of two that puts the
+// tensor's largest |w| into [2^13, 2^14) (scale_kernel); the units hold the fp16 pieces of w * s.
+__device__ __forceinline__ float pack_inv_scale(const u32x4* wp) { return reinterpret_cast<const float*>(wp - 1)[1]; }
+// Activation scale of one BatchNorm + ReLU operand: {s, 1 / s} with s = 2^5 / (largest hypot(gamma_c, beta_c), rounded up to a
+// power of two): relu(gamma * xhat + beta) * s <= 32 (|xhat| + 1) stays below fp16's maximum for |xhat| < 2046 (|xhat| <=
+// sqrt(pixels per plane): planes up to 4 M pixels), typical values sit around 2^5 - 17 binades above the subnormal floor.
+struct ActScale { float s, inv; };
+__device__ __forceinline__ ActScale act_scale(const float* asc) { ActScale a; a.s = asc ? asc[0] : 1.f; a.inv = asc ? asc[1] : 1.f; return a; }
+// Gradient scale of one (tensor, stream): its producer recorded the largest |element| as float bits in kAmaxRep replicas
+// (atomicMax per workgroup); s = 2^(13 - floor(log2 max)) puts the maximum into [2^13, 2^14): elements down to 2^-17 of it keep
+// all 22 bits, smaller ones an absolute error of 2^-39 of it.  The address is workgroup-uniform: scalar loads, scalar maxima.
+constexpr int kAmaxRep = 16;
+__device__ __forceinline__ ActScale amax_scale(const unsigned* amax_n) {
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < kAmaxRep; ++r) m = max(m, amax_n[r]);
+    int e = (int)(m >> 23) - 127;                 // floor(log2 max) of a normal float (0 -> -127)
+    e = e < -100 ? -100 : e;
+    ActScale a;
+    a.s = __uint_as_float((unsigned)(140 - e) << 23);      // 2^(13 - e)
+    a.inv = __uint_as_float((unsigned)(114 + e) << 23);    // 2^(e - 13)
+    return a;
+}
+__device__ __forceinline__ float4 mul4(float4 v, float s) { return make_float4(v.x * s, v.y * s, v.z * s, v.w * s); }
 
 // BatchNorm statistics of one activation buffer as fp32, finished ONCE per (stream, channel): mean | invstd tables of
 // [rows][ld] (rows = streams or pairs), plus the affine parameters of the consuming BN layer.  Who writes them: the first
@@ -544,9 +593,9 @@ template <class P>
 __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* smem) {
     using C = typename P::Cfg;
     using Z = GeoOf<P>;
-    constexpr int OP = P::kOp, NP = OP ? 1 : NPIECE, AE = P::kAE, BE = P::kBE;
+    constexpr int OP = P::kOp, NP = np_of(OP), AE = P::kAE, BE = P::kBE;
     static_assert((AE == 4 || AE == 8) && (BE == 4 || BE == 8), "16-byte staging slots");
-    static_assert(OP != 0 || (AE == 4 && BE == 4), "the fp32-class split reads fp32 storage");
+    static_assert((OP != 0 && OP != 3) || (AE == 4 && BE == 4), "the fp32-class splits read fp32 storage");
     char* As = reinterpret_cast<char*>(smem);
     char* Bs = As + 2 * Z::A_BYTES;
     float* sp = smem + Z::TILE_FLOATS;
@@ -726,6 +775,22 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
             for (int i = 0; i < C::TM; ++i) ah[i] = frag(A, C::LDUA, C::LDTA, wm0 + i * 32, s, 0);
 #pragma unroll
             for (int j = 0; j < C::TN; ++j) bh[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 0);
+            if constexpr (OP == 3) {         // two fp16 pieces: h*l, l*h, h*h (small terms first, tiles innermost)
+                u32x4 al_[C::TM], bl_[C::TN];
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i) al_[i] = frag(A, C::LDUA, C::LDTA, wm0 + i * 32, s, 1);
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j) bl_[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 1);
+                SMG_PIN();
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::TN; ++j)
+                            acc[i][j] = mfma_f16(g == 1 ? al_[i] : ah[i], g == 0 ? bl_[j] : bh[j], acc[i][j]);
+                SMG_PIN();
+            } else
             if constexpr (OP != 0) {         // single-piece operands: one term per tile
                 SMG_PIN();
 #pragma unroll
@@ -1132,8 +1197,9 @@ struct FwdConvP {
     static constexpr bool F32IO = F32IO_ || MODE == 3 || MODE == 4;      // F_STEM, F_STEM1
     using SrcT = typename std::conditional<F32IO, e_f32, act_t<PREC>>::type;
     using DstT = SrcT;
-    static constexpr int kOp = fwd_op(PREC), kAE = 16 / SrcT::size, kBE = 4, ESZ = SrcT::size;
+    static constexpr int kOp = (MODE == 3 || MODE == 4) ? fwd_op_plain(PREC) : fwd_op(PREC), kAE = 16 / SrcT::size, kBE = 4, ESZ = SrcT::size;
     static constexpr bool kARawCopy = false;
+    const float* asc;               // operand kind 3: {s, 1 / s} of the BN + ReLU operand (scale_kernel)
     const void* src; int lds_;
     Plane ps, po;
     int K;
@@ -1184,19 +1250,21 @@ struct FwdConvP {
             const int t = threadIdx.x;
             const float* tmean = tab_mean(bt, c.n);
             const float* tinv = tab_invstd(bt, c.n);
+            // operand kind 3: relu(s * t) = s * relu(t) - the activation scale is folded into gamma * invstd and beta (no VALU in the k-loop)
+            const float sa = kOp == 3 ? asc[0] : 1.f;
             for (int ch = 4 * t; ch < K && ch < fresh0; ch += 1024) {
                 const f32x4 m = ldv4(tmean + ch), iv = ldv4(tinv + ch), g = ldv4(bt.gamma + ch), be = ldv4(bt.beta + ch);
                 *reinterpret_cast<f32x4*>(sp + ch) = m;
-                *reinterpret_cast<f32x4*>(sp + K + ch) = g * iv;
-                *reinterpret_cast<f32x4*>(sp + 2 * K + ch) = be;
+                *reinterpret_cast<f32x4*>(sp + K + ch) = g * iv * sa;
+                *reinterpret_cast<f32x4*>(sp + 2 * K + ch) = be * sa;
             }
             if (fresh0 < K && t < kFresh) {
                 const int ch = fresh0 + t;
                 float mean, invstd;
                 bn_moments(fsum, fsq, (int64_t)c.n * fstride + ch, 1.0 / (double)ps.HW, eps, mean, invstd);
                 sp[ch] = mean;
-                sp[K + ch] = bt.gamma[ch] * invstd;
-                sp[2 * K + ch] = bt.beta[ch];
+                sp[K + ch] = bt.gamma[ch] * invstd * sa;
+                sp[2 * K + ch] = bt.beta[ch] * sa;
                 if (c.n0 == 0 && c.m0 == c.n * po.HWp) {
                     tw_mean[(int64_t)c.n * bt.ld + ch] = mean;
                     tw_invstd[(int64_t)c.n * bt.ld + ch] = invstd;
@@ -1327,6 +1395,18 @@ struct FwdConvP {
         double v[2][Cfg::TN];
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) v[0][j] = v[1][j] = 0.0;
+        if constexpr (kOp == 3) {          // the products were formed on scaled operands: exact power-of-two correction
+#ifdef SMG_EPI_NOP
+            __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+#endif
+            const float inv = asc[1] * pack_inv_scale(wp);
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+        }
         const int pbase = c.m0 - c.n * po.HWp;
         if (pbase + Cfg::BM <= po.HW && c.n0 + Cfg::BN <= N) {
             // Whole tile inside the plane (every tile of the 160^2 / 80^2 / 40^2 stages): straight-line stores, and the
@@ -1428,8 +1508,10 @@ struct BwdDataP {
     using GT = typename std::conditional<F32IO, e_f32, grd_t<PREC>>::type;      // gradients in (gbuf) and out (dst)
     using XT = typename std::conditional<F32IO, e_f32, act_t<PREC>>::type;      // activations (xbuf, mbuf)
     static_assert(GT::size == XT::size, "one slot geometry for the gradient and its activation");
-    static constexpr int kOp = bwd_op(PREC), kAE = 16 / GT::size, kBE = 4, GSZ = GT::size, XSZ = XT::size;
+    // operand kind 3 needs the gradient operand's recorded maximum: the pointwise form on a FINISHED gradient only
+    static constexpr int kOp = (AFF || SHIFT3) ? bwd_op_plain(PREC) : bwd_op(PREC), kAE = 16 / GT::size, kBE = 4, GSZ = GT::size, XSZ = XT::size;
     static constexpr bool kARawCopy = !AFF && !SHIFT3 && kAE == 8;              // finished bf16 gradient: copied to LDS as it is
+    const unsigned* gamax;          // operand kind 3: [streams][kAmaxRep] recorded maxima of gbuf (bn_bwd_apply_kernel)
     const void* gbuf; int ldg; int gcoff;
     const void* xbuf; int ldx; int xcoff;
     Plane pa;
@@ -1466,6 +1548,7 @@ struct BwdDataP {
     static constexpr bool kWide = GT::size == 2;
     struct Ctx {
         int n, m0, n0; bool whole;
+        float gs, ginv;             // operand kind 3: scale of this stream's gradient operand, inverse of (gradient x weight) scale
         // mask source x and old G' of a whole tile, fetched at the start of the workgroup: per element in accumulator layout
         // (fp32 storage), or as loaded row segments of four accumulator rows each (16-bit storage; fetch_acc_rows)
         float xv[(kEarly && !kWide) ? Cfg::TM : 1][(kEarly && !kWide) ? Cfg::TN : 1][16];
@@ -1496,6 +1579,11 @@ struct BwdDataP {
         // boundary: an accumulator tile (wave, j) is then entirely inside or entirely outside [0, N) - a wave-uniform test (jok),
         // no per-element predicate.  (The narrow per-layer launches of a layer group have N = 32 / 64 / 96.)
         c.whole = kEarly && pbase + Cfg::BM <= pa.HW && (c.n0 + Cfg::BN <= N || (N & 31) == 0);
+        c.gs = 1.f; c.ginv = 1.f;
+        if constexpr (kOp == 3) {
+            const ActScale g = amax_scale(gamax + (int64_t)c.n * kAmaxRep);
+            c.gs = g.s; c.ginv = g.inv * pack_inv_scale(wp);
+        }
         return true;
     }
     __device__ void early_fetch(Ctx& c) const {
@@ -1614,8 +1702,8 @@ struct BwdDataP {
         if (xbuf) o.v[1] = ld16(xbuf, (int64_t)XSZ * (pix * ldx + xcoff + ch));      // (launch-uniform)
         return o;
     }
-    __device__ float4 a_xform(const Ctx&, const ARaw& o, const KPrm&, int kt, int q, const float* sp) const {
-        if constexpr (kFast) return o.v[0];
+    __device__ float4 a_xform(const Ctx& c, const ARaw& o, const KPrm&, int kt, int q, const float* sp) const {
+        if constexpr (kFast) { if constexpr (kOp == 3) return mul4(o.v[0], c.gs); else return o.v[0]; }
         if (!o.ok) return zero4();
         if (!xbuf) return o.v[0];                      // gradient already BN-corrected (bn_bwd_apply_kernel)
         return affine2(o.v[0], o.v[1], sp + a_chan(kt, q), KA);
@@ -1636,6 +1724,14 @@ struct BwdDataP {
         float v[2][Cfg::TN];
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) v[0][j] = v[1][j] = 0.f;
+        if constexpr (kOp == 3) {          // products of scaled operands: exact power-of-two correction
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= c.ginv;
+        }
         const int pbase = c.m0 - c.n * pa.HWp;
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) {
@@ -1828,6 +1924,7 @@ struct BwdDataP {
 // ------------------------------------------------------------------------------------
 constexpr int GROUP_MAX = 4;
 struct GroupSeg {
+    const unsigned* amax;           // operand kind 3: [streams][kAmaxRep] recorded maxima of g
     const void* g;                  // finished bottleneck gradient D2_i [n][HWp][KA] (fp32 / bf16 by mode)
     const u32x4* wp; int ldn;       // conv1 weight, packed data-gradient units [piece][KA/8][cin_i]
     const float* gamma; const float* beta;
@@ -1886,12 +1983,23 @@ struct BwdDataGroupP {
     __device__ KFin k_finish(const Ctx&, const KPrm&, int, int, const float*) const { return KFin{}; }
 
     // LDS parameters: mean | invstd | per segment: gamma*invstd | beta | gamma      (BN floats each)
-    __host__ __device__ int param_floats() const { return (2 + 3 * GROUP_MAX) * Cfg::BN; }
+    // operand kind 3: + per segment the scale of its gradient operand | the inverse of its (gradient x weight) scale
+    static constexpr int kScaleAt = (2 + 3 * GROUP_MAX) * Cfg::BN;
+    __host__ __device__ int param_floats() const { return kScaleAt + 2 * GROUP_MAX; }
 
     __device__ void d_init(const Ctx&, DRow&, int) const {}
     __device__ void d_next(const Ctx&, DRow&) const {}
     __device__ void init_params(const Ctx& c, float* sp) const {
         const double minv = 1.0 / (double)pa.HW;
+        if constexpr (kOp == 3) {
+            if (threadIdx.x >= 64 && threadIdx.x < 64 + GROUP_MAX) {      // (wave 1: wave 0 carries the parameter loads below)
+                const int z = threadIdx.x - 64;
+                ActScale g{1.f, 1.f};
+                if (z < nseg) { g = amax_scale(seg[z].amax + (int64_t)c.n * kAmaxRep); g.inv *= pack_inv_scale(seg[z].wp); }
+                sp[kScaleAt + z] = g.s;
+                sp[kScaleAt + GROUP_MAX + z] = g.inv;
+            }
+        }
         for (int j = threadIdx.x; j < Cfg::BN; j += 256) {
             const int col = c.n0 + j;
             float mean = 0.f, invstd = 0.f;
@@ -2033,7 +2141,10 @@ struct BwdDataGroupP {
         return o;
     }
     __device__ ARaw a_quad(const ARaw& o, int h) const { ARaw r; r.ok = o.ok; r.v[0] = slot_quad<GT>(o.v[0], h); return r; }
-    __device__ float4 a_xform(const Ctx&, const ARaw& o, const KPrm&, int, int, const float*) const { return o.v[0]; }
+    __device__ float4 a_xform(const Ctx&, const ARaw& o, const KPrm&, int kt, int, const float* sp) const {
+        if constexpr (kOp == 3) return mul4(o.v[0], sp[kScaleAt + kt / kps()]);      // (one LDS broadcast read per k-tile)
+        else return o.v[0];
+    }
     __device__ ARaw a_fetch_d(const Ctx&, const DRow&, int, int, int) const { return ARaw{}; }
     __device__ BRaw b_unit(const Ctx& c, int kt, int piece, int k8, int r) const {
         const int s = kt / kps(), k80 = (kt - s * kps()) * Cfg::K8;
@@ -2067,10 +2178,12 @@ struct BwdDataGroupP {
                     }
         }
         const float* q = sp + (2 + 3 * s) * Cfg::BN;
+        float ginv = 1.f;                                  // operand kind 3: this segment's inverse scale, folded into gamma and the sums
+        if constexpr (kOp == 3) ginv = sp[kScaleAt + GROUP_MAX + s];
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) {
             const int cj = wn0 + j * 32 + l31;
-            const float mean = sp[cj], sc = q[cj], be = q[Cfg::BN + cj], gam = q[2 * Cfg::BN + cj];
+            const float mean = sp[cj], sc = q[cj], be = q[Cfg::BN + cj], gam = q[2 * Cfg::BN + cj] * ginv;
             float v0 = 0.f, v1 = 0.f;
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i)
@@ -2085,8 +2198,8 @@ struct BwdDataGroupP {
                 }
 #pragma unroll
             for (int z = 0; z < GROUP_MAX; ++z) {          // static register indices: predicated adds, no scratch
-                c.ls[z][0][j] += z == s ? v0 : 0.f;
-                c.ls[z][1][j] += z == s ? v1 : 0.f;
+                c.ls[z][0][j] += z == s ? v0 * ginv : 0.f;
+                c.ls[z][1][j] += z == s ? v1 * ginv : 0.f;
             }
         }
     }
@@ -2215,8 +2328,11 @@ struct BwdWeightP {
     using GT = typename std::conditional<F32IO, e_f32, grd_t<PREC>>::type;      // output gradient (gbuf)
     using XT = typename std::conditional<F32IO, e_f32, act_t<PREC>>::type;      // activations (xbuf, bbuf)
     static_assert(GT::size == XT::size, "one slot geometry");
-    static constexpr int kOp = bwd_op(PREC), kAE = 16 / GT::size, kBE = 16 / XT::size, GSZ = GT::size, XSZ = XT::size;
+    // operand kind 3: the dense layers' 1x1 weight gradient (finished gradient with a recorded maximum x BN + ReLU activation)
+    static constexpr int kOp = (!AFF && BMODE == 0) ? bwd_op(PREC) : bwd_op_plain(PREC), kAE = 16 / GT::size, kBE = 16 / XT::size, GSZ = GT::size, XSZ = XT::size;
     static constexpr bool kARawCopy = !AFF && kAE == 8;      // finished bf16 gradient: copied to LDS as it is
+    const unsigned* gamax;          // operand kind 3: [streams][kAmaxRep] recorded maxima of gbuf
+    const float* basc;              // operand kind 3: {s, 1 / s} of the BN + ReLU operand B (scale_kernel)
     const void* gbuf; int ldg; int gcoff;
     const void* xbuf; int ldx; int xcoff;
     Plane pa; int MA;
@@ -2240,7 +2356,7 @@ struct BwdWeightP {
     static constexpr bool kEarlyFetch = false;
     static constexpr int kMinWaves = 1;
 
-    struct Ctx { int n, p0, m0, n0, tap, kt, z; };
+    struct Ctx { int n, p0, m0, n0, tap, kt, z; float gs, ginv; };      // gs / ginv: operand kind 3 (gradient scale, inverse of gradient x activation scale)
     using KPrm = KPrm0;
     using KFin = KPrm0;
     __device__ KPrm k_fetch(const Ctx&, int, int) const { return KPrm{}; }
@@ -2283,6 +2399,11 @@ struct BwdWeightP {
         int len = pa.HWp - c.p0;
         len = len < chunk ? len : chunk;
         c.kt = sgpr(len / Cfg::BK);
+        c.gs = 1.f; c.ginv = 1.f;
+        if constexpr (kOp == 3) {
+            const ActScale g = amax_scale(gamax + (int64_t)c.n * kAmaxRep);
+            c.gs = g.s; c.ginv = g.inv * basc[1];
+        }
         return true;
     }
     __device__ void init_params(const Ctx& c, float* sp) const {
@@ -2312,8 +2433,9 @@ struct BwdWeightP {
                 float mean = 0.f, invstd = 0.f, sc = 0.f, be = 0.f;
                 if (ch < NB) {
                     tab_or_moments(btab, c.n, ch, bsum, bsq, (int64_t)c.n * bstride + ch, binv, eps, mean, invstd);
-                    sc = bgamma[ch] * invstd;
-                    be = bbeta[ch];
+                    const float sa = kOp == 3 ? basc[0] : 1.f;      // the activation scale, folded into the BN + ReLU parameters
+                    sc = bgamma[ch] * invstd * sa;
+                    be = bbeta[ch] * sa;
                 }
                 bp[j] = mean;
                 bp[Cfg::BN + j] = sc;
@@ -2359,8 +2481,8 @@ struct BwdWeightP {
         for (int j = 0; j < (BMODE == W_POOL ? 4 : 1); ++j) r.v[j] = slot_quad<XT>(o.v[j], h);
         return r;
     }
-    __device__ float4 a_xform(const Ctx&, const ARaw& o, const KPrm&, int, int q, const float* sp) const {
-        if constexpr (!AFF) return o.v[0];
+    __device__ float4 a_xform(const Ctx& c, const ARaw& o, const KPrm&, int, int q, const float* sp) const {
+        if constexpr (!AFF) { if constexpr (kOp == 3) return mul4(o.v[0], c.gs); else return o.v[0]; }
         if (!o.ok) return zero4();
         if (!xbuf) return o.v[0];
         return affine2(o.v[0], o.v[1], sp + 4 * q, Cfg::BM);
@@ -2440,6 +2562,14 @@ struct BwdWeightP {
     __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float*, float*, bool active) const {
         const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
         const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
+        if constexpr (kOp == 3) {          // products of scaled operands: exact power-of-two correction (per stream: before any sum over streams)
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= c.ginv;
+        }
         if (CMAP == C_IDENT && c.m0 + Cfg::BM <= MA && c.n0 + Cfg::BN <= NB) {
             // whole tile inside the weight matrix: uniform base + running lane offset, no per-element predicates
             if (!active) return;

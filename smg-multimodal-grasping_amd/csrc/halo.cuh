@@ -45,7 +45,8 @@ struct Halo3x3FwdArgs {
     const double* ssum; const double* ssq; int sstride;     // fp64 statistics of src (norm2 input)
     const float* gamma; const float* beta; float eps;
     float* tw_mean; float* tw_invstd;               // [n][C]: the first tile of every stream stores mean / invstd for the backward
-    const u32x4* wu;                                // weight units [chunk][piece][tap][k8][n] (PK_HF)
+    const u32x4* wu;                                // weight units [chunk][piece][tap][k8][n] (PK_HF); operand kind 3: header unit in front
+    const float* asc;                               // operand kind 3: {s, 1 / s} of the BN + ReLU operand
     void* dst; int ldd, dcoff;
     double* dsum; double* dsq; int dstride;
     int tiles_x;
@@ -66,7 +67,7 @@ constexpr int halo_ck(int prec) { return prec ? 32 : 16; }
 // ------------------------------------------------------------------------------------
 template <int TS, int PREC> struct HaloFwdSGeo : HaloGeo<TS> {
     using G = HaloGeo<TS>;
-    static constexpr int NP = PREC ? 1 : NPIECE, CK = halo_ck(PREC), K8C = CK / 8;
+    static constexpr int NP = np_of(fwd_op(PREC)), CK = halo_ck(PREC), K8C = CK / 8;
     static constexpr int LDH = G::PX;
     static constexpr int A_UNITS = NP * K8C * LDH;
     static constexpr int A_N = (G::PX * 4 + 255) / 256;                  // 16-byte slots per thread: 6 / 2
@@ -92,12 +93,13 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const H
     const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
     const int y0 = ty * TS, x0 = tx * TS;
     const int C = a.C, kq = t & 3;                           // this thread's 16-byte slot inside every chunk (E channels)
+    const float sa = OP == 3 ? a.asc[0] : 1.f;               // operand kind 3: the activation scale rides on gamma * invstd and beta
     for (int k = t; k < C; k += 256) {                       // BN parameters of this stream
         float mean, invstd;
         bn_moments(a.ssum, a.ssq, (int64_t)n * a.sstride + k, 1.0 / (double)a.pl.HW, a.eps, mean, invstd);
         prm[k] = mean;
-        prm[C + k] = a.gamma[k] * invstd;
-        prm[2 * C + k] = a.beta[k];
+        prm[C + k] = a.gamma[k] * invstd * sa;
+        prm[2 * C + k] = a.beta[k] * sa;
         if (blockIdx.x == 0) { a.tw_mean[(int64_t)n * C + k] = mean; a.tw_invstd[(int64_t)n * C + k] = invstd; }
     }
 
@@ -177,14 +179,25 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const H
                 for (int m = 0; m < MT; ++m) ah[set][ks][m] = fa(m, tap, ks, 0);
                 bh[set][ks] = fb(tap, ks, 0);
             }
-            if constexpr (OP == 0) {
+            if constexpr (OP == 0 || OP == 3) {             // the lowest piece: index 2 of three, 1 of two
 #pragma unroll
-                for (int m = 0; m < MT; ++m) al[set][m] = fa(m, tap, 0, 2);
-                bl[set] = fb(tap, 0, 2);
+                for (int m = 0; m < MT; ++m) al[set][m] = fa(m, tap, 0, NP - 1);
+                bl[set] = fb(tap, 0, NP - 1);
             }
         };
         auto tap_body = [&](int set, int tap, bool more) {
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (OP == 3) {                        // two fp16 pieces: h*l, l*h, h*h; the next tap's fragments under them
+                if (more) load_hl(set ^ 1, tap + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_f16(ah[set][0][m], bl[set], acc[m]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_f16(al[set][m], bh[set][0], acc[m]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_f16(ah[set][0][m], bh[set][0], acc[m]);
+                return;
+            } else
             if constexpr (OP != 0) {                        // single-piece operands: one term per k16-step
                 if (more) load_hl(set ^ 1, tap + 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -244,6 +257,13 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const H
     }
 
     // epilogue: raw output + per-(stream, channel) sum / sum of squares (fp64)
+    if constexpr (OP == 3) {                      // products of scaled operands: exact power-of-two correction
+        const float inv = a.asc[1] * pack_inv_scale(a.wu);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] *= inv;
+    }
     double s = 0.0, ss = 0.0;
     if (wk == 0) {
 #pragma unroll
@@ -290,6 +310,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const H
 //   g = invstd * ((G' - SA/n) - (x - mean) * invstd * SB/n)
 // Statistics pointers are already offset to the slice's first channel; sstride = floats per stream.
 struct GradSrc {
+    const unsigned* amax;           // operand kind 3 (x == nullptr only): [streams][kAmaxRep] recorded maxima of g (bn_bwd_apply_kernel)
     const void* g; int ldg;         // gradient storage: fp32 / bf16 by mode
     const void* x; int ldx;         // activation storage: fp32 / bf16 / fp16 by mode
     const double* xsum; const double* xsq; const double* s1; const double* s2; int sstride;
@@ -330,8 +351,8 @@ struct Halo3x3DgradArgs {
 // ------------------------------------------------------------------------------------
 template <int TS, int PREC> struct HaloDgradSGeo : HaloGeo<TS> {
     using G = HaloGeo<TS>;
-    static constexpr int NP = PREC ? 1 : NPIECE;
-    static constexpr int BU = NP * 4 * 32;                               // weight units per (tap, 32-channel chunk): 384 / 128
+    static constexpr int NP = np_of(bwd_op(PREC));
+    static constexpr int BU = NP * 4 * 32;                               // weight units per (tap, 32-channel chunk): 384 / 256 / 128
     static constexpr int LDH = G::PX;
     static constexpr int A_UNITS = NP * 4 * LDH;
     static constexpr int A_N = (G::PX * (PREC ? 4 : 8) + 255) / 256;     // 16-byte slots per thread (32 gradient channels per pixel)
@@ -371,6 +392,8 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
     }
     float* gp = prm + 4 * C + 256;                     // GradSrc parameters [4][32]
     grad_src_params(a.g, n, a.pl.HW, gp);
+    ActScale gsc{1.f, 1.f};                            // operand kind 3: scale of this stream's gradient operand; inverse of (gradient x weight) scale
+    if constexpr (OP == 3) { gsc = amax_scale(a.g.amax + (int64_t)n * kAmaxRep); gsc.inv *= pack_inv_scale(a.wu); }
     const int cg0 = blockIdx.z * a.cg_per_wg;
     const int NSTAGE = a.cg_per_wg * 9;                // channel-chunk groups x 9 taps
     // Weight stages: stage = cgroup * 9 + tap (a cgroup holds NCW chunks).  Three register slots and three LDS buffers,
@@ -418,6 +441,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
                 if constexpr (E == 4) {
                     float4 v = rv[i];
                     if (x_n) v = affine2(rv[i], rx[i], gp + 4 * q, 32);
+                    if constexpr (OP == 3) v = mul4(v, gsc.s);
                     if (!ok) v = zero4();
                     const Split4 sp = split4<OP>(v);
 #pragma unroll
@@ -488,6 +512,23 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
         auto fb = [&](int ks, int pc) -> u32x4 {
             return *reinterpret_cast<const u32x4*>(Bw + ((pc * 4 + 2 * ks + half) * 32 + l31) * 16);
         };
+        if constexpr (OP == 3) {                            // two fp16 pieces: every fragment of the stage up front, then h*l, l*h, h*h per k16-step
+            u32x4 af[2][MT][2], bf[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) af[ks][m][pc] = fa(m, ks, pc);
+                    bf[ks][pc] = fb(ks, pc);
+                }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m] = mfma_f16(af[ks][m][g == 1 ? 1 : 0], bf[ks][g == 0 ? 1 : 0], acc[m]);
+        } else
         if constexpr (OP != 0) {                            // single-piece operands: one term per k16-step
             u32x4 ah[2][MT], bh[2];
 #pragma unroll
@@ -540,7 +581,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
                             const int i = k + 8 * g + 4 * half;
                             const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
                             const bool in = TS == 16 || (py < a.pl.H && px < a.pl.W);
-                            const float dyv = (in && bn1(xv[k], mean, sc, be) > 0.f) ? acc[m][4 * g + k] : 0.f;
+                            const float dyv = (in && bn1(xv[k], mean, sc, be) > 0.f) ? acc[m][4 * g + k] * gsc.inv : 0.f;      // (gsc.inv == 1 unless operand kind 3)
                             o[k] = dyv;
                             s1 += dyv;
                             s2 += dyv * ((xv[k] - mean) * invstd);
@@ -580,6 +621,7 @@ struct Halo3x3WgradArgs {
     GradSrc g; Plane pl;                             // finished output gradient (32 channels)
     const void* src; int C;                          // raw bottleneck [n][HWp][C]
     BnTab bt;                                        // norm2 statistics of this layer (stored by the forward) + gamma / beta
+    const float* asc;                                // operand kind 3: {s, 1 / s} of the BN + ReLU operand
     float* part;                                     // partial sums [gridDim.x*gridDim.z][9][32][C]
     int tiles_x, n_tiles, tiles_per_wg;
 };
@@ -596,7 +638,7 @@ struct Halo3x3WgradArgs {
 // ------------------------------------------------------------------------------------
 template <int TW, int PREC> struct HaloWgradSGeo {
     static_assert(TW == 16 || TW == 8, "tile width");
-    static constexpr int NP = PREC ? 1 : NPIECE, SPP = PREC ? 4 : 8;      // pieces per operand; 16-byte slots per pixel (32 channels)
+    static constexpr int NP = np_of(bwd_op(PREC)), SPP = PREC ? 4 : 8;    // pieces per operand; 16-byte slots per pixel (32 channels)
     static constexpr int TH = 8, HW_ = TW + 2, HH = TH + 2, PX = HW_ * HH, NPIX = TW * TH;
     static constexpr int KSTEPS = NPIX / 16 / 4;                          // k16-steps per wave per tile: 2 / 1
     static constexpr int B_BYTES = NP * PX * 64, A_BYTES = NP * NPIX * 64;
@@ -622,10 +664,13 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, half = lane >> 5;
     const int n = blockIdx.z, cc0 = blockIdx.y * 32;
     const int C = a.C;
+    ActScale gsc{1.f, 1.f};                             // operand kind 3: scale of this stream's gradient operand; inverse of (gradient x activation) scale
+    float sa = 1.f;
+    if constexpr (OP == 3) { gsc = amax_scale(a.g.amax + (int64_t)n * kAmaxRep); gsc.inv *= a.asc[1]; sa = a.asc[0]; }
     if (t < 32) {
         prm[t] = tab_mean(a.bt, n)[cc0 + t];
-        prm[32 + t] = a.bt.gamma[cc0 + t] * tab_invstd(a.bt, n)[cc0 + t];
-        prm[64 + t] = a.bt.beta[cc0 + t];
+        prm[32 + t] = a.bt.gamma[cc0 + t] * tab_invstd(a.bt, n)[cc0 + t] * sa;
+        prm[64 + t] = a.bt.beta[cc0 + t] * sa;
     }
     grad_src_params(a.g, n, a.pl.HW, gp);
     f32x16 acc[9];
@@ -693,7 +738,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const
                 if (idx < G::NPIX * SPP) {
                     const int q = idx % SPP, px = idx / SPP;
                     if constexpr (E == 4) {
-                        const Split4 sp = split4<OP>(okg[i] ? rg[i] : zero4());
+                        const Split4 sp = split4<OP>(okg[i] ? (OP == 3 ? mul4(rg[i], gsc.s) : rg[i]) : zero4());
 #pragma unroll
                         for (int pc = 0; pc < NP; ++pc)
                             *reinterpret_cast<uint2*>(Ag + ((pc * G::NPIX + px) * 32 + 4 * q) * 2) = sp.p[pc];
@@ -726,7 +771,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const
             u32x4 af[NPIECE];
 #pragma unroll
             for (int pc = 0; pc < NPIECE; ++pc)
-                if (pc == 0 || OP == 0) af[pc] = tr2(ga + pc * G::NPIX * 64, 4 * 64);
+                if (pc < NP) af[pc] = tr2(ga + pc * G::NPIX * 64, 4 * 64);
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 u32x4 bf[3][NPIECE];
@@ -734,8 +779,14 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const
                 for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
                     for (int pc = 0; pc < NPIECE; ++pc)
-                        if (pc == 0 || OP == 0) bf[dx][pc] = tr2(hb + pc * G::PX * 64 + (dy * G::HW_ + dx) * 64, 4 * 64);
+                        if (pc < NP) bf[dx][pc] = tr2(hb + pc * G::PX * 64 + (dy * G::HW_ + dx) * 64, 4 * 64);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (OP == 3) {                    // two fp16 pieces: h*l, l*h, h*h over the three taps of the kernel row
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) acc[dy * 3 + dx] = mfma_f16(af[g == 1 ? 1 : 0], bf[dx][g == 0 ? 1 : 0], acc[dy * 3 + dx]);
+                } else
                 if constexpr (OP != 0) {                    // single-piece operands: one term per tap
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) acc[dy * 3 + dx] = mfma_1p<OP>(af[0], bf[dx][0], acc[dy * 3 + dx]);
@@ -762,7 +813,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const
         for (int k = 0; k < 4; ++k) {
             const int e = t + 256 * k;                  // e = r*64 + lane'
             const int r = e >> 6, ln = e & 63;
-            const float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+            const float v = (red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e]) * gsc.inv;      // (1 unless operand kind 3: per-stream scale, removed before streams are summed)
             const int nn = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), cc = ln & 31;
             a.part[((((int64_t)blockIdx.x * gridDim.z + n) * 9 + tap) * 32 + nn) * C + cc0 + cc] = v;
         }

@@ -21,25 +21,32 @@ struct Fwd1x1WsArgs {
     int K;
     BnTab bt; int fresh0; const double* fsum; const double* fsq; int fstride; float eps;
     float* tw_mean; float* tw_invstd;
-    const u32x4* wp; int N;                        // packed weight units [piece][K/8][N]
+    const u32x4* wp; int N;                        // packed weight units [piece][K/8][N]; operand kind 3: header unit in front
+    const float* asc;                              // operand kind 3: {s, 1 / s} of the BN + ReLU operand
     float* dst; int ldd;                           // raw output [n][HWp][ldd]
     double* dsum; double* dsq; int dstride;        // per-(stream, channel) sum / sum of squares
     TileMap tm;                                    // XCD-aware order: the N tiles of one M tile are consecutive on one XCD
 };
 
-struct WsGeo {
+template <int NP_>
+struct WsGeoT {
+    static constexpr int NP = NP_;                                    // pieces per operand (3: bf16 split, 2: fp16 split)
     static constexpr int BM = 64, BN = 64, BK = 32, K8 = BK / 8;
     static constexpr int LDUA = BM + 2, LDUB = BN;                    // A rows padded as in GemmCfg (64 / BK units)
-    static constexpr int A_BYTES = NPIECE * K8 * LDUA * 16, B_BYTES = NPIECE * K8 * LDUB * 16;
+    static constexpr int A_BYTES = NP * K8 * LDUA * 16, B_BYTES = NP * K8 * LDUB * 16;
     static constexpr int A_N = BM * (BK / 4) / 256;                   // 2 float4 per producer thread
-    static constexpr int B_N = NPIECE * K8 * BN / 256;                // 3 units per producer thread
+    static constexpr int B_N = NP * K8 * BN / 256;                    // units per producer thread
     static constexpr int TILE_BYTES = 2 * (A_BYTES + B_BYTES);
     __host__ __device__ static constexpr int smem_bytes(int K) { return TILE_BYTES + 3 * K * 4; }
 };
 
+using WsGeo = WsGeoT<np_of(fwd_op(0))>;
+
 template <int PREC = 0>
 static __global__ __launch_bounds__(512, 1) void conv1x1_fwd_ws_kernel(const Fwd1x1WsArgs a) {
+    static_assert(PREC == 0, "fp32 storage only");
     using G = WsGeo;
+    constexpr int OP = fwd_op(PREC), NP = G::NP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* As = reinterpret_cast<char*>(smem);
     char* Bs = As + 2 * G::A_BYTES;
@@ -81,10 +88,10 @@ static __global__ __launch_bounds__(512, 1) void conv1x1_fwd_ws_kernel(const Fwd
         f.mean = ldv4(sp + ch); f.scale = ldv4(sp + K + ch); f.beta = ldv4(sp + 2 * K + ch);
 #pragma unroll
         for (int i = 0; i < G::A_N; ++i) {
-            const Split4 s = split4<PREC>(bnrelu4(xa[i], f));
+            const Split4 s = split4<OP>(bnrelu4(xa[i], f));
             const int row = al + 32 * i;
 #pragma unroll
-            for (int pc = 0; pc < (PREC ? 1 : NPIECE); ++pc)
+            for (int pc = 0; pc < NP; ++pc)
                 *reinterpret_cast<uint2*>(A + ((pc * G::K8 + (aq >> 1)) * G::LDUA + row) * 16 + (aq & 1) * 8) = s.p[pc];
         }
 #pragma unroll
@@ -98,19 +105,20 @@ static __global__ __launch_bounds__(512, 1) void conv1x1_fwd_ws_kernel(const Fwd
     {
         const float* tmean = tab_mean(a.bt, n);
         const float* tinv = tab_invstd(a.bt, n);
+        const float sa = OP == 3 ? a.asc[0] : 1.f;                       // operand kind 3: the activation scale rides on gamma * invstd and beta
         for (int ch = 4 * t; ch < K && ch < a.fresh0; ch += 2048) {
             const f32x4 m = ldv4(tmean + ch), iv = ldv4(tinv + ch), g = ldv4(a.bt.gamma + ch), be = ldv4(a.bt.beta + ch);
             *reinterpret_cast<f32x4*>(sp + ch) = m;
-            *reinterpret_cast<f32x4*>(sp + K + ch) = g * iv;
-            *reinterpret_cast<f32x4*>(sp + 2 * K + ch) = be;
+            *reinterpret_cast<f32x4*>(sp + K + ch) = g * iv * sa;
+            *reinterpret_cast<f32x4*>(sp + 2 * K + ch) = be * sa;
         }
         if (a.fresh0 < K && t < 32) {
             const int ch = a.fresh0 + t;
             float mean, invstd;
             bn_moments(a.fsum, a.fsq, (int64_t)n * a.fstride + ch, 1.0 / (double)a.pl.HW, a.eps, mean, invstd);
             sp[ch] = mean;
-            sp[K + ch] = a.bt.gamma[ch] * invstd;
-            sp[2 * K + ch] = a.bt.beta[ch];
+            sp[K + ch] = a.bt.gamma[ch] * invstd * sa;
+            sp[2 * K + ch] = a.bt.beta[ch] * sa;
             if (n0 == 0 && pbase == 0) {
                 a.tw_mean[(int64_t)n * a.bt.ld + ch] = mean;
                 a.tw_invstd[(int64_t)n * a.bt.ld + ch] = invstd;
@@ -134,12 +142,14 @@ static __global__ __launch_bounds__(512, 1) void conv1x1_fwd_ws_kernel(const Fwd
             const int k8 = 2 * s + half;
             u32x4 af[NPIECE], bf[NPIECE];
 #pragma unroll
-            for (int pc = 0; pc < (PREC ? 1 : NPIECE); ++pc) {
+            for (int pc = 0; pc < NP; ++pc) {
                 af[pc] = *reinterpret_cast<const u32x4*>(A + ((pc * G::K8 + k8) * G::LDUA + wm0 + l31) * 16);
                 bf[pc] = *reinterpret_cast<const u32x4*>(B + ((pc * G::K8 + k8) * G::LDUB + wn0 + l31) * 16);
             }
-            if constexpr (PREC != 0) {
-                acc = mfma_1p<PREC>(af[0], bf[0], acc);
+            if constexpr (OP == 3) {
+                acc = mfma_f16(af[0], bf[1], acc);
+                acc = mfma_f16(af[1], bf[0], acc);
+                acc = mfma_f16(af[0], bf[0], acc);
             } else {
                 acc = mfma_bf16(af[0], bf[2], acc);
                 acc = mfma_bf16(af[2], bf[0], acc);
@@ -179,6 +189,11 @@ static __global__ __launch_bounds__(512, 1) void conv1x1_fwd_ws_kernel(const Fwd
     // ---- epilogue (consumers): raw output + per-(stream, channel) sum / sum of squares (fp64)
     double v0 = 0.0, v1 = 0.0;
     if (role == 0) {
+        if constexpr (OP == 3) {               // products of scaled operands: exact power-of-two correction
+            const float inv = a.asc[1] * pack_inv_scale(a.wp);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] *= inv;
+        }
         const int cj = wn0 + l31, col = n0 + cj;
         if (pbase + G::BM <= a.pl.HW) {
             // whole tile inside the plane: shifted fp32 sums per 16-row strip, widened once (see FwdConvP::epilogue)

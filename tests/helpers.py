@@ -100,4 +100,5 @@ def grads_within_fp32_class(prod_named_params, oracle_named_params, g64, factor=
     for _, name, e_prod, e_orc, nrm in over:
         assert e_prod <= outlier_cap * nrm, "%s: |err| %.3e of |g| %.3e" % (name, e_prod, nrm)
     assert np.median(rel_p) <= factor * np.median(rel_o) + 1e-4, (np.median(rel_p), np.median(rel_o))
+    assert np.percentile(rel_p, 90) <= factor * np.percentile(rel_o, 90) + 1e-4, (np.percentile(rel_p, 90), np.percentile(rel_o, 90))
     return np.asarray(rel_p), np.asarray(rel_o), worst[:5]

@@ -4,7 +4,7 @@
 name=$1; extra=$2
 cd "$(dirname "$0")/../smg-multimodal-grasping_amd/csrc" || exit 1
 B=build_$name; mkdir -p $B
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wall -Wno-unused-function $extra"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fno-slp-vectorize -Wall -Wno-unused-function $extra"
 for f in engine forward backward; do /opt/rocm/bin/hipcc $F -c $f.hip -o $B/$f.o & done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $B/engine.o $B/forward.o $B/backward.o -o ../libsmg_$name.so && echo built ../libsmg_$name.so

@@ -1,7 +1,9 @@
 #!/bin/bash
-# dev helper: VGPR / scratch / occupancy / LDS of every kernel in engine.hip (hipcc -Rpass-analysis=kernel-resource-usage)
+# dev helper: VGPR / AGPR / SGPR / scratch / occupancy / LDS of every kernel of the three translation units
+# (hipcc -Rpass-analysis=kernel-resource-usage); `tools/resource_usage.sh > profiles/resource_usage_rNN.txt`
 cd "$(dirname "$0")/../smg-multimodal-grasping_amd/csrc"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Rpass-analysis=kernel-resource-usage -c engine.hip -o /dev/null 2>&1 | python3 -c "
+for f in forward backward engine; do
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fno-slp-vectorize -Rpass-analysis=kernel-resource-usage -c $f.hip -o /dev/null 2>&1 | python3 -c "
 import sys,re,subprocess
 cur=None;rows=[]
 for l in sys.stdin:
@@ -11,8 +13,10 @@ for l in sys.stdin:
         m=re.search(pat,l)
         if m and cur is not None: cur[key]=m.group(1)
 names=subprocess.run(['c++filt']+[r['name'] for r in rows],capture_output=True,text=True).stdout.split('\n')
+print('== $f.hip')
 for r,n in zip(rows,names):
     n=n.replace('smg::','').replace('GemmCfg','Cfg')
     n=re.sub(r'\(.*','',n)
-    print(n[:100].ljust(100),'V',r.get('V'),'A',r.get('A'),'S',r.get('S'),'scr',r.get('scr'),'occ',r.get('occ'),'lds',r.get('lds'))
+    print(n[:130].ljust(130),'V',r.get('V'),'A',r.get('A'),'S',r.get('S'),'scr',r.get('scr'),'occ',r.get('occ'),'lds',r.get('lds'))
 "
+done
