@@ -8,8 +8,8 @@ R = 16 rotations, every rotation a training sample:
     gradient all-reduce over RCCL when N > 1, ONE Adam step (code/trainer.py:383).
 Inputs (heightmaps, labels, weights) are resident in HBM when the timed region starts.
 fp32 in, fp32 out (the reference runs apex O0 = fp32 and parity is gated in fp32, SURVEY.md
-section 7); the convolutions run on the bf16 matrix cores as 3-way split products with
-fp32-class accuracy (csrc/gemm.cuh).
+section 7); the convolutions run on the fp16 matrix cores as scaled two-piece split products
+(three MFMA terms) with fp32-class accuracy (csrc/gemm.cuh, operand kind 3).
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -40,11 +40,13 @@ PASS_GFLOP = 2331.30
 SWEEP_GFLOP = 788.02
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz (the fp32 roof the split scheme breaks)
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA peak (MI355X_MICROARCH.md)
-SPLIT_TERMS = 6                       # v_mfma_f32_32x32x16_bf16 per fp32 product (gemm.cuh): the convolutions' MFMA roof is 2500 / 6
+SPLIT_TERMS = 3                       # v_mfma_f32_32x32x16_f16 per fp32 product of the hot classes (two-piece fp16 split, gemm.cuh operand kind 3): MFMA roof 2500 / 3
+SPLIT_TERMS_PLAIN = 6                 # ... of the classes that stay on the three-piece bf16 split (operand kind 0)
+PLAIN_CLASSES = ("stem7x7_fwd", "transition_wgrad", "transition_dgrad", "stem_wgrad", "head_conv0_wgrad", "head_conv0_dgrad")
 PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / SPLIT_TERMS
 PEAK_HBM_GBS = 8000.0                 # HBM3E peak (MI355X_MICROARCH.md; ~6300 achievable)
-PMC_FILE = "pmc_r03_hbm_traffic.json"                     # tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes
-SERIAL_CSV = "rocprof_r03_kernel_stats_serialized.csv"    # rocprofv3 --kernel-trace --stats of `bench.py --train-only --serialize`
+PMC_FILE = "pmc_r04_hbm_traffic.json"                     # tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes
+SERIAL_CSV = "rocprof_r04_kernel_stats_serialized.csv"    # rocprofv3 --kernel-trace --stats of `bench.py --train-only --serialize`
 PASS5_GFLOP = 36767.6                 # S=1824, R=32 fwd+bwd pass, masked stream de-duplicated
 # rocprofv3 kernel-name fragments that make up each class of roofline.per_kernel (profiles/*kernel_stats*.csv)
 # (reduce_partials_kernel serves every weight gradient that goes through partial tiles - the 3x3 ones, since round 3 the 1x1 ones too,
@@ -166,13 +168,17 @@ def kernel_roofline(step_fn, eng, dev, terms, ms_per_step, step_rl, n_prof=3, pm
     eng.profile_enable(False)
     mfma_roof = PEAK_BF16_MFMA_TFLOPS / terms
 
-    def roof(v):
+    def terms_of(k):      # MFMA terms per product of class k: the classes on the three-piece bf16 split in the fp32-class mode pay six
+        return SPLIT_TERMS_PLAIN if (terms == SPLIT_TERMS and k in PLAIN_CLASSES) else terms
+
+    def roof(v, k=None):
         ms, n, fl, by = v
-        t_mfma, t_hbm = fl * terms / (PEAK_BF16_MFMA_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9)
+        tk = terms_of(k)
+        t_mfma, t_hbm = fl * tk / (PEAK_BF16_MFMA_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9)
         bound = "mfma" if t_mfma >= t_hbm else "hbm"
         t = ms * 1e-3
         if bound == "mfma":
-            r = {"bound": "mfma", "achieved": fl / t / 1e12, "peak": mfma_roof, "unit": "TFLOP/s"}
+            r = {"bound": "mfma", "achieved": fl / t / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS / tk, "unit": "TFLOP/s"}
         else:
             r = {"bound": "hbm", "achieved": by / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s"}
         r["frac"] = max(t_mfma, t_hbm) / t
@@ -197,7 +203,7 @@ def kernel_roofline(step_fn, eng, dev, terms, ms_per_step, step_rl, n_prof=3, pm
                                % (PMC_FILE, meta.get("command", "?"), meta.get("train_steps", "?"), meta.get("commit", "?")))
         except (OSError, ValueError, KeyError):
             pass
-    rl = roof(conv[dom])
+    rl = roof(conv[dom], dom)
     rl.update({
         "kernel": dom, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
         "algorithmic_bytes_per_launch": by / n, "flops_per_launch": fl / n,
@@ -205,15 +211,17 @@ def kernel_roofline(step_fn, eng, dev, terms, ms_per_step, step_rl, n_prof=3, pm
         "kernel_symbols": CLASS_SYMBOLS.get(dom, []),        # rocprofv3 kernel names that make up `kernel`
         "timing": "hipEvents around every launch of the class, all launches serialised on one stream (smg_profile_enable), %d training steps" % n_prof,
         "rocprof_serialized": csv_class_avg_ms(CLASS_SYMBOLS.get(dom, [])) if pmc else None,   # the same class in the tracked serialised rocprofv3 CSV
-        "arithmetic": ("fp32 in / fp32 out; every product = 6 v_mfma_f32_32x32x16_bf16 terms of a 3-piece bf16 split (fp32-class accuracy, "
-                       "tools/split_probe.hip): MFMA roof %.1f TFLOP/s fp32-equivalent" % mfma_roof) if terms > 1 else
+        "mfma_terms": terms,
+        "arithmetic": ("fp32 in / fp32 out; every product of the dense layers = 3 v_mfma_f32_32x32x16_f16 terms of a scaled 2-piece fp16 split "
+                       "(fp32-class accuracy, tools/split16_probe.hip): MFMA roof %.1f TFLOP/s fp32-equivalent; stem / transition and head "
+                       "gradients: 6 bf16 terms" % mfma_roof) if terms > 1 else
                       "16-bit storage of activations and gradients, one 16-bit MFMA term per product: MFMA roof %.0f TFLOP/s, bytes counted at 2 B / element" % mfma_roof,
         "all_conv_kernels": {"achieved": conv_fl / (conv_ms * 1e-3) / 1e12, "frac_of_mfma_roof": conv_fl / (conv_ms * 1e-3) / 1e12 / mfma_roof,
                              "frac_of_fp32_mfma_peak": conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                              "ms_per_step": conv_ms / n_prof, "executed_gflop_per_step": conv_fl / n_prof / 1e9},
         "elementwise_ms_per_step": prof["elementwise"][0] / n_prof,
         "launches_per_step_all": sum(v[1] for v in prof.values()) // n_prof,
-        "per_kernel": {k: dict(roof(v), ms_per_step=v[0] / n_prof, launches_per_step=v[1] // n_prof,
+        "per_kernel": {k: dict(roof(v, k), ms_per_step=v[0] / n_prof, launches_per_step=v[1] // n_prof,
                                tflops=(v[2] / (v[0] * 1e-3) / 1e12) if v[0] > 0 else 0.0,
                                algorithmic_gb_per_step=v[3] / n_prof / 1e9) for k, v in prof.items() if v[1] > 0 and (v[2] > 0 or v[3] > 0)},
         # [ms per step, TFLOP/s] inside dense block 1..4 (160^2, 80^2, 40^2, 20^2 planes at S=640)
@@ -221,7 +229,7 @@ def kernel_roofline(step_fn, eng, dev, terms, ms_per_step, step_rl, n_prof=3, pm
                       for k, rows in stages.items() if any(r[1] > 0 for r in rows)},
     })
     # whole step: the sum of the per-class roofline times against the measured step
-    floor_s = sum(max(v[2] * terms / (PEAK_BF16_MFMA_TFLOPS * 1e12), v[3] / (PEAK_HBM_GBS * 1e9)) for v in prof.values()) / n_prof
+    floor_s = sum(max(v[2] * terms_of(k) / (PEAK_BF16_MFMA_TFLOPS * 1e12), v[3] / (PEAK_HBM_GBS * 1e9)) for k, v in prof.items()) / n_prof
     rl["step"] = dict(step_rl or {}, roofline_ms=floor_s * 1e3, measured_ms=ms_per_step, frac=floor_s * 1e3 / ms_per_step)
     return rl
 
@@ -427,7 +435,7 @@ def main():
     depth_d, mdepth_d, labels_d = on_dev(depth), on_dev(mdepth), on_dev(labels, np.float32)
 
     leg = args.leg
-    dtype, dtype_note = "f32", "fp32 storage and results; matrix products on the bf16 MFMA as exact 3-way splits (6 terms, fp32 accumulate)"
+    dtype, dtype_note = "f32", "fp32 storage and results; matrix products on the fp16 MFMA as scaled two-piece splits (3 terms, fp32 accumulate; fp32-class accuracy)"
     if leg == "headline":
         units_per_step, pass_gflop, input_size = 1.0, PASS_GFLOP, 640
         workload = ("reinforcement_net style 0 (grasp trunk + graspnet_val head): 1 scene x 1 mask x 16 rotations per GPU per "

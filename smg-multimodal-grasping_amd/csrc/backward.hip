@@ -250,7 +250,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             const int cs = T.layers[b][g_lo].cin;                       // channels below the group
             if (d.cin > cs) {                                           // [cs, cin): per-layer accumulate
                 auto run = [&](auto tag, auto ptag) {
-                    using Cfg = MC<decltype(tag), decltype(ptag)::value>;
+                    using Cfg = MCD<decltype(tag), decltype(ptag)::value, SMG_DEEP_D1N>;
                     BwdDataP<Cfg, false, E_ACCUM, false, decltype(ptag)::value> p{};
                     p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kBottleneck; p.gamax = gamax_of(e, b, i, 1);
                     p.wp = e->packed_u + e->pk_d1[b][i]; p.K8tot = kBottleneck / 8; p.ldn = d.cin; p.wcol0 = cs; p.N = d.cin - cs;
@@ -267,7 +267,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             }
             if (i == g_lo) {                                            // [0, cs): the whole group at once
                 auto run = [&](auto tag, auto ptag) {
-                    using Cfg = MC<decltype(tag), decltype(ptag)::value>;
+                    using Cfg = MCD<decltype(tag), decltype(ptag)::value, SMG_DEEP_D1G>;
                     BwdDataGroupP<Cfg, decltype(ptag)::value> p{};
                     const int g_hi = L - 1 - ((L - 1 - g_lo) / kGroup) * kGroup;      // top layer of this group
                     p.nseg = g_hi - g_lo + 1;
@@ -292,7 +292,11 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 PREC_DISPATCH(e, if (pl.HWp % 128 == 0) run(GemmCfg<128, 64, 32, 2, 2, 1, true>{}, PTAG); else run(CfgP64x64{}, PTAG));
             }
             {   // conv1 weight gradient.  ~320 workgroups: it shares the chip with the data-gradient chain on the other stream
+#ifdef SMG_W1_WIDE      // dev A/B: 128 x 128 tiles (the gradient operand is split once per 128 columns instead of once per 64)
+                using Cfg = CfgW128x128;
+#else
                 using Cfg = CfgW128x64;
+#endif
                 const int nt = (d.cin + Cfg::BN - 1) / Cfg::BN;
                 int chunk, cps;
                 static const int w1_target = getenv("SMG_W1_WGS") ? atoi(getenv("SMG_W1_WGS")) : 320;            // dev A/B
@@ -302,7 +306,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 const int w1_prec = (e->prec && NS >= 16 && !getenv("SMG_W1_WGS")) ? 160 : w1_target;
                 pick_chunk(pl, NS, nt, chunk, cps, pl.HW <= 1600 ? (getenv("SMG_W1_WGS_SMALL") ? w1_small : w1_prec) : w1_prec);   // 256..384 measure the same (22.46 ms per step), 512: 22.6, 768: 22.8, 1024: 23.2
                 auto go = [&](auto ptag) -> int {
-                BwdWeightP<MC<Cfg, decltype(ptag)::value>, W_ONE, C_IDENT, SMG_PD_WGRAD, false, decltype(ptag)::value> p{};
+                BwdWeightP<MCD<Cfg, decltype(ptag)::value, SMG_DEEP_W1>, W_ONE, C_IDENT, SMG_PD_WGRAD, false, decltype(ptag)::value> p{};
                 p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck; p.gamax = gamax_of(e, b, i, 1); p.basc = asc_n1(e, b, i);
                 p.bbuf = e->X[b]; p.ldb = Ct; p.pb = pl; p.NB = d.cin;
                 p.bsum = fsum(e, e->st_X[b]); p.bsq = fsq(e, e->st_X[b]); p.bstride = Ct; p.btab = use_tabs ? stat_table(e, e->sx_tab[b], e->max_streams, Ct) : StatTab{};

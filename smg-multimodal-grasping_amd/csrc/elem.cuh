@@ -103,9 +103,9 @@ struct PackDesc { int64_t src, dst; int cout, cin, mode, K8tot, N, count, op0; }
 //   blockIdx.y >= n_pack: BatchNorm + ReLU operand y - n_pack: m = max_c hypot(gamma_c, beta_c), s = 2^(4 - floor(log2 m))
 //                         (m * s in [16, 32)) -> asc[2 * (y - n_pack)] = {s, 1 / s}
 struct ActScaleDesc { int64_t gamma, beta; int C; };
-static __global__ void scale_kernel(const PackDesc* descs, int n_pack, const ActScaleDesc* adescs, const float* params, u32x4* packed_u,
-                                    float* asc, int prec) {
-    __shared__ float red[4];
+static __global__ __launch_bounds__(1024) void scale_kernel(const PackDesc* descs, int n_pack, const ActScaleDesc* adescs, const float* params, u32x4* packed_u,
+                                                           float* asc, int prec) {
+    __shared__ float red[16];
     const int t = threadIdx.x, y = blockIdx.y;
     float m = 0.f;
     int target;
@@ -115,11 +115,18 @@ static __global__ void scale_kernel(const PackDesc* descs, int n_pack, const Act
         const int taps = (d.mode == PK_3F || d.mode == PK_3D || d.mode == PK_HF || d.mode == PK_HD) ? 9 : 1;
         const int64_t count = (int64_t)d.cout * d.cin * taps;
         const float* w = params + d.src;
-        for (int64_t i = t; i < count; i += 256) m = fmaxf(m, fabsf(w[i]));
+        float m4[4] = {0.f, 0.f, 0.f, 0.f};                 // four independent loads in flight per thread (127 k floats in the largest tensor)
+        int64_t i = t;
+        for (; i + 3 * 1024 < count; i += 4 * 1024) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m4[u] = fmaxf(m4[u], fabsf(w[i + u * 1024]));
+        }
+        for (; i < count; i += 1024) m4[0] = fmaxf(m4[0], fabsf(w[i]));
+        m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
         target = 13;
     } else {
         const ActScaleDesc d = adescs[y - n_pack];
-        for (int c = t; c < d.C; c += 256) { const float g = params[d.gamma + c], b = params[d.beta + c]; m = fmaxf(m, g * g + b * b); }
+        for (int c = t; c < d.C; c += 1024) { const float g = params[d.gamma + c], b = params[d.beta + c]; m = fmaxf(m, g * g + b * b); }
         m = sqrtf(m);
         target = 4;
     }
@@ -128,7 +135,9 @@ static __global__ void scale_kernel(const PackDesc* descs, int n_pack, const Act
     if ((t & 63) == 0) red[t >> 6] = m;
     __syncthreads();
     if (t == 0) {
-        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        m = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) m = fmaxf(m, red[u]);
         int e = (int)(__float_as_uint(m) >> 23) - 127;     // floor(log2 m); 0, subnormal or non-finite maxima: scale 1
         float sc = 1.f, inv = 1.f;
         if (m > 0.f && e > -100 && e < 100) { sc = __uint_as_float((unsigned)(127 + target - e) << 23); inv = __uint_as_float((unsigned)(127 - target + e) << 23); }

@@ -55,11 +55,6 @@ using CfgP64x128d = GemmCfg<64, 128, 32, 2, 2, 1, true>;     // the same for pla
 using CfgP64x64w = GemmCfg<64, 64, 32, 1, 2, 2, true>;       // 64x64 with 64x32 wave tiles over half the k-steps each: 25% fewer fragment reads per MFMA
 using CfgP64x128 = GemmCfg<64, 128, 16, 2, 2, 1, true>;      // 3x3 dgrad, late 1x1 fwd / transitions (A operand read once)
 using CfgP64x32 = GemmCfg<64, 32, 64, 2, 1, 2, true>;        // 3x3 fwd, k-tile split over 2 waves
-// row-streaming forms (gemm_tile_rs): a wave spans all BN columns of its 32 rows
-using CfgR128x128 = GemmCfg<128, 128, 32, 4, 1, 1, true>;    // 1x1 fwd
-using CfgR64x128 = GemmCfg<64, 128, 32, 2, 1, 2, true>;      // 1x1 fwd on planes that tile by 64 rows only: the k-tile split over 2 wave pairs
-using CfgR128x64 = GemmCfg<128, 64, 32, 4, 1, 1, true>;      // 1x1 dgrad
-using CfgR64x64 = GemmCfg<64, 64, 32, 2, 1, 2, true>;
 // weight gradients (reduction over pixels)
 using CfgW32x128 = GemmCfg<32, 128, 32, 1, 4, 1, false>;     // 3x3 wgrad (32 x 128 per tap)
 using CfgW128x64 = GemmCfg<128, 64, 16, 2, 2, 1, false>;     // 1x1 wgrad (128 x cin)
@@ -71,6 +66,22 @@ using CfgW64x256 = GemmCfg<64, 256, 16, 2, 2, 1, false>;     // stem wgrad: all 
 // k-tiles are MUL times deeper (the single-piece LDS images are a third of the fp32-class ones, so the tiles still fit).
 template <class C, int PREC, int MUL = 2>
 using MC = typename std::conditional<PREC == 0, C, GemmCfg<C::BM, C::BN, MUL * C::BK, C::WM, C::WN, C::WK, C::AT>>::type;
+// ... and per kernel family in mode 0 under the two-piece fp16 split (LDS images two thirds of the bf16 split's, half the MFMA
+// terms per k-tile): dev knobs, A/B with tools/build_variant.sh
+#ifndef SMG_DEEP_C1
+#define SMG_DEEP_C1 0
+#endif
+#ifndef SMG_DEEP_D1N
+#define SMG_DEEP_D1N 0
+#endif
+#ifndef SMG_DEEP_D1G
+#define SMG_DEEP_D1G 0
+#endif
+#ifndef SMG_DEEP_W1
+#define SMG_DEEP_W1 0
+#endif
+template <class C, int PREC, int DEEP0, int MUL = 2>
+using MCD = typename std::conditional<(PREC == 0 && !DEEP0), C, GemmCfg<C::BM, C::BN, MUL * C::BK, C::WM, C::WN, C::WK, C::AT>>::type;
 
 enum Kind {
     K_STEM = 0, K_C1, K_C3, K_TRANS, K_HEAD0, K_D3, K_W3, K_D1, K_W1, K_TW, K_TD, K_SW, K_HW0, K_HD0, K_OTHER, K_COUNT
@@ -312,26 +323,6 @@ static void launch_gemm(smg_engine* e, hipStream_t st, P p, dim3 grid, int kind,
         ProfScope ps(e, st, kind, flops);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_kernel<P>), dim3((unsigned)(grid.x * grid.y * grid.z)), dim3(256), smem, st, p, (int)grid.x, (int)grid.y);
     }
-}
-
-// The row-streaming k-loop (gemm_tile_rs) for an AT policy with WN == 1.
-template <class P>
-static void launch_gemm_rs(smg_engine* e, hipStream_t st, P p, dim3 grid, int kind, double flops) {
-    const size_t smem = (size_t)(RsGeo<P>::TILE_FLOATS + p.param_floats()) * sizeof(float);
-    if (smem > 64 * 1024) {
-        static bool raised[64] = {};
-        if (!raised[e->device & 63]) {
-            (void)hipFuncSetAttribute((const void*)gemm_rs_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            raised[e->device & 63] = true;
-        }
-    }
-    p.tm = TileMap{0, 0, 0};
-    if (grid.y > 1 && grid.z == 1) {
-        p.tm = TileMap{(int)grid.x, (int)grid.y, 0};
-        grid = dim3(8 * ((grid.x + 7) / 8) * grid.y, 1, 1);
-    }
-    ProfScope ps(e, st, kind, flops);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemm_rs_kernel<P>), dim3((unsigned)(grid.x * grid.y * grid.z)), dim3(256), smem, st, p, (int)grid.x, (int)grid.y);
 }
 
 // Weight-gradient launch: partial tiles to the workspace + one reduce kernel (falls back to

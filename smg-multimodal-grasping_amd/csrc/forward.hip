@@ -65,7 +65,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
         const unsigned n_pack = (unsigned)(e->h_pack[trunk_id].size() + e->h_pack_head[head_id].size());
         if (e->prec == 0 && kSplitOp == 3) {       // scales of the fp16-split operands: weight headers + activation scales (gemm.cuh, operand kind 3)
             ProfScope ps(e, st, K_OTHER, 0);
-            hipLaunchKernelGGL(scale_kernel, dim3(1, n_pack + (unsigned)e->n_asc), dim3(256), 0, st,
+            hipLaunchKernelGGL(scale_kernel, dim3(1, n_pack + (unsigned)e->n_asc), dim3(1024), 0, st,
                                e->d_pack + (trunk_id * 3 + head_id) * e->pack_stride, (int)n_pack, e->d_asc + (trunk_id * 3 + head_id) * e->n_asc,
                                net->params, e->packed_u, e->asc, e->prec);
         }
@@ -150,7 +150,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                     if (i == 0) bn_stat(cs, t1, ns, xsum, xsq, Ct, 0, d.cin, pl.HW);     // block input: from pool0 / the transition
                     auto run_p = [&](auto tag, auto ptag) {
                         using Cfg0 = decltype(tag);
-                        using Cfg = MC<Cfg0, decltype(ptag)::value, (Cfg0::BK < 32 ? 2 : 1)>;      // (cin is a multiple of 32 only)
+                        using Cfg = MCD<Cfg0, decltype(ptag)::value, SMG_DEEP_C1, (Cfg0::BK < 32 ? 2 : 1)>;      // (cin is a multiple of 32 only)
                         FwdConvP<Cfg, F_ONE, decltype(ptag)::value> p{};
                         p.src = xs(b); p.lds_ = Ct; p.ps = pl; p.po = pl; p.K = d.cin; p.asc = asc_n1(e, b, (int)i);
                         p.bt = t1; p.fresh0 = i == 0 ? d.cin : d.cin - kGrowth; p.fsum = xsum; p.fsq = xsq; p.fstride = Ct; p.eps = kEps;

@@ -71,6 +71,9 @@
 #ifndef SMG_PD_WGRAD
 #define SMG_PD_WGRAD 3
 #endif
+#ifndef SMG_PD_DGRAD_GROUP      // the layer-grouped 1x1 data gradient with deep k-tiles
+#define SMG_PD_DGRAD_GROUP 1
+#endif
 
 // The order of fragment reads and MFMAs inside a k-tile is left to hipcc (with two k-tiles of loads in flight it interleaves
 // the next tile's split / LDS stores with the MFMAs: k-loop of the 64x64 forward -17 %, of the 1x1 data gradient -27 %);
@@ -976,186 +979,6 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
     if (trace) trace[6] = __builtin_amdgcn_s_memrealtime();
 }
 
-// ------------------------------------------------------------------------------------
-// Row-streaming variant of the k-loop for the pixel-major (AT) policies whose A operand is a plain row of channels
-// (1x1 forward, 1x1 data gradients): the MFMA A fragment IS the memory layout - lane (row, half) needs 8 consecutive k of its
-// row - so every wave loads, transforms (BN + ReLU ...) and splits the fragments of its own 32 rows in REGISTERS: no LDS image,
-// no LDS store, no barrier and no cross-wave dependency on the A side, and a load ring of D k16-steps per wave whose depth is
-// bounded by registers only (the LDS-staged loop holds 1-2 k-tiles per WORKGROUP in flight and serialises store -> barrier ->
-// fragment read per k-tile).  Only the weights go through LDS (register-staged, double-buffered, one barrier per k-tile).
-// Wave layout: WN == 1 (a wave spans all BN columns of its 32 rows: the transform of an A element happens exactly once),
-// WM x WK waves, TM == 1.  Summation order per output element = k ascending within a wave, as in gemm_tile.
-// ------------------------------------------------------------------------------------
-template <class P> struct RsGeo {
-    using C = typename P::Cfg;
-    static constexpr int NP = NPIECE;
-    static constexpr int B_BYTES = NP * C::K8 * C::LDUB * 16;
-    static constexpr int B_N = (NP * C::K8 * C::BN + 255) / 256;
-    static constexpr bool B_FULL = (NP * C::K8 * C::BN) % 256 == 0;
-    static constexpr int TILE_FLOATS = (2 * B_BYTES / 4 > C::RED_FLOATS) ? 2 * B_BYTES / 4 : C::RED_FLOATS;
-};
-
-template <class P>
-__device__ __forceinline__ void gemm_tile_rs(const P& p, const VBlock vb, float* smem) {
-    using C = typename P::Cfg;
-    using Z = RsGeo<P>;
-    static_assert(C::AT && C::WN == 1 && C::TM == 1 && P::kOp == 0 && P::kAE == 4, "row-streaming form: fp32 rows, split products");
-    constexpr int TN = C::TN, KS = C::KS, NP = NPIECE;
-    constexpr int D = 4;                                  // k16-steps of A loads in flight per wave (8 VGPRs each)
-    static_assert(D % KS == 0, "ring depth in whole k-tiles");
-    constexpr int UNR = D / KS;                           // k-tiles per unrolled trip: every ring slot index is a compile-time constant
-    char* Bs = reinterpret_cast<char*>(smem);
-    float* sp = smem + Z::TILE_FLOATS;
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int wk = wave / C::WM, wm0 = (wave % C::WM) * 32;
-    typename P::Ctx ctx;
-    if (!p.init_ctx(ctx, vb)) return;      // tile made of padding rows only (block-uniform)
-    const int KT = p.ktiles(ctx);
-
-    f32x16 acc[1][TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
-
-    typename P::ARow arow;
-    p.a_row_init(ctx, arow, wm0 + l31);
-    // this lane's two channel quads of k16-step s of a k-tile: quads 4 * (wk * KS + s) + 2 * half + {0, 1}
-    typename P::ARaw ring[D][2];
-    typename P::KPrm kp0 = p.k_fetch(ctx, 0, 0);
-    auto a_issue = [&](int kt, int s, typename P::ARaw (&r)[2]) {
-        const int ktc = kt < KT ? kt : KT - 1;            // past the end: a clamped re-load nobody consumes (same load count on every path)
-        const int q = 4 * (wk * KS + s) + 2 * half;
-        r[0] = p.a_fetch(ctx, arow, ktc, q);
-        r[1] = p.a_fetch(ctx, arow, ktc, q + 1);
-    };
-    u32x4 rb[Z::B_N];
-    auto b_issue = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < Z::B_N; ++i) {
-            const int id = t + 256 * i;
-            const int r = id % C::BN, pk = id / C::BN;
-            if (Z::B_FULL || pk < NP * C::K8) rb[i] = p.b_unit(ctx, kt, pk / C::K8, pk % C::K8, r);
-        }
-    };
-    auto b_store = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < Z::B_N; ++i) {
-            const int id = t + 256 * i;
-            if (Z::B_FULL || id < NP * C::K8 * C::BN) *reinterpret_cast<u32x4*>(Bs + buf * Z::B_BYTES + id * 16) = rb[i];
-        }
-    };
-    // prologue: the ring's first D steps and the first weight tile go out before the parameter prologue
-#pragma unroll
-    for (int g = 0; g < D; ++g) a_issue(g / KS, g % KS, ring[g]);
-    b_issue(0);
-    p.init_params(ctx, sp);
-    b_store(0);
-    __syncthreads();
-
-    auto step = [&](int kt, int s, typename P::ARaw (&r)[2], const char* B) {
-        // transform + split of this lane's 8 k of its row (registers only)
-        const int q = 4 * (wk * KS + s) + 2 * half;
-        const Split4 s0 = split4<0>(p.a_xform(ctx, r[0], p.k_finish(ctx, kp0, kt, q, sp), kt, q, sp));
-        const Split4 s1 = split4<0>(p.a_xform(ctx, r[1], p.k_finish(ctx, kp0, kt, q + 1, sp), kt, q + 1, sp));
-        u32x4 a[NP];
-#pragma unroll
-        for (int pc = 0; pc < NP; ++pc) a[pc] = u32x4{s0.p[pc].x, s0.p[pc].y, s1.p[pc].x, s1.p[pc].y};
-        a_issue(kt + UNR, s, r);                          // the slot's next occupant: D steps ahead
-        __builtin_amdgcn_sched_barrier(0);                // (issued before this step's MFMAs, not after them)
-        const int k8 = (wk * KS + s) * 2 + half;
-        auto fb = [&](int j, int pc) -> u32x4 {
-            return *reinterpret_cast<const u32x4*>(B + ((pc * C::K8 + k8) * C::LDUB + j * 32 + l31) * 16);
-        };
-        u32x4 bh[TN], bx[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) { bh[j] = fb(j, 0); bx[j] = fb(j, 2); }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[0][j] = mfma_bf16(a[0], bx[j], acc[0][j]);        // hi * lo
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[0][j] = mfma_bf16(a[2], bh[j], acc[0][j]);        // lo * hi
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bx[j] = fb(j, 1);                                     // mid pieces into the registers lo occupied
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[0][j] = mfma_bf16(a[1], bx[j], acc[0][j]);        // mid * mid
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[0][j] = mfma_bf16(a[0], bx[j], acc[0][j]);        // hi * mid
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[0][j] = mfma_bf16(a[1], bh[j], acc[0][j]);        // mid * hi
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[0][j] = mfma_bf16(a[0], bh[j], acc[0][j]);        // hi * hi
-    };
-    // Whole trips of UNR k-tiles run branch-free: unconditional, tail-clamped loads (and at the very end a dead LDS store of the
-    // clamped re-load) - with the same loads issued on every path hipcc counts vmcnt exactly, so the ring really stays D steps
-    // deep (a conditional around the weight loads made it drain to vmcnt(0) once per trip).  The last KT % UNR k-tiles are peeled.
-    int kt0 = 0;
-    for (; kt0 + UNR <= KT; kt0 += UNR) {
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int kt = kt0 + u, buf = u & 1;          // kt0 is a multiple of UNR (even): k-tile parity = u & 1
-            b_issue(kt + 1 < KT ? kt + 1 : KT - 1);
-            __builtin_amdgcn_sched_barrier(0);            // the loads go out HERE (hipcc otherwise sinks them to their first use: a full
-                                                          // memory round trip in front of every barrier)
-#pragma unroll
-            for (int s2 = 0; s2 < KS; ++s2) step(kt, s2, ring[u * KS + s2], Bs + buf * Z::B_BYTES);
-            if constexpr (P::kSegmented) p.k_hook(ctx, kt, acc, sp);
-            b_store(buf ^ 1);
-            __syncthreads();
-        }
-    }
-#pragma unroll
-    for (int u = 0; u + 1 < UNR; ++u) {
-        const int kt = kt0 + u, buf = u & 1;
-        if (kt < KT) {                                    // (workgroup-uniform)
-            if (kt + 1 < KT) b_issue(kt + 1);
-#pragma unroll
-            for (int s2 = 0; s2 < KS; ++s2) step(kt, s2, ring[u * KS + s2], Bs + buf * Z::B_BYTES);
-            if constexpr (P::kSegmented) p.k_hook(ctx, kt, acc, sp);
-            if (kt + 1 < KT) b_store(buf ^ 1);
-            __syncthreads();
-        }
-    }
-    static_assert(UNR % 2 == 0, "the weight double buffer alternates with the k-tile parity");
-    if constexpr (C::WK > 1) {              // in-block split-K: fold the partial tiles into the wk == 0 waves
-        constexpr int PER = TN * 16 * 64;
-        const int wmn = wave % C::WM;
-        if (wk > 0) {
-            float* r = smem + ((wk - 1) * C::WM + wmn) * PER + lane;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) r[(j * 16 + q) * 64] = acc[0][j][q];
-        }
-        __syncthreads();
-        if (wk == 0) {
-#pragma unroll
-            for (int w = 1; w < C::WK; ++w) {
-                const float* r = smem + ((w - 1) * C::WM + wmn) * PER + lane;
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) acc[0][j][q] += r[(j * 16 + q) * 64];
-            }
-        }
-        __syncthreads();
-    }
-    p.epilogue(ctx, acc, smem, sp, wk == 0);
-}
-
-template <class P>
-static __global__ __launch_bounds__(256, P::kMinWaves) void gemm_rs_kernel(const P p, const int vgx, const int vgy) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    VBlock vb;
-    vb.linear = blockIdx.x;
-    vb.x = vb.linear % vgx;
-    const int q = vb.linear / vgx;
-    vb.y = q % vgy;
-    vb.z = q / vgy;
-    gemm_tile_rs<P>(p, vb, smem);
-}
-
 // One workgroup per virtual block (x fastest).  A persistent variant (resident workgroups striding over the virtual
 // grid) was measured and rejected: hipcc hoists the per-thread addressing out of the tile loop (+50..70 VGPRs, one
 // workgroup less per CU) and the launch is not dispatch-bound.
@@ -1954,7 +1777,7 @@ struct BwdDataGroupP {
     // deep k-tiles with ONE tile of loads in flight (the staging registers of two half-as-deep tiles, half the barriers): mode 0
     // 128 x 64 x 32 (serialised 1.61 -> 1.47 ms per step), 16-bit modes 128 x 64 x 64 and 64 x 64 x 64 (config 3: 1.95 -> 1.79 and
     // 1.54 -> 1.35 ms, step 28.8 -> 28.3 ms)
-    static constexpr int kPrefetch = ((PREC == 0 && Cfg::BK >= 32 && Cfg::TM * Cfg::TN >= 2) || (PREC != 0 && Cfg::BK >= 64)) ? 1
+    static constexpr int kPrefetch = ((PREC == 0 && Cfg::BK >= 32 && Cfg::TM * Cfg::TN >= 2) || (PREC != 0 && Cfg::BK >= 64)) ? SMG_PD_DGRAD_GROUP
                                      : (Cfg::TM * Cfg::TN <= 1) ? SMG_PD_DGRAD : SMG_PD_DGRAD_BIG;
     static constexpr bool kSegmented = true;
     static constexpr bool kHasPrologue = true;
