@@ -202,6 +202,8 @@ static int w3_tiles_per_wg(int n_tiles, int ts, int n_streams, int64_t part_floa
         const double cost = rounds * (tpw + fix);
         if (cost < best - 1e-9) { best = cost; tpw_best = tpw; }
     }
+    // (taking the LONGEST run length within 4-40 % of the shortest total - fewer partial tiles for the reduce to read back - measured
+    //  17.3-17.4 against 17.27 ms per step: the partial-tile traffic is not what the side stream waits for)
     while (tpw_best < n_tiles && (int64_t)((n_tiles + tpw_best - 1) / tpw_best) * n_streams * 9 * 32 * kBottleneck > part_floats) ++tpw_best;
     return tpw_best;
 }

@@ -24,6 +24,14 @@
 #pragma once
 #include "gemm.cuh"
 
+// dev knobs: waves per SIMD the register allocator is held to (512 / n registers per lane)
+#ifndef SMG_HALO_FWD_WAVES
+#define SMG_HALO_FWD_WAVES 2
+#endif
+#ifndef SMG_HALO_WGRAD_WAVES
+#define SMG_HALO_WGRAD_WAVES 2
+#endif
+
 namespace smg {
 
 template <int TS>
@@ -77,7 +85,7 @@ template <int TS, int PREC> struct HaloFwdSGeo : HaloGeo<TS> {
 };
 
 template <int TS, int PREC = 0>
-static __global__ __launch_bounds__(256, 2) void conv3x3_halo_fwd_kernel(const Halo3x3FwdArgs a) {
+static __global__ __launch_bounds__(256, SMG_HALO_FWD_WAVES) void conv3x3_halo_fwd_kernel(const Halo3x3FwdArgs a) {
     using G = HaloFwdSGeo<TS, PREC>;
     using ST = act_t<PREC>;
     constexpr int OP = fwd_op(PREC), NP = G::NP, CK = G::CK, K8C = G::K8C, KSTEP = CK / 16;
@@ -650,7 +658,7 @@ template <int TW, int PREC> struct HaloWgradSGeo {
 };
 
 template <int TW, int PREC = 0>
-static __global__ __launch_bounds__(256, 2) void conv3x3_halo_wgrad_kernel(const Halo3x3WgradArgs a) {
+static __global__ __launch_bounds__(256, SMG_HALO_WGRAD_WAVES) void conv3x3_halo_wgrad_kernel(const Halo3x3WgradArgs a) {
     using G = HaloWgradSGeo<TW, PREC>;
     using GT = grd_t<PREC>;
     using XT = act_t<PREC>;
