@@ -256,6 +256,51 @@ def test_g5_backward_gradients(gpu, golden, style, rot, label):
         assert (mine == has).all()
 
 
+def test_split_scales_cover_extreme_magnitudes(gpu):
+    """The fp16-split products (csrc/gemm.cuh, operand kind 3) rest on three scales: per weight tensor (its maximum), per BN + ReLU
+    operand (hypot(gamma, beta)), per gradient tensor and stream (its recorded maximum).  Push every one of them far from the synthetic
+    nets' comfortable magnitudes and hold the result to the SAME fp32-class gates against the fp64 oracle: the bottleneck weights of dense
+    block 2 x 4096 and of block 3 x 2^-12 (the BN behind a convolution removes the factor again: the activations stay put, the weight
+    tensors and their gradients move by 3.6 decades each way), gamma / beta of every norm2 in block 1 x 2^-10 (tiny BN + ReLU operands;
+    the next convolution's weights x 2^10 restore the signal), and a label 1e-6 away from Q (gradients of 1e-6 of their usual size
+    through the whole backward)."""
+    on = oracle_net(0)
+    sd = {k: v.clone() for k, v in on.state_dict().items()}
+    for k in sd:
+        if ".denseblock2." in k and k.endswith("conv1.weight"):
+            sd[k] *= 4096.0
+        if ".denseblock3." in k and k.endswith("conv1.weight"):
+            sd[k] *= 2.0 ** -12
+        if ".denseblock1." in k and (k.endswith("norm2.weight") or k.endswith("norm2.bias")):
+            sd[k] *= 2.0 ** -10
+        if ".denseblock1." in k and k.endswith("conv2.weight"):
+            sd[k] *= 2.0 ** 10
+    on.load_state_dict(sd)
+    style, rot = 0, 5
+    x, mx = scene_tensors(0, [0])
+    rx = orc.rotate(x, rot, 16)
+    q64, _ = _fp64_truth(on, rx, mx, style, 0.0)
+    label = q64 - 1e-6                                     # |dq| = 1e-6: the quadratic Huber branch, gradients scaled by 1e-6
+    q64, g64 = _fp64_truth(on, rx, mx, style, label)
+    net = product_net(0)
+    net.load_state_dict(sd)
+    net.zero_grad()
+    qp = net.forward(x, mx, style, False, rot)
+    assert abs(float(qp.detach()) - q64) <= 1e-3 * max(abs(q64), 1e-2), (float(qp.detach()), q64)
+    # the label sits 1e-6 from the fp64 Q; the product's own Q differs from it by its fp32-class error, which would swamp the 1e-6:
+    # drive the backward with the oracle's dq so that both sides differentiate the same loss
+    dq = torch.full_like(qp.detach(), float(q64 - label))
+    qp.backward(dq)
+    on.zero_grad()
+    qo = orc.forward(on, x, mx, style, False, rot)
+    qo.backward(torch.full_like(qo.detach(), float(q64 - label)))
+    rel_p, rel_o, _ = grads_within_fp32_class(net.named_parameters(), on.named_parameters(), g64, 3.0, "extreme scales", max_outliers=4, outlier_cap=0.05)
+    assert len(rel_p) == 368
+    gn = {n: float(p.grad.double().norm()) for n, p in net.named_parameters() if p.grad is not None}
+    assert all(np.isfinite(v) for v in gn.values()) and min(gn.values()) > 0.0
+    print("extreme scales: gradient norms span %.1e .. %.1e; median rel err %.2e (oracle %.2e)" % (min(gn.values()), max(gn.values()), np.median(rel_p), np.median(rel_o)))
+
+
 def test_g5_g6_trainer_steps_vs_reference(gpu, golden):
     """Trainer.backprop x3 (grasp, suction, grasp_then_suction): q, loss and Adam-updated
     weights against the reference's own trajectory; then the diverged target network."""

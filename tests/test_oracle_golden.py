@@ -207,3 +207,58 @@ def test_heightmap_restatement_known_answers():
     pose[:3, 3] = [-0.5, 0.0, 0.6]
     z = hm.world_z(np.full((480, 640), 0.55), k, pose)       # a plane 0.55 m in front of a downward camera 0.6 m up
     assert np.allclose(z, 0.05)
+
+
+# ---------------------------------------------------------------------------------------
+# The arithmetic of the HIP path's dense-layer products (csrc/gemm.cuh, operand kind 3), restated in numpy: a scaled two-piece fp16
+# split with three fp32-accumulated terms h*l + l*h + h*h.  No GPU: this pins the CLAIMS the kernels rest on - the
+# GPU-side measurement of the same scheme is tools/split16_probe.hip, the product's own gate test_layer_products_within_fp32_chain_error.
+def _split16(x, s):
+    y = (x * np.float32(s)).astype(np.float32)
+    h = y.astype(np.float16)                                  # round to nearest even, subnormals kept (v_cvt_pk_f16_f32)
+    l = (y - h.astype(np.float32)).astype(np.float16)         # the residual is exact in fp32
+    return h.astype(np.float64), l.astype(np.float64)
+
+
+def _pow2_scale(m, target):
+    return 2.0 ** (target - int(np.floor(np.log2(m))))
+
+
+def _chain_fp32(a, b):
+    acc = np.zeros((a.shape[0], b.shape[1]), dtype=np.float32)
+    for k in range(a.shape[1]):                               # one fp32 FMA per k, like v_mfma_f32_32x32x2_f32 (rounded once per step)
+        acc = (acc.astype(np.float64) + a[:, k:k + 1].astype(np.float64) * b[k:k + 1, :].astype(np.float64)).astype(np.float32)
+    return acc.astype(np.float64)
+
+
+@pytest.mark.parametrize("K,mode", [(64, "act"), (128, "act"), (288, "grad"), (128, "small")])
+def test_two_piece_fp16_split_is_fp32_class_when_scaled(K, mode):
+    rng = np.random.RandomState(K + len(mode))
+    if mode == "grad":                                        # gradient-like: tiny, heavy-tailed; dynamic scale from the recorded maximum
+        a = (rng.randn(32, K) * 1e-6 * np.exp(2.0 * rng.randn(32, K))).astype(np.float32)
+        sa = _pow2_scale(np.abs(a).max(), 13)
+    else:                                                     # BN + ReLU activations; scale from hypot(gamma, beta) ~ 1.4 -> 2^4
+        a = np.maximum(rng.randn(32, K) * 1.3 + 0.1, 0.0).astype(np.float32) * (1e-3 if mode == "small" else 1.0)
+        sa = 16.0
+    w = (rng.randn(K, 32) * np.sqrt(2.0 / K)).astype(np.float32)
+    sw = _pow2_scale(np.abs(w).max(), 13)
+    assert np.abs(w).max() * sw < 65504 and np.abs(a).max() * sa < 65504          # nothing overflows fp16
+    ref = a.astype(np.float64) @ w.astype(np.float64)
+    mag = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64)
+    ah, al = _split16(a, sa)
+    wh, wl = _split16(w, sw)
+    got = (ah @ wl + al @ wh + ah @ wh) / (sa * sw)           # three terms; the inverse scales are exact powers of two
+    e_split = np.sqrt((((got - ref) / mag) ** 2).mean())
+    e_chain = np.sqrt((((_chain_fp32(a, w) - ref) / mag) ** 2).mean())
+    # pieces alone (no accumulation rounding here): the representation error of the scheme against the fp32 chain's total error
+    if mode == "small":
+        # unscaled-small activations sit in fp16's subnormal floor: the scheme is NOT fp32-class there - which is what the per-BN
+        # activation scale (from gamma / beta) exists to prevent; with the scale the kernels would use (values near 2^5) it is again
+        assert e_split > 1.5 * e_chain
+        ah, al = _split16(a, 16.0 * 1024.0)
+        got = (ah @ wl + al @ wh + ah @ wh) / (16.0 * 1024.0 * sw)
+        e_split = np.sqrt((((got - ref) / mag) ** 2).mean())
+    assert e_split <= 1.0 * e_chain, (e_split, e_chain)
+    # a single fp16 piece is three orders of magnitude off: the low piece carries the accuracy
+    e_one = np.sqrt(((((ah @ wh) / (sa * (1024.0 if mode == "small" else 1.0) * sw) - ref) / mag) ** 2).mean())
+    assert e_one > 100 * e_chain
