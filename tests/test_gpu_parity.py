@@ -858,12 +858,13 @@ def test_g8_reactive_gradients_and_adam(gpu, golden):
     loss = torch.nn.functional.nll_loss(torch.log_softmax(q[0].view(1, 3, 1, 1), dim=1), label, weight=w).sum()
     loss.backward()                                            # torch autograd on the 3 logits -> smg_backward
     assert abs(float(loss.detach()) - float(golden["g8_loss"])) < 2e-3
-    # (5x, and up to four tensors may sit outside it up to 20 % of their norm.  This sample is ill-conditioned at the stem: on the
+    # (5x, and up to three tensors may sit outside it up to 20 % of their norm - measured in round 4: two, norm0.bias at 2.7 and
+    # norm0.weight at 1.6 of the bound, the next one (a block-4 norm1.bias) AT 1.00.  This sample is ill-conditioned at the stem: on the
     # un-rotated image's constant background stem channel 46 normalises to ~0, so the sign of its ReLU mask over most of the plane
     # is decided by the last bits of the fp64 statistics - tests/gpu_diag_reactive.py: the whole error of norm0.bias (7 %) is
     # that one channel, with every 3x3 / chain variant of the kernels; the fp32 oracle lands on the fp64 side, the engine
     # on either side from run to run (the order of the statistics' atomics).  The old check allowed 10 % on every norm.)
-    rel_p, _, _ = grads_within_fp32_class(net.named_parameters(), on.named_parameters(), g64, 5.0, "reactive", max_outliers=4)
+    rel_p, _, _ = grads_within_fp32_class(net.named_parameters(), on.named_parameters(), g64, 5.0, "reactive", max_outliers=3)
     assert len(rel_p) == 368
     ref = golden["g8_gradnorm"]
     mine = np.asarray([float(p.grad.double().norm()) if p.grad is not None else 0.0 for p in net.parameters()])
