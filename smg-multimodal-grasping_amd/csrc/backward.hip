@@ -166,6 +166,11 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                     PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_dgrad_kernel<16, PREC>), dim3((pl.H / 16) * a.tiles_x, NS), dim3(256),
                                        (HaloDgradSGeo<16, PREC>::smem_bytes(kBottleneck)), st, a));
                 } else {
+                    static bool raised8[64][3] = {};         // two buffers of a whole kernel row's weights: past the default 64 KB in the fp32-class mode
+                    if (!raised8[e->device & 63][e->prec]) {
+                        PREC_DISPATCH(e, (void)hipFuncSetAttribute((const void*)conv3x3_halo_dgrad_kernel<8, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, (HaloDgradSGeo<8, PREC>::smem_bytes(kBottleneck))));
+                        raised8[e->device & 63][e->prec] = true;
+                    }
                     a.tiles_x = (pl.W + 7) / 8; a.cg_per_wg = 1;      // small planes: one 64-channel group per workgroup
                     PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_dgrad_kernel<8, PREC>), dim3(((pl.H + 7) / 8) * a.tiles_x, NS, kBottleneck / 64), dim3(256),
                                        (HaloDgradSGeo<8, PREC>::smem_bytes(kBottleneck)), st, a));

@@ -365,10 +365,11 @@ template <int TS, int PREC> struct HaloDgradSGeo : HaloGeo<TS> {
     static constexpr int A_UNITS = NP * 4 * LDH;
     static constexpr int A_N = (G::PX * (PREC ? 4 : 8) + 255) / 256;     // 16-byte slots per thread (32 gradient channels per pixel)
     static constexpr int NCW = G::WX;                                    // output-channel chunks per stage
-    static constexpr int B_UNITS = NCW * BU;                             // per buffer
+    static constexpr int ST = 3;                                         // taps per stage: one kernel row (a stage per tap spent more on its barrier than on its 12 MFMAs)
+    static constexpr int B_UNITS = NCW * ST * BU;                        // per buffer
     static constexpr int B_N = (B_UNITS + 255) / 256;
     static constexpr int B_PAD = B_N * 256;                              // units per buffer incl. the padding the last copy round touches
-    __host__ __device__ static constexpr int smem_bytes(int C) { return (A_UNITS + 3 * B_PAD) * 16 + (4 * C + 256 + 128) * 4; }
+    __host__ __device__ static constexpr int smem_bytes(int C) { return (A_UNITS + 2 * B_PAD) * 16 + (4 * C + 256 + 128) * 4; }
 };
 
 template <int TS, int PREC = 0>
@@ -380,8 +381,8 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
     constexpr int MT = G::MT, NCW = G::NCW, A_N = G::A_N, B_N = G::B_N, LDH = G::LDH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* As = reinterpret_cast<char*>(smem);                            // [piece][k8][LDH] units
-    char* Bs = As + G::A_UNITS * 16;                                     // [3][NCW][piece][k8][32] units
-    float* prm = reinterpret_cast<float*>(Bs + 3 * G::B_PAD * 16);       // scale | beta | mean | invstd, C each
+    char* Bs = As + G::A_UNITS * 16;                                     // [2][NCW][3 taps][piece][k8][32] units
+    float* prm = reinterpret_cast<float*>(Bs + 2 * G::B_PAD * 16);       // scale | beta | mean | invstd, C each
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
     const int wq = wave % G::WQ, wc = wave / G::WQ;     // pixel slice, output-channel chunk of the stage
     const int n = blockIdx.y;
@@ -403,23 +404,24 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
     ActScale gsc{1.f, 1.f};                            // operand kind 3: scale of this stream's gradient operand; inverse of (gradient x weight) scale
     if constexpr (OP == 3) { gsc = amax_scale(a.g.amax + (int64_t)n * kAmaxRep); gsc.inv *= pack_inv_scale(a.wu); }
     const int cg0 = blockIdx.z * a.cg_per_wg;
-    const int NSTAGE = a.cg_per_wg * 9;                // channel-chunk groups x 9 taps
-    // Weight stages: stage = cgroup * 9 + tap (a cgroup holds NCW chunks).  Three register slots and three LDS buffers,
-    // indexed by stage % 3 (compile-time inside the three-stage trip): the loads of stage s + 2 are issued at stage s and
-    // stored to LDS at stage s + 1, so a stage never waits for the loads it issued itself (round 2a: 3.9k cycles per stage
-    // for 0.8k of MFMA issue).  Unconditional, tail-clamped loads keep the number of loads in flight equal on every path.
-    u32x4 rb[3][B_N];
+    const int NSTAGE = a.cg_per_wg * 3;                // channel-chunk groups x 3 kernel rows
+    // Weight stages: stage = cgroup * 3 + kernel row (a cgroup holds NCW chunks, a stage the row's three taps of each: they are
+    // contiguous in the pack).  Two LDS buffers; the loads of stage s + 1 are issued at the top of stage s, fly under its 36 MFMAs
+    // per wave and are stored at its end - ONE barrier per kernel row (round 3: one per tap - 1.6k cycles per stage for 0.77k
+    // of MFMA issue; with three MFMA terms a tap is 0.38k).  Unconditional, tail-clamped loads: the same loads on every path.
+    constexpr int ST = G::ST;
+    u32x4 rb[B_N];
     unsigned b_voff[B_N];
 #pragma unroll
     for (int i = 0; i < B_N; ++i) {
         const int idx = t + 256 * i;                                       // past B_UNITS: padding (slack behind the packed array)
-        const int j = min(idx / HDS_BU, NCW - 1), rem = idx - j * HDS_BU;
+        const int j = min(idx / (ST * HDS_BU), NCW - 1), rem = idx - j * ST * HDS_BU;
         b_voff[i] = 16u * (unsigned)(j * 9 * HDS_BU + rem);
     }
-    auto g_load = [&](int stage, u32x4 (&r)[B_N]) {
-        const int cg = cg0 + stage / 9, tap = stage % 9;
+    auto g_load = [&](int stage) {
+        const int cg = cg0 + stage / 3, dy = stage % 3;
 #pragma unroll
-        for (int i = 0; i < B_N; ++i) r[i] = bload_u4(a.wu, kWholeBuf, b_voff[i], 16u * (unsigned)((cg * NCW * 9 + tap) * HDS_BU));
+        for (int i = 0; i < B_N; ++i) rb[i] = bload_u4(a.wu, kWholeBuf, b_voff[i], 16u * (unsigned)((cg * NCW * 9 + ST * dy) * HDS_BU));
     };
     // gradient halo (zero outside the image), split at the store
     const char* g_n = static_cast<const char*>(a.g.g) + (int64_t)GSZ * n * a.pl.HWp * a.g.ldg;
@@ -465,25 +467,24 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
             }
         }
     }
-    auto s_store = [&](int buf, const u32x4 (&r)[B_N]) {
+    auto s_store = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < B_N; ++i) *reinterpret_cast<u32x4*>(Bs + (buf * G::B_PAD + t + 256 * i) * 16) = r[i];
+        for (int i = 0; i < B_N; ++i) *reinterpret_cast<u32x4*>(Bs + (buf * G::B_PAD + t + 256 * i) * 16) = rb[i];
     };
     int abase[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) abase[m] = G::row(wq, m, l31) * G::W + G::col(l31);
 
-    g_load(0, rb[0]);
-    g_load(NSTAGE > 1 ? 1 : 0, rb[1]);
-    s_store(0, rb[0]);
+    g_load(0);
+    s_store(0);
     __syncthreads();
     if (trace) trace[1] = __builtin_amdgcn_s_memtime();
     f32x16 acc[MT];
     // Mask / xhat source of this wave's output tile (32 output channels from c0), prefetched: one row segment (a pixel's four
     // consecutive channels, 16 / 8 bytes per lane; finish_acc_rows turns it into accumulator layout) per four accumulator rows,
-    // MT x 4 of them per output-channel group - issued ONE PER STAGE through the first eight stages of the group (statically
-    // unrolled: every path issues the same loads, the exact vmcnt waits of the weight ring survive), consumed by the epilogue
-    // at the ninth.  (Fetching them only in the epilogue cost 5.5 - 6k of a group's 21k cycles.)
+    // MT x 4 of them per output-channel group - issued behind the weight loads of the group's first two kernel rows (every path
+    // issues the same loads: exact vmcnt waits), consumed by the epilogue after the third.  (Fetching them only in the epilogue
+    // cost 5.5 - 6k of a group's 21k cycles.)
     rawq_t<XT> xq[MT][4];
     auto load_mask_seg = [&](int c0, int m, int g) {
         const int i = (lane & 3) + 8 * g + 4 * half;
@@ -493,34 +494,33 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
         if constexpr (std::is_same<XT, e_f32>::value) xq[m][g] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.mbuf) + idx);
         else xq[m][g] = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(a.mbuf) + idx);
     };
-    for (int s9 = 0; s9 < NSTAGE; s9 += 9) {           // NSTAGE is a multiple of 9: one output-channel group (nine taps) per trip
+    for (int s3 = 0; s3 < NSTAGE; s3 += 3) {           // one output-channel group (three kernel rows) per trip
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-      const int cmask0 = ((cg0 + s9 / 9) * NCW + wc) * 32;
+      const int cmask0 = ((cg0 + s3 / 3) * NCW + wc) * 32;
 #pragma unroll
-     for (int dy = 0; dy < 3; ++dy) {
-      const int s3 = s9 + 3 * dy;
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int stage = s3 + dx, buf = dx, tap = 3 * dy + dx;
-        g_load(stage + 2 < NSTAGE ? stage + 2 : NSTAGE - 1, rb[(dx + 2) % 3]);
-        if (tap < 8) {                                    // (compile-time after unrolling)
+      for (int dy = 0; dy < 3; ++dy) {
+        const int stage = s3 + dy, buf = stage & 1;
+        g_load(stage + 1 < NSTAGE ? stage + 1 : NSTAGE - 1);             // (tail: a clamped re-load, stored dead)
+        if (dy < 2) {                                     // (compile-time after unrolling) the group's mask segments: half behind each of the first two rows' weight loads
             constexpr int SEGS = MT * 4;
-            const int sg = tap - (8 - SEGS);              // TS == 16: stages 0..7 load segments 0..7; TS == 8: stages 4..7 load 0..3
-            if (sg >= 0) load_mask_seg(cmask0, sg / 4, sg % 4);
+#pragma unroll
+            for (int sg = 0; sg < SEGS / 2; ++sg) { const int q = dy * (SEGS / 2) + sg; load_mask_seg(cmask0, q / 4, q % 4); }
         }
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
         // output pixel (ry, rx), tap (dy, dx) reads g at halo (ry + 2 - dy, rx + 2 - dx)
         const int toff = (2 - dy) * G::W + (2 - dx);
-        const char* Bw = Bs + (buf * G::B_PAD + wc * HDS_BU) * 16;
+        const char* Bw = Bs + (buf * G::B_PAD + (wc * ST + dx) * HDS_BU) * 16;
         auto fa = [&](int m, int ks, int pc) -> u32x4 {
             return *reinterpret_cast<const u32x4*>(As + ((pc * 4 + 2 * ks + half) * LDH + abase[m] + toff) * 16);
         };
         auto fb = [&](int ks, int pc) -> u32x4 {
             return *reinterpret_cast<const u32x4*>(Bw + ((pc * 4 + 2 * ks + half) * 32 + l31) * 16);
         };
-        if constexpr (OP == 3) {                            // two fp16 pieces: every fragment of the stage up front, then h*l, l*h, h*h per k16-step
+        if constexpr (OP == 3) {                            // two fp16 pieces: every fragment of the tap up front, then h*l, l*h, h*h per k16-step
             u32x4 af[2][MT][2], bf[2][2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -550,7 +550,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[m] = mfma_1p<OP>(ah[ks][m], bh[ks], acc[m]);
         } else {
-            // every fragment of the stage is requested up front (18 ds_read_b128, 72 registers): one LDS round trip per stage
+            // every fragment of the tap is requested up front (18 ds_read_b128, 72 registers): one LDS round trip per tap
             // instead of four read -> wait -> MFMA phases; hipcc waits per operand (lgkmcnt(N)) as the MFMAs come up
             u32x4 af[2][MT][NPIECE], bf[2][NPIECE];
 #pragma unroll
@@ -570,11 +570,12 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
 #pragma unroll
                     for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(af[ks][m][PA[g]], bf[ks][PB[g]], acc[m]);
         }
-        s_store((dx + 1) % 3, rb[(dx + 1) % 3]);        // that buffer was last read two stages ago (at the very end: a dead store)
-        if (tap == 8) {
-            if (trace && s9 == 0) trace[2] = __builtin_amdgcn_s_memtime();
+        }   // dx
+        s_store(buf ^ 1);                               // that buffer was last read one stage ago, behind that stage's barrier (at the very end: a dead store)
+        if (dy == 2) {
+            if (trace && s3 == 0) trace[2] = __builtin_amdgcn_s_memtime();
             // epilogue of this wave's output-channel chunk: ReLU mask, store dy, BN(norm2) backward sums
-            const int c = ((cg0 + stage / 9) * NCW + wc) * 32 + l31;
+            const int c = ((cg0 + stage / 3) * NCW + wc) * 32 + l31;
             const float sc = prm[c], be = prm[C + c], mean = prm[2 * C + c], invstd = prm[3 * C + c];
             float s1 = 0.f, s2 = 0.f;
             auto finish = [&](rawq_t<XT> (&xq)[MT][4]) {
@@ -612,14 +613,13 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
                 float tot = 0.f;
 #pragma unroll
                 for (int w = 0; w < G::WQ; ++w) tot += red[q * 128 + (j * G::WQ + w) * 32 + cc];
-                const int ch = ((cg0 + stage / 9) * NCW + j) * 32 + cc;
+                const int ch = ((cg0 + stage / 3) * NCW + j) * 32 + cc;
                 atomicAdd((q ? a.o2 : a.o1) + (int64_t)n * a.ostride + ch + stat_rep(), (double)tot);
             }
-            if (trace && s9 == 0) trace[3] = __builtin_amdgcn_s_memtime();
+            if (trace && s3 == 0) trace[3] = __builtin_amdgcn_s_memtime();
         }
         __syncthreads();
       }
-     }
     }
     if (trace) { trace[4] = __builtin_amdgcn_s_memtime(); trace[6] = __builtin_amdgcn_s_memrealtime(); }
 }
