@@ -131,7 +131,9 @@ typedef struct {
  * 1 graspnet_val, 2 gsnet_val).  q_out_dev: float32 [n_pairs][head_out][OH][OW]
  * (OH=OW=1 for S=640).  Keeps every activation needed by smg_backward until the next
  * forward on this engine.  Replaces reinforcement_net.forward / reactive_net.forward
- * (code/models.py:361-586, :72-296) for any of their branches. */
+ * (code/models.py:361-586, :72-296) for any of their branches.
+ * NaN / inf: a non-finite BatchNorm batch statistic of a stream (pair) makes every Q value of the samples that use it NaN,
+ * as it does in the reference (checked where the running statistics are updated: needs bn_seq_trunk / bn_seq_head). */
 int smg_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id,
                 const smg_batch* batch, float* q_out_dev, void* stream);
 
@@ -152,15 +154,20 @@ int smg_backward(smg_engine* e, const smg_net* net, const float* dq_dev, void* s
  * phase 0 runs the head and dense blocks 4, 3, 2; when it returns (in stream order) every gradient of the parameters from
  * smg_layout_trunk_split() to the end of the trunk range, and of the head range, is final - their all-reduce can start while
  * phase 1 (dense block 1, pool0, the stem: about a third of the backward) computes the rest, [trunk begin, split).
- * smg_backward == phase 0 followed by phase 1. */
+ * smg_backward == phase 0 followed by phase 1.
+ * Phase 1 never reads or writes a gradient element of [split, trunk end) or of the head range (they may be in an in-place
+ * all-reduce on another stream).  The order is enforced: phase 1 without phase 0 of the SAME forward, phase 0 twice, or
+ * smg_backward between the two halves return -22 and launch nothing. */
 int smg_backward_phase(smg_engine* e, const smg_net* net, const float* dq_dev, void* stream, int phase);
 /* Element offset (params / grads) of the first parameter behind dense block 1 of trunk `trunk_id` (transition1.norm.weight). */
 int smg_layout_trunk_split(int head_out, int trunk_id, int64_t* offset);
 
 /* Precision mode of the engine (the reference runs apex O0 = fp32, code/trainer.py:101; modes 1 and 2 are BASELINE.json configs 3
  * and 5):
- *   0  (default) fp32 storage; every product as three bf16 pieces per fp32 operand, six MFMA terms - fp32-class accuracy,
- *      what the parity suite gates;
+ *   0  (default) fp32 storage; fp32-class accuracy, what the parity suite gates: the dense layers' products as a scaled
+ *      two-piece fp16 split per operand, three MFMA terms (scales per weight tensor, per BatchNorm operand and per gradient
+ *      tensor and stream, maintained by the engine); the stem's, the transitions' and the head's gradient products as three
+ *      bf16 pieces, six terms;
  *   1  bf16 STORAGE of activations and gradients (dense-block buffers, bottlenecks, G', the backward ring), one bf16 MFMA term
  *      per product;
  *   2  fp16 storage of activations with fp16 forward products; gradients stored and multiplied in bf16 (fp32 exponent range:
@@ -174,7 +181,8 @@ int smg_engine_set_precision(smg_engine* e, int precision);
  * convolution weight gradients of two identical calls are bit-identical like the reference's (code/trainer.py:350-351 on one
  * device); BatchNorm affine gradients and the head's value convolution keep their fp32 atomics.  (Since round 3 the fixed-order
  * path is also the default for batches of more than four streams whenever the partial tiles fit the workspace - it is the
- * faster one there; the option guarantees it for every batch.)
+ * faster one there; the option guarantees it for every batch: a launch whose partial tiles do not fit the workspace fails
+ * with -12 instead of falling back to atomics.)
  * "serialize" (0 / 1): every kernel on the caller's stream in issue order instead of two concurrent chains (profiling). */
 int smg_engine_set_option(smg_engine* e, const char* name, int value);
 
