@@ -54,7 +54,12 @@
 #define SMG_PD_FWD_SMALL 2
 #endif
 #ifndef SMG_PD_FWD_BIG
-#define SMG_PD_FWD_BIG 1
+#define SMG_PD_FWD_BIG 2      // round 4 (three-term products: 384 cycles of MFMA per k-tile no longer cover a load): 128 x 128 forward 72.4 -> 67.6 us per launch
+#endif
+#ifndef SMG_PIN_LOADS
+#define SMG_PIN_LOADS 1       // keep the next tile's loads AT the top of the k-tile: hipcc sinks them to their first use (the weight loads ended up
+                              // directly in front of their LDS store, the activation loads in the middle of the MFMA block - one exposed memory
+                              // latency each per k-tile).  Serialised kernel total 19.33 -> 18.94 ms (with SMG_PD_FWD_BIG = 2: 18.82)
 #endif
 #ifndef SMG_FWD_BIG_MINWAVES      // waves per SIMD the 128x128 forward is held to (register cap 512 / n)
 #define SMG_FWD_BIG_MINWAVES 3
@@ -885,6 +890,9 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
             if (tr) trace[0] = smg_stamp();
 #endif
             if (more) g_load(kt + 1, ra[0], rb[0], kp[0]);
+#if SMG_PIN_LOADS
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             compute(buf);
             if constexpr (P::kSegmented) p.k_hook(ctx, kt, acc, sp);   // end of a K segment: fold acc away
 #ifdef SMG_TRACE_ITER
@@ -921,6 +929,9 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
                 if (tr) trace[0] = smg_stamp();
 #endif
                 g_load(kt + PD < KT ? kt + PD : KT - 1, ra[u], rb[u], kp[u]);   // slot u went to LDS one step ago
+#if SMG_PIN_LOADS
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 compute(buf);
                 if constexpr (P::kSegmented) p.k_hook(ctx, kt, acc, sp);
 #ifdef SMG_TRACE_ITER
