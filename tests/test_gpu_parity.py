@@ -1350,3 +1350,25 @@ def test_bench_two_ranks_config4_leg_on_one_gpu(gpu):
     st = out["roofline"]["step"]
     assert 0 < st["frac_of_mfma_roof"] < 1 and st["mfma_roof_tflops"] > 800          # 2 x 416.7
     assert abs(out["value"] - 2 * 2 * 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]    # passes/s of the whole job
+
+
+def test_bench_two_ranks_strong_scaling_leg_on_one_gpu(gpu):
+    """`python bench.py --gpus 2 --scaling strong`: ONE scene per step, its 16 rotations dealt contiguously to the ranks (8 each + the
+    masked stream on both), one all-reduce, one Adam; whole-job value = one pass per step.  The N > 1 line reports what the process
+    group saw (rccl_world, device_count, devices_seen) - here two ranks sharing this box's one GPU over gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from helpers import REPO
+    env = dict(os.environ, SMG_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--scaling", "strong", "--steps", "2", "--warmup", "1",
+                        "--train-only"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    assert len(line) < 2000
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["leg"] == "headline"
+    assert out["rccl_world"] == 2 and out["device_count"] >= 1 and out["devices_seen"] >= 1 and out["allreduce_backend"] == "gloo"
+    assert abs(out["config"]["passes_per_step_per_gpu"] - 0.5) < 1e-9
+    assert abs(out["value"] - 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]          # one pass per step for the whole job
