@@ -1349,7 +1349,7 @@ def test_bench_two_ranks_config4_leg_on_one_gpu(gpu):
     assert out["allreduce_exposed_ms_per_step"] > 0 and out["allreduce_bytes"] == 4 * (6953856 + 160896)
     st = out["roofline"]["step"]
     assert 0 < st["frac_of_mfma_roof"] < 1 and st["mfma_roof_tflops"] > 800          # 2 x 416.7
-    assert abs(out["value"] - 2 * 2 * 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]    # passes/s of the whole job
+    assert abs(out["value"] - 2 * 2 * 1e3 / out["ms_per_step"]) <= 1e-4 * out["value"]    # passes/s of the whole job (the compact line rounds to 4 decimals)
 
 
 def test_bench_two_ranks_strong_scaling_leg_on_one_gpu(gpu):
@@ -1371,4 +1371,4 @@ def test_bench_two_ranks_strong_scaling_leg_on_one_gpu(gpu):
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["leg"] == "headline"
     assert out["rccl_world"] == 2 and out["device_count"] >= 1 and out["devices_seen"] >= 1 and out["allreduce_backend"] == "gloo"
     assert abs(out["config"]["passes_per_step_per_gpu"] - 0.5) < 1e-9
-    assert abs(out["value"] - 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]          # one pass per step for the whole job
+    assert abs(out["value"] - 1e3 / out["ms_per_step"]) <= 1e-4 * out["value"]          # one pass per step for the whole job (the compact line rounds to 4 decimals)
