@@ -120,7 +120,14 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             const int db = layer_no % kRing;
             float* GSb = e->GS[db];
             float* D2b = e->D2[db];
-            if (layer_no >= kRing) HIP_OK(hipStreamWaitEvent(st, e->ev_side[db], 0));   // side stream done with these buffers (kRing layers ago)
+            static const bool one_fork = !(getenv("SMG_BWD_FORKS") && atoi(getenv("SMG_BWD_FORKS")) == 0);      // (0: round 3's two forks + a ring wait per layer, A/B)
+            {
+                const bool sparse_wait = one_fork;
+                if (!sparse_wait) { if (layer_no >= kRing) HIP_OK(hipStreamWaitEvent(st, e->ev_side[db], 0)); }   // side stream done with these buffers (kRing layers ago)
+                // sparse form: at every third layer wait for the side stream's event of the LATEST of the next three slots' previous users
+                // (layer_no + 2 - kRing; the side stream is in order, so the two before it are done as well)
+                else if (layer_no >= kRing && layer_no % 3 == 0) HIP_OK(hipStreamWaitEvent(st, e->ev_side[(layer_no + 2) % kRing], 0));
+            }
             ++layer_no;
             // This layer's finished output-slice gradient GS = invstd*(G' - SA/n - xhat*SB/n), materialised once (dense
             // [px][32]) for the 3x3 data- and weight-gradient kernels.  They can also apply it while loading the G' / X
@@ -145,7 +152,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_bwd_apply_kernel<PREC>), dim3((pl.HWp + bn_apply_rows(PREC) - 1) / bn_apply_rows(PREC), NS), dim3(256), 0, st, a));
                 if (gs_mat) { gsrc = GradSrc{}; gsrc.g = GSb; gsrc.ldg = kGrowth; gsrc.amax = gamax_of(e, b, i, 0); }
             }
-            if (fork(e->ev_gs[db])) return -5;
+            if (!one_fork || e->generic3x3) { if (fork(e->ev_gs[db])) return -5; }
             if (!e->generic3x3) {
                 // conv2 (3x3) data gradient with the gradient halo resident in LDS (halo.cuh)
                 Halo3x3DgradArgs a;
@@ -192,7 +199,10 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 };
                 if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
             }
-            if (!e->generic3x3) {
+            // ONE fork per layer - the 3x3 weight gradient waits with the 1x1 one for the event behind the norm2 apply - and the ring
+            // wait only every third layer: two event records / waits per layer less on the data-gradient chain (17.07-17.54 -> 17.05-17.44 ms
+            // per step, alternating: inside the noise, kept for the shorter queue)
+            auto launch_w3 = [&]() -> int {
                 // conv2 weight gradient with the activation halo resident in LDS (halo.cuh)
                 const int ts = halo_tile(pl, NS);
                 Halo3x3WgradArgs a;
@@ -221,6 +231,10 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 r.dw = Gr + d.c2.w; r.ldw_out = kBottleneck * 9; r.cmap = C_3x3;
                 ProfScope ps(e, s2, K_W3, 0);
                 hipLaunchKernelGGL(reduce_partials_kernel, dim3((9 * kGrowth * kBottleneck + 63) / 64), dim3(256), 0, s2, r);
+                return 0;
+            };
+            if (!e->generic3x3) {
+                if (!one_fork) { if (int rc = launch_w3()) return rc; }
             } else {   // conv2 weight gradient (generic implicit GEMM, one launch slice per tap)
                 const int chunk = 512, cps = (pl.HWp + chunk - 1) / chunk;   // latency-bound: many short workgroups
                 BwdWeightP<CfgW32x128, W_THREE, C_3x3, SMG_PD_WGRAD, false> p{};
@@ -245,6 +259,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_bwd_apply_kernel<PREC>), dim3((pl.HWp + bn_apply_rows(PREC) - 1) / bn_apply_rows(PREC), NS), dim3(256), 0, st, a));
             }
             if (fork(e->ev_d2[db])) return -5;
+            if (one_fork && !e->generic3x3) { if (int rc = launch_w3()) return rc; }
             // conv1 (1x1) data gradient -> relu1/norm1 backward accumulated into G'.  Layers are grouped (kGroup,
             // from the top of the block): inside a group only the channels the group itself produced - needed by
             // the very next layer - are accumulated per layer; everything below the group's lowest layer is done
