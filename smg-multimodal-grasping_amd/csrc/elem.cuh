@@ -91,7 +91,8 @@ static __global__ void prep_rotate_kernel(const PrepArgs a) {
 // Weight repack: reference layout [cout][cin][kh][kw] -> what the kernels stream.  One launch for a
 // whole trunk + head through a descriptor table.
 //   split modes: the B operand of the MFMA GEMMs as 16-byte units [piece][K/8][N] of 8 consecutive k of one
-//   output column n, already split into the three bf16 pieces (gemm.cuh) - staging them is a plain copy;
+//   output column n, already split into its pieces (two scaled fp16 pieces behind a header unit for operand kind 3, three bf16
+//   pieces for kind 0; gemm.cuh) - staging them is a plain copy;
 //   PK_HF / PK_HD: the per-stage LDS images of the LDS-halo 3x3 kernels; PK_HEAD: the value convolution's fp32 layout.
 // ------------------------------------------------------------------------------------
 enum { PK_T1 = 0, PK_D1 = 1, PK_3F = 2, PK_3D = 3, PK_STEM = 4, PK_HEAD = 5, PK_HF = 6, PK_HD = 7, PK_STEM1 = 8 };
@@ -151,7 +152,7 @@ static __global__ __launch_bounds__(1024) void scale_kernel(const PackDesc* desc
 }
 
 // prec: the engine's precision mode.  Operand kind of a pack: the forward packs (PK_T1, PK_STEM, PK_3F, PK_HF) take the
-// forward kind (3-piece split / bf16 / fp16), the data-gradient packs (PK_D1, PK_3D, PK_HD) the backward kind (split / bf16).
+// forward kind (the desc's split kind op0 / bf16 / fp16), the data-gradient packs (PK_D1, PK_3D, PK_HD) the backward kind (op0 / bf16).
 // Single-piece kinds store ONE piece (the kernels copy a third of the bytes); the halo forward image then holds 32 channels
 // per chunk instead of 16 (halo_ck).
 static __global__ void pack_weights_kernel(const PackDesc* descs, const float* params, u32x4* packed_u, float* packed_f, const int prec) {

@@ -4,7 +4,9 @@
 //
 //   D[i][j] = sum_r A(i, r) * B(r, j)
 //
-// Arithmetic: fp32 in, fp32 out, on the bf16 matrix cores.  Every fp32 operand is split into
+// Arithmetic: fp32 in, fp32 out, on the 16-bit matrix cores, in one of two split schemes ("operand kinds", below):
+// kind 3 (the dense layers' products, since round 4): a scaled two-piece fp16 split, three v_mfma_f32_32x32x16_f16 terms;
+// kind 0 (rounds 2-3; still the stem's, the transitions' and the head's gradient products): every fp32 operand is split into
 // three bf16 pieces  x = hi + mid + lo  (round-to-nearest pieces, v_cvt_pk_bf16_f32; the residuals
 // are exact, 3 x 8 significand bits cover the 24 of an fp32), and a product is accumulated from six
 // v_mfma_f32_32x32x16_bf16 terms
@@ -106,13 +108,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr int NPIECE = 3;
 // Precision mode of an engine (compile-time PREC of every kernel; smg_engine_set_precision picks the instantiation):
-//   0  fp32 storage; every product a 3-piece bf16 split, six MFMA terms: fp32-class (default; what the parity suite gates)
+//   0  fp32 storage; fp32-class products (default; what the parity suite gates): operand kind 3 for the dense layers, kind 0 elsewhere
 //   1  bf16 storage of activations AND gradients (dense-block buffers, bottlenecks, G', the backward ring), ONE
 //      v_mfma_f32_32x32x16_bf16 per product                                              (BASELINE.json config 3)
 //   2  fp16 storage of activations with fp16 forward products (v_mfma_f32_32x32x16_f16); gradients are stored and multiplied in
 //      bf16 (fp32 exponent range: no loss scaling, no underflow of small gradients)      (config 5)
 // In every mode BN statistics, every accumulation, the parameters, their gradients and Adam stay fp32 (fp64 for the sums).
-// Operand kind of one kernel's MFMAs (OP): 0 = 3-piece bf16 split, 1 = bf16, 2 = fp16.
+// Operand kind of one kernel's MFMAs (OP): 0 = 3-piece bf16 split (six terms), 1 = bf16, 2 = fp16, 3 = scaled 2-piece fp16 split (three terms).
 struct e_f32 { static constexpr int size = 4; };
 struct e_bf16 { static constexpr int size = 2; };
 struct e_f16 { static constexpr int size = 2; };
@@ -189,8 +191,6 @@ __device__ __forceinline__ Split4 split4(float4 v) {
     o.p[2] = make_uint2(pack_bf16(s0, s1), pack_bf16(s2, s3));
     return o;
 }
-// One operand fragment of a 32-row tile for one k16-step: 8 consecutive k per lane, three pieces.
-struct Frag { u32x4 p[NPIECE]; };
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -248,19 +248,6 @@ template <int OP> __device__ __forceinline__ u32x4 pack_unit(float4 lo, float4 h
     else return u32x4{pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w)};
 }
 __device__ __forceinline__ u32x4 as_u4(float4 v) { return u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}; }
-// acc[i][j] += A_i * B_j for a TM x TN grid of tiles: six piece products, small terms first, tiles innermost so that
-// consecutive MFMAs never share an accumulator.
-template <int TM, int TN>
-__device__ __forceinline__ void mma_split(f32x16 (&acc)[TM][TN], const Frag (&a)[TM], const Frag (&b)[TN]) {
-    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
-#pragma unroll
-    for (int t = 0; t < 6; ++t)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(a[i].p[PA[t]], b[j].p[PB[t]], acc[i][j]);
-}
-
 // ------------------------------------------------------------------------------------
 // Accumulator tiles <-> memory in full-width accesses.  A 32x32 MFMA accumulator has lane = column (channel) and
 // register r = row (r & 3) + 8 (r >> 2) + 4 half: a group of four registers 4g .. 4g + 3 of the four lanes of a quad is a

@@ -10,7 +10,8 @@
 //
 //   out[p][n] = sum_{tap, c} relu(bn(in[p + d(tap)][c])) * W[n][c][tap]
 //
-// Arithmetic and LDS images: the split-precision scheme of gemm.cuh (three bf16 pieces per fp32 operand, six
+// Arithmetic and LDS images: the split-precision schemes of gemm.cuh - in the fp32-class mode operand kind 3 (two scaled fp16
+// pieces per fp32 operand, three v_mfma_f32_32x32x16_f16 per product); kind 0 (three bf16 pieces per fp32 operand, six
 // v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; 16-byte units of 8 consecutive k).
 //
 // Two tile sizes:

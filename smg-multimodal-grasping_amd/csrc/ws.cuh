@@ -5,7 +5,7 @@
 // loads -> BN + ReLU + split -> LDS stores -> barrier.  Inside one workgroup those phases are serial, the chip overlaps them
 // only across workgroups, and LDS admits two of those per CU: the per-workgroup stamps show 1500 cycles per 64x64x32
 // k-tile against 384 of MFMA issue.  Here a workgroup is EIGHT waves with two roles:
-//   waves 0..3  consumers: fragment reads + the six-term MFMA blocks of k-tile kt (LDS buffer kt & 1), the epilogue
+//   waves 0..3  consumers: fragment reads + the three-term (operand kind 3; six-term: kind 0) MFMA blocks of k-tile kt (LDS buffer kt & 1), the epilogue
 //   waves 4..7  producers: global loads (two k-tiles in flight), BN + ReLU + split, LDS stores of k-tile kt + 1
 // One barrier per k-tile.  Every SIMD holds one consumer and one producer wave of the workgroup, so the MFMA pipe works
 // while the VALU splits the next tile - inside one workgroup, whatever else is resident.

@@ -162,8 +162,9 @@ class _AffordanceNet(nn.Module):
                 node._buffers[leaf] = self._flat_nbt[off:off + 1].view(())
 
     def set_precision(self, name):
-        """Precision mode of the engine calls of this model: 'fp32' (default - fp32 storage, every fp32 operand as three bf16
-        pieces, six MFMA terms per product: the accuracy of the reference's apex O0 arithmetic, code/trainer.py:101), 'bf16'
+        """Precision mode of the engine calls of this model: 'fp32' (default - fp32 storage, fp32-class products on the 16-bit
+        matrix cores - scaled two-piece fp16 splits for the dense layers, three-piece bf16 splits elsewhere: the accuracy of
+        the reference's apex O0 arithmetic, code/trainer.py:101), 'bf16'
         (activations and gradients STORED in bf16, one bf16 MFMA term per product; BASELINE.json config 3) or 'fp16' (activations
         stored in fp16 with fp16 forward products, gradients stored and multiplied in bf16; config 5).  Parameters, their
         gradients, BN statistics, every accumulation and Adam stay fp32 in every mode."""

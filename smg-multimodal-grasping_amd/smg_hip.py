@@ -172,7 +172,7 @@ class Engine(object):
             pass
 
     def set_precision(self, name):
-        """Precision mode: 'fp32' (fp32 storage, 3-piece bf16 split products: fp32-class; default), 'bf16' (bf16 storage of
+        """Precision mode: 'fp32' (fp32 storage, split products on the 16-bit matrix cores: fp32-class; default), 'bf16' (bf16 storage of
         activations and gradients) or 'fp16' (fp16 activations, bf16 gradients); include/smg_hip.h."""
         code = PRECISIONS[str(name).replace("torch.", "")]
         check(lib().smg_engine_set_precision(self.h, code))
