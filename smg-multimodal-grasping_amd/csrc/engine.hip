@@ -492,6 +492,8 @@ int64_t smg_debug_read(smg_engine* e, const char* name, float* host_out, int64_t
         int b = 0, i = 0;
         if (std::sscanf(name, "bt%d_%d", &b, &i) != 2 || b < 1 || b > 4 || i < 1 || i > kBlockLayers[b - 1]) return fail(-22, "bad bt name");
         src = el(e, e->Bt, e->bt_off[b - 1][i - 1]); n = (int64_t)NS * e->p_blk[b - 1].HWp * kBottleneck;      // bt_off counts ELEMENTS of the mode
+    } else if (s == "asc") {      // the activation scales {s, 1 / s} of the last forward: dense layers (norm1, norm2 per layer), transitions, head norm0
+        src = e->asc; n = 2 * e->n_asc;
     } else if (s.size() >= 6 && s.substr(0, 5) == "fs_bt") {   // "fs_bt<block>_<layer>": the fp64 forward sums of that bottleneck, raw doubles [sum | sumsq][streams][128] in the float buffer
         int b = 0, i = 0;
         if (std::sscanf(name, "fs_bt%d_%d", &b, &i) != 2 || b < 1 || b > 4 || i < 1 || i > kBlockLayers[b - 1]) return fail(-22, "bad fs_bt name");

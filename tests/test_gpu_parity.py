@@ -301,6 +301,34 @@ def test_split_scales_cover_extreme_magnitudes(gpu):
     print("extreme scales: gradient norms span %.1e .. %.1e; median rel err %.2e (oracle %.2e)" % (min(gn.values()), max(gn.values()), np.median(rel_p), np.median(rel_o)))
 
 
+def test_activation_scales_follow_gamma_and_beta(gpu):
+    """scale_kernel (csrc/elem.cuh): the per-BatchNorm activation scale of the fp16-split products is the power of two that puts
+    max_c hypot(gamma_c, beta_c) into [16, 32) - recomputed here in numpy from the state dict for every norm1 / norm2 of the grasp
+    trunk, its transitions and the head's norm0, and compared exactly (powers of two)."""
+    net = product_net(0)
+    x, mx = scene_tensors(0, [0])
+    net.forward(x, mx, 0, True, 3)                          # style 0: grasp trunk + graspnet_val
+    asc = engine_of(net).debug_read("asc").reshape(-1, 2)
+    sd = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in net.state_dict().items()}
+
+    def expect(prefix):
+        m = np.sqrt((sd[prefix + ".weight"] ** 2 + sd[prefix + ".bias"] ** 2).max())
+        return 2.0 ** (4 - int(np.floor(np.log2(np.float32(m)))))
+    names = []
+    for b, nl in enumerate((6, 12, 24, 16)):
+        for i in range(nl):
+            for nrm in ("norm1", "norm2"):
+                names.append("grasp_depth_trunk.features.denseblock%d.denselayer%d.%s" % (b + 1, i + 1, nrm))
+    names += ["grasp_depth_trunk.features.transition%d.norm" % (b + 1) for b in range(3)]
+    names.append("graspnet_val.grasp-val-norm0")
+    assert asc.shape[0] == len(names) == 120
+    for k, nm in enumerate(names):
+        s_ = expect(nm)
+        assert asc[k, 0] == np.float32(s_) and asc[k, 1] == np.float32(1.0 / s_), (nm, asc[k], s_)
+        m = np.sqrt((sd[nm + ".weight"] ** 2 + sd[nm + ".bias"] ** 2).max())
+        assert 16.0 <= m * s_ < 32.0, (nm, m, s_)
+
+
 def test_g5_g6_trainer_steps_vs_reference(gpu, golden):
     """Trainer.backprop x3 (grasp, suction, grasp_then_suction): q, loss and Adam-updated
     weights against the reference's own trajectory; then the diverged target network."""
