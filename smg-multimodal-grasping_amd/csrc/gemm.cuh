@@ -171,6 +171,10 @@ template <int OP = 0>
 __device__ __forceinline__ Split4 split4(float4 v) {
     Split4 o;
     if constexpr (OP == 3) {                             // two fp16 pieces of an operand the caller has scaled into range
+#ifdef SMG_EXP_NOSPLIT
+        o.p[0] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)); o.p[1] = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w)); o.p[2] = make_uint2(0u, 0u);
+        return o;
+#endif
         const unsigned h01 = pack_f16(v.x, v.y), h23 = pack_f16(v.z, v.w);
         o.p[0] = make_uint2(h01, h23);
         o.p[1] = make_uint2(pack_f16(v.x - f16_lo(h01), v.y - f16_hi(h01)), pack_f16(v.z - f16_lo(h23), v.w - f16_hi(h23)));
@@ -355,6 +359,25 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 // global_load needs a 64-bit add per load per k-tile; hipcc widens the lane offset outside the loop and cannot pick the
 // scalar-base form).  Bytes at or past `bytes` read as zero: lanes whose element does not exist carry kOOB as offset.
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }   // workgroup-uniform by construction
+// TIMING-ONLY experiments (wrong results): the 1x1 forward's / 1x1 weight gradient's activation rows wrapped into the first 1024
+// pixels of the stream, i.e. served from cache - what would the step gain if those bytes never came from HBM?
+// SMG_EXP_TERMS1: only the h*h term of the fp16-split products is issued; SMG_EXP_NOSPLIT: the split's arithmetic is replaced by a
+// register move - what would the step gain if the matrix / the split work were free?
+#ifdef SMG_EXP_TERMS1
+#define SMG_TERM(is_small, call, c) ((is_small) ? (c) : (call))
+#else
+#define SMG_TERM(is_small, call, c) (call)
+#endif
+#ifdef SMG_EXP_F1X
+#define SMG_EXP_WRAP_F1(p) ((p) & 1023)
+#else
+#define SMG_EXP_WRAP_F1(p) (p)
+#endif
+#ifdef SMG_EXP_W1X
+#define SMG_EXP_WRAP_W1(p) ((p) & 1023)
+#else
+#define SMG_EXP_WRAP_W1(p) (p)
+#endif
 constexpr unsigned kOOB = 0xC0000000u;          // + any scalar offset (< 1 GiB) stays past every descriptor's extent
 constexpr unsigned kWholeBuf = 0xBFFFFFFFu;     // extent of descriptors without a tight bound
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ubase, unsigned bytes) {
@@ -783,7 +806,7 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
                     for (int i = 0; i < C::TM; ++i)
 #pragma unroll
                         for (int j = 0; j < C::TN; ++j)
-                            acc[i][j] = mfma_f16(g == 1 ? al_[i] : ah[i], g == 0 ? bl_[j] : bh[j], acc[i][j]);
+                            acc[i][j] = SMG_TERM(g < 2, mfma_f16(g == 1 ? al_[i] : ah[i], g == 0 ? bl_[j] : bh[j], acc[i][j]), acc[i][j]);
                 SMG_PIN();
             } else
             if constexpr (OP != 0) {         // single-piece operands: one term per tile
@@ -1106,7 +1129,7 @@ struct FwdConvP {
         r.valid = p < po.HW;
         r.y = p / po.W;
         r.x = p - r.y * po.W;
-        r.off = (unsigned)ESZ * (unsigned)(p * lds_);    // byte offset of the row inside its stream
+        r.off = (unsigned)ESZ * (unsigned)((MODE == F_ONE ? SMG_EXP_WRAP_F1(p) : p) * lds_);    // byte offset of the row inside its stream
     }
     struct RawTaps { float4 v[1]; bool ok; unsigned m; };      // F_STEM1: four gathered taps + which of them exist
     using ARaw = typename std::conditional<MODE == F_STEM1, RawTaps, RawT<(MODE == F_POOL) ? 4 : 1>>::type;
@@ -1355,7 +1378,7 @@ struct BwdDataP {
     static constexpr bool kSegmented = false;
     static constexpr bool kHasPrologue = true;
     static constexpr bool kEarlyFetch = EMODE != E_UNPOOL;     // early_fetch(): the epilogue's operands, issued behind the first k-tiles' loads
-    static constexpr int kMinWaves = 1;
+    static constexpr int kMinWaves = 1;       // (3 waves per SIMD for the 128 x 64 accumulate form: 168 VGPRs + 88 bytes of scratch, serialised total 19.0 -> 19.4 ms)
 
     // AFF = false: the gradient operand is finished (xbuf unused).  Pointwise and finished -> descriptor loads, rows outside
     // the plane carry the out-of-range offset and read as zero (no mask, no address arithmetic in the k-loop).
@@ -1780,7 +1803,10 @@ struct BwdDataGroupP {
     static constexpr bool kSegmented = true;
     static constexpr bool kHasPrologue = true;
     static constexpr bool kEarlyFetch = true;
-    static constexpr int kMinWaves = 2;       // (x, the running sum and the old G' of the tile live in registers)
+#ifndef SMG_DGG_SMALL_WAVES
+#define SMG_DGG_SMALL_WAVES 3      // mode 0, 64-row tile: 176 -> 168 VGPRs (40 bytes of scratch), 3 workgroups per SIMD: 121.7 -> 100.2 us per launch (blocks 3-4)
+#endif
+    static constexpr int kMinWaves = (PREC == 0 && Cfg::BM == 64) ? SMG_DGG_SMALL_WAVES : 2;       // (x, the running sum and the old G' of the tile live in registers)
 
     struct Ctx {
         int n, m0, n0; bool whole;
@@ -2317,7 +2343,7 @@ struct BwdWeightP {
             // past NB read the neighbouring channels of the row - their columns are never stored
             o.ok = true;
             o.v[0] = bload4(static_cast<const char*>(bbuf) + (int64_t)XSZ * c.n * pb.HWp * ldb, (unsigned)XSZ * (unsigned)(pb.HW * ldb), (unsigned)XSZ * (unsigned)(kr * ldb + ch),
-                            (unsigned)XSZ * (unsigned)((c.p0 + kt * Cfg::BK) * ldb));
+                            (unsigned)XSZ * (unsigned)(SMG_EXP_WRAP_W1(c.p0 + kt * Cfg::BK) * ldb));
         } else if constexpr (BMODE == W_THREE) {
             const int yy = r.y + c.tap / 3 - 1, xx = r.x + c.tap % 3 - 1;
             o.ok = o.ok && (unsigned)yy < (unsigned)pb.H && (unsigned)xx < (unsigned)pb.W;

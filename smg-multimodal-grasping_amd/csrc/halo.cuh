@@ -200,9 +200,9 @@ static __global__ __launch_bounds__(256, SMG_HALO_FWD_WAVES) void conv3x3_halo_f
                 if (more) load_hl(set ^ 1, tap + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = mfma_f16(ah[set][0][m], bl[set], acc[m]);
+                for (int m = 0; m < MT; ++m) acc[m] = SMG_TERM(true, mfma_f16(ah[set][0][m], bl[set], acc[m]), acc[m]);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = mfma_f16(al[set][m], bh[set][0], acc[m]);
+                for (int m = 0; m < MT; ++m) acc[m] = SMG_TERM(true, mfma_f16(al[set][m], bh[set][0], acc[m]), acc[m]);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[m] = mfma_f16(ah[set][0][m], bh[set][0], acc[m]);
                 return;
@@ -536,7 +536,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[m] = mfma_f16(af[ks][m][g == 1 ? 1 : 0], bf[ks][g == 0 ? 1 : 0], acc[m]);
+                    for (int m = 0; m < MT; ++m) acc[m] = SMG_TERM(g < 2, mfma_f16(af[ks][m][g == 1 ? 1 : 0], bf[ks][g == 0 ? 1 : 0], acc[m]), acc[m]);
         } else
         if constexpr (OP != 0) {                            // single-piece operands: one term per k16-step
             u32x4 ah[2][MT], bh[2];
@@ -794,7 +794,7 @@ static __global__ __launch_bounds__(256, SMG_HALO_WGRAD_WAVES) void conv3x3_halo
 #pragma unroll
                     for (int g = 0; g < 3; ++g)
 #pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) acc[dy * 3 + dx] = mfma_f16(af[g == 1 ? 1 : 0], bf[dx][g == 0 ? 1 : 0], acc[dy * 3 + dx]);
+                        for (int dx = 0; dx < 3; ++dx) acc[dy * 3 + dx] = SMG_TERM(g < 2, mfma_f16(af[g == 1 ? 1 : 0], bf[dx][g == 0 ? 1 : 0], acc[dy * 3 + dx]), acc[dy * 3 + dx]);
                 } else
                 if constexpr (OP != 0) {                    // single-piece operands: one term per tap
 #pragma unroll

@@ -66,7 +66,7 @@ static __global__ __launch_bounds__(512, 1) void conv1x1_fwd_ws_kernel(const Fwd
     const float* a_base = a.src + (int64_t)n * a.pl.HWp * a.lds_;
     unsigned a_voff[G::A_N];
 #pragma unroll
-    for (int i = 0; i < G::A_N; ++i) a_voff[i] = 4u * (unsigned)((pbase + al + 32 * i) * a.lds_ + 4 * aq);
+    for (int i = 0; i < G::A_N; ++i) a_voff[i] = 4u * (unsigned)(SMG_EXP_WRAP_F1(pbase + al + 32 * i) * a.lds_ + 4 * aq);
     unsigned b_voff[G::B_N];
 #pragma unroll
     for (int i = 0; i < G::B_N; ++i) {
@@ -147,8 +147,8 @@ static __global__ __launch_bounds__(512, 1) void conv1x1_fwd_ws_kernel(const Fwd
                 bf[pc] = *reinterpret_cast<const u32x4*>(B + ((pc * G::K8 + k8) * G::LDUB + wn0 + l31) * 16);
             }
             if constexpr (OP == 3) {
-                acc = mfma_f16(af[0], bf[1], acc);
-                acc = mfma_f16(af[1], bf[0], acc);
+                acc = SMG_TERM(true, mfma_f16(af[0], bf[1], acc), acc);
+                acc = SMG_TERM(true, mfma_f16(af[1], bf[0], acc), acc);
                 acc = mfma_f16(af[0], bf[0], acc);
             } else {
                 acc = mfma_bf16(af[0], bf[2], acc);
