@@ -1378,7 +1378,10 @@ struct BwdDataP {
     static constexpr bool kSegmented = false;
     static constexpr bool kHasPrologue = true;
     static constexpr bool kEarlyFetch = EMODE != E_UNPOOL;     // early_fetch(): the epilogue's operands, issued behind the first k-tiles' loads
-    static constexpr int kMinWaves = 1;       // (3 waves per SIMD for the 128 x 64 accumulate form: 168 VGPRs + 88 bytes of scratch, serialised total 19.0 -> 19.4 ms)
+#ifndef SMG_DGU_WAVES
+#define SMG_DGU_WAVES 3      // the transitions' un-pooling data gradient: 172 -> 152 registers without scratch, 169 -> 163 us per launch
+#endif
+    static constexpr int kMinWaves = (PREC == 0 && EMODE == E_UNPOOL) ? SMG_DGU_WAVES : 1;       // (3 waves per SIMD for the 128 x 64 accumulate form: 168 VGPRs + 88 bytes of scratch, serialised total 19.0 -> 19.4 ms)
 
     // AFF = false: the gradient operand is finished (xbuf unused).  Pointwise and finished -> descriptor loads, rows outside
     // the plane carry the out-of-range offset and read as zero (no mask, no address arithmetic in the k-loop).
@@ -2201,7 +2204,7 @@ struct BwdWeightP {
     static constexpr bool kSegmented = false;
     static constexpr bool kHasPrologue = true;
     static constexpr bool kEarlyFetch = false;
-    static constexpr int kMinWaves = 1;
+    static constexpr int kMinWaves = 1;      // (the transitions' pooling form held to 3 waves per SIMD: 92 bytes of scratch, 117 -> 209 us per launch)
 
     struct Ctx { int n, p0, m0, n0, tap, kt, z; float gs, ginv; };      // gs / ginv: operand kind 3 (gradient scale, inverse of gradient x activation scale)
     using KPrm = KPrm0;
