@@ -290,6 +290,14 @@ struct TraceScope {
             life += (double)(r[6] - r[5]);
         }
         const double span = (double)(t_max - t_min) * 0.01, resid = life / (double)(t_max - t_min) / 256.0;
+        {   // distribution: when workgroups start (relative to the first) and how long they live
+            std::vector<double> st0, lf;
+            for (size_t w = 0; w < n_wg; ++w) { const unsigned long long* r = &h[w * 8]; if (!r[4]) continue; st0.push_back((double)(r[5] - t_min) * 0.01); lf.push_back((double)(r[6] - r[5]) * 0.01); }
+            std::sort(st0.begin(), st0.end()); std::sort(lf.begin(), lf.end());
+            auto q = [](const std::vector<double>& v, double f) { return v.empty() ? 0.0 : v[std::min(v.size() - 1, (size_t)(f * v.size()))]; };
+            fprintf(stderr, "[smg trace]   start us p50 %.1f p90 %.1f max %.1f | life us p10 %.1f p50 %.1f p90 %.1f max %.1f\n",
+                    q(st0, 0.5), q(st0, 0.9), q(st0, 1.0), q(lf, 0.1), q(lf, 0.5), q(lf, 0.9), q(lf, 1.0));
+        }
         fprintf(stderr, "[smg trace] kind %d grid %ux%ux%u live %zu: init %.0f | first tile %.0f | k-loop %.0f | epilogue %.0f cycles/WG (mean); span %.1f us, %.2f workgroups resident per CU, mean life %.1f us  %.160s\n",
                 kind, grid.x, grid.y, grid.z, live, sum[0] / live, sum[1] / live, sum[2] / live, sum[3] / live, span, resid, life / live * 0.01, strstr(what, "[P = ") ? strstr(what, "[P = ") : what);
     }

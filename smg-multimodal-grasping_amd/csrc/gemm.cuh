@@ -373,6 +373,11 @@ __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstla
 #else
 #define SMG_EXP_WRAP_F1(p) (p)
 #endif
+#ifdef SMG_EXP_W1A
+#define SMG_EXP_WRAP_W1A(p) ((p) & 1023)
+#else
+#define SMG_EXP_WRAP_W1A(p) (p)
+#endif
 #ifdef SMG_EXP_W1X
 #define SMG_EXP_WRAP_W1(p) ((p) & 1023)
 #else
@@ -2309,7 +2314,7 @@ struct BwdWeightP {
         if constexpr (!AFF) {
             o.ok = true;
             o.v[0] = bload4(static_cast<const char*>(gbuf) + (int64_t)GSZ * ((int64_t)c.n * pa.HWp * ldg + gcoff), (unsigned)GSZ * (unsigned)(pa.HW * ldg - gcoff),
-                            ch < MA ? (unsigned)GSZ * (unsigned)(kr * ldg + ch) : kOOB, (unsigned)GSZ * (unsigned)((c.p0 + kt * Cfg::BK) * ldg));
+                            ch < MA ? (unsigned)GSZ * (unsigned)(kr * ldg + ch) : kOOB, (unsigned)GSZ * (unsigned)(SMG_EXP_WRAP_W1A(c.p0 + kt * Cfg::BK) * ldg));
             return o;
         }
         o.ok = r.p < pa.HW && ch < MA;
