@@ -501,7 +501,10 @@ __device__ __forceinline__ ActScale amax_scale(const unsigned* amax_n) {
     a.inv = __uint_as_float((unsigned)(114 + e) << 23);    // 2^(e - 13)
     return a;
 }
-__device__ __forceinline__ float4 mul4(float4 v, float s) { return make_float4(v.x * s, v.y * s, v.z * s, v.w * s); }
+__device__ __forceinline__ float4 mul4(float4 v, float s) {      // two elements per instruction (v_pk_mul_f32)
+    const f32x2 a = f32x2{v.x, v.y} * s, b = f32x2{v.z, v.w} * s;
+    return make_float4(a.x, a.y, b.x, b.y);
+}
 
 // BatchNorm statistics of one activation buffer as fp32, finished ONCE per (stream, channel): mean | invstd tables of
 // [rows][ld] (rows = streams or pairs), plus the affine parameters of the consuming BN layer.  Who writes them: the first
