@@ -830,7 +830,13 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
                     for (int i = 0; i < C::TM; ++i)
 #pragma unroll
                         for (int j = 0; j < C::TN; ++j)
-                            acc[i][j] = SMG_TERM(g < 2, mfma_f16(g == 1 ? al_[i] : ah[i], g == 0 ? bl_[j] : bh[j], acc[i][j]), acc[i][j]);
+                            {
+#ifdef SMG_EXP_NOMFMA
+                                acc[i][j][0] += __uint_as_float(ah[i].x ^ bh[j].x ^ al_[i].y ^ bl_[j].y);      // keeps the fragment reads alive
+#else
+                                acc[i][j] = SMG_TERM(g < 2, mfma_f16(g == 1 ? al_[i] : ah[i], g == 0 ? bl_[j] : bh[j], acc[i][j]), acc[i][j]);
+#endif
+                            }
                 SMG_PIN();
             } else
             if constexpr (OP != 0) {         // single-piece operands: one term per tile
@@ -962,7 +968,9 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
                 const bool tr = trace && kt == 4;
                 if (tr) trace[0] = smg_stamp();
 #endif
+#ifndef SMG_EXP_NOLOAD
                 g_load(kt + PD < KT ? kt + PD : KT - 1, ra[u], rb[u], kp[u]);   // slot u went to LDS one step ago
+#endif
 #if SMG_PIN_LOADS
                 __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -971,11 +979,15 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
 #ifdef SMG_TRACE_ITER
                 if (tr) { trace[1] = smg_stamp(); trace[2] = trace[1]; }
 #endif
+#ifndef SMG_EXP_NOSTORE
                 s_store(buf ^ 1, kt + 1 < KT ? kt + 1 : KT - 1, ra[(u + 1) % PD], rb[(u + 1) % PD], kp[(u + 1) % PD]);   // at kt + 1 == KT: a dead store of the clamped re-load
+#endif
 #ifdef SMG_TRACE_ITER
                 if (tr) trace[3] = smg_stamp();
 #endif
+#ifndef SMG_EXP_NOBARRIER
                 __syncthreads();
+#endif
 #ifdef SMG_TRACE_ITER
                 if (tr) trace[4] = smg_stamp();
 #endif
