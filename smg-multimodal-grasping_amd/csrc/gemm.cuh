@@ -793,6 +793,9 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
     // One operand fragment piece of a 32-row tile for this wave's k16-step s: ds_read_b128 of a unit (forward / data
     // gradient) or two transposing reads (weight gradient).
     auto frag = [&](const char* img, int ldu, int ldt, int r0, int s, int pc) -> u32x4 {
+#ifdef SMG_EXP_NOFRAG      // timing only: no fragment reads from LDS
+        return u32x4{(unsigned)(r0 + s), (unsigned)pc, (unsigned)lane, 0x3c003c00u};
+#endif
         if constexpr (C::AT) {
             const int k8 = (wk * C::KS + s) * 2 + half;
             return *reinterpret_cast<const u32x4*>(img + ((pc * C::K8 + k8) * ldu + r0 + l31) * 16);
