@@ -318,14 +318,14 @@ static void launch_gemm(smg_engine* e, hipStream_t st, P p, dim3 grid, int kind,
     if constexpr (P::kSwizzle == 1) {            // x = M tiles, y = N tiles sharing one A operand
         if (grid.y > 1 && grid.z == 1) {
             p.tm = TileMap{(int)grid.x, (int)grid.y, 0};
-            grid = dim3(8 * ((grid.x + 7) / 8) * grid.y, 1, 1);
+            grid = dim3(tile_grid(p.tm), 1, 1);
         }
     } else {                                     // weight gradient: z = pixel chunks, x*y = tiles sharing them
         p.gx = grid.x; p.gy = grid.y;
         const int tiles = grid.x * grid.y;
         if (tiles > 1) {
             p.tm = TileMap{(int)grid.z, tiles, (int)grid.x};
-            grid = dim3(8 * ((grid.z + 7) / 8) * tiles, 1, 1);
+            grid = dim3(tile_grid(p.tm), 1, 1);
         }
     }
     TraceScope ts(st, kind, grid, __PRETTY_FUNCTION__);

@@ -188,7 +188,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                             (void)hipFuncSetAttribute((const void*)conv1x1_fwd_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                             raised[e->device & 63] = true;
                         }
-                        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_fwd_ws_kernel<0>), dim3(8 * ((nM + 7) / 8) * nN), dim3(512), smem, cs, a);
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_fwd_ws_kernel<0>), dim3(tile_grid(a.tm)), dim3(512), smem, cs, a);
                     } else
                     if (pl.HWp % 128 == 0 && wg128 >= small_wgs) run(CfgP128x128{});
                     else if (pl.HWp % 128 == 0 && wg128 >= deep_min && d.cin % 32 == 0) run(CfgP128x128d{});

@@ -567,12 +567,22 @@ __device__ __forceinline__ float4 affine2(float4 g, float4 x, const float* prm, 
 // speed only): sibling tiles that re-read the same A operand (the N-tiles of one M-tile, or of one
 // pixel chunk in a weight gradient) are made consecutive on ONE XCD so the re-reads hit its private L2
 // instead of going out to the fabric.  nM == 0 -> plain (x, y, z) block coordinates.
+// The grid is EXACT (nM * nN workgroups): the last nM % 8 majors, which do not fill a group of eight, are dealt round-robin behind the
+// full groups (their tiles lose the shared XCD, nobody else does) - no padding workgroups that take a slot only to leave at once.
 struct TileMap { int nM, nN, gx; };
+__host__ __device__ __forceinline__ unsigned tile_grid(const TileMap& tm) { return (unsigned)tm.nM * (unsigned)tm.nN; }
 __device__ __forceinline__ bool tile_decode(const TileMap& tm, int b, int& major, int& minor) {
-    const int x = b & 7, slot = b >> 3;
-    major = (slot / tm.nN) * 8 + x;
-    minor = slot % tm.nN;
-    return major < tm.nM;
+    const int full = 8 * tm.nN * (tm.nM >> 3);
+    if (b < full) {
+        const int x = b & 7, slot = b >> 3;
+        major = (slot / tm.nN) * 8 + x;
+        minor = slot % tm.nN;
+    } else {
+        const int r = b - full, rem = tm.nM & 7;
+        major = (tm.nM & ~7) + r % rem;
+        minor = r / rem;
+    }
+    return true;
 }
 
 // Sum per-lane column partials over the rows of the whole workgroup tile.
