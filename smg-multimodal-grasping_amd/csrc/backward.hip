@@ -34,7 +34,8 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
     const Plane p4 = e->p_blk[3];
     const bool ph_a = phases & 1, ph_b = phases & 2;
     if (ph_a) HIP_OK(hipMemset2DAsync(e->bstat, kStatRepStride * sizeof(double), 0, 2 * e->bstat_span * sizeof(double), kStatRep, st));      // every replica
-    const bool split16 = e->prec == 0 && kSplitOp == 3;      // the hot classes run on fp16-split operands scaled by recorded maxima
+    const bool split16 = e->prec == 0 && kSplitOp == 3;      // the hot classes run on fp16-split operands: GS scaled by its recorded maximum,
+                                                             // D2 written in unit form with per-block scales (bn_bwd_apply_split_kernel)
     if (ph_a && split16) HIP_OK(hipMemsetAsync(e->gamax, 0, (size_t)e->gamax_words * sizeof(unsigned), st));
     // Weight-gradient kernels only read what the data-gradient chain produces and write disjoint
     // gradient ranges, so they run on a second stream beside it (their MFMA/L2-bound phases overlap the
@@ -43,14 +44,13 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
     // (a lowest-priority stream for the weight gradients gains 0.2 ms per step with one engine alive, and LOSES 10 ms as soon
     // as a second engine - two more streams - exists in the process: the streams then share hardware queues and serialise)
     const hipStream_t s2 = (e->prof || e->serialize) ? st : e->side;
-    static const bool use_tabs = !(getenv("SMG_BWD_TABS") && atoi(getenv("SMG_BWD_TABS")) == 0);      // dev A/B: 0 = the fp64 sums, as before
     auto fork = [&](hipEvent_t ev) -> int {      // side stream continues after everything enqueued on st so far
         HIP_OK(hipEventRecord(ev, st));
         HIP_OK(hipStreamWaitEvent(s2, ev, 0));
         return 0;
     };
-    if (ph_a) e->bw_layer_no = 0;
-    int layer_no = e->bw_layer_no;
+    // operand kind 3 needs the finished GS's recorded maximum (always materialised there); few streams: launch-bound, the fused form wins
+    const bool gs_materialised = split16 || NS > 4;
 
     if (ph_a) {
     {   // value conv backward + relu1 + norm1 sums
@@ -110,6 +110,108 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(norm5_bwd_kernel<PREC>), dim3(4, NS, (p4.HW + 15) / 16), dim3(256), 0, st, a));
     }
     }   // ph_a: head
+    // Buffers of a dense layer's finished gradients (GS: its 32 output channels, D2: its bottleneck, D2S: D2's block scales): a ring of
+    // kRing slots in backward order, which the side stream releases as its weight gradients finish.  The ring position of a layer is
+    // static (a two-phase backward's second half continues where the first stopped).
+    // (Measured and rejected in round 5: own buffers for the layers of blocks 3-4 and their weight gradients DEFERRED to the
+    // bandwidth-bound kernels of block 2 - the idea being that a concurrent kernel stretches the 10-20 us chain kernels of the small
+    // planes.  Same box, alternating: 16.44-16.66 ms per step without, 17.13-17.40 with four deferred layers per layer of block 2,
+    // 17.37-17.50 with eight: the side stream's work on the small planes is what fills an otherwise idle chip.)
+    struct LayerBuf { float* GS; float* D2; float* D2S; int ring; };
+    auto buf_of = [&](int b, int i) -> LayerBuf {
+        int r = kBlockLayers[b] - 1 - i;
+        for (int bb = 3; bb > b; --bb) r += kBlockLayers[bb];
+        return LayerBuf{e->GS[r % kRing], e->D2[r % kRing], e->D2S[r % kRing], r};
+    };
+    // The two weight gradients of dense layer (b, i) and their shared reduce, on the side stream (which must already wait for the
+    // layer's D2 / GS).
+    auto issue_wgrads = [&](int b, int i) -> int {
+        const Plane pl = e->p_blk[b];
+        const int Ct = kBlockCtot[b];
+        const DenseLayerRef& d = T.layers[b][i];
+        float* bt = el(e, e->Bt, e->bt_off[b][i]);
+        const LayerBuf lb = buf_of(b, i);
+        GradSrc gsrc{};
+        if (gs_materialised) { gsrc.g = lb.GS; gsrc.ldg = kGrowth; gsrc.amax = gamax_of(e, b, i, 0); }
+        else {
+            gsrc.g = el(e, e->G[b], d.cin); gsrc.ldg = Ct; gsrc.x = el(e, e->X[b], d.cin); gsrc.ldx = Ct;
+            gsrc.xsum = fsum(e, e->st_X[b]) + d.cin; gsrc.xsq = fsq(e, e->st_X[b]) + d.cin;
+            gsrc.s1 = b1(e, e->bs_X[b]) + d.cin; gsrc.s2 = b2(e, e->bs_X[b]) + d.cin; gsrc.sstride = Ct; gsrc.eps = kEps;
+        }
+        ReduceArgs red3{}; red3.Z = 0;            // the 3x3 weight gradient's reduction, launched together with the 1x1 one below
+        int64_t part3_floats = 0;                 // ... and the partial-tile floats it occupies
+        if (!e->generic3x3) {
+            // conv2 weight gradient with the activation halo resident in LDS (halo.cuh)
+            const int ts = halo_tile(pl, NS);
+            Halo3x3WgradArgs a;
+            a.g = gsrc; a.pl = pl; a.src = bt; a.C = kBottleneck;
+            const int th = 8;                              // tiles are ts x 8 pixels
+            a.bt = bn_table(e, e->sb_tab[b][i], e->max_streams, 0, kBottleneck, P + d.n2.w, P + d.n2.b);
+            a.asc = asc_n2(e, b, i);
+            a.part = e->part; a.tiles_x = (pl.W + ts - 1) / ts; a.n_tiles = ((pl.H + th - 1) / th) * a.tiles_x;
+            a.tiles_per_wg = w3_tiles_per_wg(a.n_tiles, ts, NS, e->part_floats, (double)ts / th);
+            const int groups = (a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+            if ((int64_t)groups * NS * 9 * 32 * kBottleneck > e->part_floats) return fail(-12, "partial-gradient workspace too small");
+            {
+                BY(e, ESZ(e) * NS * pl.HW * (kGrowth + kBottleneck));
+                ProfScope ps(e, s2, K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
+                if (ts == 16) {
+                    PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_wgrad_kernel<16, PREC>), dim3(groups, kBottleneck / 32, NS), dim3(256),
+                                                        (HaloWgradSGeo<16, PREC>::smem_bytes()), s2, a));
+                } else {
+                    PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_wgrad_kernel<8, PREC>), dim3(groups, kBottleneck / 32, NS), dim3(256),
+                                                        (HaloWgradSGeo<8, PREC>::smem_bytes()), s2, a));
+                }
+            }
+            red3.part = e->part; red3.Z = groups * NS; red3.taps = 9; red3.rows = kGrowth; red3.cols = kBottleneck; red3.ldp = kBottleneck;
+            red3.z_stride = (int64_t)9 * kGrowth * kBottleneck; red3.tap_stride = (int64_t)kGrowth * kBottleneck;
+            red3.dw = Gr + d.c2.w; red3.ldw_out = kBottleneck * 9; red3.cmap = C_3x3;
+            part3_floats = (int64_t)groups * NS * 9 * kGrowth * kBottleneck;
+        } else {   // conv2 weight gradient (generic implicit GEMM, one launch slice per tap)
+            const int chunk = 512, cps = (pl.HWp + chunk - 1) / chunk;   // latency-bound: many short workgroups
+            BwdWeightP<CfgW32x128, W_THREE, C_3x3, SMG_PD_WGRAD, false> p{};
+            p.gbuf = lb.GS; p.ldg = kGrowth; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kGrowth;
+            p.bbuf = bt; p.ldb = kBottleneck; p.pb = pl; p.NB = kBottleneck;
+            p.bsum = fsum(e, e->st_Bt[b][i]); p.bsq = fsq(e, e->st_Bt[b][i]); p.bstride = kBottleneck;
+            p.bgamma = P + d.n2.w; p.bbeta = P + d.n2.b; p.eps = kEps;
+            p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
+            p.dw = Gr + d.c2.w; p.ldw_out = kBottleneck * 9;
+            BY(e, ESZ(e) * NS * pl.HW * (kGrowth + kBottleneck));
+            if (int rc = launch_wgrad(e, s2, p, dim3(1, 1, 9 * NS * cps), K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth, 9, C_3x3)) return rc;
+        }
+        {   // conv1 weight gradient.  ~320 workgroups: it shares the chip with the data-gradient chain on the other stream
+            // (256..384 measure the same, 512 / 768 / 1024 cost the step 0.15 / 0.35 / 0.75 ms)
+            using Cfg = CfgW128x64;
+            const int nt = (d.cin + Cfg::BN - 1) / Cfg::BN;
+            int chunk, cps;
+            // 16-bit storage: the k-loop is a third as long, the 128 x 64 atomics per workgroup are not - half as many workgroups
+            // on many-stream batches (config 3: 28.9 -> 28.5 ms at 160; 120 / 80: 28.6 / 28.8; S = 1824 with 5 streams: 320 stays)
+            pick_chunk(pl, NS, nt, chunk, cps, (e->prec && NS >= 16) ? 160 : 320);
+            auto go = [&](auto ptag) -> int {
+                BwdWeightP<MC<Cfg, decltype(ptag)::value>, W_ONE, C_IDENT, SMG_PD_WGRAD, false, decltype(ptag)::value> p{};
+                p.gbuf = lb.D2; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck; p.binv = lb.D2S; p.basc = asc_n1(e, b, i);
+                p.bbuf = e->X[b]; p.ldb = Ct; p.pb = pl; p.NB = d.cin;
+                p.bsum = fsum(e, e->st_X[b]); p.bsq = fsq(e, e->st_X[b]); p.bstride = Ct; p.btab = stat_table(e, e->sx_tab[b], e->max_streams, Ct);
+                p.bgamma = P + d.n1.w; p.bbeta = P + d.n1.b; p.eps = kEps;
+                p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
+                p.dw = Gr + d.c1.w; p.ldw_out = d.cin;
+                BY(e, ESZ(e) * NS * pl.HW * (kBottleneck + d.cin));
+                // partial tiles + the fixed-order reduce (reproducible; since reduce_partials splits the partials over four waves it
+                // beats 128 x 64 fp32 atomics per workgroup); a few streams: host-launch-bound, atomics save the reduce launches
+                const bool w1_part = e->deterministic || NS > 4;
+                // both reductions of the layer in ONE launch: the 1x1 partial tiles go behind the 3x3 ones (if they fit; else the 3x3
+                // reduction runs first and the workspace is reused)
+                ReduceArgs red1{}; red1.Z = 0;
+                int64_t off1 = part3_floats;
+                if (red3.Z && (!w1_part || off1 + (int64_t)NS * cps * Cfg::BM * nt * Cfg::BN > e->part_floats)) { launch_reduce2(e, s2, K_W3, red3, ReduceArgs{}); red3.Z = 0; off1 = 0; }
+                if (int rc = launch_wgrad(e, s2, p, dim3(1, nt, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck, 1, C_IDENT, w1_part, off1, &red1)) return rc;
+                launch_reduce2(e, s2, K_W1, red3, red1);
+                return 0;
+            };
+            PREC_DISPATCH(e, if (int rc = go(PTAG)) return rc);
+        }
+        return 0;
+    };
     for (int b = ph_a ? 3 : 0; b >= (ph_b ? 0 : 1); --b) {
         e->prof_stage = b;
         const Plane pl = e->p_blk[b];
@@ -117,48 +219,38 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         for (int i = (int)T.layers[b].size() - 1; i >= 0; --i) {
             const DenseLayerRef& d = T.layers[b][i];
             float* bt = el(e, e->Bt, e->bt_off[b][i]);
-            const int db = layer_no % kRing;
-            float* GSb = e->GS[db];
-            float* D2b = e->D2[db];
-            static const bool one_fork = !(getenv("SMG_BWD_FORKS") && atoi(getenv("SMG_BWD_FORKS")) == 0);      // (0: round 3's two forks + a ring wait per layer, A/B)
-            {
-                const bool sparse_wait = one_fork;
-                if (!sparse_wait) { if (layer_no >= kRing) HIP_OK(hipStreamWaitEvent(st, e->ev_side[db], 0)); }   // side stream done with these buffers (kRing layers ago)
-                // sparse form: at every third layer wait for the side stream's event of the LATEST of the next three slots' previous users
-                // (layer_no + 2 - kRing; the side stream is in order, so the two before it are done as well)
-                else if (layer_no >= kRing && layer_no % 3 == 0) HIP_OK(hipStreamWaitEvent(st, e->ev_side[(layer_no + 2) % kRing], 0));
-            }
-            ++layer_no;
+            const LayerBuf lb = buf_of(b, i);
+            float* GSb = lb.GS;
+            float* D2b = lb.D2;
+            // ring slots: at every third layer wait for the side stream's event of the LATEST of the next three slots' previous users
+            // (ring position + 2 - kRing; the side stream is in order, so the two before it are done as well)
+            static_assert(kRing % 3 == 0 && kRing > 3, "the sparse ring wait covers three slots at a time");
+            if (lb.ring >= kRing && lb.ring % 3 == 0) HIP_OK(hipStreamWaitEvent(st, e->ev_side[(lb.ring + 2) % kRing], 0));
             // This layer's finished output-slice gradient GS = invstd*(G' - SA/n - xhat*SB/n), materialised once (dense
             // [px][32]) for the 3x3 data- and weight-gradient kernels.  They can also apply it while loading the G' / X
-            // slices (GradSrc with x set; SMG_GS_FUSED=1): one launch less on the dependency chain, but measured 0.5 ms
-            // per step slower - two strided 128-B-per-pixel reads replace one dense one in both consumers.
+            // slices (GradSrc with x set): one launch less on the dependency chain, but measured 0.5 ms per step slower on
+            // many-stream batches - two strided 128-B-per-pixel reads replace one dense one in both consumers.
             GradSrc gsrc{};
             gsrc.g = el(e, e->G[b], d.cin); gsrc.ldg = Ct; gsrc.x = el(e, e->X[b], d.cin); gsrc.ldx = Ct;
             gsrc.xsum = fsum(e, e->st_X[b]) + d.cin; gsrc.xsq = fsq(e, e->st_X[b]) + d.cin;
             gsrc.s1 = b1(e, e->bs_X[b]) + d.cin; gsrc.s2 = b2(e, e->bs_X[b]) + d.cin; gsrc.sstride = Ct; gsrc.eps = kEps;
-            static const bool gs_env_fused = getenv("SMG_GS_FUSED") != nullptr;
-            static const int gs_fused_hw = getenv("SMG_GS_FUSED_HW") ? atoi(getenv("SMG_GS_FUSED_HW")) : 0;   // dev A/B: fuse on planes up to this many pixels
-            // (operand kind 3 needs the finished gradient's recorded maximum: always materialised there)
-            const bool gs_mat = split16 || (!gs_env_fused && NS > 4 && pl.HW > gs_fused_hw);      // few streams: launch-bound, the fused form wins (8.78 -> 8.56 ms per sample)
-            if (e->generic3x3 || gs_mat) {
+            if (e->generic3x3 || gs_materialised) {
                 BnBwdApplyArgs a{};
                 a.g = e->G[b]; a.ldg = Ct; a.gcoff = d.cin; a.x = e->X[b]; a.ldx = Ct; a.xcoff = d.cin; a.pl = pl; a.C = kGrowth;
-                a.xsum = fsum(e, e->st_X[b]); a.xsq = fsq(e, e->st_X[b]); a.xstride = Ct; a.xtab = use_tabs ? stat_table(e, e->sx_tab[b], e->max_streams, Ct) : StatTab{};
+                a.xsum = fsum(e, e->st_X[b]); a.xsq = fsq(e, e->st_X[b]); a.xstride = Ct; a.xtab = stat_table(e, e->sx_tab[b], e->max_streams, Ct);
                 a.s1 = b1(e, e->bs_X[b]); a.s2 = b2(e, e->bs_X[b]); a.sstride = Ct; a.scoff = d.cin; a.gamma = nullptr; a.eps = kEps;
                 a.out = GSb; a.ldo = kGrowth; a.amax = split16 ? gamax_of(e, b, i, 0) : nullptr;
                 BY(e, ESZ(e) * NS * pl.HW * 3 * kGrowth);
                 ProfScope ps(e, st, K_OTHER, 0);
                 PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_bwd_apply_kernel<PREC>), dim3((pl.HWp + bn_apply_rows(PREC) - 1) / bn_apply_rows(PREC), NS), dim3(256), 0, st, a));
-                if (gs_mat) { gsrc = GradSrc{}; gsrc.g = GSb; gsrc.ldg = kGrowth; gsrc.amax = gamax_of(e, b, i, 0); }
+                if (gs_materialised) { gsrc = GradSrc{}; gsrc.g = GSb; gsrc.ldg = kGrowth; gsrc.amax = gamax_of(e, b, i, 0); }
             }
-            if (!one_fork || e->generic3x3) { if (fork(e->ev_gs[db])) return -5; }
             if (!e->generic3x3) {
                 // conv2 (3x3) data gradient with the gradient halo resident in LDS (halo.cuh)
                 Halo3x3DgradArgs a;
                 a.g = gsrc; a.pl = pl; a.C = kBottleneck;
                 a.mbuf = bt;
-                a.dst = D2b; a.o1 = b1(e, e->bs_Bt[b][i]); a.o2 = b2(e, e->bs_Bt[b][i]); a.ostride = kBottleneck;
+                a.dst = split16 ? e->DY2 : D2b; a.o1 = b1(e, e->bs_Bt[b][i]); a.o2 = b2(e, e->bs_Bt[b][i]); a.ostride = kBottleneck;
                 a.wu = e->packed_u + e->pk_hd[b][i]; a.bt = bn_table(e, e->sb_tab[b][i], e->max_streams, 0, kBottleneck, P + d.n2.w, P + d.n2.b);
                 BY(e, ESZ(e) * NS * pl.HW * (kGrowth + 2 * kBottleneck));      // gradient in, mask source in, dy out
                 ProfScope ps(e, st, K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
@@ -191,7 +283,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                     p.mbuf = bt; p.ldm = kBottleneck; p.mcoff = 0; p.pm = pl;
                     p.msum = fsum(e, e->st_Bt[b][i]); p.msq = fsq(e, e->st_Bt[b][i]); p.mstride = kBottleneck;
                     p.egamma = P + d.n2.w; p.ebeta = P + d.n2.b;
-                    p.dst = D2b; p.ldd = kBottleneck; p.dcoff = 0;
+                    p.dst = split16 ? e->DY2 : D2b; p.ldd = kBottleneck; p.dcoff = 0;
                     p.o1 = b1(e, e->bs_Bt[b][i]); p.o2 = b2(e, e->bs_Bt[b][i]); p.ostride = kBottleneck; p.ocoff = 0;
                     p.dbeta = Gr + d.n2.b; p.dgamma = Gr + d.n2.w; p.eps = kEps;
                     BY(e, ESZ(e) * NS * pl.HW * (kGrowth + 2 * kBottleneck));
@@ -199,67 +291,31 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 };
                 if (pl.HWp % 128 == 0) run(CfgP128x128{}); else run(CfgP64x128{});
             }
-            // ONE fork per layer - the 3x3 weight gradient waits with the 1x1 one for the event behind the norm2 apply - and the ring
-            // wait only every third layer: two event records / waits per layer less on the data-gradient chain (17.07-17.54 -> 17.05-17.44 ms
-            // per step, alternating: inside the noise, kept for the shorter queue)
-            auto launch_w3 = [&]() -> int {
-                // conv2 weight gradient with the activation halo resident in LDS (halo.cuh)
-                const int ts = halo_tile(pl, NS);
-                Halo3x3WgradArgs a;
-                a.g = gsrc; a.pl = pl; a.src = bt; a.C = kBottleneck;
-                const int th = 8;                              // tiles are ts x 8 pixels
-                a.bt = bn_table(e, e->sb_tab[b][i], e->max_streams, 0, kBottleneck, P + d.n2.w, P + d.n2.b);
-                a.asc = asc_n2(e, b, i);
-                a.part = e->part; a.tiles_x = (pl.W + ts - 1) / ts; a.n_tiles = ((pl.H + th - 1) / th) * a.tiles_x;
-                a.tiles_per_wg = w3_tiles_per_wg(a.n_tiles, ts, NS, e->part_floats, (double)ts / th);
-                const int groups = (a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
-                if ((int64_t)groups * NS * 9 * 32 * kBottleneck > e->part_floats) return fail(-12, "partial-gradient workspace too small");
-                {
-                    BY(e, ESZ(e) * NS * pl.HW * (kGrowth + kBottleneck));
-                    ProfScope ps(e, s2, K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
-                    if (ts == 16) {
-                        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_wgrad_kernel<16, PREC>), dim3(groups, kBottleneck / 32, NS), dim3(256),
-                                                            (HaloWgradSGeo<16, PREC>::smem_bytes()), s2, a));
-                    } else {
-                        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_wgrad_kernel<8, PREC>), dim3(groups, kBottleneck / 32, NS), dim3(256),
-                                                            (HaloWgradSGeo<8, PREC>::smem_bytes()), s2, a));
-                    }
-                }
-                ReduceArgs r;
-                r.part = e->part; r.Z = groups * NS; r.taps = 9; r.rows = kGrowth; r.cols = kBottleneck; r.ldp = kBottleneck;
-                r.z_stride = (int64_t)9 * kGrowth * kBottleneck; r.tap_stride = (int64_t)kGrowth * kBottleneck;
-                r.dw = Gr + d.c2.w; r.ldw_out = kBottleneck * 9; r.cmap = C_3x3;
-                ProfScope ps(e, s2, K_W3, 0);
-                hipLaunchKernelGGL(reduce_partials_kernel, dim3((9 * kGrowth * kBottleneck + 63) / 64), dim3(256), 0, s2, r);
-                return 0;
-            };
-            if (!e->generic3x3) {
-                if (!one_fork) { if (int rc = launch_w3()) return rc; }
-            } else {   // conv2 weight gradient (generic implicit GEMM, one launch slice per tap)
-                const int chunk = 512, cps = (pl.HWp + chunk - 1) / chunk;   // latency-bound: many short workgroups
-                BwdWeightP<CfgW32x128, W_THREE, C_3x3, SMG_PD_WGRAD, false> p{};
-                p.gbuf = GSb; p.ldg = kGrowth; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kGrowth;
-                p.bbuf = bt; p.ldb = kBottleneck; p.pb = pl; p.NB = kBottleneck;
-                p.bsum = fsum(e, e->st_Bt[b][i]); p.bsq = fsq(e, e->st_Bt[b][i]); p.bstride = kBottleneck;
-                p.bgamma = P + d.n2.w; p.bbeta = P + d.n2.b; p.eps = kEps;
-                p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
-                p.dw = Gr + d.c2.w; p.ldw_out = kBottleneck * 9;
-                BY(e, ESZ(e) * NS * pl.HW * (kGrowth + kBottleneck));
-                if (int rc = launch_wgrad(e, s2, p, dim3(1, 1, 9 * NS * cps), K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth, 9, C_3x3)) return rc;
-            }
-            {   // norm2 backward applied once, in place: D2 <- gamma2*invstd*(dy - s1/n - xhat*s2/n)
+            if (split16) {   // norm2 backward applied once: D2 (unit form, per-block scales) <- gamma2*invstd*(dy - s1/n - xhat*s2/n)
+                BnBwdApplySplitArgs a{};
+                a.g = e->DY2; a.x = bt; a.pl = pl;
+                a.xsum = fsum(e, e->st_Bt[b][i]); a.xsq = fsq(e, e->st_Bt[b][i]); a.xstride = kBottleneck; a.xtab = !e->generic3x3 ? stat_table(e, e->sb_tab[b][i], e->max_streams, kBottleneck) : StatTab{};
+                a.s1 = b1(e, e->bs_Bt[b][i]); a.s2 = b2(e, e->bs_Bt[b][i]); a.sstride = kBottleneck;
+                a.gamma = P + d.n2.w; a.eps = kEps; a.out = reinterpret_cast<u32x4*>(D2b); a.binv = lb.D2S;
+                if (!e->generic3x3) { a.dbeta = Gr + d.n2.b; a.dgamma = Gr + d.n2.w; }   // the halo dgrad leaves these to us
+                BY(e, 4.0 * NS * pl.HW * 3 * kBottleneck);
+                ProfScope ps(e, st, K_OTHER, 0);
+                hipLaunchKernelGGL(bn_bwd_apply_split_kernel, dim3(pl.HWp / kScaleBlock, NS), dim3(256), 0, st, a);
+            } else {   // 16-bit modes: norm2 backward applied once, in place: D2 <- gamma2*invstd*(dy - s1/n - xhat*s2/n)
                 BnBwdApplyArgs a{};
                 a.g = D2b; a.ldg = kBottleneck; a.gcoff = 0; a.x = bt; a.ldx = kBottleneck; a.xcoff = 0; a.pl = pl; a.C = kBottleneck;
-                a.xsum = fsum(e, e->st_Bt[b][i]); a.xsq = fsq(e, e->st_Bt[b][i]); a.xstride = kBottleneck; a.xtab = (use_tabs && !e->generic3x3) ? stat_table(e, e->sb_tab[b][i], e->max_streams, kBottleneck) : StatTab{};
+                a.xsum = fsum(e, e->st_Bt[b][i]); a.xsq = fsq(e, e->st_Bt[b][i]); a.xstride = kBottleneck; a.xtab = !e->generic3x3 ? stat_table(e, e->sb_tab[b][i], e->max_streams, kBottleneck) : StatTab{};
                 a.s1 = b1(e, e->bs_Bt[b][i]); a.s2 = b2(e, e->bs_Bt[b][i]); a.sstride = kBottleneck; a.scoff = 0;
-                a.gamma = P + d.n2.w; a.eps = kEps; a.out = D2b; a.ldo = kBottleneck; a.amax = split16 ? gamax_of(e, b, i, 1) : nullptr;
+                a.gamma = P + d.n2.w; a.eps = kEps; a.out = D2b; a.ldo = kBottleneck; a.amax = nullptr;
                 if (!e->generic3x3) { a.dbeta = Gr + d.n2.b; a.dgamma = Gr + d.n2.w; }   // the halo dgrad leaves these to us
                 BY(e, ESZ(e) * NS * pl.HW * 3 * kBottleneck);
                 ProfScope ps(e, st, K_OTHER, 0);
                 PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_bwd_apply_kernel<PREC>), dim3((pl.HWp + bn_apply_rows(PREC) - 1) / bn_apply_rows(PREC), NS), dim3(256), 0, st, a));
             }
-            if (fork(e->ev_d2[db])) return -5;
-            if (one_fork && !e->generic3x3) { if (int rc = launch_w3()) return rc; }
+            // the layer's weight gradients: ONE fork per layer, behind the norm2 apply (GS and D2 are both final there)
+            if (fork(e->ev_d2[lb.ring % kRing])) return -5;
+            if (int rc = issue_wgrads(b, i)) return rc;
+            HIP_OK(hipEventRecord(e->ev_side[lb.ring % kRing], s2));
             // conv1 (1x1) data gradient -> relu1/norm1 backward accumulated into G'.  Layers are grouped (kGroup,
             // from the top of the block): inside a group only the channels the group itself produced - needed by
             // the very next layer - are accumulated per layer; everything below the group's lowest layer is done
@@ -270,12 +326,12 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             const int cs = T.layers[b][g_lo].cin;                       // channels below the group
             if (d.cin > cs) {                                           // [cs, cin): per-layer accumulate
                 auto run = [&](auto tag, auto ptag) {
-                    using Cfg = MCD<decltype(tag), decltype(ptag)::value, SMG_DEEP_D1N>;
+                    using Cfg = MC<decltype(tag), decltype(ptag)::value>;
                     BwdDataP<Cfg, false, E_ACCUM, false, decltype(ptag)::value> p{};
-                    p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kBottleneck; p.gamax = gamax_of(e, b, i, 1);
+                    p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.KA = kBottleneck; p.binv = lb.D2S;
                     p.wp = e->packed_u + e->pk_d1[b][i]; p.K8tot = kBottleneck / 8; p.ldn = d.cin; p.wcol0 = cs; p.N = d.cin - cs;
                     p.mbuf = e->X[b]; p.ldm = Ct; p.mcoff = cs; p.pm = pl;
-                    p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct; p.mtab = use_tabs ? stat_table(e, e->sx_tab[b], e->max_streams, Ct) : StatTab{};
+                    p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct; p.mtab = stat_table(e, e->sx_tab[b], e->max_streams, Ct);
                     p.egamma = P + d.n1.w + cs; p.ebeta = P + d.n1.b + cs;
                     p.dst = e->G[b]; p.ldd = Ct; p.dcoff = cs;
                     p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.ocoff = cs;
@@ -287,20 +343,20 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             }
             if (i == g_lo) {                                            // [0, cs): the whole group at once
                 auto run = [&](auto tag, auto ptag) {
-                    using Cfg = MCD<decltype(tag), decltype(ptag)::value, SMG_DEEP_D1G>;
+                    using Cfg = MC<decltype(tag), decltype(ptag)::value>;
                     BwdDataGroupP<Cfg, decltype(ptag)::value> p{};
                     const int g_hi = L - 1 - ((L - 1 - g_lo) / kGroup) * kGroup;      // top layer of this group
                     p.nseg = g_hi - g_lo + 1;
-                    for (int k = 0; k < p.nseg; ++k) {                  // layer g_lo + k ran (k layers) before this one
+                    for (int k = 0; k < p.nseg; ++k) {
                         const DenseLayerRef& dk = T.layers[b][g_lo + k];
-                        const int slot = (layer_no - 1 - k + kRing * 4) % kRing;
-                        p.seg[k].g = e->D2[slot]; p.seg[k].wp = e->packed_u + e->pk_d1[b][g_lo + k]; p.seg[k].ldn = dk.cin; p.seg[k].amax = gamax_of(e, b, g_lo + k, 1);
+                        const LayerBuf lk = buf_of(b, g_lo + k);
+                        p.seg[k].g = lk.D2; p.seg[k].wp = e->packed_u + e->pk_d1[b][g_lo + k]; p.seg[k].ldn = dk.cin; p.seg[k].binv = lk.D2S;
                         p.seg[k].gamma = P + dk.n1.w; p.seg[k].beta = P + dk.n1.b;
                         p.seg[k].dbeta = e->dbscr + e->db_off[b][g_lo + k]; p.seg[k].dgamma = e->dbscr + e->db_off[b][g_lo + k] + dk.cin;
                     }
                     p.ldg = kBottleneck; p.pa = pl; p.KA = kBottleneck; p.N = cs;
                     p.mbuf = e->X[b]; p.ldm = Ct;
-                    p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct; p.mtab = use_tabs ? stat_table(e, e->sx_tab[b], e->max_streams, Ct) : StatTab{};
+                    p.msum = fsum(e, e->st_X[b]); p.msq = fsq(e, e->st_X[b]); p.mstride = Ct; p.mtab = stat_table(e, e->sx_tab[b], e->max_streams, Ct);
                     p.dst = e->G[b]; p.ldd = Ct;
                     p.o1 = b1(e, e->bs_X[b]); p.o2 = b2(e, e->bs_X[b]); p.ostride = Ct; p.rep_stride = e->db_total; p.eps = kEps;
                     BY(e, ESZ(e) * NS * pl.HW * ((double)p.nseg * kBottleneck + 3.0 * cs));
@@ -310,39 +366,6 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 // tiles, half the barriers (k-loop 65k -> 50k cycles per workgroup, launches -7 %; same k16 order, same bits)
                 // (MC doubles the depth in the 16-bit modes: 128 x 64 x 64 / 64 x 64 x 64)
                 PREC_DISPATCH(e, if (pl.HWp % 128 == 0) run(GemmCfg<128, 64, 32, 2, 2, 1, true>{}, PTAG); else run(CfgP64x64{}, PTAG));
-            }
-            {   // conv1 weight gradient.  ~320 workgroups: it shares the chip with the data-gradient chain on the other stream
-#ifdef SMG_W1_WIDE      // dev A/B: 128 x 128 tiles (the gradient operand is split once per 128 columns instead of once per 64)
-                using Cfg = CfgW128x128;
-#else
-                using Cfg = CfgW128x64;
-#endif
-                const int nt = (d.cin + Cfg::BN - 1) / Cfg::BN;
-                int chunk, cps;
-                static const int w1_target = getenv("SMG_W1_WGS") ? atoi(getenv("SMG_W1_WGS")) : 320;            // dev A/B
-                static const int w1_small = getenv("SMG_W1_WGS_SMALL") ? atoi(getenv("SMG_W1_WGS_SMALL")) : w1_target;      // dev A/B: planes of <= 1600 pixels
-                // 16-bit storage: the k-loop is a third as long, the 128 x 64 atomics per workgroup are not - half as many workgroups
-                // on many-stream batches (config 3: 28.9 -> 28.5 ms at 160; 120 / 80: 28.6 / 28.8; S = 1824 with 5 streams: 320 stays)
-                const int w1_prec = (e->prec && NS >= 16 && !getenv("SMG_W1_WGS")) ? 160 : w1_target;
-                pick_chunk(pl, NS, nt, chunk, cps, pl.HW <= 1600 ? (getenv("SMG_W1_WGS_SMALL") ? w1_small : w1_prec) : w1_prec);   // 256..384 measure the same (22.46 ms per step), 512: 22.6, 768: 22.8, 1024: 23.2
-                auto go = [&](auto ptag) -> int {
-                BwdWeightP<MCD<Cfg, decltype(ptag)::value, SMG_DEEP_W1>, W_ONE, C_IDENT, SMG_PD_WGRAD, false, decltype(ptag)::value> p{};
-                p.gbuf = D2b; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck; p.gamax = gamax_of(e, b, i, 1); p.basc = asc_n1(e, b, i);
-                p.bbuf = e->X[b]; p.ldb = Ct; p.pb = pl; p.NB = d.cin;
-                p.bsum = fsum(e, e->st_X[b]); p.bsq = fsq(e, e->st_X[b]); p.bstride = Ct; p.btab = use_tabs ? stat_table(e, e->sx_tab[b], e->max_streams, Ct) : StatTab{};
-                p.bgamma = P + d.n1.w; p.bbeta = P + d.n1.b; p.eps = kEps;
-                p.chunk = chunk; p.chunks_per_stream = cps; p.n_chunks = NS * cps;
-                p.dw = Gr + d.c1.w; p.ldw_out = d.cin;
-                BY(e, ESZ(e) * NS * pl.HW * (kBottleneck + d.cin));
-                // partial tiles + the fixed-order reduce (reproducible) - since reduce_partials splits the partials over four waves this beats
-                // 128 x 64 fp32 atomics per workgroup everywhere (same box: headline 20.99 -> 20.84 ms, config 3 27.36 -> 27.16, config 5
-                // share 25.68 -> 25.49); SMG_W1_PART=0: the atomics, for A/B (the "deterministic" option overrides it)
-                static const bool w1_atomics = getenv("SMG_W1_PART") && atoi(getenv("SMG_W1_PART")) == 0;
-                const bool w1_part = e->deterministic || (!w1_atomics && NS > 4);      // (a few streams: host-launch-bound - atomics save the 58 reduce launches)
-                return launch_wgrad(e, s2, p, dim3(1, nt, NS * cps), K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck, 1, C_IDENT, w1_part);
-                };
-                PREC_DISPATCH(e, if (int rc = go(PTAG)) return rc);
-                HIP_OK(hipEventRecord(e->ev_side[db], s2));
             }
         }
         if (b > 0) {   // transition b-1: X[b-1] (all channels) -> X[b][:, 0:C0]
@@ -393,7 +416,6 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         }
     }
     e->prof_stage = -1;
-    e->bw_layer_no = layer_no;
     if (ph_b) {
     {   // pool0 / relu0 backward + norm0 sums
         Pool0BwdArgs a;

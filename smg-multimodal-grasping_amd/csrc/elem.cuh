@@ -825,6 +825,80 @@ static __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApp
     }
 }
 
+// ------------------------------------------------------------------------------------
+// The same for the bottleneck gradient of precision mode 0 (C = 128, through norm2), written in UNIT form (gemm.cuh, kD2K8):
+// a workgroup owns one 64-pixel scale block of one stream - it computes the block's 64 x 128 outputs in registers, takes their
+// largest magnitude, scales by the power of two that puts it into [2^13, 2^14), splits into the two fp16 pieces and stores them
+// as 16-byte units [piece][channel / 8][pixel]: what the three consumers' MFMAs read, with no arithmetic left for their k-loops.
+// Rows of the plane padding are written as zeros (the consumers need no row mask).  Thread t: channel quad t / 8, rows t % 8 + 8 k -
+// eight consecutive pixels of one quad side by side, so loads and stores both move 128-byte runs.
+// ------------------------------------------------------------------------------------
+struct BnBwdApplySplitArgs {
+    const float* g;                               // raw 3x3 data gradient dy [n][HWp][128]
+    const float* x;                               // the bottleneck activation norm2 normalised [n][HWp][128]
+    Plane pl;
+    const double* xsum; const double* xsq; int xstride; StatTab xtab;
+    const double* s1; const double* s2; int sstride;
+    const float* gamma; float eps;
+    u32x4* out;                                   // units of this ring slot
+    float* binv;                                  // [streams][HWp / 64] inverse block scales
+    float* dbeta; float* dgamma;                  // norm2's affine gradients (one fp32 atomic per stream and channel)
+};
+static __global__ __launch_bounds__(256) void bn_bwd_apply_split_kernel(const BnBwdApplySplitArgs a) {
+    constexpr int C = 8 * kD2K8;
+    __shared__ float prm[4 * C];
+    __shared__ float red[4];
+    const int n = blockIdx.y, t = threadIdx.x;
+    const int cs = t >> 3, rr = t & 7;
+    const int r0 = blockIdx.x * kScaleBlock + rr;
+    float4 gv[8], xv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                 // the data loads first: one memory round trip with the parameter prologue
+        const int r = r0 + 8 * k;
+        const int64_t pix = (int64_t)n * a.pl.HWp + (r < a.pl.HW ? r : 0);
+        gv[k] = ld4(a.g + pix * C + 4 * cs);
+        xv[k] = ld4(a.x + pix * C + 4 * cs);
+    }
+    if (t < C) {
+        const double inv = 1.0 / (double)a.pl.HW;
+        float mean, invstd;
+        tab_or_moments(a.xtab, n, t, a.xsum, a.xsq, (int64_t)n * a.xstride + t, inv, a.eps, mean, invstd);
+        const double s1 = stat_get(a.s1, (int64_t)n * a.sstride + t), s2 = stat_get(a.s2, (int64_t)n * a.sstride + t);
+        prm[t] = a.gamma[t] * invstd;
+        prm[C + t] = (float)(s1 * inv);
+        prm[2 * C + t] = mean;
+        prm[3 * C + t] = invstd * (float)(s2 * inv);
+        if (a.dbeta && blockIdx.x == 0) {
+            atomicAdd(a.dbeta + t, (float)s1);
+            atomicAdd(a.dgamma + t, (float)s2);
+        }
+    }
+    __syncthreads();
+    float vmax = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float4 o = r0 + 8 * k < a.pl.HW ? affine2(gv[k], xv[k], prm + 4 * cs, C) : zero4();
+        gv[k] = o;
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if ((t & 63) == 0) red[t >> 6] = vmax;
+    __syncthreads();
+    vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    ActScale sc{1.f, 1.f};
+    if (vmax > 0.f) sc = scale_of_max(__float_as_uint(vmax));      // (a block of zeros keeps scale 1)
+    if (t == 0) a.binv[(int64_t)n * (a.pl.HWp / kScaleBlock) + blockIdx.x] = sc.inv;
+    char* ob = reinterpret_cast<char*>(a.out + d2_stream_units(n, a.pl.HWp));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const Split4 s = split4<3>(mul4(gv[k], sc.s));
+        const int64_t at = ((int64_t)(cs >> 1) * a.pl.HWp + r0 + 8 * k) * 16 + (cs & 1) * 8;
+        *reinterpret_cast<uint2*>(ob + at) = s.p[0];
+        *reinterpret_cast<uint2*>(ob + at + (int64_t)kD2K8 * a.pl.HWp * 16) = s.p[1];
+    }
+}
+
 // Sum the replicas of the dbeta / dgamma scratch (engine.h) into the gradient array and leave the scratch zeroed for the next call.
 struct DbSegD { int64_t grad_off; int scr_off; int n; };
 static __global__ void db_flush_kernel(const DbSegD* segs, float* scr, int rep_stride, int reps, float* grads,

@@ -121,6 +121,9 @@ struct smg_engine {
     float* F = nullptr; float* H1 = nullptr;
     // gradients
     float* G[4] = {}; float* GS[kRing] = {}; float* D2[kRing] = {}; float* part = nullptr; int64_t part_floats = 0;
+    // precision mode 0: the ring's D2 slots hold the bottleneck gradient in UNIT form (gemm.cuh, kD2K8: two fp16 pieces per element,
+    // the same bytes) with one inverse scale per 64-pixel block in D2S; the raw 3x3 data gradient of the layer in flight goes to DY2
+    float* DY2 = nullptr; float* D2S[kRing] = {};
     // second stream for the weight-gradient kernels (independent of the data-gradient chain)
     hipStream_t side = nullptr; hipEvent_t ev_gs[kRing] = {}, ev_d2[kRing] = {}, ev_side[kRing] = {}, ev_misc = nullptr, ev_end = nullptr; float* DY0 = nullptr; float* DH1 = nullptr; float* DF = nullptr;
     // statistics arenas (doubles). fwd: [sum | sumsq] halves; bwd: [s1 | s2] halves
@@ -155,7 +158,6 @@ struct smg_engine {
     BnUpdDesc* d_bnupd = nullptr;
     // last forward
     bool have_fwd = false; int f_trunk = 0, f_head = 0, f_streams = 0, f_pairs = 0;
-    int bw_layer_no = 0;       // backward ring position, carried from the first half of a two-phase backward to the second
     bool bw_phase0_done = false;   // smg_backward_phase(0) ran on the last forward and its second half is still due (reset by every forward / precision change)
     bool f_stem1 = false;      // the last forward ran the one-channel stem (heightmap input form): img4 holds [streams][HWp] single floats
     int* d_stream_image = nullptr; int* d_stream_rot = nullptr; int* d_pair_a = nullptr; int* d_pair_b = nullptr;
@@ -337,26 +339,38 @@ static void launch_gemm(smg_engine* e, hipStream_t st, P p, dim3 grid, int kind,
 
 // Weight-gradient launch: partial tiles to the workspace + one reduce kernel (falls back to
 // atomics if the workspace is too small for this launch).
+// part_off: first float of the partial-tile workspace this launch may use (a dense layer's two weight gradients keep their partial
+// tiles side by side and share ONE reduce launch: `defer` receives this launch's reduction instead of it being launched here).
 template <class P>
-static int launch_wgrad(smg_engine* e, hipStream_t st, P& p, dim3 grid, int kind, double flops, int taps, int cmap, bool use_part = true) {
+static int launch_wgrad(smg_engine* e, hipStream_t st, P& p, dim3 grid, int kind, double flops, int taps, int cmap, bool use_part = true,
+                        int64_t part_off = 0, ReduceArgs* defer = nullptr) {
     using C = typename P::Cfg;
     const int64_t ldp = (int64_t)grid.y * C::BN, rowsp = (int64_t)grid.x * C::BM;
     const int64_t need = (int64_t)grid.z * rowsp * ldp;
-    p.part = (use_part && need <= e->part_floats) ? e->part : nullptr;
+    p.part = (use_part && part_off + need <= e->part_floats) ? e->part + part_off : nullptr;
     if (use_part && !p.part && e->deterministic)      // never a silent loss of the bit-reproducibility the option promises
         return fail(-12, "deterministic: a weight-gradient launch needs " + std::to_string(need) + " partial-tile floats, the workspace holds " +
-                             std::to_string(e->part_floats) + " (smaller batch per call, or a larger engine)");
+                             std::to_string(e->part_floats - part_off) + " (smaller batch per call, or a larger engine)");
     launch_gemm(e, st, p, grid, kind, flops);
+    if (defer) defer->Z = 0;
     if (p.part) {
         ReduceArgs r;
-        r.part = e->part; r.Z = p.n_chunks; r.taps = taps; r.rows = p.MA; r.cols = p.NB; r.ldp = (int)ldp;
+        r.part = p.part; r.Z = p.n_chunks; r.taps = taps; r.rows = p.MA; r.cols = p.NB; r.ldp = (int)ldp;
         r.z_stride = rowsp * ldp; r.tap_stride = (int64_t)p.n_chunks * rowsp * ldp;
         r.dw = p.dw; r.ldw_out = p.ldw_out; r.cmap = cmap;
+        if (defer) { *defer = r; return 0; }
         const int total = taps * p.MA * p.NB;
         ProfScope ps(e, st, kind, 0);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((total + 63) / 64), dim3(256), 0, st, r);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((total + 63) / 64), dim3(256), 0, st, r, ReduceArgs{}, (total + 63) / 64);
     }
     return 0;
+}
+// ONE launch for two pending reductions (either may be empty: Z == 0)
+static void launch_reduce2(smg_engine* e, hipStream_t st, int kind, const ReduceArgs& ra, const ReduceArgs& rb) {
+    const int ba = ra.Z ? (ra.taps * ra.rows * ra.cols + 63) / 64 : 0, bb = rb.Z ? (rb.taps * rb.rows * rb.cols + 63) / 64 : 0;
+    if (ba + bb == 0) return;
+    ProfScope ps(e, st, kind, 0);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ba + bb), dim3(256), 0, st, ra, rb, ba);
 }
 
 // element `elems` of a mode-typed buffer (X, Bt, G, GS, D2): 4-byte elements in mode 0, 2-byte elements in modes 1 / 2

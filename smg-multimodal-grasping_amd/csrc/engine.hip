@@ -46,10 +46,12 @@ static int engine_build(smg_engine* e) {
     for (int k = 0; k < kRing; ++k) {   // ring: see kRing
         ALLOC(e->D2[k], (int64_t)NS * e->p_blk[0].HWp * kBottleneck);
         ALLOC(e->GS[k], (int64_t)NS * e->p_blk[0].HWp * kGrowth);
+        ALLOC(e->D2S[k], (int64_t)NS * (e->p_blk[0].HWp / kScaleBlock));
         HIP_OK(hipEventCreateWithFlags(&e->ev_gs[k], hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&e->ev_d2[k], hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&e->ev_side[k], hipEventDisableTiming));
     }
+    ALLOC(e->DY2, (int64_t)NS * e->p_blk[0].HWp * kBottleneck);
     HIP_OK(hipEventCreateWithFlags(&e->ev_misc, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&e->ev_end, hipEventDisableTiming));
     HIP_OK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
@@ -331,13 +333,14 @@ void smg_engine_destroy(smg_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     void* ptrs[] = {e->img4, e->stem, e->DY0, e->argmax, e->X[0], e->X[1], e->X[2], e->X[3], e->G[0], e->G[1], e->G[2], e->G[3],
-                    e->Bt, e->part, e->F, e->DF, e->H1, e->DH1, e->fstat, e->bstat, e->dbscr, e->d_dbseg, e->asc, e->d_asc, e->gamax, e->packed_u, e->packed_f, e->stab, e->d_pack, e->d_bnupd,
+                    e->Bt, e->DY2, e->part, e->F, e->DF, e->H1, e->DH1, e->fstat, e->bstat, e->dbscr, e->d_dbseg, e->asc, e->d_asc, e->gamax, e->packed_u, e->packed_f, e->stab, e->d_pack, e->d_bnupd,
                     e->d_stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) { if (e->h_stage[k]) (void)hipHostFree(e->h_stage[k]); if (e->ev_stage[k]) (void)hipEventDestroy(e->ev_stage[k]); }
     for (int k = 0; k < kRing; ++k) {
         if (e->D2[k]) (void)hipFree(e->D2[k]);
         if (e->GS[k]) (void)hipFree(e->GS[k]);
+        if (e->D2S[k]) (void)hipFree(e->D2S[k]);
         if (e->ev_gs[k]) (void)hipEventDestroy(e->ev_gs[k]); if (e->ev_d2[k]) (void)hipEventDestroy(e->ev_d2[k]); if (e->ev_side[k]) (void)hipEventDestroy(e->ev_side[k]);
     }
     if (e->ev_misc) (void)hipEventDestroy(e->ev_misc);

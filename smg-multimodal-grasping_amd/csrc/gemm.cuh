@@ -490,10 +490,7 @@ __device__ __forceinline__ ActScale act_scale(const float* asc) { ActScale a; a.
 // (atomicMax per workgroup); s = 2^(13 - floor(log2 max)) puts the maximum into [2^13, 2^14): elements down to 2^-17 of it keep
 // all 22 bits, smaller ones an absolute error of 2^-39 of it.  The address is workgroup-uniform: scalar loads, scalar maxima.
 constexpr int kAmaxRep = 16;
-__device__ __forceinline__ ActScale amax_scale(const unsigned* amax_n) {
-    unsigned m = 0;
-#pragma unroll
-    for (int r = 0; r < kAmaxRep; ++r) m = max(m, amax_n[r]);
+__device__ __forceinline__ ActScale scale_of_max(unsigned m) {      // m: the float bits of the largest |element|
     int e = (int)(m >> 23) - 127;                 // floor(log2 max) of a normal float (0 -> -127)
     e = e < -100 ? -100 : e;
     ActScale a;
@@ -501,6 +498,24 @@ __device__ __forceinline__ ActScale amax_scale(const unsigned* amax_n) {
     a.inv = __uint_as_float((unsigned)(114 + e) << 23);    // 2^(e - 13)
     return a;
 }
+__device__ __forceinline__ ActScale amax_scale(const unsigned* amax_n) {
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < kAmaxRep; ++r) m = max(m, amax_n[r]);
+    return scale_of_max(m);
+}
+// The bottleneck gradient D2 (the norm2 backward of a dense layer's 3x3 data gradient) reaches its three consumers - the grouped and
+// the per-layer 1x1 data gradient, the 1x1 weight gradient - in UNIT form (operand kind 3, precision mode 0): bn_bwd_apply_split_kernel
+// (elem.cuh) writes the two fp16 pieces ONCE, as the 16-byte units the MFMAs take (8 consecutive channels of one pixel),
+//     unit(stream n, piece pc, k8, pixel p)  at  (((n * 2 + pc) * kD2K8 + k8) * HWp + p)
+// scaled per 64-pixel block of a stream by the power of two that puts the block's largest |element| into [2^13, 2^14)
+// (inverse scales: [streams][HWp / 64] floats).  The consumers stage the operand with straight 16-byte copies - no scale, no
+// split, no conversion in their k-loops (the 1x1 weight gradient used to redo them once per 64 input channels, the grouped data
+// gradient once per 64 output channels) - and a block's scale is exact for that block (the per-stream maximum it replaces left
+// elements below 2^-17 of the STREAM's maximum with fewer than 22 bits).
+constexpr int kD2K8 = 16;                        // 128 bottleneck channels / 8
+constexpr int kScaleBlock = 64;                  // pixels per scale block (= the plane padding granule: a tile never straddles two streams)
+__device__ __forceinline__ int64_t d2_stream_units(int n, int HWp) { return (int64_t)n * 2 * kD2K8 * HWp; }
 __device__ __forceinline__ float4 mul4(float4 v, float s) {      // two elements per instruction (v_pk_mul_f32)
     const f32x2 a = f32x2{v.x, v.y} * s, b = f32x2{v.z, v.w} * s;
     return make_float4(a.x, a.y, b.x, b.y);
@@ -677,30 +692,54 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
 
     const int aq = t % Z::A_Q, al = t / Z::A_Q;
     const int bq = t % Z::B_Q, bl = t / Z::B_Q;
+    // A operand that arrives as FINISHED units (P::kAUnit: the bottleneck gradient D2, see kD2K8): staged with straight 16-byte
+    // copies like the packed weights.  Forward form: the usual image [piece][k8][row]; weight-gradient form: the units as they
+    // are, [piece][channel / 8][pixel of the k-tile] with the planes AU_PLANE units apart (the 64 bytes of padding put the four
+    // planes a transposing read gathers on distinct banks), read with the same ds_read_b64_tr_b16.
+    constexpr bool AU = P::kAUnit;
+    constexpr int AU_PLANE = C::BK + 4;
+    constexpr int AU_UNITS = C::AT ? NP * C::K8 * C::BM : NP * (C::BM / 8) * C::BK;
+    constexpr int A_CNT = AU ? AU_UNITS / 256 : Z::A_N;
+    static_assert(!AU || AU_UNITS % 256 == 0, "unit copies: whole rounds of the workgroup");
+    static_assert(!AU || C::AT || NP * (C::BM / 8) * AU_PLANE * 16 <= Z::A_BYTES, "the unit image fits the row-major one");
+    using ARawT = typename std::conditional<AU, u32x4, typename P::ARaw>::type;
     // Register ring of PD k-tiles in flight (global loads issued PD tiles ahead of their LDS store).
     constexpr int PD = P::kPrefetch;
-    typename P::ARaw ra[PD][Z::A_N];
+    ARawT ra[PD][A_CNT];
     typename P::BRaw rb[PD][Z::B_N];
     typename P::KPrm kp[PD];
     typename P::ARow arow[Z::A_N];
     typename P::DRow da[Z::A_N], db[C::AT ? 1 : Z::B_N];
     KPrm3 bfix[BE / 4] = {};   // weight gradient: BN parameters of this thread's (fixed) B channel quad(s), read from LDS once
     if constexpr (C::AT) {
+        if constexpr (!AU) {
 #pragma unroll
-        for (int i = 0; i < Z::A_N; ++i) p.a_row_init(ctx, arow[i], al + i * Z::A_STEP);
+            for (int i = 0; i < Z::A_N; ++i) p.a_row_init(ctx, arow[i], al + i * Z::A_STEP);
+        }
     } else {
+        if constexpr (!AU) {
 #pragma unroll
-        for (int i = 0; i < Z::A_N; ++i) p.d_init(ctx, da[i], al + i * Z::A_STEP);
+            for (int i = 0; i < Z::A_N; ++i) p.d_init(ctx, da[i], al + i * Z::A_STEP);
+        }
 #pragma unroll
         for (int i = 0; i < Z::B_N; ++i) p.d_init(ctx, db[i], bl + i * Z::B_STEP);
     }
 
-    auto g_load = [&](int kt, typename P::ARaw (&xa)[Z::A_N], typename P::BRaw (&xb)[Z::B_N], typename P::KPrm& xk) {
+    auto g_load = [&](int kt, ARawT (&xa)[A_CNT], typename P::BRaw (&xb)[Z::B_N], typename P::KPrm& xk) {
         if constexpr (C::AT) {
             xk = p.k_fetch(ctx, kt, aq);
+            if constexpr (AU) {
+#pragma unroll
+                for (int i = 0; i < A_CNT; ++i) {            // consecutive lanes -> consecutive rows of one (piece, k8) plane
+                    const int id = t + 256 * i;
+                    const int r = id % C::BM, pk = id / C::BM;
+                    xa[i] = p.a_unit(ctx, kt, pk / C::K8, pk % C::K8, r);
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < Z::A_N; ++i)
                 if (Z::A_FULL || al + i * Z::A_STEP < C::BM) xa[i] = p.a_fetch(ctx, arow[i], kt, aq);
+            }
 #pragma unroll
             for (int i = 0; i < Z::B_N; ++i) {           // weight units [piece][k8][row]: consecutive lanes -> consecutive rows
                 const int id = t + 256 * i;
@@ -708,11 +747,20 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
                 if (Z::B_FULL || pk < NP * C::K8) xb[i] = p.b_unit(ctx, kt, pk / C::K8, pk % C::K8, r);
             }
         } else {
+            if constexpr (AU) {
+#pragma unroll
+                for (int i = 0; i < A_CNT; ++i) {            // consecutive lanes -> consecutive pixels of one (piece, k8) plane
+                    const int id = t + 256 * i;
+                    const int kr = id % C::BK, q = id / C::BK;
+                    xa[i] = p.a_unit_d(ctx, kt, q / (C::BM / 8), q % (C::BM / 8), kr);
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < Z::A_N; ++i) {
                 const int kr = al + i * Z::A_STEP;
                 if (Z::A_FULL || kr < C::BK) xa[i] = p.a_fetch_d(ctx, da[i], kt, kr, aq);
                 p.d_next(ctx, da[i]);
+            }
             }
 #pragma unroll
             for (int i = 0; i < Z::B_N; ++i) {
@@ -725,10 +773,17 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
     // transform (BN / ReLU / BN-backward) + split (or 16-bit pack) + LDS store of k-tile kt.  A staging slot is 16 bytes of
     // the operand's storage: one channel quad (fp32: ds_write_b64 per piece) or two (16-bit storage: the two quads go through
     // the policy's quad transform one after the other and leave as ONE 16-byte unit / row segment, ds_write_b128).
-    auto s_store = [&](int buf, int kt, const typename P::ARaw (&xa)[Z::A_N], const typename P::BRaw (&xb)[Z::B_N], const typename P::KPrm& xk) {
+    auto s_store = [&](int buf, int kt, const ARawT (&xa)[A_CNT], const typename P::BRaw (&xb)[Z::B_N], const typename P::KPrm& xk) {
         char* A = As + buf * Z::A_BYTES;
         char* B = Bs + buf * Z::B_BYTES;
         if constexpr (C::AT) {
+            if constexpr (AU) {
+#pragma unroll
+                for (int i = 0; i < A_CNT; ++i) {
+                    const int id = t + 256 * i;
+                    *reinterpret_cast<u32x4*>(A + ((id / C::BM) * C::LDUA + id % C::BM) * 16) = xa[i];
+                }
+            } else
             if constexpr (AE == 4) {
                 const typename P::KFin kf = p.k_finish(ctx, xk, kt, aq, sp);
 #pragma unroll
@@ -761,6 +816,13 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
                 if (Z::B_FULL || id < NP * C::K8 * C::BN) *reinterpret_cast<u32x4*>(B + id * 16) = p.b_unit_xform(ctx, xb[i], id % C::BN);
             }
         } else {
+            if constexpr (AU) {
+#pragma unroll
+                for (int i = 0; i < A_CNT; ++i) {
+                    const int id = t + 256 * i;
+                    *reinterpret_cast<u32x4*>(A + ((id / C::BK) * AU_PLANE + id % C::BK) * 16) = xa[i];
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < Z::A_N; ++i) {
                 const int kr = al + i * Z::A_STEP;
@@ -817,6 +879,18 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
             return u32x4{lo.x, lo.y, hi.x, hi.y};
         }
     };
+    // the A fragment: as above, or (weight-gradient form, unit image) the same transposing reads with unit addressing - channel
+    // quad cq of pixel k sits at ((piece * BM / 8 + cq / 2) * AU_PLANE + k) * 16 + (cq & 1) * 8
+    auto fragA = [&](const char* img, int r0, int s, int pc) -> u32x4 {
+        if constexpr (AU && !C::AT) {
+            const int k0 = (wk * C::KS + s) * 16 + 8 * half + tr_row;
+            const int ch = r0 + tr_col;
+            const char* a0 = img + ((pc * (C::BM / 8) + (ch >> 3)) * AU_PLANE + k0) * 16 + ((ch >> 2) & 1) * 8;
+            const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0));
+            const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * 16)));
+            return u32x4{lo.x, lo.y, hi.x, hi.y};
+        } else return frag(img, C::LDUA, C::LDTA, r0, s, pc);
+    };
     auto compute = [&](int buf) {
         const char* A = As + buf * Z::A_BYTES;
         const char* B = Bs + buf * Z::B_BYTES;
@@ -827,13 +901,13 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
         for (int s = 0; s < C::KS; ++s) {
             u32x4 ah[C::TM], bh[C::TN];
 #pragma unroll
-            for (int i = 0; i < C::TM; ++i) ah[i] = frag(A, C::LDUA, C::LDTA, wm0 + i * 32, s, 0);
+            for (int i = 0; i < C::TM; ++i) ah[i] = fragA(A, wm0 + i * 32, s, 0);
 #pragma unroll
             for (int j = 0; j < C::TN; ++j) bh[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 0);
             if constexpr (OP == 3) {         // two fp16 pieces: h*l, l*h, h*h (small terms first, tiles innermost)
                 u32x4 al_[C::TM], bl_[C::TN];
 #pragma unroll
-                for (int i = 0; i < C::TM; ++i) al_[i] = frag(A, C::LDUA, C::LDTA, wm0 + i * 32, s, 1);
+                for (int i = 0; i < C::TM; ++i) al_[i] = fragA(A, wm0 + i * 32, s, 1);
 #pragma unroll
                 for (int j = 0; j < C::TN; ++j) bl_[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 1);
                 SMG_PIN();
@@ -863,7 +937,7 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
                 {
                     u32x4 al_[C::TM], bl_[C::TN];
 #pragma unroll
-                    for (int i = 0; i < C::TM; ++i) al_[i] = frag(A, C::LDUA, C::LDTA, wm0 + i * 32, s, 2);
+                    for (int i = 0; i < C::TM; ++i) al_[i] = fragA(A, wm0 + i * 32, s, 2);
 #pragma unroll
                     for (int j = 0; j < C::TN; ++j) bl_[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 2);
                     SMG_PIN();   // keep every ds_read ahead of the MFMA block (hipcc re-interleaves them otherwise)
@@ -879,7 +953,7 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
                 }
                 u32x4 am[C::TM], bm[C::TN];
 #pragma unroll
-                for (int i = 0; i < C::TM; ++i) am[i] = frag(A, C::LDUA, C::LDTA, wm0 + i * 32, s, 1);
+                for (int i = 0; i < C::TM; ++i) am[i] = fragA(A, wm0 + i * 32, s, 1);
 #pragma unroll
                 for (int j = 0; j < C::TN; ++j) bm[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 1);
                 SMG_PIN();
@@ -1091,7 +1165,7 @@ struct FwdConvP {
     using SrcT = typename std::conditional<F32IO, e_f32, act_t<PREC>>::type;
     using DstT = SrcT;
     static constexpr int kOp = (MODE == 3 || MODE == 4) ? fwd_op_plain(PREC) : fwd_op(PREC), kAE = 16 / SrcT::size, kBE = 4, ESZ = SrcT::size;
-    static constexpr bool kARawCopy = false;
+    static constexpr bool kARawCopy = false, kAUnit = false;
     const float* asc;               // operand kind 3: {s, 1 / s} of the BN + ReLU operand (scale_kernel)
     const void* src; int lds_;
     Plane ps, po;
@@ -1404,7 +1478,8 @@ struct BwdDataP {
     // operand kind 3 needs the gradient operand's recorded maximum: the pointwise form on a FINISHED gradient only
     static constexpr int kOp = (AFF || SHIFT3) ? bwd_op_plain(PREC) : bwd_op(PREC), kAE = 16 / GT::size, kBE = 4, GSZ = GT::size, XSZ = XT::size;
     static constexpr bool kARawCopy = !AFF && !SHIFT3 && kAE == 8;              // finished bf16 gradient: copied to LDS as it is
-    const unsigned* gamax;          // operand kind 3: [streams][kAmaxRep] recorded maxima of gbuf (bn_bwd_apply_kernel)
+    static constexpr bool kAUnit = !AFF && !SHIFT3 && kOp == 3;                 // finished gradient in unit form (kD2K8): gbuf = units, ldg unused
+    const float* binv;              // operand kind 3: [streams][HWp / 64] inverse block scales of gbuf (bn_bwd_apply_split_kernel)
     const void* gbuf; int ldg; int gcoff;
     const void* xbuf; int ldx; int xcoff;
     Plane pa;
@@ -1444,7 +1519,7 @@ struct BwdDataP {
     static constexpr bool kWide = GT::size == 2;
     struct Ctx {
         int n, m0, n0; bool whole;
-        float gs, ginv;             // operand kind 3: scale of this stream's gradient operand, inverse of (gradient x weight) scale
+        float ginv[2];              // operand kind 3: inverse of (gradient x weight) scale of the tile's (up to two) 64-row scale blocks
         // mask source x and old G' of a whole tile, fetched at the start of the workgroup: per element in accumulator layout
         // (fp32 storage), or as loaded row segments of four accumulator rows each (16-bit storage; fetch_acc_rows)
         float xv[(kEarly && !kWide) ? Cfg::TM : 1][(kEarly && !kWide) ? Cfg::TN : 1][16];
@@ -1475,13 +1550,22 @@ struct BwdDataP {
         // boundary: an accumulator tile (wave, j) is then entirely inside or entirely outside [0, N) - a wave-uniform test (jok),
         // no per-element predicate.  (The narrow per-layer launches of a layer group have N = 32 / 64 / 96.)
         c.whole = kEarly && pbase + Cfg::BM <= pa.HW && (c.n0 + Cfg::BN <= N || (N & 31) == 0);
-        c.gs = 1.f; c.ginv = 1.f;
+        c.ginv[0] = c.ginv[1] = 1.f;
         if constexpr (kOp == 3) {
-            const ActScale g = amax_scale(gamax + (int64_t)c.n * kAmaxRep);
-            c.gs = g.s; c.ginv = g.inv * pack_inv_scale(wp);
+            static_assert(Cfg::BM == kScaleBlock || (Cfg::BM == 2 * kScaleBlock && Cfg::WM == 2), "a wave's rows lie in one scale block");
+            const float* bi = binv + (int64_t)c.n * (pa.HWp / kScaleBlock) + pbase / kScaleBlock;      // (workgroup-uniform: scalar loads)
+            const float wi = pack_inv_scale(wp);
+            c.ginv[0] = bi[0] * wi;
+            c.ginv[1] = (Cfg::BM > kScaleBlock ? bi[1] : bi[0]) * wi;
         }
         return true;
     }
+    // unit (piece, k8 of this k-tile, tile row) of the finished gradient: plane-major units, consecutive rows consecutive
+    __device__ u32x4 a_unit(const Ctx& c, int kt, int piece, int k8, int row) const {
+        return bload_u4(static_cast<const u32x4*>(gbuf) + d2_stream_units(c.n, pa.HWp), kWholeBuf,
+                        16u * (unsigned)((piece * kD2K8 + k8) * pa.HWp + row), 16u * (unsigned)(kt * Cfg::K8 * pa.HWp + (c.m0 - c.n * pa.HWp)));
+    }
+    __device__ u32x4 a_unit_d(const Ctx&, int, int, int, int) const { return u32x4{}; }
     __device__ void early_fetch(Ctx& c) const {
         if constexpr (kEarly) {
             if (c.whole) {
@@ -1599,7 +1683,7 @@ struct BwdDataP {
         return o;
     }
     __device__ float4 a_xform(const Ctx& c, const ARaw& o, const KPrm&, int kt, int q, const float* sp) const {
-        if constexpr (kFast) { if constexpr (kOp == 3) return mul4(o.v[0], c.gs); else return o.v[0]; }
+        if constexpr (kFast) return o.v[0];            // (operand kind 3 takes the unit path: a_unit)
         if (!o.ok) return zero4();
         if (!xbuf) return o.v[0];                      // gradient already BN-corrected (bn_bwd_apply_kernel)
         return affine2(o.v[0], o.v[1], sp + a_chan(kt, q), KA);
@@ -1620,13 +1704,14 @@ struct BwdDataP {
         float v[2][Cfg::TN];
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) v[0][j] = v[1][j] = 0.f;
-        if constexpr (kOp == 3) {          // products of scaled operands: exact power-of-two correction
+        if constexpr (kOp == 3) {          // products of scaled operands: exact power-of-two correction (this wave's scale block)
+            const float gi = wm0 >= kScaleBlock ? c.ginv[1] : c.ginv[0];
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
                 for (int j = 0; j < Cfg::TN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= c.ginv;
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= gi;
         }
         const int pbase = c.m0 - c.n * pa.HWp;
 #pragma unroll
@@ -1820,8 +1905,8 @@ struct BwdDataP {
 // ------------------------------------------------------------------------------------
 constexpr int GROUP_MAX = 4;
 struct GroupSeg {
-    const unsigned* amax;           // operand kind 3: [streams][kAmaxRep] recorded maxima of g
-    const void* g;                  // finished bottleneck gradient D2_i [n][HWp][KA] (fp32 / bf16 by mode)
+    const float* binv;              // operand kind 3: [streams][HWp / 64] inverse block scales of g
+    const void* g;                  // finished bottleneck gradient D2_i: units (operand kind 3, see kD2K8) or [n][HWp][KA] fp32 / bf16 by mode
     const u32x4* wp; int ldn;       // conv1 weight, packed data-gradient units [piece][KA/8][cin_i]
     const float* gamma; const float* beta;
     float* dbeta; float* dgamma;
@@ -1835,6 +1920,7 @@ struct BwdDataGroupP {
     using XT = act_t<PREC>;      // the block buffer X
     static constexpr int kOp = bwd_op(PREC), kAE = 16 / GT::size, kBE = 4, GSZ = GT::size;
     static constexpr bool kARawCopy = kAE == 8;
+    static constexpr bool kAUnit = kOp == 3;            // D2 in unit form: straight copies, per-block scales
     static constexpr bool kWide = GT::size == 2;        // 16-bit storage: quad-transposed 8-byte epilogue loads / stores (see BwdDataP)
     GroupSeg seg[GROUP_MAX]; int nseg;
     int ldg; Plane pa; int KA;
@@ -1882,7 +1968,7 @@ struct BwdDataGroupP {
     __device__ KFin k_finish(const Ctx&, const KPrm&, int, int, const float*) const { return KFin{}; }
 
     // LDS parameters: mean | invstd | per segment: gamma*invstd | beta | gamma      (BN floats each)
-    // operand kind 3: + per segment the scale of its gradient operand | the inverse of its (gradient x weight) scale
+    // operand kind 3: + per segment the inverse (gradient x weight) scale of the tile's two 64-row scale blocks
     static constexpr int kScaleAt = (2 + 3 * GROUP_MAX) * Cfg::BN;
     __host__ __device__ int param_floats() const { return kScaleAt + 2 * GROUP_MAX; }
 
@@ -1891,12 +1977,12 @@ struct BwdDataGroupP {
     __device__ void init_params(const Ctx& c, float* sp) const {
         const double minv = 1.0 / (double)pa.HW;
         if constexpr (kOp == 3) {
-            if (threadIdx.x >= 64 && threadIdx.x < 64 + GROUP_MAX) {      // (wave 1: wave 0 carries the parameter loads below)
-                const int z = threadIdx.x - 64;
-                ActScale g{1.f, 1.f};
-                if (z < nseg) { g = amax_scale(seg[z].amax + (int64_t)c.n * kAmaxRep); g.inv *= pack_inv_scale(seg[z].wp); }
-                sp[kScaleAt + z] = g.s;
-                sp[kScaleAt + GROUP_MAX + z] = g.inv;
+            static_assert(Cfg::BM == kScaleBlock || (Cfg::BM == 2 * kScaleBlock && Cfg::WM == 2), "a wave's rows lie in one scale block");
+            if (threadIdx.x >= 64 && threadIdx.x < 64 + 2 * GROUP_MAX) {      // (wave 1: wave 0 carries the parameter loads below)
+                const int z = (threadIdx.x - 64) >> 1, b = (threadIdx.x - 64) & 1;
+                float inv = 1.f;
+                if (z < nseg) inv = seg[z].binv[(int64_t)c.n * (pa.HWp / kScaleBlock) + (c.m0 - c.n * pa.HWp) / kScaleBlock + (Cfg::BM > kScaleBlock ? b : 0)] * pack_inv_scale(seg[z].wp);
+                sp[kScaleAt + 2 * z + b] = inv;
             }
         }
         for (int j = threadIdx.x; j < Cfg::BN; j += 256) {
@@ -2040,10 +2126,14 @@ struct BwdDataGroupP {
         return o;
     }
     __device__ ARaw a_quad(const ARaw& o, int h) const { ARaw r; r.ok = o.ok; r.v[0] = slot_quad<GT>(o.v[0], h); return r; }
-    __device__ float4 a_xform(const Ctx&, const ARaw& o, const KPrm&, int kt, int, const float* sp) const {
-        if constexpr (kOp == 3) return mul4(o.v[0], sp[kScaleAt + kt / kps()]);      // (one LDS broadcast read per k-tile)
-        else return o.v[0];
+    __device__ float4 a_xform(const Ctx&, const ARaw& o, const KPrm&, int, int, const float*) const { return o.v[0]; }
+    // unit (piece, k8 of this k-tile, tile row) of the segment's D2 (operand kind 3): plane-major units, rows consecutive
+    __device__ u32x4 a_unit(const Ctx& c, int kt, int piece, int k8, int row) const {
+        const int s = kt / kps(), k80 = (kt - s * kps()) * Cfg::K8;
+        return bload_u4(static_cast<const u32x4*>(seg[s].g) + d2_stream_units(c.n, pa.HWp), kWholeBuf,
+                        16u * (unsigned)((piece * kD2K8 + k8) * pa.HWp + row), 16u * (unsigned)(k80 * pa.HWp + (c.m0 - c.n * pa.HWp)));
     }
+    __device__ u32x4 a_unit_d(const Ctx&, int, int, int, int) const { return u32x4{}; }
     __device__ ARaw a_fetch_d(const Ctx&, const DRow&, int, int, int) const { return ARaw{}; }
     __device__ BRaw b_unit(const Ctx& c, int kt, int piece, int k8, int r) const {
         const int s = kt / kps(), k80 = (kt - s * kps()) * Cfg::K8;
@@ -2078,7 +2168,7 @@ struct BwdDataGroupP {
         }
         const float* q = sp + (2 + 3 * s) * Cfg::BN;
         float ginv = 1.f;                                  // operand kind 3: this segment's inverse scale, folded into gamma and the sums
-        if constexpr (kOp == 3) ginv = sp[kScaleAt + GROUP_MAX + s];
+        if constexpr (kOp == 3) ginv = sp[kScaleAt + 2 * s + ((t >> 6) % (Cfg::WM * Cfg::WN) / Cfg::WN * Cfg::TM * 32 >= kScaleBlock ? 1 : 0)];      // this wave's scale block
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) {
             const int cj = wn0 + j * 32 + l31;
@@ -2230,7 +2320,8 @@ struct BwdWeightP {
     // operand kind 3: the dense layers' 1x1 weight gradient (finished gradient with a recorded maximum x BN + ReLU activation)
     static constexpr int kOp = (!AFF && BMODE == 0) ? bwd_op(PREC) : bwd_op_plain(PREC), kAE = 16 / GT::size, kBE = 16 / XT::size, GSZ = GT::size, XSZ = XT::size;
     static constexpr bool kARawCopy = !AFF && kAE == 8;      // finished bf16 gradient: copied to LDS as it is
-    const unsigned* gamax;          // operand kind 3: [streams][kAmaxRep] recorded maxima of gbuf
+    static constexpr bool kAUnit = !AFF && BMODE == 0 && kOp == 3;      // the gradient operand arrives in unit form (kD2K8): gbuf = units
+    const float* binv;              // operand kind 3: [streams][HWp / 64] inverse block scales of gbuf (bn_bwd_apply_split_kernel)
     const float* basc;              // operand kind 3: {s, 1 / s} of the BN + ReLU operand B (scale_kernel)
     const void* gbuf; int ldg; int gcoff;
     const void* xbuf; int ldx; int xcoff;
@@ -2250,12 +2341,14 @@ struct BwdWeightP {
     TileMap tm;
     static constexpr int kSwizzle = 2;
     static constexpr int kPrefetch = PD_;     // k-tiles of global loads in flight per thread
-    static constexpr bool kSegmented = false;
+    static constexpr bool kSegmented = kAUnit;      // k_hook: the accumulators follow the gradient operand's per-block scale
     static constexpr bool kHasPrologue = true;
     static constexpr bool kEarlyFetch = false;
     static constexpr int kMinWaves = 1;      // (the transitions' pooling form held to 3 waves per SIMD: 92 bytes of scratch, 117 -> 209 us per launch)
+    static_assert(!kAUnit || (kScaleBlock % Cfg::BK == 0 && Cfg::WK == 1 && Cfg::BM == 8 * kD2K8), "unit form: whole k-tiles per scale block, all 128 gradient channels");
 
-    struct Ctx { int n, p0, m0, n0, tap, kt, z; float gs, ginv; };      // gs / ginv: operand kind 3 (gradient scale, inverse of gradient x activation scale)
+    // cur_inv (operand kind 3): the inverse scale the accumulators currently carry - that of the scale block being reduced
+    struct Ctx { int n, p0, m0, n0, tap, kt, z; float cur_inv; };
     using KPrm = KPrm0;
     using KFin = KPrm0;
     __device__ KPrm k_fetch(const Ctx&, int, int) const { return KPrm{}; }
@@ -2263,7 +2356,8 @@ struct BwdWeightP {
     struct ARow { int dummy; };
     struct DRow { int p, y, x; };     // the pixel this staging slot reads, advanced BK per k-tile
 
-    __host__ __device__ int param_floats() const { return 4 * Cfg::BM + 3 * Cfg::BN; }
+    static constexpr int kInvAt = 4 * Cfg::BM + 3 * Cfg::BN;      // operand kind 3: the inverse scales of the chunk's blocks
+    __host__ __device__ int param_floats() const { return kInvAt + (kAUnit ? chunk / kScaleBlock + 1 : 0); }
 
     __device__ void d_init(const Ctx& c, DRow& r, int kr) const {
         r.p = c.p0 + kr;
@@ -2298,12 +2392,34 @@ struct BwdWeightP {
         int len = pa.HWp - c.p0;
         len = len < chunk ? len : chunk;
         c.kt = sgpr(len / Cfg::BK);
-        c.gs = 1.f; c.ginv = 1.f;
-        if constexpr (kOp == 3) {
-            const ActScale g = amax_scale(gamax + (int64_t)c.n * kAmaxRep);
-            c.gs = g.s; c.ginv = g.inv * basc[1];
-        }
+        c.cur_inv = 1.f;
+        if constexpr (kAUnit) c.cur_inv = binv[(int64_t)c.n * (pa.HWp / kScaleBlock) + c.p0 / kScaleBlock];      // (workgroup-uniform: a scalar load)
         return true;
+    }
+    // unit (piece, channel group k8, pixel kr of k-tile kt) of the gradient operand: plane-major units, consecutive pixels consecutive
+    __device__ u32x4 a_unit_d(const Ctx& c, int kt, int piece, int k8, int kr) const {
+        return bload_u4(static_cast<const u32x4*>(gbuf) + d2_stream_units(c.n, pa.HWp), 16u * (unsigned)(2 * kD2K8 * pa.HWp),
+                        16u * (unsigned)((piece * kD2K8 + k8) * pa.HWp + kr), 16u * (unsigned)(c.p0 + kt * Cfg::BK));
+    }
+    __device__ u32x4 a_unit(const Ctx&, int, int, int, int) const { return u32x4{}; }
+    // End of k-tile kt: when the next k-tile starts another scale block, bring the accumulators to that block's scale (exact: a
+    // power of two; a block of zeros keeps inverse scale 1).
+    __device__ void k_hook(Ctx& c, int kt, f32x16 (&acc)[Cfg::TM][Cfg::TN], const float* sp) const {
+        if constexpr (kAUnit) {
+            const int nx = (kt + 1) * Cfg::BK;
+            if (nx % kScaleBlock || kt + 1 >= c.kt) return;            // (workgroup-uniform)
+            const float inv = sp[kInvAt + nx / kScaleBlock];
+            if (inv != c.cur_inv) {
+                const float f = c.cur_inv * __uint_as_float((254u << 23) - __float_as_uint(inv));      // cur_inv / inv
+#pragma unroll
+                for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
+                c.cur_inv = inv;
+            }
+        }
     }
     __device__ void init_params(const Ctx& c, float* sp) const {
         const double inv = 1.0 / (double)pa.HW;
@@ -2340,6 +2456,10 @@ struct BwdWeightP {
                 bp[Cfg::BN + j] = sc;
                 bp[2 * Cfg::BN + j] = be;
             }
+        }
+        if constexpr (kAUnit) {
+            const float* bi = binv + (int64_t)c.n * (pa.HWp / kScaleBlock) + c.p0 / kScaleBlock;
+            for (int j = threadIdx.x; j * kScaleBlock < c.kt * Cfg::BK; j += 256) sp[kInvAt + j] = bi[j];
         }
     }
     __device__ int ktiles(const Ctx& c) const { return c.kt; }
@@ -2381,7 +2501,7 @@ struct BwdWeightP {
         return r;
     }
     __device__ float4 a_xform(const Ctx& c, const ARaw& o, const KPrm&, int, int q, const float* sp) const {
-        if constexpr (!AFF) { if constexpr (kOp == 3) return mul4(o.v[0], c.gs); else return o.v[0]; }
+        if constexpr (!AFF) return o.v[0];             // (operand kind 3 takes the unit path: a_unit_d)
         if (!o.ok) return zero4();
         if (!xbuf) return o.v[0];
         return affine2(o.v[0], o.v[1], sp + 4 * q, Cfg::BM);
@@ -2461,13 +2581,14 @@ struct BwdWeightP {
     __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float*, float*, bool active) const {
         const int t = threadIdx.x, lane = t & 63, wmn = (t >> 6) % (Cfg::WM * Cfg::WN), l31 = lane & 31, half = lane >> 5;
         const int wm0 = (wmn / Cfg::WN) * Cfg::TM * 32, wn0 = (wmn % Cfg::WN) * Cfg::TN * 32;
-        if constexpr (kOp == 3) {          // products of scaled operands: exact power-of-two correction (per stream: before any sum over streams)
+        if constexpr (kOp == 3) {          // products of scaled operands: exact power-of-two correction (the last block's scale x the activation scale)
+            const float gi = c.cur_inv * basc[1];
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
                 for (int j = 0; j < Cfg::TN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= c.ginv;
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= gi;
         }
         if (CMAP == C_IDENT && c.m0 + Cfg::BM <= MA && c.n0 + Cfg::BN <= NB) {
             // whole tile inside the weight matrix: uniform base + running lane offset, no per-element predicates
@@ -2530,11 +2651,16 @@ struct ReduceArgs {
 // A workgroup sums 64 elements: its four waves take every fourth partial tile each (coalesced 256-byte reads, four loads in
 // flight per lane) and meet in LDS - a fixed order, so the result is reproducible.  (One thread per element over all Z partials
 // was a serial chain of Z / 4 memory round trips on a grid of 144 workgroups: 10-12 us per launch, 189 launches per step.)
-static __global__ void reduce_partials_kernel(const ReduceArgs a) {
+// One launch serves up to two reductions (a dense layer's 3x3 and 1x1 weight gradients: one launch less per layer on the side
+// stream): workgroups [0, blocks_a) take `ra`, the rest `rb`; each owns exactly one group of 64 elements.
+static __global__ void reduce_partials_kernel(const ReduceArgs ra, const ReduceArgs rb, const int blocks_a) {
     __shared__ float red[3][64];
+    const bool second = (int)blockIdx.x >= blocks_a;
+    const ReduceArgs& a = second ? rb : ra;
     const int total = a.taps * a.rows * a.cols;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int e0 = blockIdx.x * 64; e0 < total; e0 += gridDim.x * 64) {      // (block-uniform trip count)
+    {
+        const int e0 = ((int)blockIdx.x - (second ? blocks_a : 0)) * 64;
         const int e = e0 + lane;
         const bool on = e < total;
         const int ec = on ? e : 0;
