@@ -183,7 +183,11 @@ int smg_engine_set_precision(smg_engine* e, int precision);
  * path is also the default for batches of more than four streams whenever the partial tiles fit the workspace - it is the
  * faster one there; the option guarantees it for every batch: a launch whose partial tiles do not fit the workspace fails
  * with -12 instead of falling back to atomics.)
- * "serialize" (0 / 1): every kernel on the caller's stream in issue order instead of two concurrent chains (profiling). */
+ * "serialize" (0 / 1): every kernel on the caller's stream in issue order instead of two concurrent chains (profiling).
+ * "debug_stop" (tests only; -1 = off): the next smg_backward returns behind the launches of dense layer (block, layer) =
+ * (value / 100, value % 100), 0-based - or, with value % 100 == 50, in front of that block's first layer - with both streams
+ * joined, so that smg_debug_read sees the ring slots, "dy2" and G' as that layer left them.  The forward's saved state is
+ * consumed (run a new smg_forward before the next backward). */
 int smg_engine_set_option(smg_engine* e, const char* name, int value);
 
 /* Heightmap generation in front of the path (utils.get_heightmap, code/utils.py:38-68): the robot-frame height of every
@@ -210,7 +214,11 @@ int smg_layout_head_range(int head_out, int head_id, int64_t* offset, int64_t* c
 
 /* ---- debug / test access (used by tests/ only) ------------------------------------ */
 /* Copies an internal buffer to host as float32 (16-bit storage is widened).  name: "img", "stem", "x1".."x4",
- * "feat", "g1".."g4" ...; returns the element count or a negative error. */
+ * "feat", "g1".."g4", "bt<block>_<layer>", "fs_bt<block>_<layer>", "asc" ...; precision mode 0 only: "dy2" (raw 3x3 data
+ * gradient of the dense layer the backward processed last), "gs_<block>_<layer>" / "d2_<block>_<layer>" (that layer's ring
+ * slot: its finished output-slice gradient [streams][HWp][32] / bottleneck gradient [streams][HWp][128], the latter rebuilt from
+ * its fp16 units and block scales - exactly the operand the consumers' MFMAs see).  Block / layer are 1-based.
+ * Returns the element count or a negative error. */
 int64_t smg_debug_read(smg_engine* e, const char* name, float* host_out, int64_t cap, void* stream);
 /* Geometry of the engine: fills H (per block spatial size), HWp (padded rows). */
 int smg_engine_geometry(const smg_engine* e, int H[6], int HWp[6]);

@@ -66,7 +66,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
     pick_chunk(p4, NP, 2 * kFeat / 64, chunk4, cps4);
     {   // head conv0 weight gradient
         auto go = [&](auto ptag) -> int {
-        BwdWeightP<CfgW64x64, W_ONE, C_IDENT, SMG_PD_WGRAD, true, decltype(ptag)::value, true> p{};      // fp32 head buffers in every mode
+        BwdWeightP<CfgW64x64, W_ONE, C_IDENT, kPdWgrad, true, decltype(ptag)::value, true> p{};      // fp32 head buffers in every mode
         p.gbuf = e->DH1; p.ldg = kHeadMid; p.gcoff = 0; p.xbuf = e->H1; p.ldx = kHeadMid; p.xcoff = 0; p.pa = p4; p.MA = kHeadMid;
         p.xsum = fsum(e, e->st_H1); p.xsq = fsq(e, e->st_H1); p.xstride = kHeadMid;
         p.s1 = b1(e, e->bs_H1); p.s2 = b2(e, e->bs_H1); p.sstride = kHeadMid; p.scoff = 0; p.agamma = P + Hd.n1.w;
@@ -119,8 +119,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
     // 17.37-17.50 with eight: the side stream's work on the small planes is what fills an otherwise idle chip.)
     struct LayerBuf { float* GS; float* D2; float* D2S; int ring; };
     auto buf_of = [&](int b, int i) -> LayerBuf {
-        int r = kBlockLayers[b] - 1 - i;
-        for (int bb = 3; bb > b; --bb) r += kBlockLayers[bb];
+        const int r = ring_pos(b, i);
         return LayerBuf{e->GS[r % kRing], e->D2[r % kRing], e->D2S[r % kRing], r};
     };
     // The two weight gradients of dense layer (b, i) and their shared reduce, on the side stream (which must already wait for the
@@ -169,7 +168,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             part3_floats = (int64_t)groups * NS * 9 * kGrowth * kBottleneck;
         } else {   // conv2 weight gradient (generic implicit GEMM, one launch slice per tap)
             const int chunk = 512, cps = (pl.HWp + chunk - 1) / chunk;   // latency-bound: many short workgroups
-            BwdWeightP<CfgW32x128, W_THREE, C_3x3, SMG_PD_WGRAD, false> p{};
+            BwdWeightP<CfgW32x128, W_THREE, C_3x3, kPdWgrad, false> p{};
             p.gbuf = lb.GS; p.ldg = kGrowth; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kGrowth;
             p.bbuf = bt; p.ldb = kBottleneck; p.pb = pl; p.NB = kBottleneck;
             p.bsum = fsum(e, e->st_Bt[b][i]); p.bsq = fsq(e, e->st_Bt[b][i]); p.bstride = kBottleneck;
@@ -188,7 +187,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             // on many-stream batches (config 3: 28.9 -> 28.5 ms at 160; 120 / 80: 28.6 / 28.8; S = 1824 with 5 streams: 320 stays)
             pick_chunk(pl, NS, nt, chunk, cps, (e->prec && NS >= 16) ? 160 : 320);
             auto go = [&](auto ptag) -> int {
-                BwdWeightP<MC<Cfg, decltype(ptag)::value>, W_ONE, C_IDENT, SMG_PD_WGRAD, false, decltype(ptag)::value> p{};
+                BwdWeightP<MC<Cfg, decltype(ptag)::value>, W_ONE, C_IDENT, kPdWgrad, false, decltype(ptag)::value> p{};
                 p.gbuf = lb.D2; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck; p.binv = lb.D2S; p.basc = asc_n1(e, b, i);
                 p.bbuf = e->X[b]; p.ldb = Ct; p.pb = pl; p.NB = d.cin;
                 p.bsum = fsum(e, e->st_X[b]); p.bsq = fsq(e, e->st_X[b]); p.bstride = Ct; p.btab = stat_table(e, e->sx_tab[b], e->max_streams, Ct);
@@ -212,10 +211,19 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         }
         return 0;
     };
+    // debug_stop (engine.h): leave the backward here - both streams joined, the forward's state consumed
+    auto debug_stop = [&]() -> int {
+        HIP_OK(hipEventRecord(e->ev_end, s2));
+        HIP_OK(hipStreamWaitEvent(st, e->ev_end, 0));
+        HIP_OK(hipGetLastError());
+        e->have_fwd = false; e->bw_phase0_done = false; e->prof_stage = -1;
+        return 0;
+    };
     for (int b = ph_a ? 3 : 0; b >= (ph_b ? 0 : 1); --b) {
         e->prof_stage = b;
         const Plane pl = e->p_blk[b];
         const int Ct = kBlockCtot[b];
+        if (e->dbg_stop == b * 100 + 50) return debug_stop();
         for (int i = (int)T.layers[b].size() - 1; i >= 0; --i) {
             const DenseLayerRef& d = T.layers[b][i];
             float* bt = el(e, e->Bt, e->bt_off[b][i]);
@@ -321,6 +329,16 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             // the very next layer - are accumulated per layer; everything below the group's lowest layer is done
             // once for the whole group by BwdDataGroupP (gemm.cuh), which touches G' and x once instead of once
             // per layer.
+            if (e->dbg_stop == b * 100 + i && e->prec == 0) {      // tests: G' of the block in front of this layer's 1x1 data gradients
+                const int64_t nf = (int64_t)NS * pl.HWp * Ct;
+                if (e->dbg_gsnap_floats < nf) {
+                    if (e->dbg_gsnap) (void)hipFree(e->dbg_gsnap);
+                    e->dbg_gsnap = nullptr; e->dbg_gsnap_floats = 0;
+                    HIP_OK(hipMalloc((void**)&e->dbg_gsnap, (size_t)nf * sizeof(float)));
+                    e->dbg_gsnap_floats = nf;
+                }
+                HIP_OK(hipMemcpyAsync(e->dbg_gsnap, e->G[b], (size_t)nf * sizeof(float), hipMemcpyDeviceToDevice, st));
+            }
             const int L = (int)T.layers[b].size();
             const int g_lo = i - ((L - 1 - i) % kGroup == kGroup - 1 ? 0 : std::min(i, kGroup - 1 - (L - 1 - i) % kGroup));
             const int cs = T.layers[b][g_lo].cin;                       // channels below the group
@@ -367,6 +385,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 // (MC doubles the depth in the 16-bit modes: 128 x 64 x 64 / 64 x 64 x 64)
                 PREC_DISPATCH(e, if (pl.HWp % 128 == 0) run(GemmCfg<128, 64, 32, 2, 2, 1, true>{}, PTAG); else run(CfgP64x64{}, PTAG));
             }
+            if (e->dbg_stop == b * 100 + i) return debug_stop();
         }
         if (b > 0) {   // transition b-1: X[b-1] (all channels) -> X[b][:, 0:C0]
             const Plane pp = e->p_blk[b - 1];
@@ -440,7 +459,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         auto go = [&](auto ptag, auto mtag) -> int {
         constexpr int SM = decltype(mtag)::value;      // W_STEM (3-channel image, 196 columns) or W_STEM1 (one channel, 49 taps, replicated x3 at the flush)
         using WCfg = typename std::conditional<SM == W_STEM1, CfgW64x64, CfgW64x256>::type;
-        BwdWeightP<WCfg, SM, SM == W_STEM1 ? C_STEM1 : C_STEM, SMG_PD_WGRAD, true, decltype(ptag)::value> p{};      // (fp32 image / stem plane in every mode)
+        BwdWeightP<WCfg, SM, SM == W_STEM1 ? C_STEM1 : C_STEM, kPdWgrad, true, decltype(ptag)::value> p{};      // (fp32 image / stem plane in every mode)
         p.gbuf = e->DY0; p.ldg = 64; p.gcoff = 0; p.xbuf = e->stem; p.ldx = 64; p.xcoff = 0; p.pa = ps_; p.MA = 64;
         p.xsum = fsum(e, e->st_stem); p.xsq = fsq(e, e->st_stem); p.xstride = 64;
         p.s1 = b1(e, e->bs_stem); p.s2 = b2(e, e->bs_stem); p.sstride = 64; p.scoff = 0; p.agamma = P + T.norm0.w;

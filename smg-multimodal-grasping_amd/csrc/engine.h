@@ -48,11 +48,7 @@ using CfgP128x32 = GemmCfg<128, 32, 32, 4, 1, 1, true>;      // 3x3 fwd (N = gro
 using CfgP128x64 = GemmCfg<128, 64, 16, 2, 2, 1, true>;      // stem, head conv0, 1x1 dgrad
 // small stages (late blocks: few pixels per stream -> 64-row tiles, 4x the workgroups)
 using CfgP64x64 = GemmCfg<64, 64, 32, 2, 2, 1, true>;        // 1x1 fwd / dgrad, transitions
-using CfgP64x64k16 = GemmCfg<64, 64, 16, 2, 2, 1, true>;     // 1x1 fwd with many input channels: 29 KB LDS incl. BN parameters
 using CfgP32x64 = GemmCfg<32, 64, 32, 1, 2, 2, true>;        // 1x1 fwd of a launch too small to fill the chip: 2x the workgroups, half the K chain per wave
-using CfgP128x128d = GemmCfg<128, 128, 32, 2, 2, 1, true>;   // 1x1 fwd of launches with fewer 128-row tiles than CUs: one workgroup per CU, deep register prefetch
-using CfgP64x128d = GemmCfg<64, 128, 32, 2, 2, 1, true>;     // the same for planes that tile by 64 rows only (40^2)
-using CfgP64x64w = GemmCfg<64, 64, 32, 1, 2, 2, true>;       // 64x64 with 64x32 wave tiles over half the k-steps each: 25% fewer fragment reads per MFMA
 using CfgP64x128 = GemmCfg<64, 128, 16, 2, 2, 1, true>;      // 3x3 dgrad, late 1x1 fwd / transitions (A operand read once)
 using CfgP64x32 = GemmCfg<64, 32, 64, 2, 1, 2, true>;        // 3x3 fwd, k-tile split over 2 waves
 // weight gradients (reduction over pixels)
@@ -66,23 +62,6 @@ using CfgW64x256 = GemmCfg<64, 256, 16, 2, 2, 1, false>;     // stem wgrad: all 
 // k-tiles are MUL times deeper (the single-piece LDS images are a third of the fp32-class ones, so the tiles still fit).
 template <class C, int PREC, int MUL = 2>
 using MC = typename std::conditional<PREC == 0, C, GemmCfg<C::BM, C::BN, MUL * C::BK, C::WM, C::WN, C::WK, C::AT>>::type;
-// ... and per kernel family in mode 0 under the two-piece fp16 split (LDS images two thirds of the bf16 split's, half the MFMA
-// terms per k-tile): dev knobs, A/B with tools/build_variant.sh
-#ifndef SMG_DEEP_C1
-#define SMG_DEEP_C1 0
-#endif
-#ifndef SMG_DEEP_D1N
-#define SMG_DEEP_D1N 0
-#endif
-#ifndef SMG_DEEP_D1G
-#define SMG_DEEP_D1G 0
-#endif
-#ifndef SMG_DEEP_W1
-#define SMG_DEEP_W1 0
-#endif
-template <class C, int PREC, int DEEP0, int MUL = 2>
-using MCD = typename std::conditional<(PREC == 0 && !DEEP0), C, GemmCfg<C::BM, C::BN, MUL * C::BK, C::WM, C::WN, C::WK, C::AT>>::type;
-
 enum Kind {
     K_STEM = 0, K_C1, K_C3, K_TRANS, K_HEAD0, K_D3, K_W3, K_D1, K_W1, K_TW, K_TD, K_SW, K_HW0, K_HD0, K_OTHER, K_COUNT
 };
@@ -172,7 +151,14 @@ struct smg_engine {
     bool serialize = false;       // smg_engine_set_option("serialize"): every launch on the caller's stream in issue order (profiling: a trace's
                                   // per-kernel durations are not inflated by a kernel of the other chain sharing the chip)
     bool deterministic = false;   // smg_engine_set_option("deterministic"): 1x1 weight gradients as partial tiles + fixed-order reduce instead of fp32 atomics
-    bool generic3x3 = false;   // SMG_GENERIC_3X3=1: dense-layer 3x3 convs through the generic implicit GEMM (A/B testing)
+    // SMG_CROSSCHECK (read at engine creation; tests/test_gpu_parity.py::test_alternative_kernel_paths_agree): independent implementations of
+    // two kernel families for cross-checks - bit 0: dense-layer 3x3 convolutions through the generic implicit GEMM instead of the LDS-halo
+    // kernels; bit 1: the 1x1 forward of the small planes through the generic kernel instead of the wave-specialised one
+    bool generic3x3 = false, generic_c1 = false;
+    int dbg_stop = -1;         // smg_engine_set_option("debug_stop", block * 100 + layer) (0-based): the backward returns behind that dense layer's
+                               // launches (block * 100 + 50: in front of the block's first layer) - the GEMM-level tests read the ring
+                               // slots, DY2 and G' at that point (smg_debug_read); -1 = off
+    float* dbg_gsnap = nullptr; int64_t dbg_gsnap_floats = 0;      // ... and G' of the block as it was in front of that layer's 1x1 data gradients ("gsnap")
     // profiling
     bool prof = false; std::vector<ProfRec> recs; std::vector<hipEvent_t> ev_pool;
     // totals per kind in slot 0, and the share of dense block b (kernels issued inside its layer loops) in slot 1 + b
@@ -186,8 +172,7 @@ struct smg_engine {
 // 4.3 -> 3.6 ms).
 static inline int halo_tile(const Plane& p, int n_streams = 1 << 20) {
     if (p.H % 16 || p.W % 16) return 8;
-    static const int min16 = getenv("SMG_HALO16_MIN") ? atoi(getenv("SMG_HALO16_MIN")) : 320;      // dev A/B
-    return (int64_t)(p.H / 16) * (p.W / 16) * n_streams >= min16 ? 16 : 8;
+    return (int64_t)(p.H / 16) * (p.W / 16) * n_streams >= 320 ? 16 : 8;      // (160 / 800 measured: 24.4 / 24.8 against 24.6 ms per step)
 }
 
 // 3x3 weight-gradient halo kernel: tiles per workgroup.  The launch runs in rounds of 512 resident workgroups (2 per
@@ -383,6 +368,13 @@ static inline double* b1(smg_engine* e, const StatArr& s) { return e->bstat + s.
 static inline double* b2(smg_engine* e, const StatArr& s) { return e->bstat + e->bstat_span + s.off; }
 
 static const float kEps = 1e-5f;
+
+// position of dense layer (block b, layer i; 0-based) in the backward's ring sequence of GS / D2 / D2S slots (slot = position % kRing)
+static inline int ring_pos(int b, int i) {
+    int r = kBlockLayers[b] - 1 - i;
+    for (int bb = 3; bb > b; --bb) r += kBlockLayers[bb];
+    return r;
+}
 
 // indices into the activation-scale table / the gradient-maximum buffer
 static inline int layer_seq(int b, int i) { static const int first[4] = {0, 6, 18, 42}; return first[b] + i; }

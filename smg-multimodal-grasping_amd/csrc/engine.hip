@@ -26,8 +26,8 @@ static int engine_build(smg_engine* e) {
     if (e->OH < 1) return fail(-22, "input_size too small for the 20x20 value head");
 
     if (getenv("SMG_SERIALIZE")) e->serialize = true;        // profiling runs: serialised from the first launch (bench.py --serialize)
-    const char* g3 = getenv("SMG_GENERIC_3X3");
-    e->generic3x3 = g3 && g3[0] == '1';
+    const int cross = getenv("SMG_CROSSCHECK") ? atoi(getenv("SMG_CROSSCHECK")) : 0;
+    e->generic3x3 = cross & 1; e->generic_c1 = cross & 2;
 
     ALLOC(e->img4, (int64_t)NS * e->p_img.HWp * 4);
     ALLOC(e->stem, (int64_t)NS * e->p_stem.HWp * 64);
@@ -336,6 +336,7 @@ void smg_engine_destroy(smg_engine* e) {
                     e->Bt, e->DY2, e->part, e->F, e->DF, e->H1, e->DH1, e->fstat, e->bstat, e->dbscr, e->d_dbseg, e->asc, e->d_asc, e->gamax, e->packed_u, e->packed_f, e->stab, e->d_pack, e->d_bnupd,
                     e->d_stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (e->dbg_gsnap) (void)hipFree(e->dbg_gsnap);
     for (int k = 0; k < 2; ++k) { if (e->h_stage[k]) (void)hipHostFree(e->h_stage[k]); if (e->ev_stage[k]) (void)hipEventDestroy(e->ev_stage[k]); }
     for (int k = 0; k < kRing; ++k) {
         if (e->D2[k]) (void)hipFree(e->D2[k]);
@@ -402,7 +403,7 @@ int smg_layout_trunk_split(int head_out, int trunk_id, int64_t* offset) {
 int smg_engine_set_precision(smg_engine* e, int precision) {
     if (!e) return fail(-22, "engine is NULL");
     if (precision < 0 || precision > 2) return fail(-22, "precision must be 0 (fp32 storage, fp32-class split products), 1 (bf16 storage) or 2 (fp16 activations, bf16 gradients)");
-    if (precision && e->generic3x3) return fail(-22, "SMG_GENERIC_3X3 (the generic implicit-GEMM 3x3 path) exists in the fp32-class mode only");
+    if (precision && e->generic3x3) return fail(-22, "SMG_CROSSCHECK=1 (the generic implicit-GEMM 3x3 path) exists in the fp32-class mode only");
     e->prec = precision;
     e->have_fwd = false;        // activations saved by a forward of another precision are not backward-compatible
     e->bw_phase0_done = false;
@@ -414,6 +415,7 @@ int smg_engine_set_option(smg_engine* e, const char* name, int value) {
     const std::string s(name);
     if (s == "deterministic") { e->deterministic = value != 0; return 0; }
     if (s == "serialize") { e->serialize = value != 0; return 0; }
+    if (s == "debug_stop") { e->dbg_stop = value; return 0; }
     return fail(-22, "unknown engine option '" + s + "'");
 }
 
@@ -495,6 +497,49 @@ int64_t smg_debug_read(smg_engine* e, const char* name, float* host_out, int64_t
         int b = 0, i = 0;
         if (std::sscanf(name, "bt%d_%d", &b, &i) != 2 || b < 1 || b > 4 || i < 1 || i > kBlockLayers[b - 1]) return fail(-22, "bad bt name");
         src = el(e, e->Bt, e->bt_off[b - 1][i - 1]); n = (int64_t)NS * e->p_blk[b - 1].HWp * kBottleneck;      // bt_off counts ELEMENTS of the mode
+    } else if (s == "gsnap") {    // G' of the debug_stop layer's block in front of that layer's 1x1 data gradients (first f_streams streams)
+        src = e->dbg_gsnap; n = e->dbg_gsnap_floats;
+        if (!src) return fail(-22, "gsnap: no debug_stop backward has run");
+    } else if (s == "dy2") {      // precision mode 0: the raw 3x3 data gradient of the dense layer the backward processed last, [streams][HWp of its block][128]
+        src = e->DY2; n = (int64_t)NS * e->p_blk[0].HWp * kBottleneck;
+    } else if (s.size() >= 5 && (s.substr(0, 3) == "gs_" || s.substr(0, 3) == "d2_")) {
+        // "gs_<block>_<layer>" / "d2_<block>_<layer>" (1-based): the ring slot of that dense layer's finished gradients - valid until kRing
+        // further layers have run (debug_stop).  d2 in precision mode 0: rebuilt from the units, (h + l) * the block's inverse scale.
+        int b = 0, i = 0;
+        if (std::sscanf(name + 3, "%d_%d", &b, &i) != 2 || b < 1 || b > 4 || i < 1 || i > kBlockLayers[b - 1]) return fail(-22, "bad ring buffer name");
+        const int slot = ring_pos(b - 1, i - 1) % kRing;
+        const Plane& pl = e->p_blk[b - 1];
+        const bool gs = s[0] == 'g';
+        const int64_t per_stream = (int64_t)pl.HWp * (gs ? kGrowth : kBottleneck);
+        n = (int64_t)NS * per_stream;
+        if (!host_out) return n;
+        const int ns_out = (int)std::min<int64_t>(NS, cap / per_stream);      // a prefix of whole streams
+        n = ns_out * per_stream;
+        if (e->prec != 0) return fail(-22, "ring buffer debug reads exist in precision mode 0 only");
+        HIP_OK(hipSetDevice(e->device));
+        HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+        if (gs || kSplitOp != 3) {
+            HIP_OK(hipMemcpy(host_out, gs ? e->GS[slot] : e->D2[slot], n * sizeof(float), hipMemcpyDeviceToHost));
+            return n;
+        }
+        std::vector<unsigned short> u((size_t)ns_out * per_stream * 2);
+        std::vector<float> inv((size_t)NS * (pl.HWp / kScaleBlock));
+        HIP_OK(hipMemcpy(u.data(), e->D2[slot], u.size() * sizeof(unsigned short), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(inv.data(), e->D2S[slot], inv.size() * sizeof(float), hipMemcpyDeviceToHost));
+        auto h2f = [](unsigned h) -> double {
+            const int ex = (h >> 10) & 31, man = h & 1023;
+            const double v = ex == 0 ? std::ldexp((double)man, -24) : (ex == 31 ? (man ? NAN : INFINITY) : std::ldexp((double)(man | 1024), ex - 25));
+            return (h & 0x8000u) ? -v : v;
+        };
+        for (int sn = 0; sn < ns_out; ++sn)
+            for (int k8 = 0; k8 < kD2K8; ++k8)
+                for (int p = 0; p < pl.HWp; ++p) {
+                    const size_t uh = ((((size_t)sn * 2 + 0) * kD2K8 + k8) * pl.HWp + p) * 8, ul = ((((size_t)sn * 2 + 1) * kD2K8 + k8) * pl.HWp + p) * 8;
+                    const double iv = inv[(size_t)sn * (pl.HWp / kScaleBlock) + p / kScaleBlock];
+                    for (int j = 0; j < 8; ++j)
+                        host_out[((size_t)sn * pl.HWp + p) * kBottleneck + 8 * k8 + j] = (float)((h2f(u[uh + j]) + h2f(u[ul + j])) * iv);
+                }
+        return n;
     } else if (s == "asc") {      // the activation scales {s, 1 / s} of the last forward: dense layers (norm1, norm2 per layer), transitions, head norm0
         src = e->asc; n = 2 * e->n_asc;
     } else if (s.size() >= 6 && s.substr(0, 5) == "fs_bt") {   // "fs_bt<block>_<layer>": the fp64 forward sums of that bottleneck, raw doubles [sum | sumsq][streams][128] in the float buffer

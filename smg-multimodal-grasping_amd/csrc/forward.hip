@@ -95,8 +95,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
         auto on = [&]() { const bool r = unit >= u_lo && unit < u_hi; ++unit; return r; };
         auto xs = [&](int b) { return el(e, e->X[b], (int64_t)s0 * e->p_blk[b].HWp * kBlockCtot[b]); };
         auto st_off = [&](double* base, int stride) { return base + (int64_t)s0 * stride; };
-        static const bool stem3_env = getenv("SMG_STEM3") != nullptr;          // dev A/B: the 3-channel stem for every input form
-        const bool stem1 = B->heightmaps_dev && !stem3_env;                   // heightmap form: the three channels are identical by construction
+        const bool stem1 = B->heightmaps_dev != nullptr;                      // heightmap form: the three channels are identical by construction
         float* img4 = stem1 ? e->img4 + (int64_t)s0 * e->p_img.HWp : e->img4 + (int64_t)s0 * e->p_img.HWp * 4;
         float* stem = e->stem + (int64_t)s0 * e->p_stem.HWp * 64;
         const bool head_unit = on();
@@ -150,7 +149,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                     if (i == 0) bn_stat(cs, t1, ns, xsum, xsq, Ct, 0, d.cin, pl.HW);     // block input: from pool0 / the transition
                     auto run_p = [&](auto tag, auto ptag) {
                         using Cfg0 = decltype(tag);
-                        using Cfg = MCD<Cfg0, decltype(ptag)::value, SMG_DEEP_C1, (Cfg0::BK < 32 ? 2 : 1)>;      // (cin is a multiple of 32 only)
+                        using Cfg = MC<Cfg0, decltype(ptag)::value, (Cfg0::BK < 32 ? 2 : 1)>;      // (cin is a multiple of 32 only)
                         FwdConvP<Cfg, F_ONE, decltype(ptag)::value> p{};
                         p.src = xs(b); p.lds_ = Ct; p.ps = pl; p.po = pl; p.K = d.cin; p.asc = asc_n1(e, b, (int)i);
                         p.bt = t1; p.fresh0 = i == 0 ? d.cin : d.cin - kGrowth; p.fsum = xsum; p.fsq = xsq; p.fstride = Ct; p.eps = kEps;
@@ -165,13 +164,10 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                     // 128x128 tiles where the plane tiles by 128 rows and the launch still fills the chip; else 64x64 (BK = 32) -
                     // and when even that leaves most CUs idle (few streams per call, or the 20x20 planes), 32x64 tiles with
                     // the k-tile split over wave pairs: twice the workgroups, half the serial K chain.
-                    static const int small_wgs = getenv("SMG_C1_SMALL") ? atoi(getenv("SMG_C1_SMALL")) : 320;   // 512 / 1024 measured slower on the 17-stream step
+                    const int small_wgs = 320;      // (160 / 640: 24.4 / 24.6 ms per step against 24.6; 512 / 1024 slower on the 17-stream step)
                     const int wg128 = ns * pl.HWp / 128, wg64 = ns * pl.HWp / 64 * 2;
-                    static const int k16 = getenv("SMG_C1_K16") ? atoi(getenv("SMG_C1_K16")) : 1 << 30;      // dev A/B: BK = 16 past this many channels
-                    static const int mid = getenv("SMG_C1_MID") ? atoi(getenv("SMG_C1_MID")) : 0;                     // dev A/B
-                    static const int deep_min = getenv("SMG_C1_DEEP") ? atoi(getenv("SMG_C1_DEEP")) : 1 << 30;       // dev A/B
-                    static const bool ws_on = !(getenv("SMG_C1_WS") && atoi(getenv("SMG_C1_WS")) == 0);      // wave-specialised 64x64x32 (ws.cuh); SMG_C1_WS=0: the generic kernel (A/B, cross-check)
-                    if (ws_on && e->prec == 0 && !(pl.HWp % 128 == 0 && wg128 >= small_wgs) && wg64 >= small_wgs && d.cin % 32 == 0 && pl.HWp % 64 == 0) {
+                    if (!e->generic_c1 && e->prec == 0 && !(pl.HWp % 128 == 0 && wg128 >= small_wgs) && wg64 >= small_wgs && d.cin % 32 == 0 && pl.HWp % 64 == 0) {
+                        // wave-specialised 64 x 64 x 32 (ws.cuh)
                         Fwd1x1WsArgs a{};
                         a.src = xs(b); a.lds_ = Ct; a.pl = pl; a.K = d.cin;
                         a.bt = t1; a.fresh0 = i == 0 ? d.cin : d.cin - kGrowth; a.fsum = xsum; a.fsq = xsq; a.fstride = Ct; a.eps = kEps;
@@ -191,12 +187,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_fwd_ws_kernel<0>), dim3(tile_grid(a.tm)), dim3(512), smem, cs, a);
                     } else
                     if (pl.HWp % 128 == 0 && wg128 >= small_wgs) run(CfgP128x128{});
-                    else if (pl.HWp % 128 == 0 && wg128 >= deep_min && d.cin % 32 == 0) run(CfgP128x128d{});
                     else if (wg64 < small_wgs) run(CfgP32x64{});
-                    else if (mid == 3) run(CfgP64x64w{});
-                    else if (mid == 1) run(CfgP64x128{});
-                    else if (mid == 2 && d.cin % 32 == 0) run(CfgP64x128d{});
-                    else if (d.cin > k16) run(CfgP64x64k16{});
                     else run(CfgP64x64{});
                 }
                 const BnTab t2 = bn_table(e, e->sb_tab[b][i], e->max_streams, s0, kBottleneck, P + d.n2.w, P + d.n2.b);
@@ -264,13 +255,11 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
         }
         return 0;
     };
-    static const bool one_chain = getenv("SMG_FWD_ONE_CHAIN") != nullptr;      // dev: A/B switch
     // (two chains pay once a chain has work to overlap: a single-sample pass - 2 streams of 160^2 - is bound by the host's launch
     //  rate, and two chains launch every kernel twice: 6.2 -> 5.1 ms for config 3's enveloping-then-sucking head on one chain; 5 streams
     //  of 456^2 want two: 30.1 against 28.9 ms on one)
-    static const bool force_two = getenv("SMG_FWD_TWO_CHAINS") != nullptr;      // dev: A/B switch
-    const bool two_chains = NS >= 2 && (force_two || (int64_t)NS * e->p_blk[0].HW >= 200000);
-    if (two_chains && !e->prof && !e->serialize && !one_chain) {
+    const bool two_chains = NS >= 2 && (int64_t)NS * e->p_blk[0].HW >= 200000;
+    if (two_chains && !e->prof && !e->serialize) {
         const int h = NS / 2;
         HIP_OK(hipEventRecord(e->ev_misc, st));                 // packed weights + batch description are ready
         HIP_OK(hipStreamWaitEvent(e->side, e->ev_misc, 0));
@@ -329,7 +318,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                            e->d_pair_a, e->d_pair_b, NP, e->head_out * e->OH * e->OW, q_out);
     }
     HIP_OK(hipGetLastError());
-    e->f_stem1 = B->heightmaps_dev && getenv("SMG_STEM3") == nullptr;
+    e->f_stem1 = B->heightmaps_dev != nullptr;
     e->bw_phase0_done = false;
     e->have_fwd = true; e->f_trunk = trunk_id; e->f_head = head_id; e->f_streams = NS; e->f_pairs = NP;
     return 0;

@@ -51,45 +51,21 @@
 
 #include <type_traits>
 
-// dev knobs: k-tiles of global loads in flight per policy family (register ring depth of the staging pipeline)
-#ifndef SMG_PD_FWD_SMALL
-#define SMG_PD_FWD_SMALL 2
-#endif
-#ifndef SMG_PD_FWD_BIG
-#define SMG_PD_FWD_BIG 2      // round 4 (three-term products: 384 cycles of MFMA per k-tile no longer cover a load): 128 x 128 forward 72.4 -> 67.6 us per launch
-#endif
-#ifndef SMG_PIN_LOADS
-#define SMG_PIN_LOADS 1       // keep the next tile's loads AT the top of the k-tile: hipcc sinks them to their first use (the weight loads ended up
-                              // directly in front of their LDS store, the activation loads in the middle of the MFMA block - one exposed memory
-                              // latency each per k-tile).  Serialised kernel total 19.33 -> 18.94 ms (with SMG_PD_FWD_BIG = 2: 18.82)
-#endif
-#ifndef SMG_FWD_BIG_MINWAVES      // waves per SIMD the 128x128 forward is held to (register cap 512 / n)
-#define SMG_FWD_BIG_MINWAVES 3
-#endif
-#ifndef SMG_PD_FWD_DEEP
-#define SMG_PD_FWD_DEEP 2
-#endif
-#ifndef SMG_PD_DGRAD
-#define SMG_PD_DGRAD 2
-#endif
-#ifndef SMG_PD_DGRAD_BIG
-#define SMG_PD_DGRAD_BIG 2
-#endif
-#ifndef SMG_PD_WGRAD
-#define SMG_PD_WGRAD 3
-#endif
-#ifndef SMG_PD_DGRAD_GROUP      // the layer-grouped 1x1 data gradient with deep k-tiles
-#define SMG_PD_DGRAD_GROUP 1
-#endif
-
-// The order of fragment reads and MFMAs inside a k-tile is left to hipcc (with two k-tiles of loads in flight it interleaves
-// the next tile's split / LDS stores with the MFMAs: k-loop of the 64x64 forward -17 %, of the 1x1 data gradient -27 %);
-// SMG_PIN_ORDER restores round 2's early pinned order for A/B.
-#ifdef SMG_PIN_ORDER
-#define SMG_PIN() __builtin_amdgcn_sched_barrier(0)
-#else
-#define SMG_PIN() do {} while (0)
-#endif
+// k-tiles of global loads in flight per policy family (register ring depth of the staging pipeline) and the waves per SIMD a few
+// kernels are held to - every value below was A/B-measured on the box (profiles/README.md) and is frozen here.
+namespace smg {
+constexpr int kPdFwdSmall = 2;      // one MFMA tile per wave (small planes): 0.1 us of MFMAs per k-tile against ~1 us of memory latency
+constexpr int kPdFwdBig = 2;        // 128 x 128 forward: with three-term products 384 cycles of MFMA per k-tile no longer cover a load (72.4 -> 67.6 us per launch)
+constexpr int kPdDgrad = 2;
+constexpr int kPdDgradBig = 2;
+constexpr int kPdWgrad = 3;
+constexpr int kPdDgradGroup = 1;    // the layer-grouped 1x1 data gradient with deep k-tiles
+constexpr int kFwdBigMinWaves = 3;  // waves per SIMD the 128 x 128 forward is held to (register cap 512 / n)
+}
+// The next tile's loads are pinned AT the top of the k-tile (sched_barrier): hipcc otherwise sinks them to their first use (the weight
+// loads ended up directly in front of their LDS store, the activation loads in the middle of the MFMA block - one exposed memory
+// latency each per k-tile; serialised kernel total 19.33 -> 18.94 ms).  The order of fragment reads and MFMAs inside a k-tile is
+// left to hipcc (with two k-tiles of loads in flight it interleaves the next tile's split / LDS stores with the MFMAs).
 
 namespace smg {
 
@@ -148,16 +124,11 @@ constexpr int bwd_op_plain(int prec) { return prec ? 1 : 0; }             // ...
 struct Split4 { uint2 p[NPIECE]; };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-#ifdef SMG_SPLIT_TRUNC      // dev A/B: truncating split (exact, but every residual has the sign of x: biased dropped terms)
-__device__ __forceinline__ unsigned pack_bf16(float lo_elem, float hi_elem) {
-    return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
-}
-#else                       // round-to-nearest-even pieces: one v_cvt_pk_bf16_f32 per pair
+// round-to-nearest-even pieces: one v_cvt_pk_bf16_f32 per pair
 __device__ __forceinline__ unsigned pack_bf16(float lo_elem, float hi_elem) {
     const f32x2 v = {lo_elem, hi_elem};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
-#endif
 __device__ __forceinline__ unsigned pack_f16(float lo_elem, float hi_elem) {
     const f32x2 v = {lo_elem, hi_elem};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
@@ -165,9 +136,6 @@ __device__ __forceinline__ unsigned pack_f16(float lo_elem, float hi_elem) {
 // the fp16 residuals rn(a - lo(h)), rn(b - hi(h)) of a rounded pair h, ONE instruction per element: v_fma_mix{lo,hi}_f16 evaluates
 // a * 1.0 - h in fp32 (exact: h is a rounded to 11 bits) and rounds to fp16 - bit-identical to convert / subtract / convert, subnormal
 // residuals included (tools/mix_probe.hip: 4 M pairs over 2^-30 .. 2^15), at half the split's instructions (3 instead of 6 per pair).
-#ifndef SMG_SPLIT_MIX
-#define SMG_SPLIT_MIX 1
-#endif
 __device__ __forceinline__ unsigned resid_f16(float a, float b, unsigned h) {
     unsigned l;                     // (mixlo keeps the destination's high half, which mixhi then overwrites: no initialisation needed)
     asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "v"(h));
@@ -183,17 +151,9 @@ template <int OP = 0>
 __device__ __forceinline__ Split4 split4(float4 v) {
     Split4 o;
     if constexpr (OP == 3) {                             // two fp16 pieces of an operand the caller has scaled into range
-#ifdef SMG_EXP_NOSPLIT
-        o.p[0] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)); o.p[1] = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w)); o.p[2] = make_uint2(0u, 0u);
-        return o;
-#endif
         const unsigned h01 = pack_f16(v.x, v.y), h23 = pack_f16(v.z, v.w);
         o.p[0] = make_uint2(h01, h23);
-#if SMG_SPLIT_MIX
         o.p[1] = make_uint2(resid_f16(v.x, v.y, h01), resid_f16(v.z, v.w, h23));
-#else
-        o.p[1] = make_uint2(pack_f16(v.x - f16_lo(h01), v.y - f16_hi(h01)), pack_f16(v.z - f16_lo(h23), v.w - f16_hi(h23)));
-#endif
         o.p[2] = make_uint2(0u, 0u);
         return o;
     } else
@@ -375,30 +335,6 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 // global_load needs a 64-bit add per load per k-tile; hipcc widens the lane offset outside the loop and cannot pick the
 // scalar-base form).  Bytes at or past `bytes` read as zero: lanes whose element does not exist carry kOOB as offset.
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }   // workgroup-uniform by construction
-// TIMING-ONLY experiments (wrong results): the 1x1 forward's / 1x1 weight gradient's activation rows wrapped into the first 1024
-// pixels of the stream, i.e. served from cache - what would the step gain if those bytes never came from HBM?
-// SMG_EXP_TERMS1: only the h*h term of the fp16-split products is issued; SMG_EXP_NOSPLIT: the split's arithmetic is replaced by a
-// register move - what would the step gain if the matrix / the split work were free?
-#ifdef SMG_EXP_TERMS1
-#define SMG_TERM(is_small, call, c) ((is_small) ? (c) : (call))
-#else
-#define SMG_TERM(is_small, call, c) (call)
-#endif
-#ifdef SMG_EXP_F1X
-#define SMG_EXP_WRAP_F1(p) ((p) & 1023)
-#else
-#define SMG_EXP_WRAP_F1(p) (p)
-#endif
-#ifdef SMG_EXP_W1A
-#define SMG_EXP_WRAP_W1A(p) ((p) & 1023)
-#else
-#define SMG_EXP_WRAP_W1A(p) (p)
-#endif
-#ifdef SMG_EXP_W1X
-#define SMG_EXP_WRAP_W1(p) ((p) & 1023)
-#else
-#define SMG_EXP_WRAP_W1(p) (p)
-#endif
 constexpr unsigned kOOB = 0xC0000000u;          // + any scalar offset (< 1 GiB) stays past every descriptor's extent
 constexpr unsigned kWholeBuf = 0xBFFFFFFFu;     // extent of descriptors without a tight bound
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ubase, unsigned bytes) {
@@ -433,10 +369,7 @@ __device__ __forceinline__ f32x4 bloadv4(const void* ubase, unsigned bytes, unsi
 // stream) 27.2 / 25.7 / 25.4 / 25.6; config 3 27.2 / - / 27.2 / 27.5.  Two it is.  The forward arena stays single: its readers (every
 // workgroup's parameter prologue, 32-128 channels each) outnumber its writers (replicated eightfold: headline + 0.6 ms).
 // The stride is a compile-time constant so that no kernel needs another argument; the engine checks that its arena fits.
-#ifndef SMG_STAT_REP
-#define SMG_STAT_REP 2
-#endif
-constexpr int kStatRep = SMG_STAT_REP;
+constexpr int kStatRep = 2;
 constexpr int64_t kStatRepStride = (int64_t)1 << 23;
 __device__ __forceinline__ double stat_get(const double* p, int64_t idx) {
     double v = p[idx];
@@ -444,13 +377,10 @@ __device__ __forceinline__ double stat_get(const double* p, int64_t idx) {
     for (int r = 1; r < kStatRep; ++r) v += p[idx + r * kStatRepStride];
     return v;
 }
-#ifndef SMG_FSTAT_REP
-#define SMG_FSTAT_REP 1      // dev knob: replicas of the FORWARD statistic arena (readers: every parameter prologue).  Same box, 1 / 2 / 4:
-                             // headline 21.40 / 21.52 / 21.58 ms, config 5 share 25.4 / 24.5 / 24.7, config 3 27.0 / 27.1 / - ; with the backward's
-                             // per-layer prologues on the fp32 tables (StatTab) 2 replicas still cost the headline 0.15 ms (21.59 -> 21.75; config 5
-                             // 25.7 -> 24.8; serialised kernel total 24.11 -> 23.99): the forward's own first-consumer prologues pay.  Stays 1.
-#endif
-constexpr int kFStatRep = SMG_FSTAT_REP;
+// Replicas of the FORWARD statistic arena (readers: every parameter prologue).  Same box, 1 / 2 / 4: headline 21.40 / 21.52 / 21.58 ms,
+// config 5 share 25.4 / 24.5 / 24.7, config 3 27.0 / 27.1 / - ; with the backward's per-layer prologues on the fp32 tables (StatTab) 2
+// replicas still cost the headline 0.15 ms: the forward's own first-consumer prologues pay.  Stays 1.
+constexpr int kFStatRep = 1;
 __device__ __forceinline__ double fstat_get(const double* p, int64_t idx) {
     double v = p[idx];
 #pragma unroll
@@ -543,11 +473,19 @@ __device__ __forceinline__ float4 bnrelu4(float4 v, const float* prm, int stride
     r.w = fmaxf(bn1(v.w, prm[3], sc[3], be[3]), 0.f);
     return r;
 }
+// H: the result becomes an fp16 operand (kinds 2 and 3) - clamped to fp16's largest finite value, one v_med3_f32 in place of the
+// v_max_f32.  In-range values are untouched; what the clamp catches are the rows of the PLANE PADDING, which are read as they lie
+// (zeros): relu(gamma * (0 - mean) * invstd + beta) * s of a near-constant channel (|mean| / std in the thousands) is past 65504,
+// would become inf, and in the 1x1 weight gradient - whose other operand is zero on those rows - inf * 0 = NaN in a whole column of dW.
+constexpr float kF16Max = 65504.f;
+template <bool H = false>
 __device__ __forceinline__ float4 bnrelu4(float4 v, const KPrm3& k) {
     // two channels per instruction (v_pk_add_f32 / v_pk_fma_f32); the relu has no packed form
     const f32x2 a = __builtin_elementwise_fma(f32x2{v.x, v.y} - k.mean.xy, k.scale.xy, k.beta.xy);
     const f32x2 b = __builtin_elementwise_fma(f32x2{v.z, v.w} - k.mean.zw, k.scale.zw, k.beta.zw);
-    return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(b.x, 0.f), fmaxf(b.y, 0.f));
+    if constexpr (H) return make_float4(__builtin_amdgcn_fmed3f(a.x, 0.f, kF16Max), __builtin_amdgcn_fmed3f(a.y, 0.f, kF16Max),
+                                        __builtin_amdgcn_fmed3f(b.x, 0.f, kF16Max), __builtin_amdgcn_fmed3f(b.y, 0.f, kF16Max));
+    else return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(b.x, 0.f), fmaxf(b.y, 0.f));
 }
 // the same with an upper clamp: cap = +inf -> relu; cap = 0 -> 0 (rows of the plane padding)
 __device__ __forceinline__ float4 bnrelu4(float4 v, const KPrm3& k, float cap) {
@@ -865,9 +803,6 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
     // One operand fragment piece of a 32-row tile for this wave's k16-step s: ds_read_b128 of a unit (forward / data
     // gradient) or two transposing reads (weight gradient).
     auto frag = [&](const char* img, int ldu, int ldt, int r0, int s, int pc) -> u32x4 {
-#ifdef SMG_EXP_NOFRAG      // timing only: no fragment reads from LDS
-        return u32x4{(unsigned)(r0 + s), (unsigned)pc, (unsigned)lane, 0x3c003c00u};
-#endif
         if constexpr (C::AT) {
             const int k8 = (wk * C::KS + s) * 2 + half;
             return *reinterpret_cast<const u32x4*>(img + ((pc * C::K8 + k8) * ldu + r0 + l31) * 16);
@@ -910,37 +845,26 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
                 for (int i = 0; i < C::TM; ++i) al_[i] = fragA(A, wm0 + i * 32, s, 1);
 #pragma unroll
                 for (int j = 0; j < C::TN; ++j) bl_[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 1);
-                SMG_PIN();
-#pragma unroll
+                #pragma unroll
                 for (int g = 0; g < 3; ++g)
 #pragma unroll
                     for (int i = 0; i < C::TM; ++i)
 #pragma unroll
                         for (int j = 0; j < C::TN; ++j)
-                            {
-#ifdef SMG_EXP_NOMFMA
-                                acc[i][j][0] += __uint_as_float(ah[i].x ^ bh[j].x ^ al_[i].y ^ bl_[j].y);      // keeps the fragment reads alive
-#else
-                                acc[i][j] = SMG_TERM(g < 2, mfma_f16(g == 1 ? al_[i] : ah[i], g == 0 ? bl_[j] : bh[j], acc[i][j]), acc[i][j]);
-#endif
-                            }
-                SMG_PIN();
-            } else
+                            acc[i][j] = mfma_f16(g == 1 ? al_[i] : ah[i], g == 0 ? bl_[j] : bh[j], acc[i][j]);
+                            } else
             if constexpr (OP != 0) {         // single-piece operands: one term per tile
-                SMG_PIN();
-#pragma unroll
+                #pragma unroll
                 for (int i = 0; i < C::TM; ++i)
 #pragma unroll
                     for (int j = 0; j < C::TN; ++j) acc[i][j] = mfma_1p<OP>(ah[i], bh[j], acc[i][j]);
-                SMG_PIN();
-            } else {
+                            } else {
                 {
                     u32x4 al_[C::TM], bl_[C::TN];
 #pragma unroll
                     for (int i = 0; i < C::TM; ++i) al_[i] = fragA(A, wm0 + i * 32, s, 2);
 #pragma unroll
                     for (int j = 0; j < C::TN; ++j) bl_[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 2);
-                    SMG_PIN();   // keep every ds_read ahead of the MFMA block (hipcc re-interleaves them otherwise)
 #pragma unroll
                     for (int i = 0; i < C::TM; ++i)
 #pragma unroll
@@ -949,23 +873,20 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
                     for (int i = 0; i < C::TM; ++i)
 #pragma unroll
                         for (int j = 0; j < C::TN; ++j) acc[i][j] = mfma_bf16(al_[i], bh[j], acc[i][j]);
-                    SMG_PIN();
-                }
+                                    }
                 u32x4 am[C::TM], bm[C::TN];
 #pragma unroll
                 for (int i = 0; i < C::TM; ++i) am[i] = fragA(A, wm0 + i * 32, s, 1);
 #pragma unroll
                 for (int j = 0; j < C::TN; ++j) bm[j] = frag(B, C::LDUB, C::LDTB, wn0 + j * 32, s, 1);
-                SMG_PIN();
-#pragma unroll
+                #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int i = 0; i < C::TM; ++i)
 #pragma unroll
                         for (int j = 0; j < C::TN; ++j)
                             acc[i][j] = mfma_bf16((g & 1) ? ah[i] : am[i], g < 2 ? bm[j] : bh[j], acc[i][j]);   // mid*mid, hi*mid, mid*hi, hi*hi
-                SMG_PIN();
-            }
+                            }
         }
     };
 
@@ -1017,9 +938,7 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
             if (tr) trace[0] = smg_stamp();
 #endif
             if (more) g_load(kt + 1, ra[0], rb[0], kp[0]);
-#if SMG_PIN_LOADS
             __builtin_amdgcn_sched_barrier(0);
-#endif
             compute(buf);
             if constexpr (P::kSegmented) p.k_hook(ctx, kt, acc, sp);   // end of a K segment: fold acc away
 #ifdef SMG_TRACE_ITER
@@ -1055,26 +974,18 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
                 const bool tr = trace && kt == 4;
                 if (tr) trace[0] = smg_stamp();
 #endif
-#ifndef SMG_EXP_NOLOAD
                 g_load(kt + PD < KT ? kt + PD : KT - 1, ra[u], rb[u], kp[u]);   // slot u went to LDS one step ago
-#endif
-#if SMG_PIN_LOADS
                 __builtin_amdgcn_sched_barrier(0);
-#endif
                 compute(buf);
                 if constexpr (P::kSegmented) p.k_hook(ctx, kt, acc, sp);
 #ifdef SMG_TRACE_ITER
                 if (tr) { trace[1] = smg_stamp(); trace[2] = trace[1]; }
 #endif
-#ifndef SMG_EXP_NOSTORE
                 s_store(buf ^ 1, kt + 1 < KT ? kt + 1 : KT - 1, ra[(u + 1) % PD], rb[(u + 1) % PD], kp[(u + 1) % PD]);   // at kt + 1 == KT: a dead store of the clamped re-load
-#endif
 #ifdef SMG_TRACE_ITER
                 if (tr) trace[3] = smg_stamp();
 #endif
-#ifndef SMG_EXP_NOBARRIER
                 __syncthreads();
-#endif
 #ifdef SMG_TRACE_ITER
                 if (tr) trace[4] = smg_stamp();
 #endif
@@ -1166,6 +1077,7 @@ struct FwdConvP {
     using DstT = SrcT;
     static constexpr int kOp = (MODE == 3 || MODE == 4) ? fwd_op_plain(PREC) : fwd_op(PREC), kAE = 16 / SrcT::size, kBE = 4, ESZ = SrcT::size;
     static constexpr bool kARawCopy = false, kAUnit = false;
+    static constexpr bool kH = kOp == 2 || kOp == 3;      // the BN + ReLU operand becomes fp16: clamped to fp16's range (bnrelu4)
     const float* asc;               // operand kind 3: {s, 1 / s} of the BN + ReLU operand (scale_kernel)
     const void* src; int lds_;
     Plane ps, po;
@@ -1182,15 +1094,14 @@ struct FwdConvP {
     static constexpr int kSwizzle = 1;
     // k-tiles of global loads in flight: the one-MFMA-tile-per-wave configurations of the small planes do 0.1 us of MFMAs per
     // k-tile against ~1 us of memory latency
-    static constexpr bool kDeep = Cfg::BN == 128 && Cfg::BK == 32;      // one workgroup per CU: its own loads must cover the latency
-    static constexpr int kPrefetch = kDeep ? SMG_PD_FWD_DEEP : (Cfg::TM * Cfg::TN == 1) ? SMG_PD_FWD_SMALL : SMG_PD_FWD_BIG;
+    static constexpr int kPrefetch = (Cfg::TM * Cfg::TN == 1) ? kPdFwdSmall : kPdFwdBig;
     static constexpr bool kSegmented = false;
     static constexpr bool kStem = MODE == F_STEM || MODE == F_STEM1;
     static constexpr bool kHasPrologue = !kStem;
     static constexpr bool kEarlyFetch = false;
     static constexpr int kFresh = 32;       // growth rate: at most this many fresh channels
     // waves per SIMD the register allocator is held to: the 128x128 tile (64 accumulator registers) must stay at 3
-    static constexpr int kMinWaves = (Cfg::TM * Cfg::TN == 4 && MODE != F_POOL && !kDeep) ? SMG_FWD_BIG_MINWAVES : 1;    // (the pooling fetch holds 4 float4 per row)
+    static constexpr int kMinWaves = (Cfg::TM * Cfg::TN == 4 && MODE != F_POOL) ? kFwdBigMinWaves : 1;    // (the pooling fetch holds 4 float4 per row)
 
     struct Ctx { int n, m0, n0; };
     struct ARow { int y, x; bool valid; unsigned off; };     // off: element offset of the row inside its stream (F_ONE)
@@ -1252,7 +1163,7 @@ struct FwdConvP {
         r.valid = p < po.HW;
         r.y = p / po.W;
         r.x = p - r.y * po.W;
-        r.off = (unsigned)ESZ * (unsigned)((MODE == F_ONE ? SMG_EXP_WRAP_F1(p) : p) * lds_);    // byte offset of the row inside its stream
+        r.off = (unsigned)ESZ * (unsigned)(p * lds_);    // byte offset of the row inside its stream
     }
     struct RawTaps { float4 v[1]; bool ok; unsigned m; };      // F_STEM1: four gathered taps + which of them exist
     using ARaw = typename std::conditional<MODE == F_STEM1, RawTaps, RawT<(MODE == F_POOL) ? 4 : 1>>::type;
@@ -1334,16 +1245,16 @@ struct FwdConvP {
         } else if constexpr (MODE == F_STEM) {
             return o.ok ? o.v[0] : zero4();
         } else {
-            if constexpr (MODE == F_ONE) return bnrelu4(o.v[0], k);
+            if constexpr (MODE == F_ONE) return bnrelu4<kH>(o.v[0], k);
             if (!o.ok) return zero4();                   // zero padding applies AFTER bn + relu
             if constexpr (MODE == F_POOL) {
-                float4 s = bnrelu4(o.v[0], k);
-                s = add4(s, bnrelu4(o.v[1], k));
-                s = add4(s, bnrelu4(o.v[2], k));
-                s = add4(s, bnrelu4(o.v[3], k));
+                float4 s = bnrelu4<kH>(o.v[0], k);
+                s = add4(s, bnrelu4<kH>(o.v[1], k));
+                s = add4(s, bnrelu4<kH>(o.v[2], k));
+                s = add4(s, bnrelu4<kH>(o.v[3], k));
                 return make_float4(s.x * 0.25f, s.y * 0.25f, s.z * 0.25f, s.w * 0.25f);
             } else {
-                return bnrelu4(o.v[0], k);
+                return bnrelu4<kH>(o.v[0], k);
             }
         }
     }
@@ -1363,9 +1274,6 @@ struct FwdConvP {
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) v[0][j] = v[1][j] = 0.0;
         if constexpr (kOp == 3) {          // the products were formed on scaled operands: exact power-of-two correction
-#ifdef SMG_EPI_NOP
-            __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-#endif
             const float inv = asc[1] * pack_inv_scale(wp);
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i)
@@ -1498,14 +1406,12 @@ struct BwdDataP {
     float eps;
     TileMap tm;
     static constexpr int kSwizzle = 1;
-    static constexpr int kPrefetch = (Cfg::TM * Cfg::TN <= 2) ? SMG_PD_DGRAD : SMG_PD_DGRAD_BIG;
+    static constexpr int kPrefetch = (Cfg::TM * Cfg::TN <= 2) ? kPdDgrad : kPdDgradBig;
     static constexpr bool kSegmented = false;
     static constexpr bool kHasPrologue = true;
     static constexpr bool kEarlyFetch = EMODE != E_UNPOOL;     // early_fetch(): the epilogue's operands, issued behind the first k-tiles' loads
-#ifndef SMG_DGU_WAVES
-#define SMG_DGU_WAVES 3      // the transitions' un-pooling data gradient: 172 -> 152 registers without scratch, 169 -> 163 us per launch
-#endif
-    static constexpr int kMinWaves = (PREC == 0 && EMODE == E_UNPOOL) ? SMG_DGU_WAVES : 1;       // (3 waves per SIMD for the 128 x 64 accumulate form: 168 VGPRs + 88 bytes of scratch, serialised total 19.0 -> 19.4 ms)
+    // the transitions' un-pooling data gradient held to 3 waves per SIMD: 172 -> 152 registers without scratch, 169 -> 163 us per launch
+    static constexpr int kMinWaves = (PREC == 0 && EMODE == E_UNPOOL) ? 3 : 1;       // (3 waves per SIMD for the 128 x 64 accumulate form: 168 VGPRs + 88 bytes of scratch, serialised total 19.0 -> 19.4 ms)
 
     // AFF = false: the gradient operand is finished (xbuf unused).  Pointwise and finished -> descriptor loads, rows outside
     // the plane carry the out-of-range offset and read as zero (no mask, no address arithmetic in the k-loop).
@@ -1936,15 +1842,13 @@ struct BwdDataGroupP {
     // deep k-tiles with ONE tile of loads in flight (the staging registers of two half-as-deep tiles, half the barriers): mode 0
     // 128 x 64 x 32 (serialised 1.61 -> 1.47 ms per step), 16-bit modes 128 x 64 x 64 and 64 x 64 x 64 (config 3: 1.95 -> 1.79 and
     // 1.54 -> 1.35 ms, step 28.8 -> 28.3 ms)
-    static constexpr int kPrefetch = ((PREC == 0 && Cfg::BK >= 32 && Cfg::TM * Cfg::TN >= 2) || (PREC != 0 && Cfg::BK >= 64)) ? SMG_PD_DGRAD_GROUP
-                                     : (Cfg::TM * Cfg::TN <= 1) ? SMG_PD_DGRAD : SMG_PD_DGRAD_BIG;
+    static constexpr int kPrefetch = ((PREC == 0 && Cfg::BK >= 32 && Cfg::TM * Cfg::TN >= 2) || (PREC != 0 && Cfg::BK >= 64)) ? kPdDgradGroup
+                                     : (Cfg::TM * Cfg::TN <= 1) ? kPdDgrad : kPdDgradBig;
     static constexpr bool kSegmented = true;
     static constexpr bool kHasPrologue = true;
     static constexpr bool kEarlyFetch = true;
-#ifndef SMG_DGG_SMALL_WAVES
-#define SMG_DGG_SMALL_WAVES 3      // mode 0, 64-row tile: 176 -> 168 VGPRs (40 bytes of scratch), 3 workgroups per SIMD: 121.7 -> 100.2 us per launch (blocks 3-4)
-#endif
-    static constexpr int kMinWaves = (PREC == 0 && Cfg::BM == 64) ? SMG_DGG_SMALL_WAVES : 2;       // (x, the running sum and the old G' of the tile live in registers)
+    // mode 0, 64-row tile held to 3 waves per SIMD: 176 -> 168 VGPRs (a few bytes of scratch), 121.7 -> 100.2 us per launch (blocks 3-4)
+    static constexpr int kMinWaves = (PREC == 0 && Cfg::BM == 64) ? 3 : 2;       // (x, the running sum and the old G' of the tile live in registers)
 
     struct Ctx {
         int n, m0, n0; bool whole;
@@ -2309,7 +2213,7 @@ enum { W_ONE = 0, W_THREE = 1, W_POOL = 2, W_STEM = 3, W_STEM1 = 4 };      // W_
 enum { C_IDENT = 0, C_3x3 = 1, C_STEM = 2, C_STEM1 = 3 };                  // C_STEM1: column = tap, written to all three input channels
 
 // PREC: the engine's precision mode; F32IO: every buffer is fp32 whatever the mode (head conv0; the stem's image / plane).
-template <class Cfg_, int BMODE, int CMAP, int PD_ = SMG_PD_WGRAD, bool AFF = true, int PREC = 0, bool F32IO_ = false>
+template <class Cfg_, int BMODE, int CMAP, int PD_ = kPdWgrad, bool AFF = true, int PREC = 0, bool F32IO_ = false>
 struct BwdWeightP {
     using Cfg = Cfg_;
     static_assert(!Cfg::AT, "weight-gradient form");
@@ -2321,6 +2225,7 @@ struct BwdWeightP {
     static constexpr int kOp = (!AFF && BMODE == 0) ? bwd_op(PREC) : bwd_op_plain(PREC), kAE = 16 / GT::size, kBE = 16 / XT::size, GSZ = GT::size, XSZ = XT::size;
     static constexpr bool kARawCopy = !AFF && kAE == 8;      // finished bf16 gradient: copied to LDS as it is
     static constexpr bool kAUnit = !AFF && BMODE == 0 && kOp == 3;      // the gradient operand arrives in unit form (kD2K8): gbuf = units
+    static constexpr bool kH = kOp == 3;      // the BN + ReLU operand B becomes fp16 (the gradient side of modes 1 / 2 is bf16): clamped (bnrelu4)
     const float* binv;              // operand kind 3: [streams][HWp / 64] inverse block scales of gbuf (bn_bwd_apply_split_kernel)
     const float* basc;              // operand kind 3: {s, 1 / s} of the BN + ReLU operand B (scale_kernel)
     const void* gbuf; int ldg; int gcoff;
@@ -2478,7 +2383,7 @@ struct BwdWeightP {
         if constexpr (!AFF) {
             o.ok = true;
             o.v[0] = bload4(static_cast<const char*>(gbuf) + (int64_t)GSZ * ((int64_t)c.n * pa.HWp * ldg + gcoff), (unsigned)GSZ * (unsigned)(pa.HW * ldg - gcoff),
-                            ch < MA ? (unsigned)GSZ * (unsigned)(kr * ldg + ch) : kOOB, (unsigned)GSZ * (unsigned)(SMG_EXP_WRAP_W1A(c.p0 + kt * Cfg::BK) * ldg));
+                            ch < MA ? (unsigned)GSZ * (unsigned)(kr * ldg + ch) : kOOB, (unsigned)GSZ * (unsigned)((c.p0 + kt * Cfg::BK) * ldg));
             return o;
         }
         o.ok = r.p < pa.HW && ch < MA;
@@ -2515,7 +2420,7 @@ struct BwdWeightP {
             // past NB read the neighbouring channels of the row - their columns are never stored
             o.ok = true;
             o.v[0] = bload4(static_cast<const char*>(bbuf) + (int64_t)XSZ * c.n * pb.HWp * ldb, (unsigned)XSZ * (unsigned)(pb.HW * ldb), (unsigned)XSZ * (unsigned)(kr * ldb + ch),
-                            (unsigned)XSZ * (unsigned)(SMG_EXP_WRAP_W1(c.p0 + kt * Cfg::BK) * ldb));
+                            (unsigned)XSZ * (unsigned)((c.p0 + kt * Cfg::BK) * ldb));
         } else if constexpr (BMODE == W_THREE) {
             const int yy = r.y + c.tap / 3 - 1, xx = r.x + c.tap % 3 - 1;
             o.ok = o.ok && (unsigned)yy < (unsigned)pb.H && (unsigned)xx < (unsigned)pb.W;
@@ -2565,16 +2470,16 @@ struct BwdWeightP {
         } else if constexpr (BMODE == W_STEM) {
             return o.ok ? o.v[0] : zero4();
         } else {
-            if constexpr (BMODE == W_ONE) return bnrelu4(o.v[0], f);
+            if constexpr (BMODE == W_ONE) return bnrelu4<kH>(o.v[0], f);      // (rows of the plane padding: zeros in, clamped out - see bnrelu4)
             if (!o.ok) return zero4();
             if constexpr (BMODE == W_POOL) {
-                float4 s = bnrelu4(o.v[0], f);
-                s = add4(s, bnrelu4(o.v[1], f));
-                s = add4(s, bnrelu4(o.v[2], f));
-                s = add4(s, bnrelu4(o.v[3], f));
+                float4 s = bnrelu4<kH>(o.v[0], f);
+                s = add4(s, bnrelu4<kH>(o.v[1], f));
+                s = add4(s, bnrelu4<kH>(o.v[2], f));
+                s = add4(s, bnrelu4<kH>(o.v[3], f));
                 return make_float4(s.x * 0.25f, s.y * 0.25f, s.z * 0.25f, s.w * 0.25f);
             } else {
-                return bnrelu4(o.v[0], f);
+                return bnrelu4<kH>(o.v[0], f);
             }
         }
     }

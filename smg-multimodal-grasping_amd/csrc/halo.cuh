@@ -25,13 +25,9 @@
 #pragma once
 #include "gemm.cuh"
 
-// dev knobs: waves per SIMD the register allocator is held to (512 / n registers per lane)
-#ifndef SMG_HALO_FWD_WAVES
-#define SMG_HALO_FWD_WAVES 2
-#endif
-#ifndef SMG_HALO_WGRAD_WAVES
-#define SMG_HALO_WGRAD_WAVES 2
-#endif
+// waves per SIMD the register allocator is held to (512 / n registers per lane); three for the 16 x 16 forward: 168 VGPRs with 128 bytes
+// of scratch, 64 -> 111 us per launch
+namespace smg { constexpr int kHaloFwdWaves = 2, kHaloWgradWaves = 2; }
 
 namespace smg {
 
@@ -86,7 +82,7 @@ template <int TS, int PREC> struct HaloFwdSGeo : HaloGeo<TS> {
 };
 
 template <int TS, int PREC = 0>
-static __global__ __launch_bounds__(256, SMG_HALO_FWD_WAVES) void conv3x3_halo_fwd_kernel(const Halo3x3FwdArgs a) {
+static __global__ __launch_bounds__(256, kHaloFwdWaves) void conv3x3_halo_fwd_kernel(const Halo3x3FwdArgs a) {
     using G = HaloFwdSGeo<TS, PREC>;
     using ST = act_t<PREC>;
     constexpr int OP = fwd_op(PREC), NP = G::NP, CK = G::CK, K8C = G::K8C, KSTEP = CK / 16;
@@ -200,9 +196,9 @@ static __global__ __launch_bounds__(256, SMG_HALO_FWD_WAVES) void conv3x3_halo_f
                 if (more) load_hl(set ^ 1, tap + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = SMG_TERM(true, mfma_f16(ah[set][0][m], bl[set], acc[m]), acc[m]);
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_f16(ah[set][0][m], bl[set], acc[m]);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = SMG_TERM(true, mfma_f16(al[set][m], bh[set][0], acc[m]), acc[m]);
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_f16(al[set][m], bh[set][0], acc[m]);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[m] = mfma_f16(ah[set][0][m], bh[set][0], acc[m]);
                 return;
@@ -536,7 +532,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[m] = SMG_TERM(g < 2, mfma_f16(af[ks][m][g == 1 ? 1 : 0], bf[ks][g == 0 ? 1 : 0], acc[m]), acc[m]);
+                    for (int m = 0; m < MT; ++m) acc[m] = mfma_f16(af[ks][m][g == 1 ? 1 : 0], bf[ks][g == 0 ? 1 : 0], acc[m]);
         } else
         if constexpr (OP != 0) {                            // single-piece operands: one term per k16-step
             u32x4 ah[2][MT], bh[2];
@@ -659,7 +655,7 @@ template <int TW, int PREC> struct HaloWgradSGeo {
 };
 
 template <int TW, int PREC = 0>
-static __global__ __launch_bounds__(256, SMG_HALO_WGRAD_WAVES) void conv3x3_halo_wgrad_kernel(const Halo3x3WgradArgs a) {
+static __global__ __launch_bounds__(256, kHaloWgradWaves) void conv3x3_halo_wgrad_kernel(const Halo3x3WgradArgs a) {
     using G = HaloWgradSGeo<TW, PREC>;
     using GT = grd_t<PREC>;
     using XT = act_t<PREC>;
@@ -794,7 +790,7 @@ static __global__ __launch_bounds__(256, SMG_HALO_WGRAD_WAVES) void conv3x3_halo
 #pragma unroll
                     for (int g = 0; g < 3; ++g)
 #pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) acc[dy * 3 + dx] = SMG_TERM(g < 2, mfma_f16(af[g == 1 ? 1 : 0], bf[dx][g == 0 ? 1 : 0], acc[dy * 3 + dx]), acc[dy * 3 + dx]);
+                        for (int dx = 0; dx < 3; ++dx) acc[dy * 3 + dx] = mfma_f16(af[g == 1 ? 1 : 0], bf[dx][g == 0 ? 1 : 0], acc[dy * 3 + dx]);
                 } else
                 if constexpr (OP != 0) {                    // single-piece operands: one term per tap
 #pragma unroll

@@ -66,7 +66,7 @@ static __global__ __launch_bounds__(512, 1) void conv1x1_fwd_ws_kernel(const Fwd
     const float* a_base = a.src + (int64_t)n * a.pl.HWp * a.lds_;
     unsigned a_voff[G::A_N];
 #pragma unroll
-    for (int i = 0; i < G::A_N; ++i) a_voff[i] = 4u * (unsigned)(SMG_EXP_WRAP_F1(pbase + al + 32 * i) * a.lds_ + 4 * aq);
+    for (int i = 0; i < G::A_N; ++i) a_voff[i] = 4u * (unsigned)((pbase + al + 32 * i) * a.lds_ + 4 * aq);
     unsigned b_voff[G::B_N];
 #pragma unroll
     for (int i = 0; i < G::B_N; ++i) {
@@ -88,7 +88,7 @@ static __global__ __launch_bounds__(512, 1) void conv1x1_fwd_ws_kernel(const Fwd
         f.mean = ldv4(sp + ch); f.scale = ldv4(sp + K + ch); f.beta = ldv4(sp + 2 * K + ch);
 #pragma unroll
         for (int i = 0; i < G::A_N; ++i) {
-            const Split4 s = split4<OP>(bnrelu4(xa[i], f));
+            const Split4 s = split4<OP>(bnrelu4<OP == 3>(xa[i], f));
             const int row = al + 32 * i;
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc)
@@ -147,8 +147,8 @@ static __global__ __launch_bounds__(512, 1) void conv1x1_fwd_ws_kernel(const Fwd
                 bf[pc] = *reinterpret_cast<const u32x4*>(B + ((pc * G::K8 + k8) * G::LDUB + wn0 + l31) * 16);
             }
             if constexpr (OP == 3) {
-                acc = SMG_TERM(true, mfma_f16(af[0], bf[1], acc), acc);
-                acc = SMG_TERM(true, mfma_f16(af[1], bf[0], acc), acc);
+                acc = mfma_f16(af[0], bf[1], acc);
+                acc = mfma_f16(af[1], bf[0], acc);
                 acc = mfma_f16(af[0], bf[0], acc);
             } else {
                 acc = mfma_bf16(af[0], bf[2], acc);

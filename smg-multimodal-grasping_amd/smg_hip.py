@@ -227,15 +227,18 @@ class Engine(object):
         else:
             check(lib().smg_backward_phase(self.h, C.byref(net), dq, stream, int(phase)))
 
-    def debug_read(self, name, stream=None):
+    def debug_read(self, name, stream=None, count=None):
+        """count: read only the first `count` floats (a prefix of whole streams for the ring-slot names)."""
         n = lib().smg_debug_read(self.h, name.encode(), None, 0, stream)
         if n < 0:
             check(int(n))
+        if count is not None:
+            n = min(n, int(count))
         out = np.empty(n, dtype=np.float32)
         got = lib().smg_debug_read(self.h, name.encode(), out.ctypes.data_as(C.c_void_p), n, stream)
         if got < 0:
             check(int(got))
-        return out
+        return out[:got]
 
     def profile_enable(self, on):
         check(lib().smg_profile_enable(self.h, 1 if on else 0))

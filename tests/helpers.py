@@ -96,6 +96,8 @@ def grads_within_fp32_class(prod_named_params, oracle_named_params, g64, factor=
     for ratio, name, e_prod, e_orc, nrm in worst[:5]:
         print("grad check %s %-70s |err| %.3e  fp32-oracle |err| %.3e  |g| %.3e  (%.2f of the bound)" % (what, name, e_prod, e_orc, nrm, ratio))
     over = [w for w in worst if w[0] > 1.0]
+    print("grad check %s: %d of %d tensors past the per-tensor bound; median / 90th-percentile relative error %.2e / %.2e (fp32 oracle %.2e / %.2e)"
+          % (what, len(over), len(rows), np.median(rel_p), np.percentile(rel_p, 90), np.median(rel_o), np.percentile(rel_o, 90)))
     assert len(over) <= max_outliers, "%s: |err| %.3e vs fp32-oracle |err| %.3e, |g| %.3e" % over[max_outliers][1:]
     for _, name, e_prod, e_orc, nrm in over:
         assert e_prod <= outlier_cap * nrm, "%s: |err| %.3e of |g| %.3e" % (name, e_prod, nrm)

@@ -670,6 +670,7 @@ def test_multi_scene_batch_equals_sum_of_single_scene_gradients(gpu, case):
     np.testing.assert_allclose(q_b.reshape(-1).cpu().numpy(), q_s, rtol=0, atol=2e-5)
     num = float((g_b - g_sum).double().norm())
     den = float(g_sum.double().norm())
+    print("batch vs sum of single-scene gradients (%s): |d| / |g| = %.3e" % (case, num / den))
     # only the fp32 summation order / ReLU-mask noise differs (ill-conditioned, see header): 0.5e-3 for the small case and
     # 2.7e-3 for the 64-sample one were measured; one missing sample of 64 would be 1.5e-2
     assert num <= (1.2e-2 if len(labels) < 10 else 5e-3) * den, (num, den)
@@ -983,9 +984,9 @@ print("RESULT " + json.dumps({"q": q.tolist(), "gnorm": float(np.sqrt((g * g).su
 
 def test_alternative_kernel_paths_agree(gpu):
     """The same sweep + one backward through independent implementations: the 3x3 layers through the LDS-halo kernels (default:
-    two-piece fp16 split, three MFMA terms) and through the generic implicit GEMM (SMG_GENERIC_3X3=1: the three-piece bf16 split,
+    two-piece fp16 split, three MFMA terms) and through the generic implicit GEMM (SMG_CROSSCHECK=1: the three-piece bf16 split,
     six terms - another kernel AND another arithmetic of the same fp32-class accuracy), and the 1x1 forward of the small planes
-    through the generic kernel instead of the wave-specialised one (SMG_C1_WS=0).  Separate child processes: the switches are
+    through the generic kernel instead of the wave-specialised one (SMG_CROSSCHECK=2).  Separate child processes: the switch is
     read at engine creation."""
     import json
     import os
@@ -993,10 +994,9 @@ def test_alternative_kernel_paths_agree(gpu):
     import sys
     tests_dir = os.path.dirname(os.path.abspath(__file__))
     res = {}
-    for tag, env in (("halo", {}), ("generic", {"SMG_GENERIC_3X3": "1"}), ("c1_generic", {"SMG_C1_WS": "0"})):
+    for tag, env in (("halo", {}), ("generic", {"SMG_CROSSCHECK": "1"}), ("c1_generic", {"SMG_CROSSCHECK": "2"})):
         e = dict(os.environ)
-        for k in ("SMG_GENERIC_3X3", "SMG_GS_FUSED", "SMG_C1_WS"):
-            e.pop(k, None)
+        e.pop("SMG_CROSSCHECK", None)
         e.update(env)
         out = subprocess.run([sys.executable, "-c", _VARIANT_SCRIPT % {"tests": tests_dir}], env=e, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
@@ -1079,6 +1079,7 @@ def test_data_parallel_two_ranks_equal_single_process_batch(gpu):
     g_one = tr.model.flat_grads().cpu().numpy()
     num = float(np.sqrt(((g_dp.astype(np.float64) - g_one) ** 2).sum()))
     den = float(np.sqrt((g_one.astype(np.float64) ** 2).sum()))
+    print("two data-parallel ranks vs the single-process batch: |d| / |g| = %.3e" % (num / den))
     assert num <= 1.2e-2 * den, (num, den)          # summation order / ReLU-mask noise only (see the multi-scene test: 6.2e-3 measured)
     q_one = tr.forward(scenes[0][0], scenes[0][0] * scenes[0][1][1], 0, True)
     assert q_dp.shape == (16,)
@@ -1227,8 +1228,8 @@ def _fp32_chain(a32, w32):
 @pytest.mark.parametrize("block,layer", [(1, 1), (2, 12), (3, 24)])
 def test_layer_products_within_fp32_chain_error(gpu, block, layer):
     """GEMM-level gate on the PRODUCT's kernels at real layer shapes (K = 64 / 480 / 992 for the 1x1, K = 1152 for the 3x3):
-    the raw output of one dense layer's conv1 (BN + ReLU + 3-piece bf16 split + six MFMA terms) and conv2, read back from
-    the engine, against the same layer evaluated in fp64 from the engine's own input buffer.  The error must stay within 2x
+    the raw output of one dense layer's conv1 (BN + ReLU + scaled two-piece fp16 split + three MFMA terms, operand kind 3) and
+    conv2, read back from the engine, against the same layer evaluated in fp64 from the engine's own input buffer.  The error must stay within 2x
     that of a plain fp32 multiply-add chain over the same operands - i.e. the split products are fp32-class arithmetic,
     independent of how the gradient gates of the end-to-end tests are set."""
     net = product_net(0)
@@ -1282,6 +1283,251 @@ def test_layer_products_within_fp32_chain_error(gpu, block, layer):
     e_chain = np.sqrt((((_fp32_chain(c32, wk).astype(np.float64) - ref) / mag) ** 2).mean())
     print("conv2 block %d layer %d K 1152: err/sum|ab| rms product %.3e, fp32 chain %.3e" % (block, layer, e_prod, e_chain))
     assert e_prod <= 2.0 * e_chain, (e_prod, e_chain)
+
+
+def _bn_stats64(v):
+    """per-channel (mean, invstd) of one stream's plane [pixels][C], in fp64 (training-mode BN, biased variance, eps 1e-5)"""
+    v64 = v.astype(np.float64)
+    return v64.mean(0), 1.0 / np.sqrt(v64.var(0) + 1e-5)
+
+
+@pytest.mark.parametrize("block,layer", [(1, 1), (2, 12), (3, 24)])
+def test_backward_layer_products_within_fp32_chain_error(gpu, block, layer):
+    """GEMM-level gate on the BACKWARD products (K = 64 / 480 / 992 layers, like the forward gate above): the backward stops behind
+    one dense layer (engine option debug_stop) and the test reads what that layer's kernels consumed and produced - GS and D2 from
+    their ring slots (D2 rebuilt from its fp16 units and block scales: the operand the MFMAs see), the raw 3x3 data gradient, the
+    block's G' in front of and behind the layer's 1x1 data gradients, the two weight gradients - and recomputes the four products
+    in fp64 from those buffers: conv2 data gradient, conv2 weight gradient, conv1 data gradient (per-layer or layer-grouped form),
+    conv1 weight gradient.  Each must stay within 2x the error of a plain fp32 multiply-add chain over the same operands.
+    Sample 3 enters with dq = 1e-6 (2^-20 of the others): its stream's gradient operands sit 20 binades below the rest."""
+    import synthetic
+    net = product_net(0)
+    depth, masks = synthetic.heightmap_scene(0)
+    hm = torch.from_numpy(np.stack([depth, depth * masks[0]])).to(gpu)
+    rots = [0, 3, 7, 10, 13]
+    NSu = len(rots) + 1
+    b, i = block - 1, layer - 1
+    L = (6, 12, 24, 16)[b]
+    q = net.run(0, rots, 16, heightmaps=hm, mean=MEAN, std=STD, keep_for_backward=True)
+    eng = engine_of(net)
+    dq = torch.tensor([1.0, -1.0, 0.5, 1e-6, -0.25], device=gpu).view(5, 1, 1, 1)
+    net.zero_grad()
+    eng.set_option("debug_stop", b * 100 + i)
+    try:
+        net._engine_backward(net._saved[1], dq)
+    finally:
+        eng.set_option("debug_stop", -1)
+    torch.cuda.synchronize()
+    H, HWp = eng.H[1 + block], eng.HWp[1 + block]
+    HW = H * H
+    Ct = (256, 512, 1024, 1024)[b]
+    cin = (64, 128, 256, 512)[b] + 32 * i
+
+    def rd(name, C):
+        return eng.debug_read(name, count=NSu * HWp * C).reshape(NSu, HWp, C)[:, :HW, :]
+    X, BT = rd("x%d" % block, Ct), rd("bt%d_%d" % (block, layer), 128)
+    GS, DY = rd("gs_%d_%d" % (block, layer), 32), rd("dy2", 128)
+    D2 = rd("d2_%d_%d" % (block, layer), 128)
+    G0, G1 = rd("gsnap", Ct), rd("g%d" % block, Ct)
+    sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    pre = "grasp_depth_trunk.features.denseblock%d.denselayer%d." % (block, layer)
+    grads = {n: p.grad.detach().cpu().numpy() for n, p in net.named_parameters() if p.grad is not None}
+
+    def check(what, got, ref, mag, chain, keep=None):
+        keep = np.ones(ref.shape, dtype=bool) if keep is None else keep
+        e_prod = np.sqrt(((((got.astype(np.float64) - ref) / mag) ** 2)[keep]).mean())
+        e_chain = np.sqrt(((((chain.astype(np.float64) - ref) / mag) ** 2)[keep]).mean())
+        print("%s block %d layer %d: err/sum|ab| rms product %.3e, fp32 chain %.3e (%d elements)" % (what, block, layer, e_prod, e_chain, int(keep.sum())))
+        assert e_prod <= 2.0 * e_chain, (what, e_prod, e_chain)
+
+    def bn_act(v, g, bta, dt):
+        """relu(bn(v)) of one stream's plane, fp64 or the kernels' fp32 form; also the fp64 pre-activation (borderline test)"""
+        mean, inv = _bn_stats64(v)
+        pre64 = (v.astype(np.float64) - mean) * inv * g.astype(np.float64) + bta.astype(np.float64)
+        if dt == np.float64:
+            return np.maximum(pre64, 0.0), pre64
+        sc = (g.astype(np.float64) * inv).astype(np.float32)
+        return np.maximum((v - mean.astype(np.float32)) * sc + bta, np.float32(0)).astype(np.float32), pre64
+
+    g2, b2 = sd[pre + "norm2.weight"], sd[pre + "norm2.bias"]
+    w2 = sd[pre + "conv2.weight"]                                      # [32][128][3][3]
+    rows = min(H, 24)
+
+    # ---- conv2 data gradient on a band of rows of stream 0 and of the 2^-20 stream: dy[p][k] = mask * sum_{tap, c} gs[p - d(tap)][c] * w2[c][k][tap]
+    wk_d = np.concatenate([w2[:, :, dy, dx].T for dy in range(3) for dx in range(3)], axis=1)      # [128][9 * 32], taps in the order of the gather below
+    for n in (0, 3):
+        gs = GS[n].reshape(H, H, 32)
+        pad = np.zeros((H + 2, H + 2, 32), dtype=np.float32)
+        pad[1:-1, 1:-1] = gs
+        col = np.concatenate([pad[2 - dy:2 - dy + rows, 2 - dx:2 - dx + H].reshape(rows * H, 32) for dy in range(3) for dx in range(3)], axis=1)
+        _, pre64 = bn_act(BT[n], g2, b2, np.float64)
+        pre_b = pre64.reshape(H, H, 128)[:rows].reshape(rows * H, 128)
+        scale_b = np.abs(BT[n].astype(np.float64) - _bn_stats64(BT[n])[0]).reshape(H, H, 128)[:rows].reshape(rows * H, 128) * np.abs(g2) * _bn_stats64(BT[n])[1] + np.abs(b2)
+        on = pre_b > 1e-5 * scale_b                                      # clearly inside the ReLU (borderline signs are the mask's business, not the GEMM's)
+        ref = col.astype(np.float64) @ wk_d.astype(np.float64).T
+        mag = np.abs(col).astype(np.float64) @ np.abs(wk_d).astype(np.float64).T + 1e-300
+        got = DY[n].reshape(H, H, 128)[:rows].reshape(rows * H, 128)
+        check("conv2 dgrad (stream %d)" % n, got, ref, mag, _fp32_chain(col, wk_d), keep=on)
+
+    # ---- norm2 backward as stored for the three 1x1 consumers (units + block scales) against fp64 from the raw gradient
+    for n in (0, 3):
+        mean, inv = _bn_stats64(BT[n])
+        xh = (BT[n].astype(np.float64) - mean) * inv
+        dy = DY[n].astype(np.float64)
+        ref = g2.astype(np.float64) * inv * (dy - dy.mean(0) - xh * (dy * xh).mean(0))
+        blk = np.abs(ref).reshape(-1, 64, 128).max(axis=(1, 2), keepdims=True) if HW % 64 == 0 else np.abs(ref).max()
+        err = np.abs(D2[n].astype(np.float64) - ref)
+        rel = (err.reshape(-1, 64, 128) / np.maximum(blk, 1e-300)).max() if HW % 64 == 0 else (err / blk).max()
+        print("norm2 backward in unit form, stream %d: max |err| / block max %.3e" % (n, rel))
+        assert rel <= 2e-5, rel                                          # fp32 evaluation of the affine form + 22-bit pieces (2^-22 = 2.4e-7 of the block's maximum)
+
+    # ---- conv2 weight gradient: dW2[c][k][tap] = sum_{stream, p} gs[p][c] * relu(bn2(bt))[p + d(tap)][k]
+    a64s, a32s = [], []
+    for n in range(NSu):
+        a64, _ = bn_act(BT[n], g2, b2, np.float64)
+        a32, _ = bn_act(BT[n], g2, b2, np.float32)
+        for a, lst in ((a64, a64s), (a32, a32s)):
+            padk = np.zeros((H + 2, H + 2, 128), dtype=a.dtype)
+            padk[1:-1, 1:-1] = a.reshape(H, H, 128)
+            lst.append(np.concatenate([padk[dy:dy + H, dx:dx + H].reshape(HW, 128) for dy in range(3) for dx in range(3)], axis=1))
+    A64, A32 = np.concatenate(a64s), np.concatenate(a32s)                # [streams * HW][9 * 128]
+    Gs = GS.reshape(NSu * HW, 32)
+    sub = slice(0, None, max(1, (NSu * HW) // 20000))                   # the fp32 chain walks every term: thin the reduction on the big planes
+    ref = Gs[sub].astype(np.float64).T @ A64[sub]
+    mag = np.abs(Gs[sub]).astype(np.float64).T @ np.abs(A64[sub]) + 1e-300
+    if sub.step == 1:
+        got = grads[pre + "conv2.weight"].transpose(0, 2, 3, 1).reshape(32, 9 * 128)      # [c][tap][k] like the im2col columns
+        check("conv2 wgrad", got, ref, mag, _fp32_chain(np.ascontiguousarray(Gs[sub].T), np.ascontiguousarray(A32[sub].T)))
+    else:
+        # big planes: the whole reduction against fp64 at the fp32 chain's error of a thinned reduction scaled by sqrt(terms ratio)
+        ref_all = Gs.astype(np.float64).T @ A64
+        mag_all = np.abs(Gs).astype(np.float64).T @ np.abs(A64) + 1e-300
+        got = grads[pre + "conv2.weight"].transpose(0, 2, 3, 1).reshape(32, 9 * 128)
+        e_prod = np.sqrt((((got.astype(np.float64) - ref_all) / mag_all) ** 2).mean())
+        e_chain = np.sqrt((((_fp32_chain(np.ascontiguousarray(Gs[sub].T), np.ascontiguousarray(A32[sub].T)).astype(np.float64) - ref) / mag) ** 2).mean())
+        print("conv2 wgrad block %d layer %d: err/sum|ab| rms product %.3e (all %d terms), fp32 chain %.3e (every %dth term)" % (block, layer, e_prod, NSu * HW, e_chain, sub.step))
+        assert e_prod <= 2.0 * e_chain * np.sqrt(sub.step), (e_prod, e_chain)      # (a chain's error grows like the square root of its length)
+
+    # ---- conv1 data gradient: G'[p][c] += gamma1[c] * relu'(bn1(x))[p][c] * sum_k D2[p][k] * w1[k][c]
+    g_lo = i - (0 if (L - 1 - i) % 4 == 3 else min(i, 3 - (L - 1 - i) % 4))
+    cs = (64, 128, 256, 512)[b] + 32 * g_lo
+    segs = []                                                             # (layer, column range) pairs whose contribution landed between the snapshots
+    if cin > cs:
+        segs.append(([layer], cs, cin))
+    if i == g_lo:
+        g_hi = L - 1 - ((L - 1 - g_lo) // 4) * 4
+        segs.append((list(range(g_lo + 1, g_hi + 2)), 0, cs))
+    for layers, c0, c1 in segs:
+        for n in (0, 3):
+            take = slice(0, min(HW, 4096))
+            ref = G0[n][take, c0:c1].astype(np.float64)
+            mag = np.abs(ref) + 1e-300
+            ch = G0[n][take, c0:c1].copy()
+            keep = np.ones(ref.shape, dtype=bool)
+            mean, inv = _bn_stats64(X[n][:, c0:c1])
+            for lyr in layers:
+                prl = "grasp_depth_trunk.features.denseblock%d.denselayer%d." % (block, lyr)
+                g1, b1_ = sd[prl + "norm1.weight"][c0:c1], sd[prl + "norm1.bias"][c0:c1]
+                w1 = sd[prl + "conv1.weight"].reshape(128, -1)[:, c0:c1]                   # [128][cols]
+                d2 = rd("d2_%d_%d" % (block, lyr), 128)[n][take]
+                pre64 = (X[n][take, c0:c1].astype(np.float64) - mean) * inv * g1 + b1_
+                sc = np.abs(X[n][take, c0:c1].astype(np.float64) - mean) * inv * np.abs(g1) + np.abs(b1_)
+                keep &= np.abs(pre64) > 1e-5 * sc
+                m = pre64 > 0
+                ref = ref + g1.astype(np.float64) * m * (d2.astype(np.float64) @ w1.astype(np.float64))
+                mag = mag + np.abs(g1).astype(np.float64) * m * (np.abs(d2).astype(np.float64) @ np.abs(w1).astype(np.float64))
+                ch = (ch + (g1 * m).astype(np.float32) * _fp32_chain(d2, np.ascontiguousarray(w1.T))).astype(np.float32)
+            check("conv1 dgrad (stream %d, layers %s, columns %d..%d)" % (n, layers, c0, c1), G1[n][take, c0:c1], ref, mag, ch, keep=keep)
+
+    # ---- conv1 weight gradient: dW1[k][c] = sum_{stream, p} D2[p][k] * relu(bn1(x))[p][c]
+    g1, b1_ = sd[pre + "norm1.weight"], sd[pre + "norm1.bias"]
+    a64 = np.concatenate([bn_act(X[n][:, :cin], g1, b1_, np.float64)[0] for n in range(NSu)])
+    a32 = np.concatenate([bn_act(X[n][:, :cin], g1, b1_, np.float32)[0] for n in range(NSu)])
+    D2f = D2.reshape(NSu * HW, 128)
+    ref_all = D2f.astype(np.float64).T @ a64
+    mag_all = np.abs(D2f).astype(np.float64).T @ np.abs(a64) + 1e-300
+    got = grads[pre + "conv1.weight"].reshape(128, cin)
+    ref = D2f[sub].astype(np.float64).T @ a64[sub]
+    mag = np.abs(D2f[sub]).astype(np.float64).T @ np.abs(a64[sub]) + 1e-300
+    e_prod = np.sqrt((((got.astype(np.float64) - ref_all) / mag_all) ** 2).mean())
+    e_chain = np.sqrt((((_fp32_chain(np.ascontiguousarray(D2f[sub].T), np.ascontiguousarray(a32[sub].T)).astype(np.float64) - ref) / mag) ** 2).mean())
+    print("conv1 wgrad block %d layer %d K %d: err/sum|ab| rms product %.3e (all %d terms), fp32 chain %.3e (every %dth term)" % (block, layer, cin, e_prod, NSu * HW, e_chain, sub.step))
+    assert e_prod <= 2.0 * e_chain * np.sqrt(sub.step), (e_prod, e_chain)
+
+
+def test_padded_rows_of_a_near_constant_channel_stay_finite(gpu):
+    """Planes whose pixel count is not a multiple of 64 carry padding rows (the 20 x 20 planes of block 4: 448 rows for 400 pixels),
+    which the 1x1 kernels read as they lie: zeros.  BN + ReLU of a zero on a channel with |mean| / std in the thousands, times the
+    fp16 operand scale, lies past fp16's range; unclamped it became inf and - against the zero gradient rows of the padding - NaN
+    in a whole column of that layer's conv1 weight gradient.  Build such a channel (a 3x3 convolution reduced to its centre tap
+    over a nearly constant BN + ReLU input, with a negative mean) and require finite gradients everywhere."""
+    import synthetic
+    net = product_net(0)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    pre = "grasp_depth_trunk.features.denseblock4.denselayer3."
+    with torch.no_grad():
+        sd[pre + "norm2.weight"].fill_(1e-4)          # relu(1e-4 * xhat + 1) ~ 1: a nearly constant input of conv2
+        sd[pre + "norm2.bias"].fill_(1.0)
+        w = sd[pre + "conv2.weight"]
+        w.zero_()
+        w[:, :, 1, 1] = -0.5                            # centre tap only (no border effect), negative: mean ~ -64 at a standard deviation of ~ sqrt(eps)
+        # the next layers read those 32 channels through their norm1: positive gamma -> relu(gamma * (0 - mean) * invstd + beta) is huge on padding rows
+        for l in (4, 5):
+            sd["grasp_depth_trunk.features.denseblock4.denselayer%d.norm1.weight" % l].abs_().clamp_(min=0.5)
+    net.load_state_dict(sd)
+    depth, masks = synthetic.heightmap_scene(0)
+    hm = torch.from_numpy(np.stack([depth, depth * masks[0]])).to(gpu)
+    rots = [0, 3, 7, 10, 13]
+    q = net.run(0, rots, 16, heightmaps=hm, mean=MEAN, std=STD, keep_for_backward=True)
+    assert torch.isfinite(q).all()
+    eng = engine_of(net)
+    X4 = eng.debug_read("x4", count=6 * eng.HWp[5] * 1024).reshape(6, eng.HWp[5], 1024)[:, :400, 512 + 64:512 + 96].astype(np.float64)
+    ratio = np.abs(X4.mean(1)) / np.sqrt(X4.var(1) + 1e-5)
+    print("constructed channels: |mean| / std up to %.0f" % ratio.max())
+    assert ratio.max() > 17000, ratio.max()             # gamma (>= 0.5) * ratio * operand scale (>= 8) past 65504: the unclamped operand overflows fp16
+    net.zero_grad()
+    net._engine_backward(net._saved[1], torch.tensor([1.0, -1.0, 0.5, 0.3, -0.25], device=gpu).view(5, 1, 1, 1))
+    torch.cuda.synchronize()
+    bad = [n for n, p in net.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
+    assert not bad, bad[:5]
+
+
+def test_forward_is_bit_reproducible_run_to_run(gpu):
+    """The same 17-stream sweep three times in one process: every dense-block buffer, every bottleneck and the Q values bit for
+    bit equal to the first run; the fp64 BN sums (accumulated with fp64 atomics, whose order is not fixed) equal to rounding.
+    This is the detector of DESIGN.md 3.1's compiler fact (hipcc's SLP vectoriser packing unrelated fp32 scalars of the epilogues:
+    BN sums off by 1e-3 run to run with bit-identical stored values) - the build keeps -fno-slp-vectorize because of it."""
+    import models
+    import synthetic
+    from trainer import Trainer
+    tr = Trainer('reinforcement', 0.5, False, None, False)
+    sd = synthetic.make_state_dict(orc.state_layout(1), 0)
+    tr.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    tr.model.gnum_rotations = tr.model.snum_rotations = 16
+    depth, masks = synthetic.heightmap_scene(0)
+    hm = tr._heightmaps_to_device(depth, depth * masks[0])
+    names = ["x1", "x2", "x3", "x4"] + ["bt%d_%d" % (b + 1, i + 1) for b in range(4) for i in ((0, 5), (0, 11), (0, 23), (0, 15))[b]]
+    fs_names = ["fs_bt1_1", "fs_bt2_12", "fs_bt4_16"]
+    ref = None
+    for it in range(3):
+        q = tr.model.run(0, list(range(16)), 16, heightmaps=hm, mean=MEAN, std=STD, update_bn=False)
+        torch.cuda.synchronize()
+        eng = models._ENGINES[(0, 640, 1)]
+        def count(n):      # the 17 streams of the sweep (the engine may be sized for more)
+            blk = int(n[1] if n[0] == 'x' else n[2])
+            return 17 * eng.HWp[1 + blk] * ((256, 512, 1024, 1024)[blk - 1] if n[0] == 'x' else 128)
+        cur = {n: eng.debug_read(n, count=count(n)).copy() for n in names}
+        cur["q"] = q.reshape(-1).cpu().numpy()
+        fs = {n: eng.debug_read(n).view(np.float64).copy() for n in fs_names}
+        if ref is None:
+            ref, fs_ref = cur, fs
+            continue
+        for n in names + ["q"]:
+            assert np.array_equal(cur[n].view(np.uint32), ref[n].view(np.uint32)), "run %d: %s differs (%d elements)" % (it, n, int((cur[n] != ref[n]).sum()))
+        for n in fs_names:
+            a, b_ = fs[n].reshape(2, -1, 128)[:, :17], fs_ref[n].reshape(2, -1, 128)[:, :17]
+            rel = float(np.max(np.abs(a - b_) / np.maximum(np.abs(b_), 1e-300)))
+            assert rel <= 1e-12, (n, rel)
 
 
 def test_deterministic_option_gives_bit_identical_conv_weight_gradients(gpu):
