@@ -285,7 +285,7 @@ def compact_line(out):
         c["cpu_baseline"] = {k: _r(cb[k]) for k in ("value", "unit", "cores", "kind", "seconds_per_pass", "physical_cores",
                                                     "value_physical_cores", "seconds_per_pass_physical_cores", "sweep_fwd_seconds") if k in cb}
         c["cpu_baseline"]["sample"] = cb.get("sample", "")[:100]
-    for k in ("pass_tflops_algorithmic", "host_enqueue_ms_per_step", "ms_per_step_host_inputs", "sweep_fwd_ms", "train_step_ms",
+    for k in ("pass_tflops_algorithmic", "host_enqueue_ms_per_step", "ms_per_step_host_inputs", "sweep_fwd_ms", "train_step_ms", "train_step_host_enqueue_ms", "train_step_eager_ms",
               "train_step_kernel_ms", "train_step_launches", "forward_1rot_ms", "launches_per_step", "allreduce_overlapped", "allreduce_exposed_ms_per_step",
               "allreduce_ms", "allreduce_bytes", "allreduce_backend", "rccl_world", "device_count", "devices_seen"):
         if k in out:
@@ -597,17 +597,34 @@ def main():
             torch.cuda.synchronize(dev)
             n_1 = max(5, args.steps // 2)
             t_h = time.perf_counter()
+            enq = 0.0
             for i in range(n_1):
                 one_backprop(i)
+                enq += tr.last_enqueue_ms
             torch.cuda.synchronize(dev)
-            out["train_step_ms"] = (time.perf_counter() - t_h) / n_1 * 1e3
-            # the same step's kernels serialised on one stream with hipEvents around every launch: what the GPU needs for it
+            out["train_step_ms"] = (time.perf_counter() - t_h) / n_1 * 1e3          # one replayed hipGraph per step (smg_train_step_graph)
+            out["train_step_host_enqueue_ms"] = enq / n_1                           # host time per step up to the loss read-back
+            # the same step as separate engine calls (no graph), and its kernels serialised on one stream with hipEvents around
+            # every launch: what the GPU needs for it
+            tr.use_step_graph = False
+            for i in range(2):
+                one_backprop(i)
+            torch.cuda.synchronize(dev)
+            t_h = time.perf_counter()
+            enq = 0.0
+            for i in range(n_1):
+                one_backprop(i)
+                enq += tr.last_enqueue_ms
+            torch.cuda.synchronize(dev)
+            out["train_step_eager_ms"] = (time.perf_counter() - t_h) / n_1 * 1e3
+            out["train_step_eager_host_enqueue_ms"] = enq / n_1
             eng.profile_enable(True)
             for i in range(3):
                 one_backprop(i)
             torch.cuda.synchronize(dev)
             p1 = eng.profile_read()
             eng.profile_enable(False)
+            tr.use_step_graph = True
             out["train_step_kernel_ms"] = sum(v[0] for v in p1.values()) / 3.0
             out["train_step_launches"] = sum(v[1] for v in p1.values()) // 3
             for i in range(2):

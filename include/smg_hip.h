@@ -41,8 +41,8 @@ typedef struct smg_engine smg_engine;
 /* ---- library ------------------------------------------------------------------ */
 const char* smg_last_error(void);
 /* ABI revision of this header: a binding must refuse a library whose smg_version() differs (stale .so) and should
- * compare its own struct sizes with smg_abi_struct_bytes(0 = smg_batch, 1 = smg_net) before the first call. */
-#define SMG_ABI_VERSION 3
+ * compare its own struct sizes with smg_abi_struct_bytes(0 = smg_batch, 1 = smg_net, 2 = smg_adam) before the first call. */
+#define SMG_ABI_VERSION 4
 int smg_version(void);
 int smg_abi_struct_bytes(int which);
 
@@ -207,6 +207,22 @@ int smg_argmax(const float* values_dev, int n, int* idx_out_dev, float* val_out_
  * segment. */
 int smg_adam_step(float* params, const float* grads, float* m, float* v, int64_t offset, int64_t count,
                   int step, float lr, float beta1, float beta2, float eps, void* stream);
+
+/* One training step - zero the (trunk, head) gradient ranges, smg_forward, smg_loss, smg_backward, Adam on both ranges - as ONE
+ * replayable hipGraph: the reference's real call pattern is one (mask, rotation) sample per Trainer.backprop (code/main.py:338,
+ * code/trainer.py:334-384), ~560 launches of 2-20 us, which an eager host enqueues no faster than the GPU runs them.  The first
+ * call with a given set of pointers / shapes runs eagerly, the second is captured (stream capture across the engine's two
+ * streams), later ones replay; what changes between steps without re-capture: the CONTENTS of the input images, masks and labels,
+ * the batch description arrays of `batch` (rotations, pairings: same counts), and the Adam step counts.  Anything else
+ * (pointers, counts, precision mode, options) re-captures.  Results are bit-identical to the four separate calls with
+ * smg_adam_step(step) on the two ranges.  Asynchronous on `stream` like the calls it replaces. */
+typedef struct {
+    float* m; float* v;               /* Adam moments, flat, laid out like params */
+    float lr, beta1, beta2, eps;
+    int step_trunk, step_head;        /* 1-based step count of the trunk range / the head range for THIS step */
+} smg_adam;
+int smg_train_step_graph(smg_engine* e, const smg_net* net, int trunk_id, int head_id, const smg_batch* batch, int loss_mode,
+                         const float* labels_dev, float* q_out_dev, float* loss_out_dev, float* dq_dev, const smg_adam* adam, void* stream);
 
 /* Element range of params/grads used by (trunk_id) features or (head_id) head. */
 int smg_layout_trunk_range(int head_out, int trunk_id, int64_t* offset, int64_t* count);

@@ -51,6 +51,26 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
     };
     // operand kind 3 needs the finished GS's recorded maximum (always materialised there); few streams: launch-bound, the fused form wins
     const bool gs_materialised = split16 || NS > 4;
+    // ... and for calls of a few streams (the single-sample step of Trainer.backprop) the materialisation of the small planes (blocks 3-4,
+    // precision mode 0) leaves the data-gradient CHAIN: the 3x3 data gradient applies the BN backward on load, scaled by its own halo's
+    // maximum, and the side stream materialises GS (with the stream maximum its 3x3 weight gradient scales by) in front of the weight
+    // gradients - one dependent 10-17 us launch less per layer on a chain that is all latency there (single-sample step 7.41-7.45 ->
+    // 7.23-7.29 ms).  With 17 streams the side stream has no slack on those planes: the same move costs the headline step 0.15 ms
+    // (16.44-16.50 -> 16.62-16.64 ms, alternating on one box), and on the big planes the two strided slice reads cost more than the launch.
+    auto gs_on_side = [&](const Plane& pl) { return split16 && !e->generic3x3 && pl.HW <= 1600 && NS <= 4; };
+    auto launch_gs_apply = [&](int b, int i, hipStream_t cs, float* GSb) {
+        const Plane pl = e->p_blk[b];
+        const int Ct = kBlockCtot[b];
+        const DenseLayerRef& d = T.layers[b][i];
+        BnBwdApplyArgs a{};
+        a.g = e->G[b]; a.ldg = Ct; a.gcoff = d.cin; a.x = e->X[b]; a.ldx = Ct; a.xcoff = d.cin; a.pl = pl; a.C = kGrowth;
+        a.xsum = fsum(e, e->st_X[b]); a.xsq = fsq(e, e->st_X[b]); a.xstride = Ct; a.xtab = stat_table(e, e->sx_tab[b], e->max_streams, Ct);
+        a.s1 = b1(e, e->bs_X[b]); a.s2 = b2(e, e->bs_X[b]); a.sstride = Ct; a.scoff = d.cin; a.gamma = nullptr; a.eps = kEps;
+        a.out = GSb; a.ldo = kGrowth; a.amax = split16 ? gamax_of(e, b, i, 0) : nullptr;
+        BY(e, ESZ(e) * NS * pl.HW * 3 * kGrowth);
+        ProfScope ps(e, cs, K_OTHER, 0);
+        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_bwd_apply_kernel<PREC>), dim3((pl.HWp + bn_apply_rows(PREC) - 1) / bn_apply_rows(PREC), NS), dim3(256), 0, cs, a));
+    };
 
     if (ph_a) {
     {   // value conv backward + relu1 + norm1 sums
@@ -131,6 +151,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         float* bt = el(e, e->Bt, e->bt_off[b][i]);
         const LayerBuf lb = buf_of(b, i);
         GradSrc gsrc{};
+        if (gs_on_side(pl)) launch_gs_apply(b, i, s2, lb.GS);
         if (gs_materialised) { gsrc.g = lb.GS; gsrc.ldg = kGrowth; gsrc.amax = gamax_of(e, b, i, 0); }
         else {
             gsrc.g = el(e, e->G[b], d.cin); gsrc.ldg = Ct; gsrc.x = el(e, e->X[b], d.cin); gsrc.ldx = Ct;
@@ -242,15 +263,8 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             gsrc.g = el(e, e->G[b], d.cin); gsrc.ldg = Ct; gsrc.x = el(e, e->X[b], d.cin); gsrc.ldx = Ct;
             gsrc.xsum = fsum(e, e->st_X[b]) + d.cin; gsrc.xsq = fsq(e, e->st_X[b]) + d.cin;
             gsrc.s1 = b1(e, e->bs_X[b]) + d.cin; gsrc.s2 = b2(e, e->bs_X[b]) + d.cin; gsrc.sstride = Ct; gsrc.eps = kEps;
-            if (e->generic3x3 || gs_materialised) {
-                BnBwdApplyArgs a{};
-                a.g = e->G[b]; a.ldg = Ct; a.gcoff = d.cin; a.x = e->X[b]; a.ldx = Ct; a.xcoff = d.cin; a.pl = pl; a.C = kGrowth;
-                a.xsum = fsum(e, e->st_X[b]); a.xsq = fsq(e, e->st_X[b]); a.xstride = Ct; a.xtab = stat_table(e, e->sx_tab[b], e->max_streams, Ct);
-                a.s1 = b1(e, e->bs_X[b]); a.s2 = b2(e, e->bs_X[b]); a.sstride = Ct; a.scoff = d.cin; a.gamma = nullptr; a.eps = kEps;
-                a.out = GSb; a.ldo = kGrowth; a.amax = split16 ? gamax_of(e, b, i, 0) : nullptr;
-                BY(e, ESZ(e) * NS * pl.HW * 3 * kGrowth);
-                ProfScope ps(e, st, K_OTHER, 0);
-                PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_bwd_apply_kernel<PREC>), dim3((pl.HWp + bn_apply_rows(PREC) - 1) / bn_apply_rows(PREC), NS), dim3(256), 0, st, a));
+            if (e->generic3x3 || (gs_materialised && !gs_on_side(pl))) {
+                launch_gs_apply(b, i, st, GSb);
                 if (gs_materialised) { gsrc = GradSrc{}; gsrc.g = GSb; gsrc.ldg = kGrowth; gsrc.amax = gamax_of(e, b, i, 0); }
             }
             if (!e->generic3x3) {

@@ -1098,4 +1098,19 @@ static __global__ void adam_kernel(float* p, const float* g, float* m, float* v,
     }
 }
 
+// The same step with its two step-dependent scalars (lr / (1 - beta1^t), sqrt(1 - beta2^t)) read from device memory: the form
+// a captured training step replays (smg_train_step_graph) - the host refreshes the scalars, the graph's kernel arguments stay.
+static __global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, int64_t n, const float* sc, float b1, float b2, float eps) {
+    const float lr = sc[0], bc2_sqrt = sc[1];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - (lr / 1.f) * (mi / denom);
+    }
+}
+
 }  // namespace smg

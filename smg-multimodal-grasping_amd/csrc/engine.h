@@ -144,7 +144,13 @@ struct smg_engine {
     float* d_affine = nullptr;
     // batch description staging: one pinned ping-pong host block -> one device block per forward
     int* d_stage = nullptr; int* h_stage[2] = {}; hipEvent_t ev_stage[2] = {}; int stage_ints = 0, stage_turn = 0;
-    int so_image = 0, so_rot = 0, so_pa = 0, so_pb = 0, so_seq_t = 0, so_seq_h = 0, so_uptr = 0, so_upair = 0, so_uslot = 0, so_aff = 0, so_ma = 0, so_mb = 0;
+    int so_image = 0, so_rot = 0, so_pa = 0, so_pb = 0, so_seq_t = 0, so_seq_h = 0, so_uptr = 0, so_upair = 0, so_uslot = 0, so_aff = 0, so_ma = 0, so_mb = 0, so_adam = 0;
+    // One training step as a replayable hipGraph (smg_train_step_graph, engine.hip): while `capturing`, do_forward takes the batch
+    // description from h_stage_g - filled by the caller, together with the Adam scalars at so_adam - and issues no host
+    // synchronisation; ev_graph orders the host's next refill of h_stage_g behind the replay that reads it.
+    // The step runs on the engine's own stream gstream (the caller's may be the NULL stream, which cannot be captured), ordered
+    // behind the caller's stream by ev_gin and in front of it by ev_graph.
+    bool capturing = false; int* h_stage_g = nullptr; hipEvent_t ev_graph = nullptr, ev_gin = nullptr; hipStream_t gstream = nullptr; struct StepGraph* step_graph = nullptr;
     int64_t workspace_bytes = 0;
     int n_cu = 256;            // compute units of the device (persistent-launch sizing)
     int prec = 0;              // precision mode: 0 fp32 storage + fp32-class split products, 1 bf16 storage, 2 fp16 activations + bf16 gradients (smg_engine_set_precision)
@@ -400,5 +406,7 @@ static BnTab bn_table(smg_engine* e, int64_t at, int rows_max, int r0, int C, co
 }
 
 
+int validate_batch(const smg_engine* e, const smg_batch* B);
+void fill_stage(const smg_engine* e, const smg_batch* B, int* h);
 int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, const smg_batch* B, float* q_out, hipStream_t st);
 int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t st, int phases = 3);

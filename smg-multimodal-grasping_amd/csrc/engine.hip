@@ -254,6 +254,7 @@ static int engine_build(smg_engine* e) {
     e->so_seq_t = carve_i(4 * R + 16); e->so_seq_h = carve_i(4 * R + 16);
     e->so_uptr = carve_i(NS + 1); e->so_upair = carve_i(2 * NP); e->so_uslot = carve_i(2 * NP);
     e->so_aff = carve_i(6 * NS); e->so_ma = carve_i(NS); e->so_mb = carve_i(NS);
+    e->so_adam = carve_i(4);                  // graph path: {lr / (1 - beta1^t), sqrt(1 - beta2^t)} of the trunk range, of the head range
     e->stage_ints = so;
     ALLOC(e->d_stage, so);
     e->d_stream_image = e->d_stage + e->so_image; e->d_stream_rot = e->d_stage + e->so_rot;
@@ -265,6 +266,62 @@ static int engine_build(smg_engine* e) {
         HIP_OK(hipHostMalloc((void**)&e->h_stage[k], (size_t)so * sizeof(int), hipHostMallocDefault));
         HIP_OK(hipEventCreateWithFlags(&e->ev_stage[k], hipEventDisableTiming));
     }
+    HIP_OK(hipHostMalloc((void**)&e->h_stage_g, (size_t)so * sizeof(int), hipHostMallocDefault));
+    memset(e->h_stage_g, 0, (size_t)so * sizeof(int));
+    HIP_OK(hipEventCreateWithFlags(&e->ev_graph, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&e->ev_gin, hipEventDisableTiming));
+    HIP_OK(hipStreamCreateWithFlags(&e->gstream, hipStreamNonBlocking));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// One training step as a replayable hipGraph
+// ------------------------------------------------------------------------------------
+// Everything a captured step bakes into its nodes: a call with another key is captured anew (the old graph is dropped).
+struct StepKey {
+    const void* params; const void* grads; const void* bufs; const void* nbt;
+    int trunk_id, head_id, n_streams, n_pairs, n_images, hm_size, n_seq_t, n_seq_h, n_masks, loss_mode, prec, deterministic;
+    const void* images; const void* heightmaps; const void* masks; double mean, stdv;
+    const void* labels; const void* q; const void* loss; const void* dq; const void* m; const void* v; float lr, b1, b2, eps;
+    hipStream_t stream;
+    bool operator==(const StepKey& o) const { return memcmp(this, &o, sizeof(StepKey)) == 0; }
+};
+struct StepGraph {
+    StepKey key; bool warm = false;           // warm: one eager step with this key has run (lazy function attributes, static tables)
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+};
+static void step_graph_drop(smg_engine* e) {
+    if (!e->step_graph) return;
+    if (e->step_graph->exec) (void)hipGraphExecDestroy(e->step_graph->exec);
+    if (e->step_graph->graph) (void)hipGraphDestroy(e->step_graph->graph);
+    delete e->step_graph;
+    e->step_graph = nullptr;
+}
+static void adam_scalars(const smg_adam* a, int step, float* sc) {
+    const double bc1 = 1.0 - std::pow((double)a->beta1, step), bc2 = 1.0 - std::pow((double)a->beta2, step);
+    sc[0] = (float)((double)a->lr / bc1);
+    sc[1] = (float)std::sqrt(bc2);
+}
+// The launches of one step on `st`: zero the gradient ranges, forward, loss, backward, Adam (scalars from the device block).
+static int step_body(smg_engine* e, const smg_net* net, int trunk_id, int head_id, const smg_batch* B, int loss_mode, const float* labels,
+                     float* q, float* loss, float* dq, const smg_adam* adam, hipStream_t st) {
+    const Layout& L = *e->L;
+    const int64_t t0 = L.trunk[trunk_id].p_begin, tn = L.trunk[trunk_id].p_feat_end - t0, h0 = L.head[head_id].p_begin, hn = L.head[head_id].p_end - h0;
+    HIP_OK(hipMemsetAsync(net->grads + t0, 0, (size_t)tn * sizeof(float), st));
+    HIP_OK(hipMemsetAsync(net->grads + h0, 0, (size_t)hn * sizeof(float), st));
+    if (int rc = do_forward(e, net, trunk_id, head_id, B, q, st)) return rc;
+    const int per_pair = e->head_out * e->OH * e->OW;
+    hipLaunchKernelGGL(loss_kernel, dim3((B->n_pairs + 63) / 64), dim3(64), 0, st, loss_mode, (const float*)q, labels, B->n_pairs, per_pair, loss, dq);
+    if (int rc = do_backward(e, net, dq, st)) return rc;
+    const float* sc = reinterpret_cast<const float*>(e->d_stage + e->so_adam);
+    const int64_t off[2] = {t0, h0}, cnt[2] = {tn, hn};
+    for (int k = 0; k < 2; ++k) {
+        int blocks = (int)((cnt[k] + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, st, net->params + off[k], (const float*)net->grads + off[k], adam->m + off[k], adam->v + off[k],
+                           cnt[k], sc + 2 * k, adam->beta1, adam->beta2, adam->eps);
+    }
+    HIP_OK(hipGetLastError());
     return 0;
 }
 
@@ -278,7 +335,8 @@ int smg_version(void) { return SMG_ABI_VERSION; }
 int smg_abi_struct_bytes(int which) {
     if (which == 0) return (int)sizeof(smg_batch);
     if (which == 1) return (int)sizeof(smg_net);
-    return fail(-22, "smg_abi_struct_bytes: 0 = smg_batch, 1 = smg_net");
+    if (which == 2) return (int)sizeof(smg_adam);
+    return fail(-22, "smg_abi_struct_bytes: 0 = smg_batch, 1 = smg_net, 2 = smg_adam");
 }
 
 int smg_layout_count(int head_out) { return (int)layout_for(head_out).entries.size(); }
@@ -337,6 +395,11 @@ void smg_engine_destroy(smg_engine* e) {
                     e->d_stage};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (e->dbg_gsnap) (void)hipFree(e->dbg_gsnap);
+    step_graph_drop(e);
+    if (e->h_stage_g) (void)hipHostFree(e->h_stage_g);
+    if (e->ev_graph) (void)hipEventDestroy(e->ev_graph);
+    if (e->ev_gin) (void)hipEventDestroy(e->ev_gin);
+    if (e->gstream) (void)hipStreamDestroy(e->gstream);
     for (int k = 0; k < 2; ++k) { if (e->h_stage[k]) (void)hipHostFree(e->h_stage[k]); if (e->ev_stage[k]) (void)hipEventDestroy(e->ev_stage[k]); }
     for (int k = 0; k < kRing; ++k) {
         if (e->D2[k]) (void)hipFree(e->D2[k]);
@@ -400,11 +463,76 @@ int smg_layout_trunk_split(int head_out, int trunk_id, int64_t* offset) {
     return 0;
 }
 
+int smg_train_step_graph(smg_engine* e, const smg_net* net, int trunk_id, int head_id, const smg_batch* B, int loss_mode,
+                         const float* labels_dev, float* q_out_dev, float* loss_out_dev, float* dq_dev, const smg_adam* adam, void* stream) {
+    if (!e || !net || !B || !labels_dev || !q_out_dev || !loss_out_dev || !dq_dev || !adam) return fail(-22, "NULL argument");
+    if (!net->params || !net->grads || !net->bufs || !net->nbt || !adam->m || !adam->v) return fail(-22, "net / optimizer arrays are NULL");
+    if (trunk_id < 0 || trunk_id > 2 || head_id < 0 || head_id > 2) return fail(-22, "trunk_id / head_id out of range");
+    if (loss_mode != 0 && loss_mode != 1) return fail(-22, "loss mode must be 0 (Huber) or 1 (cross entropy)");
+    if (loss_mode == 1 && e->head_out != 3) return fail(-22, "cross-entropy loss needs a 3-class head");
+    if (adam->step_trunk < 1 || adam->step_head < 1) return fail(-22, "Adam step counts are 1-based");
+    if (e->prof || e->serialize) return fail(-22, "smg_train_step_graph: not while profiling / serialised (the graph spans two streams)");
+    HIP_OK(hipSetDevice(e->device));
+    if (int rc = validate_batch(e, B)) return rc;
+    hipStream_t caller = (hipStream_t)stream, st = e->gstream;
+    StepKey key;
+    memset(&key, 0, sizeof(key));
+    key.params = net->params; key.grads = net->grads; key.bufs = net->bufs; key.nbt = net->nbt;
+    key.trunk_id = trunk_id; key.head_id = head_id; key.n_streams = B->n_streams; key.n_pairs = B->n_pairs; key.n_images = B->n_images;
+    key.hm_size = B->hm_size; key.n_seq_t = B->bn_seq_trunk ? B->n_bn_seq_trunk : 0; key.n_seq_h = B->bn_seq_head ? B->n_bn_seq_head : 0;
+    key.n_masks = B->masks_dev ? B->n_masks : 0; key.loss_mode = loss_mode; key.prec = e->prec; key.deterministic = e->deterministic;
+    key.images = B->images_nchw_dev; key.heightmaps = B->heightmaps_dev; key.masks = B->masks_dev; key.mean = B->image_mean; key.stdv = B->image_std;
+    key.labels = labels_dev; key.q = q_out_dev; key.loss = loss_out_dev; key.dq = dq_dev; key.m = adam->m; key.v = adam->v;
+    key.lr = adam->lr; key.b1 = adam->beta1; key.b2 = adam->beta2; key.eps = adam->eps; key.stream = caller;
+    HIP_OK(hipEventSynchronize(e->ev_graph));          // the previous step (it reads the pinned block; its graph may be dropped below)
+    if (e->step_graph && !(e->step_graph->key == key)) step_graph_drop(e);
+    if (!e->step_graph) { e->step_graph = new StepGraph(); e->step_graph->key = key; }
+    StepGraph* g = e->step_graph;
+    // the pinned block: the batch description and the Adam scalars of THIS step
+    fill_stage(e, B, e->h_stage_g);
+    float* sc = reinterpret_cast<float*>(e->h_stage_g + e->so_adam);
+    adam_scalars(adam, adam->step_trunk, sc);
+    adam_scalars(adam, adam->step_head, sc + 2);
+    HIP_OK(hipEventRecord(e->ev_gin, caller));        // the step starts behind everything the caller has enqueued (input copies, label fill)
+    HIP_OK(hipStreamWaitEvent(st, e->ev_gin, 0));
+    e->capturing = true;           // (also for the eager first step: the same pinned block, the same launches)
+    int rc = 0;
+    if (!g->warm) {
+        rc = step_body(e, net, trunk_id, head_id, B, loss_mode, labels_dev, q_out_dev, loss_out_dev, dq_dev, adam, st);
+        g->warm = rc == 0;
+    } else {
+        if (!g->exec) {
+            hipError_t err = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+            if (err != hipSuccess) { e->capturing = false; return fail(-5, std::string("hipStreamBeginCapture: ") + hipGetErrorString(err)); }
+            rc = step_body(e, net, trunk_id, head_id, B, loss_mode, labels_dev, q_out_dev, loss_out_dev, dq_dev, adam, st);
+            err = hipStreamEndCapture(st, &g->graph);
+            if (rc == 0 && err != hipSuccess) rc = fail(-5, std::string("hipStreamEndCapture: ") + hipGetErrorString(err));
+            if (rc == 0) {
+                err = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+                if (err != hipSuccess) rc = fail(-5, std::string("hipGraphInstantiate: ") + hipGetErrorString(err));
+            }
+            if (rc) { e->capturing = false; step_graph_drop(e); return rc; }
+        }
+        hipError_t err = hipGraphLaunch(g->exec, st);
+        if (err != hipSuccess) rc = fail(-5, std::string("hipGraphLaunch: ") + hipGetErrorString(err));
+        // what the step leaves behind on the host side, as the eager calls would
+        e->have_fwd = true; e->bw_phase0_done = false; e->f_trunk = trunk_id; e->f_head = head_id; e->f_streams = B->n_streams; e->f_pairs = B->n_pairs;
+        e->f_stem1 = B->heightmaps_dev != nullptr;
+    }
+    e->capturing = false;
+    if (rc == 0) {
+        HIP_OK(hipEventRecord(e->ev_graph, st));
+        HIP_OK(hipStreamWaitEvent(caller, e->ev_graph, 0));      // ... and the caller's stream continues behind it (loss read-back)
+    }
+    return rc;
+}
+
 int smg_engine_set_precision(smg_engine* e, int precision) {
     if (!e) return fail(-22, "engine is NULL");
     if (precision < 0 || precision > 2) return fail(-22, "precision must be 0 (fp32 storage, fp32-class split products), 1 (bf16 storage) or 2 (fp16 activations, bf16 gradients)");
     if (precision && e->generic3x3) return fail(-22, "SMG_CROSSCHECK=1 (the generic implicit-GEMM 3x3 path) exists in the fp32-class mode only");
     e->prec = precision;
+    step_graph_drop(e);
     e->have_fwd = false;        // activations saved by a forward of another precision are not backward-compatible
     e->bw_phase0_done = false;
     return 0;

@@ -2,11 +2,8 @@
 // (code/models.py:361-586, :72-296) for one (trunk, head).
 #include "engine.h"
 
-int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, const smg_batch* B,
-                      float* q_out, hipStream_t st) {
-    const Layout& L = *e->L;
-    const TrunkRef& T = L.trunk[trunk_id];
-    const HeadRef& Hd = L.head[head_id];
+// Host-side checks of a batch against the engine (index ranges, capacities).
+int validate_batch(const smg_engine* e, const smg_batch* B) {
     const int NS = B->n_streams, NP = B->n_pairs;
     if (NS < 1 || NS > e->max_streams || NP < 1 || NP > e->max_pairs) return fail(-22, "batch exceeds engine capacity");
     if (!B->images_nchw_dev && !B->heightmaps_dev) return fail(-22, "no input images");
@@ -23,38 +20,57 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
     const int n_seq_t = B->bn_seq_trunk ? B->n_bn_seq_trunk : 0, n_seq_h = B->bn_seq_head ? B->n_bn_seq_head : 0;
     const int R = e->max_streams > e->max_pairs ? e->max_streams : e->max_pairs;
     if (n_seq_t > 4 * R + 16 || n_seq_h > 4 * R + 16) return fail(-22, "bn sequence too long");
-    int pad = 0;
     if (B->heightmaps_dev) {
-        pad = (e->S - 2 * B->hm_size) / 2;
+        const int pad = (e->S - 2 * B->hm_size) / 2;
         if (pad < 0 || 2 * B->hm_size + 2 * pad != e->S) return fail(-22, "heightmap size does not match engine input_size");
     }
+    return 0;
+}
 
-    {   // batch description -> device: no host synchronisation on the forward path
+// The batch description as the device block holds it (engine.h so_*), written to a pinned host block `h`.
+void fill_stage(const smg_engine* e, const smg_batch* B, int* h) {
+    const int NS = B->n_streams, NP = B->n_pairs;
+    const int n_seq_t = B->bn_seq_trunk ? B->n_bn_seq_trunk : 0, n_seq_h = B->bn_seq_head ? B->n_bn_seq_head : 0;
+    memcpy(h + e->so_image, B->stream_image, NS * sizeof(int));
+    memcpy(h + e->so_rot, B->stream_rotated, NS * sizeof(int));
+    memcpy(h + e->so_aff, B->stream_affine, 6 * NS * sizeof(float));
+    if (B->masks_dev) {
+        memcpy(h + e->so_ma, B->stream_mask_a, NS * sizeof(int));
+        memcpy(h + e->so_mb, B->stream_mask_b, NS * sizeof(int));
+    }
+    memcpy(h + e->so_pa, B->pair_a, NP * sizeof(int));
+    memcpy(h + e->so_pb, B->pair_b, NP * sizeof(int));
+    if (n_seq_t) memcpy(h + e->so_seq_t, B->bn_seq_trunk, n_seq_t * sizeof(int));
+    if (n_seq_h) memcpy(h + e->so_seq_h, B->bn_seq_head, n_seq_h * sizeof(int));
+    // users of each stream's features (CSR), for the backward
+    int* ptr = h + e->so_uptr; int* up = h + e->so_upair; int* us = h + e->so_uslot; int n = 0;
+    ptr[0] = 0;
+    for (int s = 0; s < NS; ++s) {
+        for (int j = 0; j < NP; ++j) {
+            if (B->pair_a[j] == s) { up[n] = j; us[n] = 0; ++n; }
+            if (B->pair_b[j] == s) { up[n] = j; us[n] = 1; ++n; }
+        }
+        ptr[s + 1] = n;
+    }
+}
+
+int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, const smg_batch* B,
+                      float* q_out, hipStream_t st) {
+    const Layout& L = *e->L;
+    const TrunkRef& T = L.trunk[trunk_id];
+    const HeadRef& Hd = L.head[head_id];
+    const int NS = B->n_streams, NP = B->n_pairs;
+    if (int rc = validate_batch(e, B)) return rc;
+    const int n_seq_t = B->bn_seq_trunk ? B->n_bn_seq_trunk : 0, n_seq_h = B->bn_seq_head ? B->n_bn_seq_head : 0;
+    const int pad = B->heightmaps_dev ? (e->S - 2 * B->hm_size) / 2 : 0;
+
+    if (e->capturing) {     // graph capture: the caller filled h_stage_g (fill_stage); the copy becomes a node that re-reads it at every replay
+        HIP_OK(hipMemcpyAsync(e->d_stage, e->h_stage_g, (size_t)e->stage_ints * sizeof(int), hipMemcpyHostToDevice, st));
+    } else {   // batch description -> device: no host synchronisation on the forward path
         const int turn = e->stage_turn; e->stage_turn ^= 1;
         HIP_OK(hipEventSynchronize(e->ev_stage[turn]));   // the copy issued two forwards ago (long done)
-        int* h = e->h_stage[turn];
-        memcpy(h + e->so_image, B->stream_image, NS * sizeof(int));
-        memcpy(h + e->so_rot, B->stream_rotated, NS * sizeof(int));
-        memcpy(h + e->so_aff, B->stream_affine, 6 * NS * sizeof(float));
-        if (B->masks_dev) {
-            memcpy(h + e->so_ma, B->stream_mask_a, NS * sizeof(int));
-            memcpy(h + e->so_mb, B->stream_mask_b, NS * sizeof(int));
-        }
-        memcpy(h + e->so_pa, B->pair_a, NP * sizeof(int));
-        memcpy(h + e->so_pb, B->pair_b, NP * sizeof(int));
-        if (n_seq_t) memcpy(h + e->so_seq_t, B->bn_seq_trunk, n_seq_t * sizeof(int));
-        if (n_seq_h) memcpy(h + e->so_seq_h, B->bn_seq_head, n_seq_h * sizeof(int));
-        // users of each stream's features (CSR), for the backward
-        int* ptr = h + e->so_uptr; int* up = h + e->so_upair; int* us = h + e->so_uslot; int n = 0;
-        ptr[0] = 0;
-        for (int s = 0; s < NS; ++s) {
-            for (int j = 0; j < NP; ++j) {
-                if (B->pair_a[j] == s) { up[n] = j; us[n] = 0; ++n; }
-                if (B->pair_b[j] == s) { up[n] = j; us[n] = 1; ++n; }
-            }
-            ptr[s + 1] = n;
-        }
-        HIP_OK(hipMemcpyAsync(e->d_stage, h, (size_t)e->stage_ints * sizeof(int), hipMemcpyHostToDevice, st));
+        fill_stage(e, B, e->h_stage[turn]);
+        HIP_OK(hipMemcpyAsync(e->d_stage, e->h_stage[turn], (size_t)e->stage_ints * sizeof(int), hipMemcpyHostToDevice, st));
         HIP_OK(hipEventRecord(e->ev_stage[turn], st));
     }
     if (kFStatRep > 1) HIP_OK(hipMemset2DAsync(e->fstat, kStatRepStride * sizeof(double), 0, 2 * e->fstat_span * sizeof(double), kFStatRep, st));

@@ -67,8 +67,12 @@ constexpr int halo_ck(int prec) { return prec ? 32 : 16; }
 // image per chunk (PK_HF), so their staging is a copy.  A fragment is one ds_read_b128 per piece: lanes 0..15 / 16..31 read
 // two runs of 16 consecutive halo pixels.  The 128 BN parameters of the stream are derived from the fp64 sums in the
 // prologue (one channel per thread) and stored once per stream for the backward kernels.
-//   TS = 16: 4 waves x 2 pixel tiles, 60 KB LDS in the fp32-class mode (2 workgroups per CU), 43 KB in the 16-bit modes.
+//   TS = 16: 4 waves x 2 pixel tiles, 43 KB LDS (2 workgroups per CU by registers).
 //   TS = 8 : 2 waves split the pixels, the other factor of two splits the TAPS (5 + 4).
+// One (halo, weights) buffer: the next chunk is transformed and stored between two barriers while the workgroup's MFMAs pause, and
+// the CU's second workgroup fills the pause.  (Round 5 measured the alternative - TWO buffers, the next chunk's conversions and LDS
+// stores dealt out one slice per tap into the shadow of that tap's MFMAs, one barrier per chunk, 84 KB and therefore ONE workgroup
+// per CU at TS = 16: 65.8 -> 93.8 us per launch on the 160^2 / 80^2 planes, 16.8 -> 16.4 us at TS = 8 - rejected.)
 // ------------------------------------------------------------------------------------
 template <int TS, int PREC> struct HaloFwdSGeo : HaloGeo<TS> {
     using G = HaloGeo<TS>;
@@ -398,8 +402,10 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
     }
     float* gp = prm + 4 * C + 256;                     // GradSrc parameters [4][32]
     grad_src_params(a.g, n, a.pl.HW, gp);
-    ActScale gsc{1.f, 1.f};                            // operand kind 3: scale of this stream's gradient operand; inverse of (gradient x weight) scale
-    if constexpr (OP == 3) { gsc = amax_scale(a.g.amax + (int64_t)n * kAmaxRep); gsc.inv *= pack_inv_scale(a.wu); }
+    // operand kind 3: scale of the gradient operand and inverse of the (gradient x weight) scale - from the stream's recorded maximum
+    // (materialised GS), or, when the BN backward is applied on load (a.g.x set), from the largest magnitude of THIS workgroup's halo
+    ActScale gsc{1.f, 1.f};
+    if constexpr (OP == 3) { if (!a.g.x) { gsc = amax_scale(a.g.amax + (int64_t)n * kAmaxRep); gsc.inv *= pack_inv_scale(a.wu); } }
     const int cg0 = blockIdx.z * a.cg_per_wg;
     const int NSTAGE = a.cg_per_wg * 3;                // channel-chunk groups x 3 kernel rows
     // Weight stages: stage = cgroup * 3 + kernel row (a cgroup holds NCW chunks, a stage the row's three taps of each: they are
@@ -437,6 +443,30 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
             if (x_n) rx[i] = ld16(x_n, (int64_t)XSZ * (pix * a.g.ldx + E * q));
         }
         __syncthreads();                           // gp (and prm) visible
+        if constexpr (OP == 3) {
+            if (x_n) {                             // (launch-uniform) BN backward on load: the halo's own maximum sets the scale
+                float vmax = 0.f;
+#pragma unroll
+                for (int i = 0; i < A_N; ++i) {
+                    const int idx = t + 256 * i;
+                    const int hp = idx / SPP, q = idx % SPP;
+                    const int hy = hp / G::W, hx = hp - hy * G::W;
+                    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+                    const bool ok = idx < G::PX * SPP && (unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W;
+                    const float4 v = ok ? affine2(rv[i], rx[i], gp + 4 * (q % 8), 32) : zero4();
+                    rv[i] = v;
+                    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+                float* red = prm + 4 * C;          // (the epilogue's scratch: free here)
+                if (lane == 0) red[wave] = vmax;
+                __syncthreads();
+                vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+                if (vmax > 0.f) gsc = scale_of_max(__float_as_uint(vmax));
+                gsc.inv *= pack_inv_scale(a.wu);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < A_N; ++i) {
             const int idx = t + 256 * i;
@@ -447,7 +477,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
                 const bool ok = (unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W;
                 if constexpr (E == 4) {
                     float4 v = rv[i];
-                    if (x_n) v = affine2(rv[i], rx[i], gp + 4 * q, 32);
+                    if (OP != 3 && x_n) v = affine2(rv[i], rx[i], gp + 4 * q, 32);      // (operand kind 3: applied above, with the maximum)
                     if constexpr (OP == 3) v = mul4(v, gsc.s);
                     if (!ok) v = zero4();
                     const Split4 sp = split4<OP>(v);

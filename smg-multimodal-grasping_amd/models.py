@@ -126,6 +126,7 @@ class _AffordanceNet(nn.Module):
         self._saved = None
         self._autograd_hook = None
         self._grads_clean = False
+        self._graph_exposed = None      # (trunk, head) whose p.grad views a graph-replayed training step left in place
         self.precision = "fp32"     # operand precision of the matrix products (set_precision)
         self._prec_from_cast = False
 
@@ -227,6 +228,7 @@ class _AffordanceNet(nn.Module):
         if self._flat_grads is not None:
             self._flat_grads.zero_()
         self._grads_clean = True
+        self._graph_exposed = None
         for p in self.parameters():
             p.grad = None
 
@@ -301,6 +303,45 @@ class _AffordanceNet(nn.Module):
                             bn_seq_head=seq_h if update_bn else None, **src)
         self._saved = (eng, token, trunk_id, head_id) if keep_for_backward else None
         return q
+
+    def train_step_graph(self, style, rot, num_rot, heightmaps, labels, loss, q, dq, optimizer, loss_mode, mean=0.0, std=1.0):
+        """One (mask, rotation) training sample - zero the (trunk, head) gradient ranges, forward (branch C), loss, backward, Adam -
+        as ONE replayed hipGraph (smg_train_step_graph; the reference's real call pattern, code/main.py:338 -> code/trainer.py:334-384).
+        `heightmaps` [2, H, H] float64 (depth, masked depth), `labels` [1], `loss` [1], `q` / `dq` [1, out, OH, OW] are PERSISTENT
+        device tensors: the graph is keyed on their addresses; their contents and the rotation may change from step to step."""
+        self._require_gpu()
+        dev = self._flat_params.device
+        hm = int(heightmaps.shape[-1])
+        diag = np.ceil(float(2 * hm) * np.sqrt(2) / 32) * 32                  # code/trainer.py:169-171
+        S = 2 * hm + 2 * int((diag - 2 * hm) / 2)
+        eng = get_engine(dev.index or 0, S, self.HEAD_OUT, 2, 1)
+        if eng.precision != self.precision:
+            eng.set_precision(self.precision)
+        trunk_id, head_id = STYLE_TRUNK[style], STYLE_HEAD[style]
+        if optimizer.m is None or optimizer.m.device != dev:
+            optimizer.m = torch.zeros_like(self._flat_params)
+            optimizer.v = torch.zeros_like(self._flat_params)
+        names = ("trunk%d" % trunk_id, "head%d" % head_id)
+        for nm in names:
+            optimizer.steps[nm] = optimizer.steps.get(nm, 0) + 1
+        adam = smg_hip.SmgAdam()
+        adam.m, adam.v = optimizer.m.data_ptr(), optimizer.v.data_ptr()
+        adam.lr, adam.beta1, adam.beta2, adam.eps = optimizer.lr, optimizer.betas[0], optimizer.betas[1], optimizer.eps
+        adam.step_trunk, adam.step_head = optimizer.steps[names[0]], optimizer.steps[names[1]]
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        try:
+            token = eng.train_step_graph(self._net_struct(True), trunk_id, head_id, loss_mode, labels.data_ptr(), q.data_ptr(), loss.data_ptr(),
+                                         dq.data_ptr(), adam, stream,
+                                         heightmaps=heightmaps.data_ptr(), hm_size=hm, mean=float(mean), std=float(std), n_images=2,
+                                         stream_image=[0, 1], stream_affine=np.concatenate([rotation_theta(rot, num_rot), rotation_theta(0, 1)]),
+                                         stream_rotated=[1, 0], pair_a=[0], pair_b=[1], bn_seq_trunk=[0, 1], bn_seq_head=[0])
+        except Exception:
+            for nm in names:
+                optimizer.steps[nm] -= 1
+            raise
+        self._saved = (eng, token, trunk_id, head_id)
+        self._grads_clean = False
+        return trunk_id, head_id
 
     def run_pairs(self, style, num_rot, heightmaps, rot_streams, mask_images, pairs, mean=0.0, std=1.0,
                   bn_seq_trunk=None, bn_seq_head=None, masks=None, mask_a=None, mask_b=None):

@@ -31,7 +31,12 @@ class SmgBatch(C.Structure):
     ]
 
 
-ABI_VERSION = 3     # SMG_ABI_VERSION of include/smg_hip.h this binding was written against
+class SmgAdam(C.Structure):
+    _fields_ = [("m", C.c_void_p), ("v", C.c_void_p), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("step_trunk", C.c_int), ("step_head", C.c_int)]
+
+
+ABI_VERSION = 4     # SMG_ABI_VERSION of include/smg_hip.h this binding was written against
 
 _lib = None
 
@@ -52,7 +57,7 @@ def lib():
     if not hasattr(L, "smg_abi_struct_bytes") or L.smg_version() != ABI_VERSION:
         raise SmgError("%s is ABI version %d, this binding needs %d: rebuild it (make -C csrc)" % (LIB_PATH, L.smg_version(), ABI_VERSION))
     L.smg_abi_struct_bytes.argtypes = [C.c_int]
-    for which, ty in ((0, SmgBatch), (1, SmgNet)):
+    for which, ty in ((0, SmgBatch), (1, SmgNet), (2, SmgAdam)):
         if L.smg_abi_struct_bytes(which) != C.sizeof(ty):
             raise SmgError("%s: struct %s is %d bytes in the library, %d in this binding" % (LIB_PATH, ty.__name__, L.smg_abi_struct_bytes(which), C.sizeof(ty)))
     L.smg_layout_count.argtypes = [C.c_int]
@@ -82,6 +87,8 @@ def lib():
     L.smg_argmax.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.smg_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    L.smg_train_step_graph.argtypes = [C.c_void_p, C.POINTER(SmgNet), C.c_int, C.c_int, C.POINTER(SmgBatch), C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.POINTER(SmgAdam), C.c_void_p]
     L.smg_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]
     L.smg_debug_read.restype = C.c_int64
     L.smg_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -98,7 +105,7 @@ EXPORTS = (
     "smg_last_error", "smg_version", "smg_abi_struct_bytes", "smg_engine_set_option", "smg_layout_count", "smg_layout_param_floats", "smg_layout_buffer_floats",
     "smg_layout_nbt_count", "smg_layout_entry", "smg_layout_trunk_range", "smg_layout_head_range",
     "smg_engine_create", "smg_engine_destroy", "smg_engine_workspace_bytes", "smg_engine_geometry",
-    "smg_forward", "smg_loss", "smg_backward", "smg_backward_phase", "smg_layout_trunk_split", "smg_adam_step", "smg_argmax", "smg_heightmap", "smg_engine_set_precision", "smg_debug_read",
+    "smg_forward", "smg_loss", "smg_backward", "smg_backward_phase", "smg_train_step_graph", "smg_layout_trunk_split", "smg_adam_step", "smg_argmax", "smg_heightmap", "smg_engine_set_precision", "smg_debug_read",
     "smg_profile_enable", "smg_profile_kinds", "smg_profile_kind_name", "smg_profile_read", "smg_profile_read_bytes",
 )
 
@@ -186,10 +193,11 @@ class Engine(object):
     def workspace_bytes(self):
         return lib().smg_engine_workspace_bytes(self.h)
 
-    def forward(self, net, trunk_id, head_id, q_out, stream, images_nchw=None, heightmaps=None, hm_size=0,
-                mean=0.0, std=1.0, n_images=0, stream_image=(), stream_affine=(), stream_rotated=(),
-                pair_a=(), pair_b=(), bn_seq_trunk=None, bn_seq_head=None, masks=None, n_masks=0, stream_mask_a=None,
-                stream_mask_b=None):
+    @staticmethod
+    def _batch(images_nchw=None, heightmaps=None, hm_size=0, mean=0.0, std=1.0, n_images=0, stream_image=(), stream_affine=(),
+               stream_rotated=(), pair_a=(), pair_b=(), bn_seq_trunk=None, bn_seq_head=None, masks=None, n_masks=0,
+               stream_mask_a=None, stream_mask_b=None):
+        """(smg_batch, arrays to keep alive while it is in use)"""
         b = SmgBatch()
         b.n_images = n_images
         b.images_nchw_dev = images_nchw
@@ -213,7 +221,20 @@ class Engine(object):
             a, p = _iarr(stream_mask_a); keep.append(a); b.stream_mask_a = p
             a, p = _iarr(stream_mask_b); keep.append(a); b.stream_mask_b = p
             assert len(stream_mask_a) == b.n_streams == len(stream_mask_b)
+        return b, keep
+
+    def forward(self, net, trunk_id, head_id, q_out, stream, **batch):
+        b, keep = self._batch(**batch)
         check(lib().smg_forward(self.h, C.byref(net), trunk_id, head_id, C.byref(b), q_out, stream))
+        self.forward_id += 1
+        return self.forward_id
+
+    def train_step_graph(self, net, trunk_id, head_id, loss_mode, labels, q_out, loss_out, dq, adam, stream, **batch):
+        """smg_train_step_graph: zero grads + forward + loss + backward + Adam as one replayable hipGraph.  Returns the
+        forward token (the engine holds that forward's activations afterwards)."""
+        b, keep = self._batch(**batch)
+        check(lib().smg_train_step_graph(self.h, C.byref(net), trunk_id, head_id, C.byref(b), loss_mode, labels, q_out, loss_out, dq,
+                                         C.byref(adam), stream))
         self.forward_id += 1
         return self.forward_id
 

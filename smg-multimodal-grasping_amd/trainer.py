@@ -15,6 +15,7 @@ Differences that are deliberate and documented:
 """
 import copy
 import os
+import time
 
 import numpy as np
 import torch
@@ -413,9 +414,48 @@ class Trainer(object):
         self.optimizer.step()
         return (loss, q) if return_q else loss
 
+    # The single-sample step of Trainer.backprop as ONE replayed hipGraph (smg_train_step_graph): ~560 launches of 2-20 us each are
+    # enqueued by one hipGraphLaunch instead of one by one.  False: the four separate engine calls (same results, bit for bit).
+    use_step_graph = True
+
+    def _train_step_graph(self, depth_heightmap, m_depth_heightmap, style, rotation, label_value):
+        t_host = time.perf_counter()
+        model = self.model
+        model._require_gpu()
+        dev = model._flat_params.device
+        hm = np.stack([np.asarray(depth_heightmap, dtype=np.float64), np.asarray(m_depth_heightmap, dtype=np.float64)])
+        if hm.ndim != 3 or hm.shape[1] != hm.shape[2]:
+            raise ValueError("heightmaps must be square 2-D arrays")
+        st = getattr(self, "_step_state", None)
+        if st is None or st["model"] is not model or st["hm"].shape != hm.shape or st["hm"].device != dev:
+            # persistent device buffers: the captured graph is keyed on their addresses
+            st = self._step_state = dict(model=model, hm=torch.empty(hm.shape, dtype=torch.float64, device=dev),
+                                         label=torch.empty(1, dtype=torch.float32, device=dev), loss=torch.empty(1, dtype=torch.float32, device=dev),
+                                         q=None, dq=None)
+        if st["q"] is None or st["q"].shape[1] != model.HEAD_OUT:
+            st["q"] = torch.empty((1, model.HEAD_OUT, 1, 1), dtype=torch.float32, device=dev)
+            st["dq"] = torch.empty_like(st["q"])
+        st["hm"].copy_(torch.from_numpy(np.ascontiguousarray(hm)))
+        st["label"].fill_(float(label_value))
+        key = (STYLE_TRUNK[style], STYLE_HEAD[style])
+        if model._graph_exposed != key:
+            self.optimizer.zero_grad()          # the reference's zero_grad: every p.grad dropped (the graph zeroes its own two ranges)
+        rot = 0 if style == 2 else rotation
+        model.train_step_graph(style, rot, model.gnum_rotations, st["hm"], st["label"], st["loss"], st["q"], st["dq"], self.optimizer,
+                               0 if self.method == 'reinforcement' else 1, mean=self.image_mean, std=self.image_std)
+        if model._graph_exposed != key:
+            model.expose_grads(*key)
+            model._graph_exposed = key
+        setattr(model, ("gra_prob", "suc_prob", "gs_prob")[style], st["q"])
+        self.last_enqueue_ms = (time.perf_counter() - t_host) * 1e3        # host time of the step up to the loss read-back (bench.py)
+        return np.asarray(st["loss"].cpu().numpy()[0])
+
     def train_step(self, depth_heightmap, m_depth_heightmap, style, rotation, label_value):
         """zero_grad -> forward (branch C) -> loss -> backward -> Adam, all on the device;
         the only host synchronisation is reading the loss back (as code/trainer.py:352 does)."""
+        if self.use_step_graph and np.shape(depth_heightmap)[-1] == 224:      # (S = 640: one Q value per sample; larger inputs keep the eager calls)
+            return self._train_step_graph(depth_heightmap, m_depth_heightmap, style, rotation, label_value)
+        t_host = time.perf_counter()
         model = self.model
         self.optimizer.zero_grad()
         q = self._evaluate(model, depth_heightmap, m_depth_heightmap, style, False, rotation)
@@ -429,4 +469,5 @@ class Trainer(object):
         model._engine_backward(token, dq)
         self.optimizer.step()
         setattr(model, ("gra_prob", "suc_prob", "gs_prob")[style], q)
+        self.last_enqueue_ms = (time.perf_counter() - t_host) * 1e3
         return np.asarray(loss.cpu().numpy()[0])

@@ -1530,6 +1530,53 @@ def test_forward_is_bit_reproducible_run_to_run(gpu):
             assert rel <= 1e-12, (n, rel)
 
 
+def test_train_step_graph_equals_eager_calls(gpu):
+    """Trainer.backprop's single-sample step as one replayed hipGraph (smg_train_step_graph: eager first call, captured second,
+    replays after) against the four separate engine calls: with the learning rate at zero the weights stay put, so every step's
+    loss must be BIT-identical to the eager path's - rotations, labels, masks and the style change from step to step (a style
+    change re-captures) - and the gradients equal to the atomics' order; with the reference's learning rate the weights after
+    eight steps agree to 1e-5 and the optimizer's step counts match."""
+    import synthetic
+    from trainer import Trainer
+    depth, masks = synthetic.heightmap_scene(0)
+    sd = synthetic.make_state_dict(orc.state_layout(1), 0)
+    steps = [('grasp', 3, 0.4, 0), ('grasp', 9, 1.7, 1), ('grasp', 14, 0.05, 2), ('suction', 5, 0.9, 0), ('suction', 6, 2.5, 1),
+             ('grasp', 1, 0.3, 3), ('grasp_then_suction', 0, 0.7, 2), ('grasp', 2, 0.6, 0)]
+
+    def run(graph, lr):
+        tr = Trainer('reinforcement', 0.5, False, None, False)
+        tr.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        tr.model.gnum_rotations = tr.model.snum_rotations = 16
+        tr.use_step_graph = graph
+        tr.optimizer.lr = lr
+        losses, grads = [], []
+        for action, rot, label, mi in steps:
+            mk = masks.copy()
+            losses.append(np.float32(tr.backprop(depth, action, (mi, rot), (mi, rot), (mi, rot), ((mi + 1) % 4, rot), label, mk, None, None, None)))
+            grads.append(tr.model.flat_grads().clone())
+        return tr, losses, grads
+
+    tr_e, l_e, g_e = run(False, 0.0)
+    tr_g, l_g, g_g = run(True, 0.0)
+    for k, (a, b_) in enumerate(zip(l_e, l_g)):
+        assert a.tobytes() == b_.tobytes(), "step %d: loss %r (eager) vs %r (graph)" % (k, a, b_)
+    for k, (a, b_) in enumerate(zip(g_e, g_g)):
+        num, den = float((a - b_).double().norm()), float(a.double().norm())
+        assert num <= 1e-5 * den, (k, num, den)
+    assert tr_e.optimizer.steps == tr_g.optimizer.steps
+    for n_, p_ in tr_g.model.named_parameters():           # only the last step's (trunk, head) carries gradients, like torch's zero_grad(set_to_none)
+        assert (p_.grad is not None) == (("grasp_depth_trunk.features" in n_) or ("graspnet_val" in n_)), n_
+    tr_e, l_e, _ = run(False, 1e-4)
+    tr_g, l_g, _ = run(True, 1e-4)
+    assert l_e[0].tobytes() == l_g[0].tobytes()
+    # (two eager runs differ as much: the order of the fp32 atomics feeds Adam, and a Huber loss near zero squares a small difference
+    #  of Q and label - the exactness check is the zero-learning-rate half above)
+    assert np.allclose(l_e, l_g, rtol=1e-2, atol=2e-3), (l_e, l_g)
+    pe, pg = tr_e.model._flat_params.double(), tr_g.model._flat_params.double()
+    assert float((pe - pg).norm()) <= 1e-5 * float(pe.norm())
+    assert tr_e.optimizer.steps == tr_g.optimizer.steps
+
+
 def test_deterministic_option_gives_bit_identical_conv_weight_gradients(gpu):
     """smg_engine_set_option("deterministic", 1): the 1x1 weight gradients are reduced from partial tiles in a fixed order
     instead of fp32 atomics.  Two identical training calls then give bit-identical gradients for every convolution weight
