@@ -273,11 +273,12 @@ struct TraceScope {
         (void)hipStreamSynchronize(st);
         (void)hipFree(tbuf);
         // phases in shader cycles (s_memtime, per-XCD base); span / residency from the device-wide 100 MHz counter
-        double sum[4] = {0, 0, 0, 0}, life = 0; size_t live = 0; unsigned long long t_min = ~0ull, t_max = 0;
+        double sum[4] = {0, 0, 0, 0}, life = 0, extra = 0; size_t live = 0; unsigned long long t_min = ~0ull, t_max = 0;
         for (size_t w = 0; w < n_wg; ++w) {
             const unsigned long long* r = &h[w * 8];
             if (!r[4]) continue;
             ++live;
+            if (r[7]) extra += (double)(r[7] - r[1]);      // (kernels with a seventh stamp: slot 1 -> slot 7)
             for (int k = 0; k < 4; ++k) sum[k] += (double)(r[k + 1] - r[k]);
             t_min = std::min(t_min, r[5]); t_max = std::max(t_max, r[6]);
             life += (double)(r[6] - r[5]);
@@ -291,6 +292,7 @@ struct TraceScope {
             fprintf(stderr, "[smg trace]   start us p50 %.1f p90 %.1f max %.1f | life us p10 %.1f p50 %.1f p90 %.1f max %.1f\n",
                     q(st0, 0.5), q(st0, 0.9), q(st0, 1.0), q(lf, 0.1), q(lf, 0.5), q(lf, 0.9), q(lf, 1.0));
         }
+        if (extra > 0) fprintf(stderr, "[smg trace]   slot 1 -> slot 7: %.0f cycles/WG (mean)\n", extra / live);
         fprintf(stderr, "[smg trace] kind %d grid %ux%ux%u live %zu: init %.0f | first tile %.0f | k-loop %.0f | epilogue %.0f cycles/WG (mean); span %.1f us, %.2f workgroups resident per CU, mean life %.1f us  %.160s\n",
                 kind, grid.x, grid.y, grid.z, live, sum[0] / live, sum[1] / live, sum[2] / live, sum[3] / live, span, resid, life / live * 0.01, strstr(what, "[P = ") ? strstr(what, "[P = ") : what);
     }

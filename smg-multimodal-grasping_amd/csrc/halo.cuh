@@ -70,7 +70,10 @@ constexpr int halo_ck(int prec) { return prec ? 32 : 16; }
 //   TS = 16: 4 waves x 2 pixel tiles, 43 KB LDS (2 workgroups per CU by registers).
 //   TS = 8 : 2 waves split the pixels, the other factor of two splits the TAPS (5 + 4).
 // One (halo, weights) buffer: the next chunk is transformed and stored between two barriers while the workgroup's MFMAs pause, and
-// the CU's second workgroup fills the pause.  (Round 5 measured the alternative - TWO buffers, the next chunk's conversions and LDS
+// the CU's second workgroup fills the pause.  Per-workgroup stamps of round 5 (TS = 16, 17 streams of 160^2: 1700 workgroups, 3.3
+// rounds of 2 per CU, 34 us of life each): prologue 9.8k cycles (fp64 moments of the 128 channels, first chunk staged), then per
+// 16-channel chunk 4.6k for the nine taps (54 MFMAs per wave = 1.7k cycles of matrix pipe, shared with the CU's other workgroup)
+// and 3.2k for barrier + BN / ReLU / split / store of the next chunk + barrier, 3k of epilogue - of 66k.  TS = 8: 4.1k + 8 x 1.9k of 19k.  (Round 5 measured the alternative - TWO buffers, the next chunk's conversions and LDS
 // stores dealt out one slice per tap into the shadow of that tap's MFMAs, one barrier per chunk, 84 KB and therefore ONE workgroup
 // per CU at TS = 16: 65.8 -> 93.8 us per launch on the 160^2 / 80^2 planes, 16.8 -> 16.4 us at TS = 8 - rejected.)
 // ------------------------------------------------------------------------------------
@@ -103,14 +106,6 @@ static __global__ __launch_bounds__(256, kHaloFwdWaves) void conv3x3_halo_fwd_ke
     const int y0 = ty * TS, x0 = tx * TS;
     const int C = a.C, kq = t & 3;                           // this thread's 16-byte slot inside every chunk (E channels)
     const float sa = OP == 3 ? a.asc[0] : 1.f;               // operand kind 3: the activation scale rides on gamma * invstd and beta
-    for (int k = t; k < C; k += 256) {                       // BN parameters of this stream
-        float mean, invstd;
-        bn_moments(a.ssum, a.ssq, (int64_t)n * a.sstride + k, 1.0 / (double)a.pl.HW, a.eps, mean, invstd);
-        prm[k] = mean;
-        prm[C + k] = a.gamma[k] * invstd * sa;
-        prm[2 * C + k] = a.beta[k] * sa;
-        if (blockIdx.x == 0) { a.tw_mean[(int64_t)n * C + k] = mean; a.tw_invstd[(int64_t)n * C + k] = invstd; }
-    }
 
     int a_off[A_N];       // global pixel index, -1 = outside the image / unused slot
     int a_hp[A_N];        // halo pixel of the slot, -1 = unused
@@ -172,7 +167,16 @@ static __global__ __launch_bounds__(256, kHaloFwdWaves) void conv3x3_halo_fwd_ke
     };
 
     const int NCH = C / CK;
-    g_load(0);
+    g_load(0);                       // (the first chunk's loads in front of the parameter prologue, which waits for its own fp64 sums: measured, no change -
+                                     //  66.5 / 16.6 us per launch both ways; the prologue's 9.8k cycles are the moments' arithmetic and the first store)
+    for (int k = t; k < C; k += 256) {                       // BN parameters of this stream
+        float mean, invstd;
+        bn_moments(a.ssum, a.ssq, (int64_t)n * a.sstride + k, 1.0 / (double)a.pl.HW, a.eps, mean, invstd);
+        prm[k] = mean;
+        prm[C + k] = a.gamma[k] * invstd * sa;
+        prm[2 * C + k] = a.beta[k] * sa;
+        if (blockIdx.x == 0) { a.tw_mean[(int64_t)n * C + k] = mean; a.tw_invstd[(int64_t)n * C + k] = invstd; }
+    }
     __syncthreads();                 // prm visible
     s_store(0);
     __syncthreads();
