@@ -199,7 +199,46 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             BY(e, ESZ(e) * NS * pl.HW * (kGrowth + kBottleneck));
             if (int rc = launch_wgrad(e, s2, p, dim3(1, 1, 9 * NS * cps), K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth, 9, C_3x3)) return rc;
         }
-        {   // conv1 weight gradient.  ~320 workgroups: it shares the chip with the data-gradient chain on the other stream
+        // conv1 weight gradient, wave-specialised (wsw.cuh): 128 x 128 tiles, 32-pixel k-tiles, loader + matrix waves - for the partial-tile
+        // form (more than four streams, or "deterministic") on layers of more than 64 input channels (a half-empty 128-column tile
+        // costs block 1's first layer 77 -> 107 us; few-stream calls keep the generic kernel's 128 x 64 atomics: 7.3 -> 7.5 ms per single-sample step)
+        if (split16 && !e->generic_w1 && d.cin > 64 && (e->deterministic || NS > 4)) {
+            using G = WswGeo;
+            const int nt = (d.cin + G::BN - 1) / G::BN;
+            int chunk, cps;
+            pick_chunk(pl, NS, nt, chunk, cps, 320);      // (256 / 512 / 768 workgroups: 16.45-16.62 / 16.64-16.67 / 16.73-16.82 ms per step against 16.47-16.53)
+            Wgrad1x1WsArgs a{};
+            a.d2 = reinterpret_cast<const u32x4*>(lb.D2); a.binv = lb.D2S; a.x = e->X[b]; a.ldb = Ct; a.pl = pl; a.NB = d.cin;
+            a.btab = stat_table(e, e->sx_tab[b], e->max_streams, Ct); a.bgamma = P + d.n1.w; a.bbeta = P + d.n1.b; a.basc = asc_n1(e, b, i);
+            a.chunk = chunk; a.chunks_per_stream = cps; a.n_chunks = NS * cps;
+            a.dw = Gr + d.c1.w; a.ldw_out = d.cin; a.ldp = nt * G::BN;
+            const bool w1_part = e->deterministic || NS > 4;
+            const int64_t need = (int64_t)a.n_chunks * G::BM * a.ldp;
+            int64_t off1 = part3_floats;
+            if (red3.Z && (!w1_part || off1 + need > e->part_floats)) { launch_reduce2(e, s2, K_W3, red3, ReduceArgs{}); red3.Z = 0; off1 = 0; }
+            a.part = (w1_part && off1 + need <= e->part_floats) ? e->part + off1 : nullptr;
+            if (w1_part && !a.part && e->deterministic)
+                return fail(-12, "deterministic: a weight-gradient launch needs " + std::to_string(need) + " partial-tile floats, the workspace holds " + std::to_string(e->part_floats - off1));
+            a.tm = TileMap{a.n_chunks, nt, 0};
+            const size_t smem = G::smem_bytes(chunk);
+            static bool raised[64] = {};
+            if (!raised[e->device & 63]) {
+                (void)hipFuncSetAttribute((const void*)conv1x1_wgrad_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                raised[e->device & 63] = true;
+            }
+            {
+                BY(e, 4.0 * NS * pl.HW * (kBottleneck + d.cin));
+                ProfScope ps(e, s2, K_W1, 2.0 * NS * pl.HW * d.cin * kBottleneck);
+                hipLaunchKernelGGL(conv1x1_wgrad_ws_kernel, dim3(tile_grid(a.tm)), dim3(512), smem, s2, a);
+            }
+            ReduceArgs red1{}; red1.Z = 0;
+            if (a.part) {
+                red1.part = a.part; red1.Z = a.n_chunks; red1.taps = 1; red1.rows = G::BM; red1.cols = d.cin; red1.ldp = a.ldp;
+                red1.z_stride = (int64_t)G::BM * a.ldp; red1.tap_stride = (int64_t)a.n_chunks * G::BM * a.ldp;
+                red1.dw = a.dw; red1.ldw_out = d.cin; red1.cmap = C_IDENT;
+            }
+            launch_reduce2(e, s2, K_W1, red3, red1);
+        } else {   // conv1 weight gradient.  ~320 workgroups: it shares the chip with the data-gradient chain on the other stream
             // (256..384 measure the same, 512 / 768 / 1024 cost the step 0.15 / 0.35 / 0.75 ms)
             using Cfg = CfgW128x64;
             const int nt = (d.cin + Cfg::BN - 1) / Cfg::BN;

@@ -17,6 +17,7 @@
 #include "gemm.cuh"
 #include "halo.cuh"
 #include "ws.cuh"
+#include "wsw.cuh"
 #include "plan.h"
 
 using namespace smg;
@@ -160,7 +161,8 @@ struct smg_engine {
     // SMG_CROSSCHECK (read at engine creation; tests/test_gpu_parity.py::test_alternative_kernel_paths_agree): independent implementations of
     // two kernel families for cross-checks - bit 0: dense-layer 3x3 convolutions through the generic implicit GEMM instead of the LDS-halo
     // kernels; bit 1: the 1x1 forward of the small planes through the generic kernel instead of the wave-specialised one
-    bool generic3x3 = false, generic_c1 = false;
+    // bit 2: the 1x1 weight gradient through the generic kernel instead of the wave-specialised one (wsw.cuh)
+    bool generic3x3 = false, generic_c1 = false, generic_w1 = false;
     int dbg_stop = -1;         // smg_engine_set_option("debug_stop", block * 100 + layer) (0-based): the backward returns behind that dense layer's
                                // launches (block * 100 + 50: in front of the block's first layer) - the GEMM-level tests read the ring
                                // slots, DY2 and G' at that point (smg_debug_read); -1 = off

@@ -27,7 +27,7 @@ static int engine_build(smg_engine* e) {
 
     if (getenv("SMG_SERIALIZE")) e->serialize = true;        // profiling runs: serialised from the first launch (bench.py --serialize)
     const int cross = getenv("SMG_CROSSCHECK") ? atoi(getenv("SMG_CROSSCHECK")) : 0;
-    e->generic3x3 = cross & 1; e->generic_c1 = cross & 2;
+    e->generic3x3 = cross & 1; e->generic_c1 = cross & 2; e->generic_w1 = cross & 4;
 
     ALLOC(e->img4, (int64_t)NS * e->p_img.HWp * 4);
     ALLOC(e->stem, (int64_t)NS * e->p_stem.HWp * 64);

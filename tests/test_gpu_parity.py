@@ -986,15 +986,15 @@ def test_alternative_kernel_paths_agree(gpu):
     """The same sweep + one backward through independent implementations: the 3x3 layers through the LDS-halo kernels (default:
     two-piece fp16 split, three MFMA terms) and through the generic implicit GEMM (SMG_CROSSCHECK=1: the three-piece bf16 split,
     six terms - another kernel AND another arithmetic of the same fp32-class accuracy), and the 1x1 forward of the small planes
-    through the generic kernel instead of the wave-specialised one (SMG_CROSSCHECK=2).  Separate child processes: the switch is
-    read at engine creation."""
+    through the generic kernel instead of the wave-specialised one (SMG_CROSSCHECK=2), likewise the 1x1 weight gradient
+    (SMG_CROSSCHECK=4).  Separate child processes: the switch is read at engine creation."""
     import json
     import os
     import subprocess
     import sys
     tests_dir = os.path.dirname(os.path.abspath(__file__))
     res = {}
-    for tag, env in (("halo", {}), ("generic", {"SMG_CROSSCHECK": "1"}), ("c1_generic", {"SMG_CROSSCHECK": "2"})):
+    for tag, env in (("halo", {}), ("generic", {"SMG_CROSSCHECK": "1"}), ("c1_generic", {"SMG_CROSSCHECK": "2"}), ("w1_generic", {"SMG_CROSSCHECK": "4"})):
         e = dict(os.environ)
         e.pop("SMG_CROSSCHECK", None)
         e.update(env)
@@ -1004,7 +1004,7 @@ def test_alternative_kernel_paths_agree(gpu):
         res[tag] = json.loads(line[7:])
     ref = res["halo"]
     qs = np.abs(np.asarray(ref["q"])).max()
-    for tag in ("generic", "c1_generic"):
+    for tag in ("generic", "c1_generic", "w1_generic"):
         r = res[tag]
         assert np.abs(np.asarray(r["q"]) - np.asarray(ref["q"])).max() <= 2e-5 * max(qs, 1e-2), tag     # fp32 summation order only
         assert int(np.argmax(r["q"])) == int(np.argmax(ref["q"])), tag
