@@ -45,8 +45,8 @@ SPLIT_TERMS_PLAIN = 6                 # ... of the classes that stay on the thre
 PLAIN_CLASSES = ("stem7x7_fwd", "transition_wgrad", "transition_dgrad", "stem_wgrad", "head_conv0_wgrad", "head_conv0_dgrad")
 PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / SPLIT_TERMS
 PEAK_HBM_GBS = 8000.0                 # HBM3E peak (MI355X_MICROARCH.md; ~6300 achievable)
-PMC_FILE = "pmc_r04_hbm_traffic.json"                     # tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes
-SERIAL_CSV = "rocprof_r04_kernel_stats_serialized.csv"    # rocprofv3 --kernel-trace --stats of `bench.py --train-only --serialize`
+PMC_FILE = "pmc_r05_hbm_traffic.json"                     # tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes
+SERIAL_CSV = "rocprof_r05_kernel_stats_serialized.csv"    # rocprofv3 --kernel-trace --stats of `bench.py --train-only --serialize`
 PASS5_GFLOP = 36767.6                 # S=1824, R=32 fwd+bwd pass, masked stream de-duplicated
 # rocprofv3 kernel-name fragments that make up each class of roofline.per_kernel (profiles/*kernel_stats*.csv)
 # (reduce_partials_kernel serves every weight gradient that goes through partial tiles - the 3x3 ones, since round 3 the 1x1 ones too,
@@ -58,7 +58,7 @@ CLASS_SYMBOLS = {      # fnmatch patterns; template arguments: FwdConvP<Cfg, MOD
     "conv1x1_fwd": ["FwdConvP<*>, 0, ?, false>", "conv1x1_fwd_ws_kernel"], "head_conv0_fwd": ["FwdConvP<*>, 0, ?, true>"],
     "conv3x3_fwd": ["conv3x3_halo_fwd_kernel"], "transition_fwd": ["FwdConvP<*>, 2, ?, false>"],
     "conv3x3_dgrad": ["conv3x3_halo_dgrad_kernel"], "conv3x3_wgrad": ["conv3x3_halo_wgrad_kernel", "reduce_partials_kernel"],
-    "conv1x1_dgrad": ["BwdDataGroupP<", "BwdDataP<*>, false, 1, false, ?, false>"], "conv1x1_wgrad": ["BwdWeightP<*>, 0, 0, 3, false, ?, false>"],
+    "conv1x1_dgrad": ["BwdDataGroupP<", "BwdDataP<*>, false, 1, false, ?, false>"], "conv1x1_wgrad": ["BwdWeightP<*>, 0, 0, 3, false, ?, false>", "conv1x1_wgrad_ws_kernel"],
     "transition_wgrad": ["BwdWeightP<*>, 2, 0, 1, true, ?, false>"], "transition_dgrad": ["BwdDataP<*>, false, 2, true, ?, false>"],
     "stem_wgrad": ["BwdWeightP<*>, 3, 2, 3, true, ?, false>", "BwdWeightP<*>, 4, 3, 3, true, ?, false>"],
     "head_conv0_wgrad": ["BwdWeightP<*>, 0, 0, 3, true, ?, true>"], "head_conv0_dgrad": ["BwdDataP<*>, false, 0, true, ?, true>"],
@@ -445,8 +445,9 @@ def main():
     dtype, dtype_note = "f32", "fp32 storage and results; matrix products on the fp16 MFMA as scaled two-piece splits (3 terms, fp32 accumulate; fp32-class accuracy)"
     if leg == "headline":
         units_per_step, pass_gflop, input_size = 1.0, PASS_GFLOP, 640
-        workload = ("reinforcement_net style 0 (grasp trunk + graspnet_val head): 1 scene x 1 mask x 16 rotations per GPU per "
-                    "step, fwd + 16 Huber losses + bwd + Adam, S=640 (224^2 heightmap), masked stream de-duplicated (17 trunk passes)")
+        # (the compact line keeps 120 characters: the discriminating facts first)
+        workload = ("16 rot x 224^2 RGB-D (S=640) fwd + Huber + bwd + Adam per GPU per step; fp32-class; 17 trunk passes; "
+                    "reinforcement_net style 0 (grasp trunk + graspnet_val head), 1 scene x 1 mask, masked stream de-duplicated")
 
         if args.scaling == "strong" and world > 1:
             # total work fixed: every rank holds the SAME scene and trains on its contiguous share of the 16 rotations; the masked
@@ -457,8 +458,8 @@ def main():
             lo, hi = rots[0], rots[-1] + 1
             depth_d, mdepth_d, labels_d = on_dev(depth), on_dev(depth * masks[0]), on_dev(labels[lo:hi], np.float32)
             units_per_step = 1.0 / world
-            workload = ("strong scaling: ONE scene x 1 mask x 16 rotations per step over all GPUs (%d rotations + the masked stream per GPU), "
-                        "fwd + Huber + bwd + all-reduce + Adam, S=640" % len(rots))
+            workload = ("strong: ONE scene x 16 rot x 224^2 (S=640) per step over all GPUs, %d rot + masked stream per GPU; "
+                        "fwd + Huber + bwd + all-reduce + Adam" % len(rots))
 
         def step():
             return tr.train_batch(depth_d, mdepth_d, 0, rots, labels_d, grad_sync=sync)

@@ -32,6 +32,7 @@ def targs(name, tmpl):
 
 def kclass(name):
     if "conv1x1_fwd_ws_kernel" in name: return "conv1x1_fwd"
+    if "conv1x1_wgrad_ws_kernel" in name: return "conv1x1_wgrad"
     if "conv3x3_halo_fwd" in name: return "conv3x3_fwd"
     if "conv3x3_halo_dgrad" in name: return "conv3x3_dgrad"
     if "conv3x3_halo_wgrad" in name or "reduce_partials" in name: return "conv3x3_wgrad"
