@@ -133,7 +133,7 @@ typedef struct {
  * forward on this engine.  Replaces reinforcement_net.forward / reactive_net.forward
  * (code/models.py:361-586, :72-296) for any of their branches.
  * NaN / inf: a non-finite BatchNorm batch statistic of a stream (pair) makes every Q value of the samples that use it NaN,
- * as it does in the reference (checked where the running statistics are updated: needs bn_seq_trunk / bn_seq_head). */
+ * as it does in the reference (checked in every forward, with or without bn_seq_trunk / bn_seq_head). */
 int smg_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id,
                 const smg_batch* batch, float* q_out_dev, void* stream);
 

@@ -1048,17 +1048,19 @@ struct BnUpdDesc { int64_t rm, rv, nbt; int64_t stat_off; int stride, coff, C, c
 static __global__ void bn_update_kernel(const BnUpdDesc* descs, const double* stats_sum, const double* stats_sq,
                                  float* bufs, int64_t* nbt, const int* seq_trunk, int n_trunk,
                                  const int* seq_head, int n_head,
-                                 const int* pair_a, const int* pair_b, int n_pairs, int per_pair, float* q_out) {
+                                 const int* pair_a, const int* pair_b, int n_pairs, int per_pair, float* q_out, int n_streams, int update) {
+    // update == 0 (a forward that leaves the running statistics alone): only the non-finite check below, over every stream / pair of the batch
     const BnUpdDesc d = descs[blockIdx.y];
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int* seq = d.head ? seq_head : seq_trunk;
-    const int ns = d.head ? n_head : n_trunk;
-    if (c == 0 && ns > 0) nbt[d.nbt] += ns;
+    const int ns = update ? (d.head ? n_head : n_trunk) : (d.head ? n_pairs : n_streams);
+    if (update && c == 0 && ns > 0) nbt[d.nbt] += ns;
     if (c >= d.C || ns == 0) return;
     double rm = bufs[d.rm + c], rv = bufs[d.rv + c];
     const double inv = 1.0 / (double)d.count;
     for (int i = 0; i < ns; ++i) {
-        const int64_t idx = d.stat_off + (int64_t)seq[i] * d.stride + d.coff + c;
+        const int sq = update ? seq[i] : i;
+        const int64_t idx = d.stat_off + (int64_t)sq * d.stride + d.coff + c;
         const double m = fstat_get(stats_sum, idx) * inv;
         double var = fstat_get(stats_sq, idx) * inv - m * m;
         var = var < 0 ? 0 : var;
@@ -1072,14 +1074,16 @@ static __global__ void bn_update_kernel(const BnUpdDesc* descs, const double* st
         // (code/trainer.py:176-185, golden G2), would go unnoticed.  Restore the reference's result here: Q of every sample that
         // used the stream (trunk statistics) / of the pair (head statistics) becomes NaN.
         if (!(m - m == 0.0) || !(var - var == 0.0)) {
-            const int s = seq[i];
+            const int s = sq;
             for (int p = 0; p < n_pairs; ++p)
                 if (d.head ? p == s : (pair_a[p] == s || pair_b[p] == s))
                     for (int j = 0; j < per_pair; ++j) q_out[(int64_t)p * per_pair + j] = __builtin_nanf("");
         }
     }
-    bufs[d.rm + c] = (float)rm;
-    bufs[d.rv + c] = (float)rv;
+    if (update) {
+        bufs[d.rm + c] = (float)rm;
+        bufs[d.rv + c] = (float)rv;
+    }
 }
 
 // ------------------------------------------------------------------------------------

@@ -326,12 +326,13 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
         ProfScope ps(e, st, K_OTHER, 0);
         hipLaunchKernelGGL(value_conv_kernel, dim3(NP * e->head_out * e->OH * e->OW), dim3(256), 0, st, a);
     }
-    if (n_seq_t || n_seq_h) {   // BN running statistics, in the reference's update order
+    {   // BN running statistics, in the reference's update order - and, with or without an update, the reference's NaN propagation: a
+        // non-finite batch statistic of a stream (pair) turns the Q values of every sample that uses it into NaN
         ProfScope ps(e, st, K_OTHER, 0);
         hipLaunchKernelGGL(bn_update_kernel, dim3(8, (unsigned)e->n_bnupd), dim3(256), 0, st,
                            e->d_bnupd + (trunk_id * 3 + head_id) * e->bnupd_stride,
                            e->fstat, e->fstat + e->fstat_span, net->bufs, net->nbt, e->d_seq_t, n_seq_t, e->d_seq_h, n_seq_h,
-                           e->d_pair_a, e->d_pair_b, NP, e->head_out * e->OH * e->OW, q_out);
+                           e->d_pair_a, e->d_pair_b, NP, e->head_out * e->OH * e->OW, q_out, NS, (n_seq_t || n_seq_h) ? 1 : 0);
     }
     HIP_OK(hipGetLastError());
     e->f_stem1 = B->heightmaps_dev != nullptr;

@@ -208,7 +208,8 @@ static __global__ __launch_bounds__(512, 1) void conv1x1_wgrad_ws_kernel(const W
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn0 + j * 32 + l31;
-            if (a.part) {        // whole tile stored (columns past NB hold zeros: their BN parameters are zero)
+            if (a.part) {        // (columns past NB are never read by the reduce: not stored)
+                if (col >= a.NB) continue;
                 float* ob = a.part + ((int64_t)z * G::BM + wm0 + i * 32 + 4 * half) * a.ldp + col;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ob[(int64_t)((r & 3) + 8 * (r >> 2)) * a.ldp] = acc[i][j][r] * gi;

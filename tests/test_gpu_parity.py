@@ -155,6 +155,10 @@ def test_g2_literal_reference_constants_reproduce_the_nan_pattern(gpu, golden):
     tr.model.gnum_rotations = tr.model.snum_rotations = 1         # as the reference's Trainer leaves them (code/models.py:312-313): G2's out shape
     qs = tr.forward(d, dm, 0, True, False, -1)
     assert tuple(qs.shape) == tuple(golden["g2_literal_out_shape"]) and np.isnan(qs).all()
+    # ... and the same from a forward that leaves the running statistics alone (models.run(update_bn=False): bench sweeps)
+    hm = tr._heightmaps_to_device(d, dm)
+    q2 = tr.model.run(0, [0, 5], 16, heightmaps=hm, mean=tr.image_mean, std=tr.image_std, update_bn=False)
+    assert torch.isnan(q2).all()
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
