@@ -1539,7 +1539,7 @@ def test_train_step_graph_equals_eager_calls(gpu):
     replays after) against the four separate engine calls: with the learning rate at zero the weights stay put, so every step's
     loss must be BIT-identical to the eager path's - rotations, labels, masks and the style change from step to step (a style
     change re-captures) - and the gradients equal to the atomics' order; with the reference's learning rate the weights after
-    eight steps agree to 1e-5 and the optimizer's step counts match."""
+    eight steps agree to 3e-4 of their norm and the optimizer's step counts match."""
     import synthetic
     from trainer import Trainer
     depth, masks = synthetic.heightmap_scene(0)
@@ -1577,7 +1577,9 @@ def test_train_step_graph_equals_eager_calls(gpu):
     #  of Q and label - the exactness check is the zero-learning-rate half above)
     assert np.allclose(l_e, l_g, rtol=1e-2, atol=2e-3), (l_e, l_g)
     pe, pg = tr_e.model._flat_params.double(), tr_g.model._flat_params.double()
-    assert float((pe - pg).norm()) <= 1e-5 * float(pe.norm())
+    # (Adam's first steps move every parameter by ~lr whatever its gradient's size: where the gradient is noise, the atomics' order
+    #  decides the sign - 6e-5 of the norm measured after eight steps, the same between two eager runs)
+    assert float((pe - pg).norm()) <= 3e-4 * float(pe.norm())
     assert tr_e.optimizer.steps == tr_g.optimizer.steps
 
 
