@@ -315,16 +315,22 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 a.wu = e->packed_u + e->pk_hd[b][i]; a.bt = bn_table(e, e->sb_tab[b][i], e->max_streams, 0, kBottleneck, P + d.n2.w, P + d.n2.b);
                 BY(e, ESZ(e) * NS * pl.HW * (kGrowth + 2 * kBottleneck));      // gradient in, mask source in, dy out
                 ProfScope ps(e, st, K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
-                TraceScope ts(st, K_D3, halo_tile(pl, NS) == 16 ? dim3((pl.H / 16) * (pl.W / 16), NS) : dim3(((pl.H + 7) / 8) * ((pl.W + 7) / 8), NS, kBottleneck / 64));
+                TraceScope ts(st, K_D3, halo_tile(pl, NS) == 16 ? dim3(((pl.H + 15) / 16) * ((pl.W + 15) / 16), NS) : dim3(((pl.H + 7) / 8) * ((pl.W + 7) / 8), NS, kBottleneck / 64));
                 if (halo_tile(pl, NS) == 16) {
                     static bool raised[64][3] = {};          // the 16x16 kernel needs more than the default 64 KB of dynamic LDS
                     if (!raised[e->device & 63][e->prec]) {
                         PREC_DISPATCH(e, (void)hipFuncSetAttribute((const void*)conv3x3_halo_dgrad_kernel<16, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, (HaloDgradSGeo<16, PREC>::smem_bytes(kBottleneck))));
+                        PREC_DISPATCH(e, (void)hipFuncSetAttribute((const void*)conv3x3_halo_dgrad_kernel<16, PREC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (HaloDgradSGeo<16, PREC>::smem_bytes(kBottleneck))));
                         raised[e->device & 63][e->prec] = true;
                     }
-                    a.tiles_x = pl.W / 16; a.cg_per_wg = kBottleneck / 32;
-                    PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_dgrad_kernel<16, PREC>), dim3((pl.H / 16) * a.tiles_x, NS), dim3(256),
-                                       (HaloDgradSGeo<16, PREC>::smem_bytes(kBottleneck)), st, a));
+                    a.tiles_x = (pl.W + 15) / 16; a.cg_per_wg = kBottleneck / 32;
+                    if (pl.H % 16 || pl.W % 16) {      // tiles hang over the edge: the bounds-checked instantiation
+                        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_dgrad_kernel<16, PREC, true>), dim3(((pl.H + 15) / 16) * a.tiles_x, NS), dim3(256),
+                                           (HaloDgradSGeo<16, PREC>::smem_bytes(kBottleneck)), st, a));
+                    } else {
+                        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_dgrad_kernel<16, PREC>), dim3((pl.H / 16) * a.tiles_x, NS), dim3(256),
+                                           (HaloDgradSGeo<16, PREC>::smem_bytes(kBottleneck)), st, a));
+                    }
                 } else {
                     static bool raised8[64][3] = {};         // two buffers of a whole kernel row's weights: past the default 64 KB in the fp32-class mode
                     if (!raised8[e->device & 63][e->prec]) {

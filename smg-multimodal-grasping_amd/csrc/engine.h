@@ -179,8 +179,8 @@ struct smg_engine {
 // forward chain): four times the workgroups fill the chip (forward sweep 9.05 -> 8.77 ms, single-rotation forward
 // 4.3 -> 3.6 ms).
 static inline int halo_tile(const Plane& p, int n_streams = 1 << 20) {
-    if (p.H % 16 || p.W % 16) return 8;
-    return (int64_t)(p.H / 16) * (p.W / 16) * n_streams >= 320 ? 16 : 8;      // (160 / 800 measured: 24.4 / 24.8 against 24.6 ms per step)
+    // (tiles that hang over the edge are masked: S = 1824's 456^2 / 228^2 / 114^2 planes take 16 x 16 tiles too - round 5)
+    return (int64_t)((p.H + 15) / 16) * ((p.W + 15) / 16) * n_streams >= 320 ? 16 : 8;      // (160 / 800 measured: 24.4 / 24.8 against 24.6 ms per step)
 }
 
 // 3x3 weight-gradient halo kernel: tiles per workgroup.  The launch runs in rounds of 512 resident workgroups (2 per

@@ -220,9 +220,14 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                     BY(e, ESZ(e) * ns * pl.HW * (kBottleneck + kGrowth));
                     ProfScope ps(e, cs, K_C3, 2.0 * ns * pl.HW * 9 * kBottleneck * kGrowth);
                     if (halo_tile(pl, ns) == 16) {
-                        a.tiles_x = pl.W / 16;
-                        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_fwd_kernel<16, PREC>), dim3((pl.H / 16) * a.tiles_x, ns), dim3(256),
-                                           (HaloFwdSGeo<16, PREC>::smem_bytes(kBottleneck)), cs, a));
+                        a.tiles_x = (pl.W + 15) / 16;
+                        if (pl.H % 16 || pl.W % 16) {      // tiles hang over the edge: the bounds-checked instantiation
+                            PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_fwd_kernel<16, PREC, true>), dim3(((pl.H + 15) / 16) * a.tiles_x, ns), dim3(256),
+                                               (HaloFwdSGeo<16, PREC>::smem_bytes(kBottleneck)), cs, a));
+                        } else {
+                            PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_fwd_kernel<16, PREC>), dim3((pl.H / 16) * a.tiles_x, ns), dim3(256),
+                                               (HaloFwdSGeo<16, PREC>::smem_bytes(kBottleneck)), cs, a));
+                        }
                     } else {
                         a.tiles_x = (pl.W + 7) / 8;
                         PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_fwd_kernel<8, PREC>), dim3(((pl.H + 7) / 8) * a.tiles_x, ns), dim3(256),

@@ -15,9 +15,9 @@
 // v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; 16-byte units of 8 consecutive k).
 //
 // Two tile sizes:
-//   TS = 16  planes that tile by 16 (160^2, 80^2 at S = 640).  4 waves, wave w owns pixel
-//            rows 4w..4w+3 (two 32x32 MFMA tiles: 2 rows x 16 cols each).
-//   TS = 8   everything else (40^2, 20^2, ragged edges masked): 64 pixels per workgroup so
+//   TS = 16  planes with enough 16 x 16 tiles to fill the chip (160^2, 80^2 at S = 640; 456^2, 228^2, 114^2 at S = 1824 - tiles
+//            may hang over the edge, masked).  4 waves, wave w owns pixel rows 4w..4w+3 (two 32x32 MFMA tiles: 2 rows x 16 cols each).
+//   TS = 8   everything else (40^2, 20^2): 64 pixels per workgroup so
 //            that a 17-stream launch still has hundreds of workgroups.  Two waves split
 //            the pixels (4 rows x 8 cols each, one MFMA tile); the other factor of two
 //            splits the taps (forward, folded through LDS at the end), the output channels
@@ -88,8 +88,11 @@ template <int TS, int PREC> struct HaloFwdSGeo : HaloGeo<TS> {
     __host__ __device__ static constexpr int smem_bytes(int C) { return (A_UNITS + B_N * 256) * 16 + 3 * C * 4; }
 };
 
-template <int TS, int PREC = 0>
+// RAG: tiles may hang over the plane's edge (stores, statistics and mask loads are bounds-checked) - always at TS = 8; at TS = 16 only
+// for planes that do not tile by 16 (S = 1824), so that the exact planes of the headline keep their check-free epilogues.
+template <int TS, int PREC = 0, bool RAG = false>
 static __global__ __launch_bounds__(256, kHaloFwdWaves) void conv3x3_halo_fwd_kernel(const Halo3x3FwdArgs a) {
+    constexpr bool kEdge = TS == 8 || RAG;
     using G = HaloFwdSGeo<TS, PREC>;
     using ST = act_t<PREC>;
     constexpr int OP = fwd_op(PREC), NP = G::NP, CK = G::CK, K8C = G::K8C, KSTEP = CK / 16;
@@ -289,7 +292,7 @@ static __global__ __launch_bounds__(256, kHaloFwdWaves) void conv3x3_halo_fwd_ke
                     const int r = 4 * g + k, i = k + 8 * g + 4 * half;
                     const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
                     v[k] = acc[m][r];
-                    if (TS == 16 || (py < a.pl.H && px < a.pl.W)) {      // TS == 8 tiles may hang over the edge
+                    if (!kEdge || (py < a.pl.H && px < a.pl.W)) {      // tiles may hang over the edge (planes that do not tile exactly)
                         const double xd = (double)v[k];
                         s += xd;
                         ss += xd * xd;
@@ -299,7 +302,7 @@ static __global__ __launch_bounds__(256, kHaloFwdWaves) void conv3x3_halo_fwd_ke
                 quad_transpose4(v[0], v[1], v[2], v[3]);
                 const int i = (lane & 3) + 8 * g + 4 * half;
                 const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
-                if (TS == 16 || (py < a.pl.H && px < a.pl.W))
+                if (!kEdge || (py < a.pl.H && px < a.pl.W))
                     stq<ST>(a.dst, ((int64_t)n * a.pl.HWp + py * a.pl.W + px) * a.ldd + a.dcoff + 4 * (l31 >> 2), make_float4(v[0], v[1], v[2], v[3]));
             }
     }
@@ -377,8 +380,9 @@ template <int TS, int PREC> struct HaloDgradSGeo : HaloGeo<TS> {
     __host__ __device__ static constexpr int smem_bytes(int C) { return (A_UNITS + 2 * B_PAD) * 16 + (4 * C + 256 + 128) * 4; }
 };
 
-template <int TS, int PREC = 0>
+template <int TS, int PREC = 0, bool RAG = false>
 static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x3DgradArgs a) {
+    constexpr bool kEdge = TS == 8 || RAG;
     using G = HaloDgradSGeo<TS, PREC>;
     using GT = grd_t<PREC>;
     using XT = act_t<PREC>;
@@ -520,7 +524,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
     auto load_mask_seg = [&](int c0, int m, int g) {
         const int i = (lane & 3) + 8 * g + 4 * half;
         const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
-        const bool ok = TS == 16 || (py < a.pl.H && px < a.pl.W);     // TS == 8 tiles may hang over the edge: clamped address
+        const bool ok = !kEdge || (py < a.pl.H && px < a.pl.W);     // tiles may hang over the edge: clamped address
         const int64_t idx = ((int64_t)n * a.pl.HWp + (ok ? py * a.pl.W + px : 0)) * C + c0 + 4 * (l31 >> 2);
         if constexpr (std::is_same<XT, e_f32>::value) xq[m][g] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.mbuf) + idx);
         else xq[m][g] = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(a.mbuf) + idx);
@@ -620,7 +624,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
                         for (int k = 0; k < 4; ++k) {
                             const int i = k + 8 * g + 4 * half;
                             const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
-                            const bool in = TS == 16 || (py < a.pl.H && px < a.pl.W);
+                            const bool in = !kEdge || (py < a.pl.H && px < a.pl.W);
                             const float dyv = (in && bn1(xv[k], mean, sc, be) > 0.f) ? acc[m][4 * g + k] * gsc.inv : 0.f;      // (gsc.inv == 1 unless operand kind 3)
                             o[k] = dyv;
                             s1 += dyv;
@@ -629,7 +633,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
                         quad_transpose4(o[0], o[1], o[2], o[3]);
                         const int i = (lane & 3) + 8 * g + 4 * half;
                         const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
-                        if (TS == 16 || (py < a.pl.H && px < a.pl.W))
+                        if (!kEdge || (py < a.pl.H && px < a.pl.W))
                             stq<GT>(a.dst, ((int64_t)n * a.pl.HWp + py * a.pl.W + px) * C + c - l31 + 4 * (l31 >> 2), make_float4(o[0], o[1], o[2], o[3]));
                     }
             };
