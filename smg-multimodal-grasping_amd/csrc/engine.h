@@ -204,7 +204,12 @@ static int w3_tiles_per_wg(int n_tiles, int ts, int n_streams, int64_t part_floa
 }
 
 static Plane make_plane(int H, int W) {
-    Plane p; p.H = H; p.W = W; p.HW = H * W; p.HWp = (p.HW + 63) / 64 * 64; return p;
+    // rows per stream: a multiple of 64 (tiles and scale blocks never straddle two streams) - of 128 on the big planes, so that the
+    // 128-row tile configurations serve them whatever the input size (S = 1824: 456^2 = 207 936 = 64 x 3249 pixels took 64-row tiles)
+    Plane p; p.H = H; p.W = W; p.HW = H * W;
+    const int g = p.HW >= 8192 ? 128 : 64;
+    p.HWp = (p.HW + g - 1) / g * g;
+    return p;
 }
 
 template <class T>
