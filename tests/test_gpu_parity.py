@@ -675,9 +675,10 @@ def test_multi_scene_batch_equals_sum_of_single_scene_gradients(gpu, case):
     num = float((g_b - g_sum).double().norm())
     den = float(g_sum.double().norm())
     print("batch vs sum of single-scene gradients (%s): |d| / |g| = %.3e" % (case, num / den))
-    # only the fp32 summation order / ReLU-mask noise differs (ill-conditioned, see header): 0.5e-3 for the small case and
-    # 2.7e-3 for the 64-sample one were measured; one missing sample of 64 would be 1.5e-2
-    assert num <= (1.2e-2 if len(labels) < 10 else 5e-3) * den, (num, den)
+    # only the fp32 summation order / ReLU-mask noise differs (ill-conditioned, see header).  Measured in round 5, default build /
+    # -DSMG_SPLIT16=0 build: 6.2e-3 / 1.4e-3 (5 samples), 1.9e-3 / 1.9e-3 (64), 1.2e-3 / 1.4e-3 (128); one missing sample of 64
+    # would be 1.5e-2
+    assert num <= (1.2e-2 if len(labels) < 10 else 4e-3) * den, (num, den)
     assert loss_b.shape == (len(labels),)
     if len(seeds) == 8:
         import models
