@@ -54,6 +54,12 @@
 // k-tiles of global loads in flight per policy family (register ring depth of the staging pipeline) and the waves per SIMD a few
 // kernels are held to - every value below was A/B-measured on the box (profiles/README.md) and is frozen here.
 namespace smg {
+// k-tiles in flight by LDS-DMA (gemm_tile; 0 = register staging) where both operands are finished 16-byte units.  Serialised ms per step,
+// register staging / 1 / 2 / 3 tiles in flight: per-layer data gradient 128 x 64 x 16 0.82 / 0.74 / 0.69 / 0.69 and 64 x 64 x 32 0.34 / 0.31 /
+// 0.31 / 0.32; grouped 128 x 64 x 32 1.24 / 1.12 / 1.08 / 1.54 (four stages: one workgroup per CU) - and 1.04 with ONE tile in flight at
+// three waves per SIMD (two stages of LDS + 168 registers let a third workgroup in); grouped 64 x 64 x 32 0.89 / 0.78 / 0.84 / 1.00.
+// What the DMA buys is the staging work (no registers, no ds_write pass), not depth: occupancy decides between the depths.
+constexpr int kDmaFlyDgrad = 2, kDmaFlyGroup = 1;
 constexpr int kPdFwdSmall = 2;      // one MFMA tile per wave (small planes): 0.1 us of MFMAs per k-tile against ~1 us of memory latency
 constexpr int kPdFwdBig = 2;        // 128 x 128 forward: with three-term products 384 cycles of MFMA per k-tile no longer cover a load (72.4 -> 67.6 us per launch)
 constexpr int kPdDgrad = 2;
@@ -302,7 +308,7 @@ struct GemmCfg {
     // Sizes that depend on the operand kind (NP pieces per operand: 3 for the fp32-class split, 1 for bf16 / fp16) and on
     // how many elements one 16-byte staging slot of a thread holds (AE for the A operand, BE for the weight gradient's B
     // operand: 4 fp32 or 8 16-bit elements).
-    template <int NP, int AE, int BE>
+    template <int NP, int AE, int BE, int NST = 2>
     struct G {
         static constexpr int A_BYTES = AT ? NP * K8 * LDUA * 16 : NP * BK * LDTA * 2;
         static constexpr int B_BYTES = AT ? NP * K8 * LDUB * 16 : NP * BK * LDTB * 2;
@@ -318,12 +324,12 @@ struct GemmCfg {
         // every staging slot of a thread maps inside the tile (no run-time range check, which would also make
         // hipcc drain vmcnt between the load groups of one k-tile)
         static constexpr bool A_FULL = A_LINES % A_STEP == 0, B_FULL = AT ? (NP * K8 * BN) % 256 == 0 : BK % B_STEP == 0;
-        static constexpr int AB_FLOATS = 2 * (A_BYTES + B_BYTES) / 4;
+        static constexpr int AB_FLOATS = NST * (A_BYTES + B_BYTES) / 4;      // NST LDS stages (2: register staging; kDmaFly + 1: LDS-DMA ring)
         static constexpr int TILE_FLOATS = AB_FLOATS > RED_FLOATS ? AB_FLOATS : RED_FLOATS;
     };
 };
 // LDS geometry of policy P's kernel
-template <class P> using GeoOf = typename P::Cfg::template G<np_of(P::kOp), P::kAE, P::kBE>;
+template <class P> using GeoOf = typename P::Cfg::template G<np_of(P::kOp), P::kAE, P::kBE, (P::kDmaFly > 0 ? P::kDmaFly + 1 : 2)>;
 
 // What a fetch leaves in registers: the untouched global loads (NV of them) and whether the
 // element exists at all (conv zero padding / padded pixel rows).  The BN transform is applied later,
@@ -343,6 +349,26 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ubase, u
 __device__ __forceinline__ u32x4 bload_u4(const void* ubase, unsigned bytes, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(ubase, bytes), (int)voff, (int)soff, 0));
 }
+// The same load as an LDS-DMA: `buffer_load_dwordx4 ... offen lds` writes the 64 lanes' 16-byte units to 64 CONSECUTIVE units of LDS from
+// the wave-uniform byte address in M0 (the global side stays per-lane: base + voff + soff).  Nothing crosses the register file; the
+// request counts in vmcnt like any load and stays in flight across s_barrier.  hipcc neither counts nor moves these statements: the
+// issuing wave waits with dma_wait<N>() (in-order completion), other waves' reads additionally need a barrier behind that wait.
+// (M0 is compiler-reserved: saved and restored inside the statement that uses it.)
+struct UnitSrc { const void* base; unsigned bytes, voff, soff; };
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma_unit(const UnitSrc& u, unsigned lds_dst) {
+    const unsigned long long a = (unsigned long long)u.base;
+    i32x4 rs;
+    rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    rs.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu));
+    rs.z = __builtin_amdgcn_readfirstlane((int)u.bytes);
+    rs.w = 0x00020000;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(u.voff), "s"(rs), "s"(__builtin_amdgcn_readfirstlane((int)u.soff)), "s"(__builtin_amdgcn_readfirstlane((int)lds_dst)) : "memory");
+}
+template <int N> __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void dma_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ float4 bload4(const void* ubase, unsigned bytes, unsigned voff, unsigned soff) {
     const u32x4 v = bload_u4(ubase, bytes, voff, soff);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
@@ -601,8 +627,12 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
     constexpr int OP = P::kOp, NP = np_of(OP), AE = P::kAE, BE = P::kBE;
     static_assert((AE == 4 || AE == 8) && (BE == 4 || BE == 8), "16-byte staging slots");
     static_assert((OP != 0 && OP != 3) || (AE == 4 && BE == 4), "the fp32-class splits read fp32 storage");
+    // LDS-DMA form (P::kDmaFly > 0; both operands finished 16-byte units): a ring of NST = kDmaFly + 1 stages, kDmaFly k-tiles in
+    // flight per workgroup without a staging register - see the k-loop below.  Otherwise two stages fed through registers.
+    constexpr int NFLY = P::kDmaFly, NST = NFLY > 0 ? NFLY + 1 : 2;
+    constexpr bool DMA = NFLY > 0;
     char* As = reinterpret_cast<char*>(smem);
-    char* Bs = As + 2 * Z::A_BYTES;
+    char* Bs = As + NST * Z::A_BYTES;
     float* sp = smem + Z::TILE_FLOATS;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -892,10 +922,37 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
 
     // First tile's global loads go out BEFORE the parameter prologue of the policies that still have one (it waits on its
     // own global loads): one memory round trip per workgroup instead of two.
+    // LDS-DMA of k-tile kt into ring stage st: every wave copies its 64-unit runs of the (piece, k8) planes - the lane -> unit mapping
+    // of the register path's copies, whose LDS targets are lane-consecutive already
+    constexpr int DMA_PER = A_CNT + Z::B_N;                 // DMA instructions per wave and k-tile
+    auto dma_tile = [&](int kt, int st) {
+        if constexpr (DMA) {
+            static_assert(C::AT && AU && C::BM % 64 == 0 && C::BN % 64 == 0 && Z::B_FULL && AU_UNITS % 256 == 0, "LDS-DMA: whole 64-unit runs per wave");
+            const unsigned lds0 = (unsigned)(uintptr_t)As;      // (low half of the flat address = the LDS byte address)
+            const unsigned a_dst = lds0 + (unsigned)st * Z::A_BYTES, b_dst = lds0 + NST * Z::A_BYTES + (unsigned)st * Z::B_BYTES;
+#pragma unroll
+            for (int i = 0; i < A_CNT; ++i) {
+                const int id = t + 256 * i;
+                const int r = id % C::BM, pk = id / C::BM;
+                dma_unit(p.a_unit_src(ctx, kt, pk / C::K8, pk % C::K8, r), a_dst + 16u * (unsigned)(pk * C::LDUA + r - lane));
+            }
+#pragma unroll
+            for (int i = 0; i < Z::B_N; ++i) {
+                const int id = t + 256 * i;
+                const int r = id % C::BN, pk = id / C::BN;
+                dma_unit(p.b_unit_src(ctx, kt, pk / C::K8, pk % C::K8, r), b_dst + 16u * (unsigned)(id - lane));
+            }
+        }
+    };
+    if constexpr (DMA) {
+#pragma unroll
+        for (int u = 0; u < NFLY; ++u) dma_tile(u < KT ? u : KT - 1, u);      // (KT < NFLY: clamped re-loads keep the counts exact)
+    } else {
 #pragma unroll
     for (int u = 0; u < PD; ++u) {
         if constexpr (PD > 1) g_load(u < KT ? u : KT - 1, ra[u], rb[u], kp[u]);   // same load count on every path: exact vmcnt
         else if (u < KT) g_load(u, ra[u], rb[u], kp[u]);
+    }
     }
 #ifdef SMG_TRACE_PRO     // dev: prologue stamps (start | first loads issued | parameters in LDS | early fetch issued | barrier passed)
     if (trace) trace[1] = smg_stamp();
@@ -926,9 +983,45 @@ __device__ __forceinline__ void gemm_tile(const P& p, const VBlock vb, float* sm
         for (int h = 0; h < BE / 4; ++h) bfix[h] = p.b_fix(ctx, (BE / 4) * bq + h, sp);
     }
     SMG_TRACE(1);
+    if constexpr (DMA) {
+        // k-tile kt: wait for this wave's pieces of it (in-order completion: at most the NFLY - 1 younger tiles stay out), barrier
+        // (everybody's pieces have landed AND everybody has left k-tile kt - 1, whose stage is free), issue k-tile kt + NFLY into
+        // that stage, compute.  One barrier per k-tile, nothing to store, NFLY tiles in flight.  The last NFLY tiles are peeled with
+        // their own exact counts.  (The epilogue operands' ordinary loads sit between the first tiles' requests: a count meant for
+        // DMA pieces only is then stricter than needed, never laxer.)
+        // The epilogue operands' loads are waited for HERE, with the first tiles: hipcc cannot see the requests above and would
+        // otherwise guard every later use of those registers (each segment hook) with a vmcnt(0) that drains the ring.
+        if constexpr (P::kEarlyFetch) __builtin_amdgcn_s_waitcnt(0x0F70);
+        SMG_TRACE(2);
+        int kt = 0, st = 0;
+        for (; kt + NFLY < KT; ++kt) {
+            dma_wait<(NFLY - 1) * DMA_PER>();
+            dma_barrier();
+            dma_tile(kt + NFLY, st == 0 ? NST - 1 : st - 1);
+            compute(st);
+            if constexpr (P::kSegmented) p.k_hook(ctx, kt, acc, sp);
+            st = st + 1 == NST ? 0 : st + 1;
+        }
+#pragma unroll
+        for (int u = NFLY - 1; u >= 0; --u) {            // u tiles stay in flight behind this one
+            if (kt < KT && KT - kt == u + 1) {
+                if (u == NFLY - 1) dma_wait<(NFLY - 1) * DMA_PER>(); else if (u == 2) dma_wait<2 * DMA_PER>(); else if (u == 1) dma_wait<DMA_PER>(); else dma_wait<0>();
+                dma_barrier();
+                compute(st);
+                if constexpr (P::kSegmented) p.k_hook(ctx, kt, acc, sp);
+                st = st + 1 == NST ? 0 : st + 1;
+                ++kt;
+            }
+        }
+        dma_wait<0>();                                   // (KT < NFLY: the clamped re-loads) nothing may land in LDS behind this point
+        dma_barrier();                                   // the epilogue reuses the stages
+    } else {
     if (KT > 0) s_store(0, 0, ra[0], rb[0], kp[0]);
     __syncthreads();
     SMG_TRACE(2);
+    }
+    if constexpr (DMA) {
+    } else
     if constexpr (PD == 1) {
         // two k-tiles per trip: the LDS buffer of every access is a compile-time constant (immediate offsets, no address VALU)
         auto step = [&](int kt, auto BUF, bool more) {
@@ -1095,6 +1188,7 @@ struct FwdConvP {
     // k-tiles of global loads in flight: the one-MFMA-tile-per-wave configurations of the small planes do 0.1 us of MFMAs per
     // k-tile against ~1 us of memory latency
     static constexpr int kPrefetch = (Cfg::TM * Cfg::TN == 1) ? kPdFwdSmall : kPdFwdBig;
+    static constexpr int kDmaFly = 0;
     static constexpr bool kSegmented = false;
     static constexpr bool kStem = MODE == F_STEM || MODE == F_STEM1;
     static constexpr bool kHasPrologue = !kStem;
@@ -1407,6 +1501,7 @@ struct BwdDataP {
     TileMap tm;
     static constexpr int kSwizzle = 1;
     static constexpr int kPrefetch = (Cfg::TM * Cfg::TN <= 2) ? kPdDgrad : kPdDgradBig;
+    static constexpr int kDmaFly = kAUnit ? kDmaFlyDgrad : 0;       // unit-form gradient + packed weights: both operands by LDS-DMA (gemm_tile)
     static constexpr bool kSegmented = false;
     static constexpr bool kHasPrologue = true;
     static constexpr bool kEarlyFetch = EMODE != E_UNPOOL;     // early_fetch(): the epilogue's operands, issued behind the first k-tiles' loads
@@ -1467,9 +1562,13 @@ struct BwdDataP {
         return true;
     }
     // unit (piece, k8 of this k-tile, tile row) of the finished gradient: plane-major units, consecutive rows consecutive
+    __device__ UnitSrc a_unit_src(const Ctx& c, int kt, int piece, int k8, int row) const {
+        return UnitSrc{static_cast<const u32x4*>(gbuf) + d2_stream_units(c.n, pa.HWp), kWholeBuf,
+                       16u * (unsigned)((piece * kD2K8 + k8) * pa.HWp + row), 16u * (unsigned)(kt * Cfg::K8 * pa.HWp + (c.m0 - c.n * pa.HWp))};
+    }
     __device__ u32x4 a_unit(const Ctx& c, int kt, int piece, int k8, int row) const {
-        return bload_u4(static_cast<const u32x4*>(gbuf) + d2_stream_units(c.n, pa.HWp), kWholeBuf,
-                        16u * (unsigned)((piece * kD2K8 + k8) * pa.HWp + row), 16u * (unsigned)(kt * Cfg::K8 * pa.HWp + (c.m0 - c.n * pa.HWp)));
+        const UnitSrc u = a_unit_src(c, kt, piece, k8, row);
+        return bload_u4(u.base, u.bytes, u.voff, u.soff);
     }
     __device__ u32x4 a_unit_d(const Ctx&, int, int, int, int) const { return u32x4{}; }
     __device__ void early_fetch(Ctx& c) const {
@@ -1595,8 +1694,12 @@ struct BwdDataP {
         return affine2(o.v[0], o.v[1], sp + a_chan(kt, q), KA);
     }
     __device__ ARaw a_fetch_d(const Ctx&, const DRow&, int, int, int) const { return ARaw{}; }
+    __device__ UnitSrc b_unit_src(const Ctx& c, int kt, int piece, int k8, int r) const {
+        return UnitSrc{wp, kWholeBuf, 16u * (unsigned)((piece * K8tot + k8) * ldn + r), 16u * (unsigned)(kt * Cfg::K8 * ldn + wcol0 + c.n0)};
+    }
     __device__ BRaw b_unit(const Ctx& c, int kt, int piece, int k8, int r) const {
-        return bload_u4(wp, kWholeBuf, 16u * (unsigned)((piece * K8tot + k8) * ldn + r), 16u * (unsigned)(kt * Cfg::K8 * ldn + wcol0 + c.n0));
+        const UnitSrc u = b_unit_src(c, kt, piece, k8, r);
+        return bload_u4(u.base, u.bytes, u.voff, u.soff);
     }
     __device__ u32x4 b_unit_xform(const Ctx&, const BRaw& o, int) const { return o; }
     __device__ void epilogue(const Ctx& c, f32x16 (&acc)[Cfg::TM][Cfg::TN], float* smem, float* sp, bool active) const {
@@ -1844,11 +1947,12 @@ struct BwdDataGroupP {
     // 1.54 -> 1.35 ms, step 28.8 -> 28.3 ms)
     static constexpr int kPrefetch = ((PREC == 0 && Cfg::BK >= 32 && Cfg::TM * Cfg::TN >= 2) || (PREC != 0 && Cfg::BK >= 64)) ? kPdDgradGroup
                                      : (Cfg::TM * Cfg::TN <= 1) ? kPdDgrad : kPdDgradBig;
+    static constexpr int kDmaFly = kAUnit ? kDmaFlyGroup : 0;       // unit-form D2 + packed weights: both operands by LDS-DMA (gemm_tile)
     static constexpr bool kSegmented = true;
     static constexpr bool kHasPrologue = true;
     static constexpr bool kEarlyFetch = true;
     // mode 0, 64-row tile held to 3 waves per SIMD: 176 -> 168 VGPRs (a few bytes of scratch), 121.7 -> 100.2 us per launch (blocks 3-4)
-    static constexpr int kMinWaves = (PREC == 0 && Cfg::BM == 64) ? 3 : 2;       // (x, the running sum and the old G' of the tile live in registers)
+    static constexpr int kMinWaves = PREC == 0 ? 3 : 2;       // (mode 0, LDS-DMA staging: 128-row tile 186 -> 168 VGPRs + 64 bytes of scratch, three workgroups per CU; x, the running sum and the old G' of the tile live in registers)
 
     struct Ctx {
         int n, m0, n0; bool whole;
@@ -2032,18 +2136,26 @@ struct BwdDataGroupP {
     __device__ ARaw a_quad(const ARaw& o, int h) const { ARaw r; r.ok = o.ok; r.v[0] = slot_quad<GT>(o.v[0], h); return r; }
     __device__ float4 a_xform(const Ctx&, const ARaw& o, const KPrm&, int, int, const float*) const { return o.v[0]; }
     // unit (piece, k8 of this k-tile, tile row) of the segment's D2 (operand kind 3): plane-major units, rows consecutive
-    __device__ u32x4 a_unit(const Ctx& c, int kt, int piece, int k8, int row) const {
+    __device__ UnitSrc a_unit_src(const Ctx& c, int kt, int piece, int k8, int row) const {
         const int s = kt / kps(), k80 = (kt - s * kps()) * Cfg::K8;
-        return bload_u4(static_cast<const u32x4*>(seg[s].g) + d2_stream_units(c.n, pa.HWp), kWholeBuf,
-                        16u * (unsigned)((piece * kD2K8 + k8) * pa.HWp + row), 16u * (unsigned)(k80 * pa.HWp + (c.m0 - c.n * pa.HWp)));
+        return UnitSrc{static_cast<const u32x4*>(seg[s].g) + d2_stream_units(c.n, pa.HWp), kWholeBuf,
+                       16u * (unsigned)((piece * kD2K8 + k8) * pa.HWp + row), 16u * (unsigned)(k80 * pa.HWp + (c.m0 - c.n * pa.HWp))};
+    }
+    __device__ u32x4 a_unit(const Ctx& c, int kt, int piece, int k8, int row) const {
+        const UnitSrc u = a_unit_src(c, kt, piece, k8, row);
+        return bload_u4(u.base, u.bytes, u.voff, u.soff);
     }
     __device__ u32x4 a_unit_d(const Ctx&, int, int, int, int) const { return u32x4{}; }
     __device__ ARaw a_fetch_d(const Ctx&, const DRow&, int, int, int) const { return ARaw{}; }
-    __device__ BRaw b_unit(const Ctx& c, int kt, int piece, int k8, int r) const {
+    __device__ UnitSrc b_unit_src(const Ctx& c, int kt, int piece, int k8, int r) const {
         const int s = kt / kps(), k80 = (kt - s * kps()) * Cfg::K8;
         const unsigned ldn16 = 16u * (unsigned)seg[s].ldn;                                  // (the row pitch changes with the segment)
-        return bload_u4(seg[s].wp, kWholeBuf, __umul24((unsigned)(piece * (KA / 8) + k8), ldn16) + 16u * (unsigned)r,
-                        (unsigned)k80 * ldn16 + 16u * (unsigned)c.n0);                     // rows past N: never stored
+        return UnitSrc{seg[s].wp, kWholeBuf, __umul24((unsigned)(piece * (KA / 8) + k8), ldn16) + 16u * (unsigned)r,
+                       (unsigned)k80 * ldn16 + 16u * (unsigned)c.n0};                       // rows past N: never stored
+    }
+    __device__ BRaw b_unit(const Ctx& c, int kt, int piece, int k8, int r) const {
+        const UnitSrc u = b_unit_src(c, kt, piece, k8, r);
+        return bload_u4(u.base, u.bytes, u.voff, u.soff);
     }
     __device__ u32x4 b_unit_xform(const Ctx&, const BRaw& o, int) const { return o; }
 
@@ -2246,6 +2358,7 @@ struct BwdWeightP {
     TileMap tm;
     static constexpr int kSwizzle = 2;
     static constexpr int kPrefetch = PD_;     // k-tiles of global loads in flight per thread
+    static constexpr int kDmaFly = 0;
     static constexpr bool kSegmented = kAUnit;      // k_hook: the accumulators follow the gradient operand's per-block scale
     static constexpr bool kHasPrologue = true;
     static constexpr bool kEarlyFetch = false;
