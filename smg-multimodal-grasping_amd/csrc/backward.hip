@@ -172,14 +172,16 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             a.tiles_per_wg = w3_tiles_per_wg(a.n_tiles, ts, NS, e->part_floats, (double)ts / th);
             const int groups = (a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
             if ((int64_t)groups * NS * 9 * 32 * kBottleneck > e->part_floats) return fail(-12, "partial-gradient workspace too small");
+            a.groups = groups; a.streams = NS;
+            const unsigned w3_grid = (unsigned)(((groups * NS + 7) / 8) * 8 * (kBottleneck / 32));      // (see the kernel: channel groups of a tile group share an XCD)
             {
                 BY(e, ESZ(e) * NS * pl.HW * (kGrowth + kBottleneck));
                 ProfScope ps(e, s2, K_W3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
                 if (ts == 16) {
-                    PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_wgrad_kernel<16, PREC>), dim3(groups, kBottleneck / 32, NS), dim3(256),
+                    PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_wgrad_kernel<16, PREC>), dim3(w3_grid), dim3(256),
                                                         (HaloWgradSGeo<16, PREC>::smem_bytes()), s2, a));
                 } else {
-                    PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_wgrad_kernel<8, PREC>), dim3(groups, kBottleneck / 32, NS), dim3(256),
+                    PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_wgrad_kernel<8, PREC>), dim3(w3_grid), dim3(256),
                                                         (HaloWgradSGeo<8, PREC>::smem_bytes()), s2, a));
                 }
             }

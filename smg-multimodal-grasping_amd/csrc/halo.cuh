@@ -665,8 +665,9 @@ struct Halo3x3WgradArgs {
     const void* src; int C;                          // raw bottleneck [n][HWp][C]
     BnTab bt;                                        // norm2 statistics of this layer (stored by the forward) + gamma / beta
     const float* asc;                                // operand kind 3: {s, 1 / s} of the BN + ReLU operand
-    float* part;                                     // partial sums [gridDim.x*gridDim.z][9][32][C]
+    float* part;                                     // partial sums [groups * streams][9][32][C]
     int tiles_x, n_tiles, tiles_per_wg;
+    int groups, streams;                             // launch geometry: 1-D grid of 8 * ceil(groups * streams / 8) * (C / 32) workgroups
 };
 
 // ------------------------------------------------------------------------------------
@@ -705,8 +706,14 @@ static __global__ __launch_bounds__(256, kHaloWgradWaves) void conv3x3_halo_wgra
     float* prm = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + G::smem_bytes()) - 96 - 128;    // mean | scale | beta (32 each)
     float* gp = prm + 96;                               // GradSrc parameters [4][32]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, half = lane >> 5;
-    const int n = blockIdx.z, cc0 = blockIdx.y * 32;
+    // Workgroup -> (tile group, stream, channel group).  The C / 32 channel groups of one (tile group, stream) read the SAME gradient
+    // tiles: they sit on ONE XCD (workgroups go to the eight XCDs round-robin by linear index) in consecutive slots, so three of the
+    // four reads hit that XCD's L2 instead of HBM (round 5: 1.9 GB per step of this kernel's 4.4 GB were such re-reads).
     const int C = a.C;
+    const int ncg = C / 32, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int gz = (slot / ncg) * 8 + xcd;             // (tile group, stream) index
+    if (gz >= a.groups * a.streams) return;
+    const int n = gz / a.groups, bx = gz - n * a.groups, cc0 = (slot % ncg) * 32;
     ActScale gsc{1.f, 1.f};                             // operand kind 3: scale of this stream's gradient operand; inverse of (gradient x activation) scale
     float sa = 1.f;
     if constexpr (OP == 3) { gsc = amax_scale(a.g.amax + (int64_t)n * kAmaxRep); gsc.inv *= a.asc[1]; sa = a.asc[0]; }
@@ -726,7 +733,7 @@ static __global__ __launch_bounds__(256, kHaloWgradWaves) void conv3x3_halo_wgra
     const char* x_n = a.g.x ? static_cast<const char*>(a.g.x) + (int64_t)XSZ * n * a.pl.HWp * a.g.ldx : nullptr;
     // transposing-read geometry: lane i of a 16-lane group fetches pixel-row (k) i/4, channel quad i%4 and receives channel i
     const int tr_row = (lane & 15) >> 2, tr_col = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
-    const int tile0 = blockIdx.x * a.tiles_per_wg;
+    const int tile0 = bx * a.tiles_per_wg;
     const int tile1 = min(tile0 + a.tiles_per_wg, a.n_tiles);
     for (int tile = tile0; tile < tile1; ++tile) {
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
@@ -858,7 +865,7 @@ static __global__ __launch_bounds__(256, kHaloWgradWaves) void conv3x3_halo_wgra
             const int r = e >> 6, ln = e & 63;
             const float v = (red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e]) * gsc.inv;      // (1 unless operand kind 3: per-stream scale, removed before streams are summed)
             const int nn = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), cc = ln & 31;
-            a.part[((((int64_t)blockIdx.x * gridDim.z + n) * 9 + tap) * 32 + nn) * C + cc0 + cc] = v;
+            a.part[((((int64_t)bx * a.streams + n) * 9 + tap) * 32 + nn) * C + cc0 + cc] = v;
         }
     }
 }
