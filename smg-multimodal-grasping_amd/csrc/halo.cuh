@@ -54,7 +54,7 @@ struct Halo3x3FwdArgs {
     const float* asc;                               // operand kind 3: {s, 1 / s} of the BN + ReLU operand
     void* dst; int ldd, dcoff;
     double* dsum; double* dsq; int dstride;
-    int tiles_x;
+    int tiles_x, n_tiles, streams;                   // 1-D grid of banded_grid(n_tiles, streams) workgroups (banded_tile)
 };
 
 // Channels per chunk of the forward: one k16-step per tap for the fp32-class split (three pieces per operand), two for the
@@ -86,26 +86,48 @@ template <int TS, int PREC> struct HaloFwdSGeo : HaloGeo<TS> {
     static constexpr int BU = NP * 9 * K8C * 32;                         // weight units per chunk: 1728 / 1152
     static constexpr int B_N = (BU + 255) / 256;                         // (the last copies of a round read / write padding)
     __host__ __device__ static constexpr int smem_bytes(int C) { return (A_UNITS + B_N * 256) * 16 + 3 * C * 4; }
+    __host__ __device__ static constexpr int smem_bytes_ws(int C) { return 2 * (A_UNITS + BU) * 16 + 3 * C * 4; }      // wave-specialised form: two buffers
 };
 
 // RAG: tiles may hang over the plane's edge (stores, statistics and mask loads are bounds-checked) - always at TS = 8; at TS = 16 only
 // for planes that do not tile by 16 (S = 1824), so that the exact planes of the headline keep their check-free epilogues.
-template <int TS, int PREC = 0, bool RAG = false>
-static __global__ __launch_bounds__(256, kHaloFwdWaves) void conv3x3_halo_fwd_kernel(const Halo3x3FwdArgs a) {
+// (tile, stream) of this workgroup of a 1-D grid of 8 * ceil(n_tiles * streams / 8): workgroups go to the eight XCDs round-robin by
+// linear index, and each XCD walks ONE contiguous run of the (stream, tile) sequence - the halo rows and columns that neighbouring
+// tiles share are read from HBM once and from that XCD's L2 after (round 5: 141 -> 113 MB fetched per launch at TS = 16, 16.2 -> 11.4
+// at TS = 8).
+__device__ __forceinline__ bool banded_tile(int n_tiles, int streams, int& tile, int& n) {
+    const int total = n_tiles * streams, per = (total + 7) / 8;
+    const int w = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || w >= total) return false;
+    n = w / n_tiles;
+    tile = w - n * n_tiles;
+    return true;
+}
+static inline unsigned banded_grid(int n_tiles, int streams) { return 8u * (unsigned)((n_tiles * streams + 7) / 8); }
+
+// WS (wave-specialised form, 512 threads): waves 0..3 are the kernel's four matrix waves and do nothing but fragment reads and
+// MFMAs; waves 4..7 fetch, transform and store the NEXT chunk into a second (halo, weights) buffer meanwhile - one barrier per chunk.
+// Measured on the plain kernel (round 5, per launch at TS = 16 / 8): 67.5 / 17.3 us as built, 38.7 / 12.1 with the loads and the
+// transform removed, 37.1 / 12.2 with the taps removed - its two halves run one after the other even at two workgroups per CU.
+template <int TS, int PREC = 0, bool RAG = false, bool WS = false>
+static __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : kHaloFwdWaves) void conv3x3_halo_fwd_kernel(const Halo3x3FwdArgs a) {
     constexpr bool kEdge = TS == 8 || RAG;
     using G = HaloFwdSGeo<TS, PREC>;
     using ST = act_t<PREC>;
     constexpr int OP = fwd_op(PREC), NP = G::NP, CK = G::CK, K8C = G::K8C, KSTEP = CK / 16;
     constexpr int MT = G::MT, A_N = G::A_N, B_N = G::B_N, LDH = G::LDH, ESZ = ST::size, E = 16 / ESZ;
+    constexpr int BUF_BYTES = WS ? (G::A_UNITS + G::BU) * 16 : 0;       // WS: two (halo, weights) buffers, the weights exactly BU units
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* As = reinterpret_cast<char*>(smem);                // [piece][k8][LDH] units
+    char* As = reinterpret_cast<char*>(smem);                // [piece][k8][LDH] units          (WS: of the buffer being read)
     char* Bs = As + G::A_UNITS * 16;                         // [piece][tap][k8][32] units
-    float* prm = reinterpret_cast<float*>(Bs + B_N * 256 * 16);      // mean | scale | beta, C each
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
+    float* prm = reinterpret_cast<float*>(WS ? reinterpret_cast<char*>(smem) + 2 * BUF_BYTES : Bs + B_N * 256 * 16);      // mean | scale | beta, C each
+    const int role = WS ? (int)(threadIdx.x >> 8) : 0;       // WS: 0 = matrix waves, 1 = staging waves
+    const int t = WS ? (int)(threadIdx.x & 255) : (int)threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
     const int wq = wave % G::WQ, wk = wave / G::WQ;          // pixel slice, tap slice
     const int tap0 = (G::WX > 1 && wk) ? 5 : 0, tap1 = (G::WX > 1 && !wk) ? 5 : 9;
-    const int n = blockIdx.y;
-    const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
+    int n, tile;
+    if (!banded_tile(a.n_tiles, a.streams, tile, n)) return;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int y0 = ty * TS, x0 = tx * TS;
     const int C = a.C, kq = t & 3;                           // this thread's 16-byte slot inside every chunk (E channels)
     const float sa = OP == 3 ? a.asc[0] : 1.f;               // operand kind 3: the activation scale rides on gamma * invstd and beta
@@ -124,8 +146,12 @@ static __global__ __launch_bounds__(256, kHaloFwdWaves) void conv3x3_halo_fwd_ke
     }
     const char* src_n = static_cast<const char*>(a.src) + (int64_t)ESZ * n * a.pl.HWp * a.lds_;
     const u32x4* wu = a.wu;
-    float4 ra[A_N]; u32x4 rb[B_N];
-    auto g_load = [&](int chunk) {
+    constexpr int NSET = 1;              // register sets of loads in flight (WS with two sets, loads two chunks ahead: 63.2 -> 72.8 us per launch at TS = 16 - the
+                                         // 128-register budget of the 16-wave CU is gone - and 15.3 -> 15.2 at TS = 8: one chunk of taps covers the loads)
+    float4 ra_[NSET][A_N]; u32x4 rb_[NSET][B_N];
+    using Set0 = std::integral_constant<int, 0>;
+    auto g_load = [&](int chunk, auto SET) {
+        float4 (&ra)[A_N] = ra_[decltype(SET)::value]; u32x4 (&rb)[B_N] = rb_[decltype(SET)::value];
         const int c0 = chunk * CK + E * kq;
 #pragma unroll
         for (int i = 0; i < A_N; ++i)                               // unconditional loads from clamped addresses
@@ -133,7 +159,8 @@ static __global__ __launch_bounds__(256, kHaloFwdWaves) void conv3x3_halo_fwd_ke
 #pragma unroll
         for (int i = 0; i < B_N; ++i) rb[i] = wu[(int64_t)chunk * G::BU + t + 256 * i];      // (slack behind the packed array)
     };
-    auto s_store = [&](int chunk) {
+    auto s_store = [&](int chunk, char* As, char* Bs, auto SET) {      // (WS: the buffer being filled)
+        const float4 (&ra)[A_N] = ra_[decltype(SET)::value]; const u32x4 (&rb)[B_N] = rb_[decltype(SET)::value];
         const float* pq = prm + chunk * CK + E * kq;
 #pragma unroll
         for (int i = 0; i < A_N; ++i) {
@@ -151,7 +178,8 @@ static __global__ __launch_bounds__(256, kHaloFwdWaves) void conv3x3_halo_fwd_ke
             }
         }
 #pragma unroll
-        for (int i = 0; i < B_N; ++i) *reinterpret_cast<u32x4*>(Bs + (t + 256 * i) * 16) = rb[i];
+        for (int i = 0; i < B_N; ++i)
+            if (!WS || t + 256 * i < G::BU) *reinterpret_cast<u32x4*>(Bs + (t + 256 * i) * 16) = rb[i];
     };
 
     f32x16 acc[MT];
@@ -170,21 +198,22 @@ static __global__ __launch_bounds__(256, kHaloFwdWaves) void conv3x3_halo_fwd_ke
     };
 
     const int NCH = C / CK;
-    g_load(0);                       // (the first chunk's loads in front of the parameter prologue, which waits for its own fp64 sums: measured, no change -
+    if (!WS || role == 1)
+    g_load(0, Set0{});                       // (the first chunk's loads in front of the parameter prologue, which waits for its own fp64 sums: measured, no change -
                                      //  66.5 / 16.6 us per launch both ways; the prologue's 9.8k cycles are the moments' arithmetic and the first store)
-    for (int k = t; k < C; k += 256) {                       // BN parameters of this stream
+    for (int k = threadIdx.x; k < C; k += (WS ? 512 : 256)) {            // BN parameters of this stream
         float mean, invstd;
         bn_moments(a.ssum, a.ssq, (int64_t)n * a.sstride + k, 1.0 / (double)a.pl.HW, a.eps, mean, invstd);
         prm[k] = mean;
         prm[C + k] = a.gamma[k] * invstd * sa;
         prm[2 * C + k] = a.beta[k] * sa;
-        if (blockIdx.x == 0) { a.tw_mean[(int64_t)n * C + k] = mean; a.tw_invstd[(int64_t)n * C + k] = invstd; }
+        if (tile == 0) { a.tw_mean[(int64_t)n * C + k] = mean; a.tw_invstd[(int64_t)n * C + k] = invstd; }
     }
     __syncthreads();                 // prm visible
-    s_store(0);
+    if (!WS || role == 1) s_store(0, As, Bs, Set0{});
+    if (WS && role == 1 && NCH > 1) g_load(1, Set0{});
     __syncthreads();
-    for (int ch = 0; ch < NCH; ++ch) {
-        if (ch + 1 < NCH) g_load(ch + 1);
+    auto taps_of_chunk = [&]() {
         // per tap: hi and lo pieces, the two hi x lo groups, then the mid pieces (fetched under those MFMAs) and the rest;
         // the next tap's hi / lo pieces are requested before the last four groups of this one
         u32x4 ah[2][KSTEP][MT], al[2][MT], bh[2][KSTEP], bl[2];
@@ -252,10 +281,35 @@ static __global__ __launch_bounds__(256, kHaloFwdWaves) void conv3x3_halo_fwd_ke
             for (int tp = 5; tp < 9; ++tp) tap_body(tp & 1, tp, tp + 1 < 9);
         }
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();                          // every wave is done reading this chunk
-        if (ch + 1 < NCH) {
-            s_store(ch + 1);
-            __syncthreads();
+    };
+    if constexpr (WS) {
+        // each role runs its own loop (one register allocation per role, not their union), one barrier per chunk
+        if (role == 1) {             // staging waves: chunk ch + 1 into the other buffer (its loads went out one chunk ago), then chunk ch + 2's loads
+            for (int ch = 0; ch < NCH; ++ch) {
+                if (ch + 1 < NCH) {
+                    char* Ad = reinterpret_cast<char*>(smem) + ((ch + 1) & 1) * BUF_BYTES;
+                    s_store(ch + 1, Ad, Ad + G::A_UNITS * 16, Set0{});
+                    if (ch + 2 < NCH) g_load(ch + 2, Set0{});
+                }
+                __syncthreads();
+            }
+            return;                  // (barriers count live waves only)
+        }
+        for (int ch = 0; ch < NCH; ++ch) {
+            As = reinterpret_cast<char*>(smem) + (ch & 1) * BUF_BYTES;
+            Bs = As + G::A_UNITS * 16;
+            taps_of_chunk();
+            __syncthreads();         // this chunk is read, the next one is in the other buffer
+        }
+    } else {
+        for (int ch = 0; ch < NCH; ++ch) {
+            if (ch + 1 < NCH) g_load(ch + 1, Set0{});
+            taps_of_chunk();
+            __syncthreads();                          // every wave is done reading this chunk
+            if (ch + 1 < NCH) {
+                s_store(ch + 1, As, Bs, Set0{});
+                __syncthreads();
+            }
         }
     }
     if constexpr (G::WX > 1) {                    // fold the tap-split partial tiles into the wk == 0 waves
@@ -739,6 +793,8 @@ static __global__ __launch_bounds__(256, kHaloWgradWaves) void conv3x3_halo_wgra
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         const int y0 = ty * G::TH, x0 = tx * TW;
         __syncthreads();                              // previous tile fully consumed (and prm visible)
+        // (the next tile's loads issued behind this tile's LDS stores, in flight under its MFMAs: 68.4 -> 69.2 / 15.6 -> 16.0 us per launch -
+        //  two workgroups per CU already cover the round trip, the 40 staging registers cost more)
         {
             float4 rv[B_N], rg[A_N], rgx[E == 4 ? 1 : A_N];
             bool okv[B_N], okg[A_N];
