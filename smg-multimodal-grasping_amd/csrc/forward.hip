@@ -219,12 +219,12 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                     a.wu = e->packed_u + e->pk_hf[b][i]; a.asc = asc_n2(e, b, (int)i);
                     BY(e, ESZ(e) * ns * pl.HW * (kBottleneck + kGrowth));
                     ProfScope ps(e, cs, K_C3, 2.0 * ns * pl.HW * 9 * kBottleneck * kGrowth);
-                    if (e->prec == 0 && halo_tile(pl, ns) == 8) {
-                        // small planes, mode 0: the wave-specialised form (halo.cuh; 17.1 -> 15.2 us per launch.  At TS = 16 it measures
+                    if (halo_tile(pl, ns) == 8) {
+                        // small planes: the wave-specialised form (halo.cuh; 17.1 -> 15.2 us per launch.  At TS = 16 it measures
                         // 67.8 -> 62.8 us serialised and nothing on the step - two forward chains already fill each other's gaps there)
                         a.tiles_x = (pl.W + 7) / 8; a.n_tiles = ((pl.H + 7) / 8) * a.tiles_x; a.streams = ns;
-                        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_fwd_kernel<8, 0, false, true>), dim3(banded_grid(a.n_tiles, ns)), dim3(512),
-                                           (HaloFwdSGeo<8, 0>::smem_bytes_ws(kBottleneck)), cs, a);
+                        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_fwd_kernel<8, PREC, false, true>), dim3(banded_grid(a.n_tiles, ns)), dim3(512),
+                                           (HaloFwdSGeo<8, PREC>::smem_bytes_ws(kBottleneck)), cs, a));
                     } else
                     if (halo_tile(pl, ns) == 16) {
                         a.tiles_x = (pl.W + 15) / 16; a.n_tiles = ((pl.H + 15) / 16) * a.tiles_x; a.streams = ns;
@@ -235,10 +235,6 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                             PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_fwd_kernel<16, PREC>), dim3(banded_grid(a.n_tiles, ns)), dim3(256),
                                                (HaloFwdSGeo<16, PREC>::smem_bytes(kBottleneck)), cs, a));
                         }
-                    } else {
-                        a.tiles_x = (pl.W + 7) / 8; a.n_tiles = ((pl.H + 7) / 8) * a.tiles_x; a.streams = ns;
-                        PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_fwd_kernel<8, PREC>), dim3(banded_grid(a.n_tiles, ns)), dim3(256),
-                                           (HaloFwdSGeo<8, PREC>::smem_bytes(kBottleneck)), cs, a));
                     }
                 } else {   // norm2 + relu + conv2 (3x3, 128 -> 32), appended to the block buffer (generic implicit GEMM)
                     auto run = [&](auto tag) {
