@@ -222,11 +222,20 @@ class _AffordanceNet(nn.Module):
         if self._flat_grads is None or self._flat_grads.device != self._flat_params.device:
             self._flat_grads = torch.zeros_like(self._flat_params)
             self._grads_clean = True
+            self._dirty_ranges = set()
         return self._flat_grads
 
     def zero_grad(self, set_to_none=True):
         if self._flat_grads is not None:
-            self._flat_grads.zero_()
+            dirty = getattr(self, "_dirty_ranges", None)
+            if dirty is None:
+                self._flat_grads.zero_()
+            else:
+                # only the (trunk, head) ranges written since the last zero_grad: 7.1 M of the 24.4 M floats for a reinforcement step
+                # (the whole-buffer fill was 70 us at the head of every step)
+                for off, n in dirty:
+                    self._flat_grads[off:off + n].zero_()
+        self._dirty_ranges = set()
         self._grads_clean = True
         self._graph_exposed = None
         for p in self.parameters():
@@ -341,6 +350,9 @@ class _AffordanceNet(nn.Module):
             raise
         self._saved = (eng, token, trunk_id, head_id)
         self._grads_clean = False
+        if getattr(self, "_dirty_ranges", None) is not None:
+            self._dirty_ranges.add(smg_hip.trunk_range(self.HEAD_OUT, trunk_id))
+            self._dirty_ranges.add(smg_hip.head_range(self.HEAD_OUT, head_id))
         return trunk_id, head_id
 
     def run_pairs(self, style, num_rot, heightmaps, rot_streams, mask_images, pairs, mean=0.0, std=1.0,
@@ -399,6 +411,8 @@ class _AffordanceNet(nn.Module):
                                     (smg_hip.head_range(self.HEAD_OUT, head_id), self._range_probe[("h", head_id)])):
                 if probe.grad is None and not self._grads_clean:
                     g[off:off + n].zero_()
+                if getattr(self, "_dirty_ranges", None) is not None:
+                    self._dirty_ranges.add((off, n))
             self._grads_clean = False
         eng.backward(self._net_struct(True), dq.data_ptr(), stream, phase)
         if phase in (None, 1):
