@@ -55,7 +55,7 @@
 // kernels are held to - every value below was A/B-measured on the box (profiles/README.md) and is frozen here.
 namespace smg {
 // k-tiles in flight by LDS-DMA (gemm_tile; 0 = register staging) where both operands are finished 16-byte units.  Serialised ms per step,
-// register staging / 1 / 2 / 3 tiles in flight: per-layer data gradient 128 x 64 x 16 0.82 / 0.74 / 0.69 / 0.69 and 64 x 64 x 32 0.34 / 0.31 /
+// register staging / 1 / 2 / 3 tiles in flight: per-layer data gradient 128 x 64 x 16 0.77-0.82 / 0.74 / 0.69 / 0.69 and 64 x 64 x 32 0.31-0.34 / 0.31 /
 // 0.31 / 0.32; grouped 128 x 64 x 32 1.24 / 1.12 / 1.08 / 1.54 (four stages: one workgroup per CU) - and 1.04 with ONE tile in flight at
 // three waves per SIMD (two stages of LDS + 168 registers let a third workgroup in); grouped 64 x 64 x 32 0.89 / 0.78 / 0.84 / 1.00.
 // What the DMA buys is the staging work (no registers, no ds_write pass), not depth: occupancy decides between the depths.
