@@ -118,6 +118,20 @@ static __global__ __launch_bounds__(1024) void scale_kernel(const PackDesc* desc
         const float* w = params + d.src;
         float m4[4] = {0.f, 0.f, 0.f, 0.f};                 // four independent loads in flight per thread (127 k floats in the largest tensor)
         int64_t i = t;
+        if ((d.src & 3) == 0) {                             // 16-byte aligned tensors (all of the layout's): four float4 in flight, 8 trips instead of 31
+            const float4* w4 = reinterpret_cast<const float4*>(w);
+            const int64_t c4 = count >> 2;
+            int64_t j = t;
+            for (; j + 3 * 1024 < c4; j += 4 * 1024) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 v = w4[j + u * 1024];
+                    m4[u] = fmaxf(m4[u], fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+                }
+            }
+            for (; j < c4; j += 1024) { const float4 v = w4[j]; m4[0] = fmaxf(m4[0], fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))); }
+            i = 4 * c4 + t;                                 // (the up to three floats behind the last whole float4)
+        } else
         for (; i + 3 * 1024 < count; i += 4 * 1024) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) m4[u] = fmaxf(m4[u], fabsf(w[i + u * 1024]));
