@@ -1374,7 +1374,9 @@ struct FwdConvP {
 #pragma unroll
                 for (int j = 0; j < Cfg::TN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+                    for (int r = 0; r < 16; ++r) {
+                        acc[i][j][r] *= inv;
+                    }
         }
         const int pbase = c.m0 - c.n * po.HWp;
         if (pbase + Cfg::BM <= po.HW && c.n0 + Cfg::BN <= N) {
@@ -1413,7 +1415,13 @@ struct FwdConvP {
                                 const float x = acc[i][j][r];
                                 st1<DstT>(tb, o, x);
                                 o += (r & 3) == 3 ? 5u * (unsigned)ldd : (unsigned)ldd;
-                                const float dx = x - s;
+                                float dx = x - s;
+                                // (opaque to the SLP vectoriser: with -fslp-vectorize hipcc pairs the statistics of DIFFERENT strips into
+                                //  v_pk_add_f32 / v_pk_fma_f32 chains - every packed form legal as written - and the fp64 sums of a launch
+                                //  then vary from run to run; this barrier, one behind `acc *= inv`, or -fno-slp-vectorize each restore
+                                //  bit-reproducible statistics, wait states do not.  The Makefile keeps the flag, this keeps the site safe
+                                //  without it, test_forward_is_bit_reproducible_run_to_run watches every other one.)
+                                asm volatile("" : "+v"(dx));
                                 s1 += dx;
                                 s2 = fmaf(dx, dx, s2);
                             }
