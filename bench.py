@@ -49,15 +49,15 @@ PMC_FILE = "pmc_r05_hbm_traffic.json"                     # tools/profile_round.
 SERIAL_CSV = "rocprof_r05_kernel_stats_serialized.csv"    # rocprofv3 --kernel-trace --stats of `bench.py --train-only --serialize`
 PASS5_GFLOP = 36767.6                 # S=1824, R=32 fwd+bwd pass, masked stream de-duplicated
 # rocprofv3 kernel-name fragments that make up each class of roofline.per_kernel (profiles/*kernel_stats*.csv)
-# (reduce_partials_kernel serves every weight gradient that goes through partial tiles - the 3x3 ones, since round 3 the 1x1 ones too,
-# the transitions, the stem - and carries no policy in its name: the CSV lists it once; it is filed under conv3x3_wgrad here, while the
-# live hipEvent classes of roofline.per_kernel charge each reduce to the class that launched it)
+# (reduce_partials_kernel serves every weight gradient that goes through partial tiles - one launch per dense layer reduces its 3x3 AND
+# 1x1 partial tiles - and carries no policy in its name: it is filed with the element-wise kernels, here, in the engine's live hipEvent
+# classes and in tools/pmc_hbm_summary.py alike, so that a class's launches, time and bytes are those of its GEMM kernels in all three)
 CLASS_SYMBOLS = {      # fnmatch patterns; template arguments: FwdConvP<Cfg, MODE, PREC, F32IO>, BwdDataP<Cfg, SHIFT3, EMODE, AFF, PREC, F32IO>,
                        # BwdDataGroupP<Cfg, PREC>, BwdWeightP<Cfg, BMODE, CMAP, PD, AFF, PREC, F32IO>, conv3x3_halo_*_kernel<tile, PREC>
     "stem7x7_fwd": ["FwdConvP<*>, 3, ?, false>", "FwdConvP<*>, 4, ?, false>"],
     "conv1x1_fwd": ["FwdConvP<*>, 0, ?, false>", "conv1x1_fwd_ws_kernel"], "head_conv0_fwd": ["FwdConvP<*>, 0, ?, true>"],
     "conv3x3_fwd": ["conv3x3_halo_fwd_kernel"], "transition_fwd": ["FwdConvP<*>, 2, ?, false>"],
-    "conv3x3_dgrad": ["conv3x3_halo_dgrad_kernel"], "conv3x3_wgrad": ["conv3x3_halo_wgrad_kernel", "reduce_partials_kernel"],
+    "conv3x3_dgrad": ["conv3x3_halo_dgrad_kernel"], "conv3x3_wgrad": ["conv3x3_halo_wgrad_kernel"],
     "conv1x1_dgrad": ["BwdDataGroupP<", "BwdDataP<*>, false, 1, false, ?, false>"], "conv1x1_wgrad": ["BwdWeightP<*>, 0, 0, 3, false, ?, false>", "conv1x1_wgrad_ws_kernel"],
     "transition_wgrad": ["BwdWeightP<*>, 2, 0, 1, true, ?, false>"], "transition_dgrad": ["BwdDataP<*>, false, 2, true, ?, false>"],
     "stem_wgrad": ["BwdWeightP<*>, 3, 2, 3, true, ?, false>", "BwdWeightP<*>, 4, 3, 3, true, ?, false>"],

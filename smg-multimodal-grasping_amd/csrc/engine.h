@@ -360,7 +360,7 @@ static int launch_wgrad(smg_engine* e, hipStream_t st, P& p, dim3 grid, int kind
         r.dw = p.dw; r.ldw_out = p.ldw_out; r.cmap = cmap;
         if (defer) { *defer = r; return 0; }
         const int total = taps * p.MA * p.NB;
-        ProfScope ps(e, st, kind, 0);
+        ProfScope ps(e, st, K_OTHER, 0);       // (the reduce is profiled with the element-wise kernels: a class's launches are its GEMM kernels only)
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((total + 63) / 64), dim3(256), 0, st, r, ReduceArgs{}, (total + 63) / 64);
     }
     return 0;
@@ -369,7 +369,8 @@ static int launch_wgrad(smg_engine* e, hipStream_t st, P& p, dim3 grid, int kind
 static void launch_reduce2(smg_engine* e, hipStream_t st, int kind, const ReduceArgs& ra, const ReduceArgs& rb) {
     const int ba = ra.Z ? (ra.taps * ra.rows * ra.cols + 63) / 64 : 0, bb = rb.Z ? (rb.taps * rb.rows * rb.cols + 63) / 64 : 0;
     if (ba + bb == 0) return;
-    ProfScope ps(e, st, kind, 0);
+    (void)kind;
+    ProfScope ps(e, st, K_OTHER, 0);           // (one launch serves the layer's 3x3 AND 1x1 partial tiles: profiled with the element-wise kernels)
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(ba + bb), dim3(256), 0, st, ra, rb, ba);
 }
 

@@ -35,7 +35,8 @@ def kclass(name):
     if "conv1x1_wgrad_ws_kernel" in name: return "conv1x1_wgrad"
     if "conv3x3_halo_fwd" in name: return "conv3x3_fwd"
     if "conv3x3_halo_dgrad" in name: return "conv3x3_dgrad"
-    if "conv3x3_halo_wgrad" in name or "reduce_partials" in name: return "conv3x3_wgrad"
+    if "conv3x3_halo_wgrad" in name: return "conv3x3_wgrad"
+    if "reduce_partials" in name: return "elementwise"       # (one launch reduces a layer's 3x3 AND 1x1 partial tiles: bench.py profiles it as element-wise too)
     if "FwdConvP<" in name:
         a = targs(name, "FwdConvP")           # MODE, PREC, F32IO
         if a[0] == "0" and len(a) > 2 and a[2] == "true": return "head_conv0_fwd"
