@@ -285,7 +285,7 @@ def compact_line(out):
         c["cpu_baseline"] = {k: _r(cb[k]) for k in ("value", "unit", "cores", "kind", "seconds_per_pass", "physical_cores",
                                                     "value_physical_cores", "seconds_per_pass_physical_cores", "sweep_fwd_seconds") if k in cb}
         c["cpu_baseline"]["sample"] = cb.get("sample", "")[:100]
-    for k in ("pass_tflops_algorithmic", "host_enqueue_ms_per_step", "ms_per_step_host_inputs", "sweep_fwd_ms", "train_step_ms", "train_step_host_enqueue_ms", "train_step_eager_ms",
+    for k in ("pass_tflops_algorithmic", "host_enqueue_ms_per_step", "ms_per_step_host_inputs", "sweep_fwd_ms", "train_step_ms", "train_step_host_enqueue_ms", "train_step_graph_ms",
               "train_step_kernel_ms", "train_step_launches", "forward_1rot_ms", "launches_per_step", "allreduce_overlapped", "allreduce_exposed_ms_per_step",
               "allreduce_ms", "allreduce_bytes", "allreduce_backend", "rccl_world", "device_count", "devices_seen"):
         if k in out:
@@ -593,6 +593,8 @@ def main():
         with contextlib.redirect_stdout(sys.stderr):
             def one_backprop(i):
                 return tr.backprop(depth, 'grasp', (0, i % R), (0, 0), (0, 0), (0, 0), float(labels[i % R]), mk3.reshape(mk3.shape[:3]), None, None, None)
+            # as ONE replayed hipGraph per step (smg_train_step_graph; Trainer.use_step_graph): less host time, not less latency
+            tr.use_step_graph = True
             for i in range(3):
                 one_backprop(i)
             torch.cuda.synchronize(dev)
@@ -603,9 +605,9 @@ def main():
                 one_backprop(i)
                 enq += tr.last_enqueue_ms
             torch.cuda.synchronize(dev)
-            out["train_step_ms"] = (time.perf_counter() - t_h) / n_1 * 1e3          # one replayed hipGraph per step (smg_train_step_graph)
-            out["train_step_host_enqueue_ms"] = enq / n_1                           # host time per step up to the loss read-back
-            # the same step as separate engine calls (no graph), and its kernels serialised on one stream with hipEvents around
+            out["train_step_graph_ms"] = (time.perf_counter() - t_h) / n_1 * 1e3
+            out["train_step_graph_host_enqueue_ms"] = enq / n_1                     # host time per step up to the loss read-back
+            # the default: the step as separate engine calls - and its kernels serialised on one stream with hipEvents around
             # every launch: what the GPU needs for it
             tr.use_step_graph = False
             for i in range(2):
@@ -617,17 +619,18 @@ def main():
                 one_backprop(i)
                 enq += tr.last_enqueue_ms
             torch.cuda.synchronize(dev)
-            out["train_step_eager_ms"] = (time.perf_counter() - t_h) / n_1 * 1e3
-            out["train_step_eager_host_enqueue_ms"] = enq / n_1
+            out["train_step_ms"] = (time.perf_counter() - t_h) / n_1 * 1e3
+            out["train_step_host_enqueue_ms"] = enq / n_1
             eng.profile_enable(True)
             for i in range(3):
                 one_backprop(i)
             torch.cuda.synchronize(dev)
             p1 = eng.profile_read()
             eng.profile_enable(False)
-            tr.use_step_graph = True
             out["train_step_kernel_ms"] = sum(v[0] for v in p1.values()) / 3.0
             out["train_step_launches"] = sum(v[1] for v in p1.values()) // 3
+            # (detail file only) where the single-sample step's serialised kernel time goes: class -> [ms per step, launches per step]
+            out["train_step_per_kernel"] = {k: [round(v[0] / 3.0, 4), v[1] // 3] for k, v in p1.items() if v[1] > 0}
             for i in range(2):
                 tr.forward(depth, mdepth, 0, True, False, i)
             t_h = time.perf_counter()
