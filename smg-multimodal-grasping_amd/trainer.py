@@ -416,9 +416,9 @@ class Trainer(object):
 
     # The single-sample step of Trainer.backprop as ONE replayed hipGraph (smg_train_step_graph): ~560 launches of 2-20 us each are
     # enqueued by one hipGraphLaunch instead of one by one (same results, bit for bit at zero learning rate).  What it buys is HOST time
-    # (2 ms per step instead of 6); the step's latency is the other way round since the round-5 kernels: the graph launch costs its 2 ms
-    # before the first kernel starts and the GPU then runs the step in ~5 ms, eagerly the first kernel starts at once and the host stays
-    # ahead of the GPU - measured 7.0-7.3 ms per step as a graph against 6.6-7.2 ms as separate calls (bench.py, four runs, the calls ahead in each).  The
+    # (2 ms per step instead of 6); the step's latency is the other way round since the round-5 kernels: the graph's ~560 dependent nodes
+    # execute no faster than the same launches from a stream (whose host stays just ahead of the GPU), and splitting the graph so that
+    # its launch cost hides changed nothing - measured 7.0-7.3 ms per step as a graph against 6.6-7.2 ms as separate calls (bench.py, four runs, the calls ahead in each).  The
     # reference's loop reads the loss of every step before it continues (latency, not throughput), so the separate calls are the default;
     # set True where the host thread is needed elsewhere.
     use_step_graph = False
