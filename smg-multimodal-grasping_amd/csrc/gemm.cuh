@@ -60,7 +60,8 @@ namespace smg {
 // three waves per SIMD (two stages of LDS + 168 registers let a third workgroup in); grouped 64 x 64 x 32 0.89 / 0.78 / 0.84 / 1.00.
 // What the DMA buys is the staging work (no registers, no ds_write pass), not depth: occupancy decides between the depths.
 constexpr int kDmaFlyDgrad = 2, kDmaFlyGroup = 1;
-constexpr int kPdFwdSmall = 2;      // one MFMA tile per wave (small planes): 0.1 us of MFMAs per k-tile against ~1 us of memory latency
+constexpr int kPdFwdSmall = 3;      // one MFMA tile per wave (small planes): 0.1 us of MFMAs per k-tile against ~1 us of memory latency (round 5, 2 -> 3: the 32 x 64
+                                    // forward of the 20^2 planes 18.3 -> 17.1 us per launch, the single-sample step's kernels 7.91 -> 7.75 ms; 4 measures like 3)
 constexpr int kPdFwdBig = 2;        // 128 x 128 forward: with three-term products 384 cycles of MFMA per k-tile no longer cover a load (72.4 -> 67.6 us per launch)
 constexpr int kPdDgrad = 2;
 constexpr int kPdDgradBig = 2;
