@@ -382,20 +382,20 @@ class Trainer(object):
             hm = torch.from_numpy(hm).to(model._flat_params.device)
         num = model.gnum_rotations                     # code/models.py:522,545,568 (gnum for every style)
         rots = [[0 if style == 2 else int(r) for r in rs] for rs in rotations]
-        q = model.run(style, rots, num, heightmaps=hm, mean=self.image_mean, std=self.image_std, keep_for_backward=True)
-        n = q.shape[0]
-        dev = q.device
-        eng, token, trunk_id, head_id = model._saved
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        dev = model._flat_params.device
         if torch.is_tensor(labels):
             lab = labels.to(device=dev, dtype=torch.float32).reshape(-1)
-        else:
+        else:      # (uploaded BEFORE the forward is enqueued: behind it, the pageable copy would hold the host until the forward has run)
             lab_h = np.asarray(labels, dtype=np.float32).reshape(-1)
             if self.method == 'reactive' and not np.isin(lab_h, (0.0, 1.0, 2.0)).all():
                 # torch's nll_loss (code/utils.py:311) raises on a class index outside [0, 3); the loss kernel would
                 # silently treat it as the weight-0 class.  (Device-resident labels are not read back: same contract.)
                 raise ValueError("reactive labels must be class indices 0, 1 or 2")
             lab = torch.as_tensor(lab_h, device=dev)
+        q = model.run(style, rots, num, heightmaps=hm, mean=self.image_mean, std=self.image_std, keep_for_backward=True)
+        n = q.shape[0]
+        eng, token, trunk_id, head_id = model._saved
+        stream = torch.cuda.current_stream(dev).cuda_stream
         if lab.numel() != n:
             raise ValueError("one label per (scene, rotation) sample")
         loss = torch.empty(n, dtype=torch.float32, device=dev)
@@ -463,11 +463,13 @@ class Trainer(object):
         t_host = time.perf_counter()
         model = self.model
         self.optimizer.zero_grad()
+        # (the label goes up BEFORE the forward is enqueued: a pageable host-to-device copy returns only when the stream has reached it -
+        #  behind the forward it held the host for the forward's ~1.5 ms, with the backward not yet enqueued)
+        labels = torch.tensor([float(label_value)], dtype=torch.float32, device=model._flat_params.device)
         q = self._evaluate(model, depth_heightmap, m_depth_heightmap, style, False, rotation)
         dev = q.device
         eng, token, trunk_id, head_id = model._saved
         stream = torch.cuda.current_stream(dev).cuda_stream
-        labels = torch.tensor([float(label_value)], dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         dq = torch.empty_like(q)
         eng.loss(0 if self.method == 'reinforcement' else 1, q.data_ptr(), labels.data_ptr(), 1, loss.data_ptr(), dq.data_ptr(), stream)
