@@ -415,12 +415,11 @@ class Trainer(object):
         return (loss, q) if return_q else loss
 
     # The single-sample step of Trainer.backprop as ONE replayed hipGraph (smg_train_step_graph): ~560 launches of 2-20 us each are
-    # enqueued by one hipGraphLaunch instead of one by one (same results, bit for bit at zero learning rate).  What it buys is HOST time
-    # (2 ms per step instead of 6); the step's latency is the other way round since the round-5 kernels: the graph's ~560 dependent nodes
-    # execute no faster than the same launches from a stream (whose host stays just ahead of the GPU), and splitting the graph so that
-    # its launch cost hides changed nothing - measured 7.0-7.3 ms per step as a graph against 6.6-7.2 ms as separate calls (bench.py, four runs, the calls ahead in each).  The
-    # reference's loop reads the loss of every step before it continues (latency, not throughput), so the separate calls are the default;
-    # set True where the host thread is needed elsewhere.
+    # enqueued by one hipGraphLaunch instead of one by one (same results, bit for bit at zero learning rate).  It saves a little host time
+    # (1.8 ms per step instead of 2.3) and costs latency: the graph's ~560 dependent nodes execute no faster than the same launches from
+    # two streams whose host stays ahead of the GPU - 6.85-6.9 ms per step as a graph against 5.8-5.9 ms as separate calls (bench.py;
+    # splitting the graph so that its launch cost hides changed nothing).  The reference's loop reads the loss of every step before it
+    # continues (latency, not throughput), so the separate calls are the default.
     use_step_graph = False
 
     def _train_step_graph(self, depth_heightmap, m_depth_heightmap, style, rotation, label_value):
