@@ -249,7 +249,9 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             int chunk, cps;
             // 16-bit storage: the k-loop is a third as long, the 128 x 64 atomics per workgroup are not - half as many workgroups
             // on many-stream batches (config 3: 28.9 -> 28.5 ms at 160; 120 / 80: 28.6 / 28.8; S = 1824 with 5 streams: 320 stays)
-            pick_chunk(pl, NS, nt, chunk, cps, (e->prec && NS >= 16) ? 160 : 320);
+            // few-stream calls on the atomics form: 128 (every workgroup adds a 128 x 64 tile with fp32 atomics; single-sample step 5.9 -> 5.65 ms;
+            // 64 / 192 / 320: 6.0 / 5.7 / 5.9)
+            pick_chunk(pl, NS, nt, chunk, cps, (e->prec && NS >= 16) ? 160 : (NS <= 4 && !e->deterministic) ? 128 : 320);
             auto go = [&](auto ptag) -> int {
                 BwdWeightP<MC<Cfg, decltype(ptag)::value>, W_ONE, C_IDENT, kPdWgrad, false, decltype(ptag)::value> p{};
                 p.gbuf = lb.D2; p.ldg = kBottleneck; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kBottleneck; p.binv = lb.D2S; p.basc = asc_n1(e, b, i);
