@@ -180,7 +180,9 @@ struct smg_engine {
 // 4.3 -> 3.6 ms).
 static inline int halo_tile(const Plane& p, int n_streams = 1 << 20) {
     // (tiles that hang over the edge are masked: S = 1824's 456^2 / 228^2 / 114^2 planes take 16 x 16 tiles too - round 5)
-    return (int64_t)((p.H + 15) / 16) * ((p.W + 15) / 16) * n_streams >= 320 ? 16 : 8;      // (160 / 800 measured: 24.4 / 24.8 against 24.6 ms per step)
+    return (int64_t)((p.H + 15) / 16) * ((p.W + 15) / 16) * n_streams >= 200 ? 16 : 8;      // (round 5, 320 -> 200: a single-sample step's 160^2 planes and the 80^2 planes of
+                                                                                            //  an 8-stream forward chain take 16 x 16 tiles - step 5.71 -> 5.63 ms, headline 16.0 both ways; 100: the 17-stream
+                                                                                            //  40^2 planes would too, 16.05)
 }
 
 // 3x3 weight-gradient halo kernel: tiles per workgroup.  The launch runs in rounds of 512 resident workgroups (2 per
