@@ -146,6 +146,12 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
     };
     // The two weight gradients of dense layer (b, i) and their shared reduce, on the side stream (which must already wait for the
     // layer's D2 / GS).
+    // Few-stream calls without "deterministic" (the 1x1 weight gradient adds with atomics, only the 3x3 one leaves partial tiles): the
+    // reduce of layer l waits for layer l - 1's and ONE launch serves both - the partial tiles alternate between the two halves of the
+    // workspace.  (The side stream is the longer one in a single-sample step: 29 reduce launches of ~7.5 us less on it.)
+    ReduceArgs pend3{}; pend3.Z = 0;
+    int pend3_half = 0;
+    auto flush_pending_reduce = [&]() { if (pend3.Z) { launch_reduce2(e, s2, K_W3, pend3, ReduceArgs{}); pend3.Z = 0; } };
     auto issue_wgrads = [&](int b, int i) -> int {
         const Plane pl = e->p_blk[b];
         const int Ct = kBlockCtot[b];
@@ -170,10 +176,14 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
             const int th = 8;                              // tiles are ts x 8 pixels
             a.bt = bn_table(e, e->sb_tab[b][i], e->max_streams, 0, kBottleneck, P + d.n2.w, P + d.n2.b);
             a.asc = asc_n2(e, b, i);
-            a.part = e->part; a.tiles_x = (pl.W + ts - 1) / ts; a.n_tiles = ((pl.H + th - 1) / th) * a.tiles_x;
+            a.tiles_x = (pl.W + ts - 1) / ts; a.n_tiles = ((pl.H + th - 1) / th) * a.tiles_x;
             a.tiles_per_wg = w3_tiles_per_wg(a.n_tiles, ts, NS, e->part_floats, (double)ts / th);
             const int groups = (a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
             if ((int64_t)groups * NS * 9 * 32 * kBottleneck > e->part_floats) return fail(-12, "partial-gradient workspace too small");
+            const bool pair_reduce = !e->deterministic && NS <= 4 && (int64_t)groups * NS * 9 * 32 * kBottleneck * 2 <= e->part_floats;
+            if (!pair_reduce) flush_pending_reduce();
+            float* part3 = e->part + (pair_reduce && pend3_half ? e->part_floats / 2 : 0);
+            a.part = part3;
             a.groups = groups; a.streams = NS;
             const unsigned w3_grid = (unsigned)(((groups * NS + 7) / 8) * 8 * (kBottleneck / 32));      // (see the kernel: channel groups of a tile group share an XCD)
             {
@@ -187,11 +197,18 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                                                         (HaloWgradSGeo<8, PREC>::smem_bytes()), s2, a));
                 }
             }
-            red3.part = e->part; red3.Z = groups * NS; red3.taps = 9; red3.rows = kGrowth; red3.cols = kBottleneck; red3.ldp = kBottleneck;
+            red3.part = part3; red3.Z = groups * NS; red3.taps = 9; red3.rows = kGrowth; red3.cols = kBottleneck; red3.ldp = kBottleneck;
             red3.z_stride = (int64_t)9 * kGrowth * kBottleneck; red3.tap_stride = (int64_t)kGrowth * kBottleneck;
             red3.dw = Gr + d.c2.w; red3.ldw_out = kBottleneck * 9; red3.cmap = C_3x3;
             part3_floats = (int64_t)groups * NS * 9 * kGrowth * kBottleneck;
+            if (pair_reduce) {       // this layer's reduce rides with the next layer's (or the final flush)
+                if (pend3.Z) { launch_reduce2(e, s2, K_W3, pend3, red3); pend3.Z = 0; }
+                else pend3 = red3;
+                pend3_half ^= 1;
+                red3.Z = 0; part3_floats = 0;
+            }
         } else {   // conv2 weight gradient (generic implicit GEMM, one launch slice per tap)
+            flush_pending_reduce();
             const int chunk = 512, cps = (pl.HWp + chunk - 1) / chunk;   // latency-bound: many short workgroups
             BwdWeightP<CfgW32x128, W_THREE, C_3x3, kPdWgrad, false> p{};
             p.gbuf = lb.GS; p.ldg = kGrowth; p.gcoff = 0; p.xbuf = nullptr; p.pa = pl; p.MA = kGrowth;
@@ -279,6 +296,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
     };
     // debug_stop (engine.h): leave the backward here - both streams joined, the forward's state consumed
     auto debug_stop = [&]() -> int {
+        flush_pending_reduce();
         HIP_OK(hipEventRecord(e->ev_end, s2));
         HIP_OK(hipStreamWaitEvent(st, e->ev_end, 0));
         HIP_OK(hipGetLastError());
@@ -470,6 +488,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 p.dw = Gr + T.tconv[b - 1].w; p.ldw_out = Cp;
                 if (fork(e->ev_misc)) return -5;
                 BY(e, ESZ(e) * NS * (2.0 * pl.HW * C0 + (double)pp.HW * Cp));
+                flush_pending_reduce();      // (the partial-tile workspace is about to be reused from its start)
                 return launch_wgrad(e, s2, p, dim3(C0 / 128, Cp / 128, NS * cps), K_TW, 2.0 * NS * pl.HW * Cp * C0, 1, C_IDENT);
                 };
                 PREC_DISPATCH(e, if (int rc = go(PTAG)) return rc);
@@ -533,6 +552,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
         p.dw = Gr + T.conv0.w; p.ldw_out = 147;
         if (fork(e->ev_misc)) return -5;
         BY(e, 4.0 * NS * (2.0 * ps_.HW * 64 + (double)e->p_img.HW * (SM == W_STEM1 ? 1 : 4)));
+        flush_pending_reduce();      // (the partial-tile workspace is about to be reused from its start)
         return launch_wgrad(e, s2, p, dim3(1, 1, NS * cps), K_SW, 2.0 * NS * ps_.HW * 64 * 147, 1, SM == W_STEM1 ? C_STEM1 : C_STEM);
         };
         if (e->f_stem1) { PREC_DISPATCH(e, if (int rc = go(PTAG, std::integral_constant<int, W_STEM1>{})) return rc); }
@@ -552,6 +572,7 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                            e->dbscr, e->db_total, kDbRep, Gr,
                            ph_b ? b1(e, e->bs_stem) : nullptr, ph_b ? b2(e, e->bs_stem) : nullptr, NS, Gr + T.norm0.b, Gr + T.norm0.w);
     }
+    flush_pending_reduce();
     HIP_OK(hipEventRecord(e->ev_end, s2));          // join: everything after the backward (or this half of it) sees every gradient
     HIP_OK(hipStreamWaitEvent(st, e->ev_end, 0));
     HIP_OK(hipGetLastError());
