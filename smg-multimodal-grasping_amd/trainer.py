@@ -417,7 +417,7 @@ class Trainer(object):
     # The single-sample step of Trainer.backprop as ONE replayed hipGraph (smg_train_step_graph): ~560 launches of 2-20 us each are
     # enqueued by one hipGraphLaunch instead of one by one (same results, bit for bit at zero learning rate).  It saves a little host time
     # (1.8 ms per step instead of 2.3) and costs latency: the graph's ~560 dependent nodes execute no faster than the same launches from
-    # two streams whose host stays ahead of the GPU - 6.6 ms per step as a graph against 5.65 ms as separate calls (bench.py;
+    # two streams whose host stays ahead of the GPU - 6.6-6.8 ms per step as a graph against 5.5 ms as separate calls (bench.py;
     # splitting the graph so that its launch cost hides changed nothing).  The reference's loop reads the loss of every step before it
     # continues (latency, not throughput), so the separate calls are the default.
     use_step_graph = False
