@@ -6,12 +6,16 @@
 // ------------------------------------------------------------------------------------
 // Pixel-chunk size of a weight-gradient launch: enough workgroups to fill the chip
 // (~768) but no more - every workgroup ends with one fp32 atomicAdd per output element.
+// Chunks are sized over the plane's VALID rows: every chunk starts inside [0, HW), so every workgroup of the launch stores its
+// partial tile (a chunk that starts in the plane's padding rows - up to 127 of them since make_plane pads the big planes to 128
+// rows - would leave without storing, and reduce_partials_kernel would add whatever the workspace held there).  The last chunk
+// may run into the padding (the kernels clamp its length to HWp; padding rows hold zero gradients).
 static void pick_chunk(const Plane& pl, int n_planes, int tiles_per_chunk, int& chunk, int& cps, int target = 768) {
     const int want = (target + tiles_per_chunk - 1) / tiles_per_chunk;
     cps = (want + n_planes - 1) / n_planes;
     if (cps < 1) cps = 1;
-    chunk = ((pl.HWp + cps - 1) / cps + 63) / 64 * 64;
-    cps = (pl.HWp + chunk - 1) / chunk;
+    chunk = ((pl.HW + cps - 1) / cps + 63) / 64 * 64;
+    cps = (pl.HW + chunk - 1) / chunk;
 }
 
 // phases: bit 0 = the head and dense blocks 4, 3, 2 (down to the gradient of block 1's buffer), bit 1 = dense block 1, pool0 and

@@ -223,6 +223,13 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                         // small planes: the wave-specialised form (halo.cuh; 17.1 -> 15.2 us per launch.  At TS = 16 it measures
                         // 67.8 -> 62.8 us serialised and nothing on the step - two forward chains already fill each other's gaps there)
                         a.tiles_x = (pl.W + 7) / 8; a.n_tiles = ((pl.H + 7) / 8) * a.tiles_x; a.streams = ns;
+                        static bool raised8[64][3] = {};      // two (halo, weights) buffers: 51 KB as built, 76 KB in the -DSMG_SPLIT16=0 A/B build (three pieces) - past the 64 KB default
+                        if (!raised8[e->device & 63][e->prec]) {
+                            PREC_DISPATCH(e, if ((HaloFwdSGeo<8, PREC>::smem_bytes_ws(kBottleneck)) > 64 * 1024)
+                                                 (void)hipFuncSetAttribute((const void*)conv3x3_halo_fwd_kernel<8, PREC, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                           (HaloFwdSGeo<8, PREC>::smem_bytes_ws(kBottleneck))));
+                            raised8[e->device & 63][e->prec] = true;
+                        }
                         PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_fwd_kernel<8, PREC, false, true>), dim3(banded_grid(a.n_tiles, ns)), dim3(512),
                                            (HaloFwdSGeo<8, PREC>::smem_bytes_ws(kBottleneck)), cs, a));
                     } else

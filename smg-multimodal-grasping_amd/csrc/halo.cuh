@@ -28,6 +28,9 @@
 // waves per SIMD the register allocator is held to (512 / n registers per lane); three for the 16 x 16 forward: 168 VGPRs with 128 bytes
 // of scratch, 64 -> 111 us per launch
 namespace smg { constexpr int kHaloFwdWaves = 2, kHaloWgradWaves = 2; }
+#ifndef SMG_HALO_REGFRAG
+#define SMG_HALO_REGFRAG 1      // dev A/B: 0 = every activation fragment of the TS = 16 forward / data gradient read from LDS (rounds 2-5)
+#endif
 
 namespace smg {
 
@@ -42,7 +45,37 @@ struct HaloGeo {
     // pixel (row, col) inside the tile of MFMA-tile row i (0..31) of tile m of pixel-wave wq
     __device__ static __forceinline__ int row(int wq, int m, int i) { return (wq * MT + m) * ROWS + i / TS; }
     __device__ static __forceinline__ int col(int i) { return i % TS; }
+    // TS = 16, kernels that derive their activation fragments in registers (round 6): the two pixel rows of a wave's tile m are rows
+    // 4 wq + m and 4 wq + m + 2 - INTERLEAVED with the other tile's - so that the fragment of kernel row dy of tile m, input rows
+    // (4 wq + m + dy, 4 wq + m + dy + 2), is the row pair i = m + dy of FOUR pairs (i = 0..3) that serve all six (tile, kernel row)
+    // combinations of the wave (consecutive rows would need six)
+    __device__ static __forceinline__ int rowi(int wq, int m, int i) { return TS == 16 ? 4 * wq + m + 2 * (i / TS) : row(wq, m, i); }
 };
+
+// compile-time loop: f(integral_constant<int, B>) ... f(integral_constant<int, N - 1>) (DPP controls must be immediates)
+template <int B, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (B < N) { f(std::integral_constant<int, B>{}); sfor<B + 1, N>(f); }
+}
+
+// Fragment of kernel column DX (1 or 2) of row pair I, derived from the pair's column-0 fragment `p` (lane c of a 16-lane DPP row =
+// halo column c of one pixel row, one k-half) and the wave's edge fragment `e` (lanes 2 I, 2 I + 1 of every DPP row = halo columns
+// 16, 17 of pair I): a row shift left by DX whose vacated lanes 16 - DX .. 15 keep what the first move put there - the edge columns,
+// shifted right into place.  Two v_mov_b32_dpp per dword instead of one ds_read_b128 per fragment: the taps of a 16-channel chunk
+// read 10 activation fragments from LDS instead of 36 (semantics pinned on the hardware with tools/dpp_probe.hip).
+template <int DX, int I>
+__device__ __forceinline__ u32x4 dpp_col_shift(const u32x4& p, const u32x4& e) {
+    if constexpr (DX == 0) return p;
+    else {
+        u32x4 r;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int edge = __builtin_amdgcn_update_dpp(0, (int)e[d], 0x110 + (16 - DX - 2 * I), 0xF, 0xF, false);      // row_shr
+            r[d] = (unsigned)__builtin_amdgcn_update_dpp(edge, (int)p[d], 0x100 + DX, 0xF, 0xF, false);                   // row_shl, bound_ctrl off
+        }
+        return r;
+    }
+}
 
 struct Halo3x3FwdArgs {
     const void* src; int lds_; Plane pl;            // [n][HWp][C] raw bottleneck output (fp32 / bf16 / fp16 by mode)
@@ -117,6 +150,7 @@ static __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : kHaloFwdWaves) void
     constexpr int OP = fwd_op(PREC), NP = G::NP, CK = G::CK, K8C = G::K8C, KSTEP = CK / 16;
     constexpr int MT = G::MT, A_N = G::A_N, B_N = G::B_N, LDH = G::LDH, ESZ = ST::size, E = 16 / ESZ;
     constexpr int BUF_BYTES = WS ? (G::A_UNITS + G::BU) * 16 : 0;       // WS: two (halo, weights) buffers, the weights exactly BU units
+    constexpr bool kRegFrag = TS == 16 && OP != 0 && SMG_HALO_REGFRAG;                       // activation fragments of a chunk from four row pairs + DPP column shifts (taps16 below)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* As = reinterpret_cast<char*>(smem);                // [piece][k8][LDH] units          (WS: of the buffer being read)
     char* Bs = As + G::A_UNITS * 16;                         // [piece][tap][k8][32] units
@@ -189,7 +223,7 @@ static __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : kHaloFwdWaves) void
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
     int abase[MT];        // halo pixel of this lane's tile row at tap (0, 0)
 #pragma unroll
-    for (int m = 0; m < MT; ++m) abase[m] = G::row(wq, m, l31) * G::W + G::col(l31);
+    for (int m = 0; m < MT; ++m) abase[m] = G::row(wq, m, l31) * G::W + G::col(l31);      // (TS = 8; TS = 16 takes its fragments from row pairs, below)
     auto fa = [&](int m, int tap, int ks, int pc) -> u32x4 {
         return *reinterpret_cast<const u32x4*>(As + ((pc * K8C + 2 * ks + half) * LDH + abase[m] + (tap / 3) * G::W + tap % 3) * 16);
     };
@@ -213,7 +247,58 @@ static __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : kHaloFwdWaves) void
     if (!WS || role == 1) s_store(0, As, Bs, Set0{});
     if (WS && role == 1 && NCH > 1) g_load(1, Set0{});
     __syncthreads();
+    // TS = 16 (round 6): the wave's two tiles are the row pairs (4 wq + m, 4 wq + m + 2).  Per chunk it reads FOUR row-pair fragments
+    // (pair i = halo rows 4 wq + i and 4 wq + i + 2, halo columns 0..15) and one edge fragment (columns 16, 17 of the four pairs) per
+    // piece and k16-step - 10 ds_read_b128 instead of 36 - and forms the fragment of tap (dy, dx) of tile m from pair m + dy with a
+    // DPP row shift by dx (dpp_col_shift).  The weights' 18 fragment reads per chunk are unchanged.
+    const int pbase = (4 * wq + 2 * (l31 >> 4)) * G::W + (l31 & 15);
+    const int ebase = (4 * wq + (((lane & 15) >> 1) & 3) + 2 * (l31 >> 4)) * G::W + 16 + (lane & 1);
+    auto taps16 = [&]() {
+        u32x4 P[4][KSTEP][NP], Eg[KSTEP][NP], bf[2][KSTEP][NP];
+#pragma unroll
+        for (int ks = 0; ks < KSTEP; ++ks)
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) {
+                const char* pl_ = As + ((pc * K8C + 2 * ks + half) * LDH) * 16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) P[i][ks][pc] = *reinterpret_cast<const u32x4*>(pl_ + (pbase + i * G::W) * 16);
+                Eg[ks][pc] = *reinterpret_cast<const u32x4*>(pl_ + ebase * 16);
+            }
+        auto load_b = [&](int set, int tap) {
+#pragma unroll
+            for (int ks = 0; ks < KSTEP; ++ks)
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) bf[set][ks][pc] = fb(tap, ks, pc);
+        };
+        load_b(0, 0);
+        sfor<0, 9>([&](auto T) {
+            constexpr int tap = decltype(T)::value, dy = tap / 3, dx = tap % 3, set = tap & 1;
+            if constexpr (tap + 1 < 9) load_b(set ^ 1, tap + 1);
+            u32x4 af[MT][KSTEP][NP];
+            sfor<0, MT>([&](auto M) {
+                constexpr int m = decltype(M)::value;
+#pragma unroll
+                for (int ks = 0; ks < KSTEP; ++ks)
+#pragma unroll
+                    for (int pc = 0; pc < NP; ++pc) af[m][ks][pc] = dpp_col_shift<dx, m + dy>(P[m + dy][ks][pc], Eg[ks][pc]);
+            });
+            if constexpr (OP == 3) {                        // h*l, l*h, h*h (small terms first; tiles innermost: consecutive MFMAs never share an accumulator)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_f16(af[m][0][0], bf[set][0][1], acc[m]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_f16(af[m][0][1], bf[set][0][0], acc[m]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = mfma_f16(af[m][0][0], bf[set][0][0], acc[m]);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KSTEP; ++ks)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m] = mfma_1p<OP>(af[m][ks][0], bf[set][ks][0], acc[m]);
+            }
+        });
+    };
     auto taps_of_chunk = [&]() {
+        if constexpr (kRegFrag) { taps16(); return; }
         // per tap: hi and lo pieces, the two hi x lo groups, then the mid pieces (fetched under those MFMAs) and the rest;
         // the next tap's hi / lo pieces are requested before the last four groups of this one
         u32x4 ah[2][KSTEP][MT], al[2][MT], bh[2][KSTEP], bl[2];
@@ -344,7 +429,7 @@ static __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : kHaloFwdWaves) void
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int r = 4 * g + k, i = k + 8 * g + 4 * half;
-                    const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
+                    const int py = y0 + (kRegFrag ? G::rowi(wq, m, i) : G::row(wq, m, i)), px = x0 + G::col(i);
                     v[k] = acc[m][r];
                     if (!kEdge || (py < a.pl.H && px < a.pl.W)) {      // tiles may hang over the edge (planes that do not tile exactly)
                         const double xd = (double)v[k];
@@ -355,7 +440,7 @@ static __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : kHaloFwdWaves) void
                 // four pixels x four channels of the quad, transposed: this lane stores ONE pixel's four consecutive channels
                 quad_transpose4(v[0], v[1], v[2], v[3]);
                 const int i = (lane & 3) + 8 * g + 4 * half;
-                const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
+                const int py = y0 + (kRegFrag ? G::rowi(wq, m, i) : G::row(wq, m, i)), px = x0 + G::col(i);
                 if (!kEdge || (py < a.pl.H && px < a.pl.W))
                     stq<ST>(a.dst, ((int64_t)n * a.pl.HWp + py * a.pl.W + px) * a.ldd + a.dcoff + 4 * (l31 >> 2), make_float4(v[0], v[1], v[2], v[3]));
             }
@@ -442,6 +527,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
     using XT = act_t<PREC>;
     constexpr int OP = bwd_op(PREC), NP = G::NP, HDS_BU = G::BU, GSZ = GT::size, XSZ = XT::size, E = 16 / GSZ, SPP = 32 / E;   // SPP: slots per pixel
     constexpr int MT = G::MT, NCW = G::NCW, A_N = G::A_N, B_N = G::B_N, LDH = G::LDH;
+    constexpr bool kRegFrag = TS == 16 && OP != 0 && SMG_HALO_REGFRAG;                       // gradient fragments resident in registers: four row pairs + DPP column shifts (below)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* As = reinterpret_cast<char*>(smem);                            // [piece][k8][LDH] units
     char* Bs = As + G::A_UNITS * 16;                                     // [2][NCW][3 taps][piece][k8][32] units
@@ -568,6 +654,26 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
     s_store(0);
     __syncthreads();
     if (trace) trace[1] = __builtin_amdgcn_s_memtime();
+    // TS = 16 (round 6): the wave's two tiles are the row pairs (4 wq + m, 4 wq + m + 2) (HaloGeo::rowi), and its whole gradient operand
+    // - four row-pair fragments (pair i = halo rows 4 wq + i, 4 wq + i + 2; halo columns 0..15) and one edge fragment (columns 16, 17
+    // of the four pairs) per piece and k16-step, 80 registers - is read from the LDS halo ONCE.  Tap (dy, dx) of tile m takes pair
+    // m + 2 - dy shifted left by 2 - dx lanes (dpp_col_shift): the stages read nothing but weights from LDS (12 instead of 36
+    // ds_read_b128 per kernel row).
+    constexpr int RP = kRegFrag ? 4 : 1;
+    u32x4 P[RP][2][NP], Eg[2][NP];
+    if constexpr (kRegFrag) {
+        const int pbase = (4 * wq + 2 * (l31 >> 4)) * G::W + (l31 & 15);
+        const int ebase = (4 * wq + (((lane & 15) >> 1) & 3) + 2 * (l31 >> 4)) * G::W + 16 + (lane & 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) {
+                const char* pl_ = As + ((pc * 4 + 2 * ks + half) * LDH) * 16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) P[i][ks][pc] = *reinterpret_cast<const u32x4*>(pl_ + (pbase + i * G::W) * 16);
+                Eg[ks][pc] = *reinterpret_cast<const u32x4*>(pl_ + ebase * 16);
+            }
+    }
     f32x16 acc[MT];
     // Mask / xhat source of this wave's output tile (32 output channels from c0), prefetched: one row segment (a pixel's four
     // consecutive channels, 16 / 8 bytes per lane; finish_acc_rows turns it into accumulator layout) per four accumulator rows,
@@ -577,7 +683,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
     rawq_t<XT> xq[MT][4];
     auto load_mask_seg = [&](int c0, int m, int g) {
         const int i = (lane & 3) + 8 * g + 4 * half;
-        const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
+        const int py = y0 + (kRegFrag ? G::rowi(wq, m, i) : G::row(wq, m, i)), px = x0 + G::col(i);
         const bool ok = !kEdge || (py < a.pl.H && px < a.pl.W);     // tiles may hang over the edge: clamped address
         const int64_t idx = ((int64_t)n * a.pl.HWp + (ok ? py * a.pl.W + px : 0)) * C + c0 + 4 * (l31 >> 2);
         if constexpr (std::is_same<XT, e_f32>::value) xq[m][g] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.mbuf) + idx);
@@ -589,8 +695,8 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
       const int cmask0 = ((cg0 + s3 / 3) * NCW + wc) * 32;
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
+      sfor<0, 3>([&](auto DY) {
+        constexpr int dy = decltype(DY)::value;
         const int stage = s3 + dy, buf = stage & 1;
         g_load(stage + 1 < NSTAGE ? stage + 1 : NSTAGE - 1);             // (tail: a clamped re-load, stored dead)
         if (dy < 2) {                                     // (compile-time after unrolling) the group's mask segments: half behind each of the first two rows' weight loads
@@ -598,8 +704,8 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
 #pragma unroll
             for (int sg = 0; sg < SEGS / 2; ++sg) { const int q = dy * (SEGS / 2) + sg; load_mask_seg(cmask0, q / 4, q % 4); }
         }
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
+        sfor<0, 3>([&](auto DX) {
+        constexpr int dx = decltype(DX)::value;
         // output pixel (ry, rx), tap (dy, dx) reads g at halo (ry + 2 - dy, rx + 2 - dx)
         const int toff = (2 - dy) * G::W + (2 - dx);
         const char* Bw = Bs + (buf * G::B_PAD + (wc * ST + dx) * HDS_BU) * 16;
@@ -609,6 +715,32 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
         auto fb = [&](int ks, int pc) -> u32x4 {
             return *reinterpret_cast<const u32x4*>(Bw + ((pc * 4 + 2 * ks + half) * 32 + l31) * 16);
         };
+        if constexpr (kRegFrag) {                           // fragments of the gradient from the resident row pairs; weights from LDS
+            u32x4 af[2][MT][NP], bf[2][NP];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) {
+                    bf[ks][pc] = fb(ks, pc);
+                    sfor<0, MT>([&](auto M) {
+                        constexpr int m = decltype(M)::value;
+                        af[ks][m][pc] = dpp_col_shift<2 - dx, m + 2 - dy>(P[m + 2 - dy][ks][pc], Eg[ks][pc]);
+                    });
+                }
+            if constexpr (OP == 3) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) acc[m] = mfma_f16(af[ks][m][g == 1 ? 1 : 0], bf[ks][g == 0 ? 1 : 0], acc[m]);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m] = mfma_1p<OP>(af[ks][m][0], bf[ks][0], acc[m]);
+            }
+        } else
         if constexpr (OP == 3) {                            // two fp16 pieces: every fragment of the tap up front, then h*l, l*h, h*h per k16-step
             u32x4 af[2][MT][2], bf[2][2];
 #pragma unroll
@@ -659,7 +791,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
 #pragma unroll
                     for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(af[ks][m][PA[g]], bf[ks][PB[g]], acc[m]);
         }
-        }   // dx
+        });   // dx
         s_store(buf ^ 1);                               // that buffer was last read one stage ago, behind that stage's barrier (at the very end: a dead store)
         if (dy == 2) {
             if (trace && s3 == 0) trace[2] = __builtin_amdgcn_s_memtime();
@@ -677,7 +809,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int i = k + 8 * g + 4 * half;
-                            const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
+                            const int py = y0 + (kRegFrag ? G::rowi(wq, m, i) : G::row(wq, m, i)), px = x0 + G::col(i);
                             const bool in = !kEdge || (py < a.pl.H && px < a.pl.W);
                             const float dyv = (in && bn1(xv[k], mean, sc, be) > 0.f) ? acc[m][4 * g + k] * gsc.inv : 0.f;      // (gsc.inv == 1 unless operand kind 3)
                             o[k] = dyv;
@@ -686,7 +818,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
                         }
                         quad_transpose4(o[0], o[1], o[2], o[3]);
                         const int i = (lane & 3) + 8 * g + 4 * half;
-                        const int py = y0 + G::row(wq, m, i), px = x0 + G::col(i);
+                        const int py = y0 + (kRegFrag ? G::rowi(wq, m, i) : G::row(wq, m, i)), px = x0 + G::col(i);
                         if (!kEdge || (py < a.pl.H && px < a.pl.W))
                             stq<GT>(a.dst, ((int64_t)n * a.pl.HWp + py * a.pl.W + px) * C + c - l31 + 4 * (l31 >> 2), make_float4(o[0], o[1], o[2], o[3]));
                     }
@@ -708,7 +840,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
             if (trace && s3 == 0) trace[3] = __builtin_amdgcn_s_memtime();
         }
         __syncthreads();
-      }
+      });
     }
     if (trace) { trace[4] = __builtin_amdgcn_s_memtime(); trace[6] = __builtin_amdgcn_s_memrealtime(); }
 }

@@ -152,6 +152,11 @@ class _AffordanceNet(nn.Module):
 
     # ---- storage management ----------------------------------------------------------------
     def _rebind(self):
+        # every p.grad is dropped below (and _apply drops the flat gradient buffer): forget the graph-replayed step's "views already in
+        # place" key and the cached views / exposed list with it, or the next graph step would skip zero_grad + expose_grads and leave p.grad None
+        self._graph_exposed = None
+        self._grad_views = None
+        self._exposed_params = None
         for node, leaf, kind, off, n, shape in self._entries:
             if kind == 0:
                 p = node._parameters[leaf]

