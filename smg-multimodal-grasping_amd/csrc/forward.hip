@@ -2,6 +2,10 @@
 // (code/models.py:361-586, :72-296) for one (trunk, head).
 #include "engine.h"
 
+#ifndef SMG_FWD16_WS
+#define SMG_FWD16_WS 0
+#endif
+
 // Host-side checks of a batch against the engine (index ranges, capacities).
 int validate_batch(const smg_engine* e, const smg_batch* B) {
     const int NS = B->n_streams, NP = B->n_pairs;
@@ -238,6 +242,15 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                         if (pl.H % 16 || pl.W % 16) {      // tiles hang over the edge: the bounds-checked instantiation
                             PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_fwd_kernel<16, PREC, true>), dim3(banded_grid(a.n_tiles, ns)), dim3(256),
                                                (HaloFwdSGeo<16, PREC>::smem_bytes(kBottleneck)), cs, a));
+                        } else if (SMG_FWD16_WS) {      // (dev A/B, -DSMG_FWD16_WS=1: the wave-specialised form on the 16 x 16 tiles too)
+                            static bool raised16[64][3] = {};
+                            if (!raised16[e->device & 63][e->prec]) {
+                                PREC_DISPATCH(e, (void)hipFuncSetAttribute((const void*)conv3x3_halo_fwd_kernel<16, PREC, false, SMG_FWD16_WS != 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                           (HaloFwdSGeo<16, PREC>::smem_bytes_ws(kBottleneck))));
+                                raised16[e->device & 63][e->prec] = true;
+                            }
+                            PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_fwd_kernel<16, PREC, false, SMG_FWD16_WS != 0>), dim3(banded_grid(a.n_tiles, ns)), dim3(512),
+                                               (HaloFwdSGeo<16, PREC>::smem_bytes_ws(kBottleneck)), cs, a));
                         } else {
                             PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_fwd_kernel<16, PREC>), dim3(banded_grid(a.n_tiles, ns)), dim3(256),
                                                (HaloFwdSGeo<16, PREC>::smem_bytes(kBottleneck)), cs, a));

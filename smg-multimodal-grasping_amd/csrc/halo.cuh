@@ -31,6 +31,9 @@ namespace smg { constexpr int kHaloFwdWaves = 2, kHaloWgradWaves = 2; }
 #ifndef SMG_HALO_REGFRAG
 #define SMG_HALO_REGFRAG 1      // dev A/B: 0 = every activation fragment of the TS = 16 forward / data gradient read from LDS (rounds 2-5)
 #endif
+#ifndef SMG_HALO_DMA
+#define SMG_HALO_DMA 1          // dev A/B: 0 = the TS = 16 data gradient's weights register-staged through two LDS buffers, one stage ahead (rounds 2-5)
+#endif
 
 namespace smg {
 
@@ -528,6 +531,10 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
     constexpr int OP = bwd_op(PREC), NP = G::NP, HDS_BU = G::BU, GSZ = GT::size, XSZ = XT::size, E = 16 / GSZ, SPP = 32 / E;   // SPP: slots per pixel
     constexpr int MT = G::MT, NCW = G::NCW, A_N = G::A_N, B_N = G::B_N, LDH = G::LDH;
     constexpr bool kRegFrag = TS == 16 && OP != 0 && SMG_HALO_REGFRAG;                       // gradient fragments resident in registers: four row pairs + DPP column shifts (below)
+    // ... and with the halo out of LDS after the prologue, the weights of the stages stream through a RING of four LDS buffers by LDS-DMA
+    // (two behind the halo, two in the halo's own area once the fragments are in registers), three stages ahead of the MFMAs - see below
+    constexpr bool kDma = kRegFrag && G::NCW == 1 && G::B_UNITS % 256 == 0 && 2 * G::B_PAD <= G::A_UNITS && SMG_HALO_DMA;
+    constexpr int NB = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* As = reinterpret_cast<char*>(smem);                            // [piece][k8][LDH] units
     char* Bs = As + G::A_UNITS * 16;                                     // [2][NCW][3 taps][piece][k8][32] units
@@ -541,6 +548,47 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
     // dev stamps (SMG_TRACE_KIND=5): start | halo staged | first output-channel group's 9 stages | its epilogue | end
     unsigned long long* trace = (g_smg_trace && t == 0) ? g_smg_trace + 8 * ((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) : nullptr;
     if (trace) { trace[0] = __builtin_amdgcn_s_memtime(); trace[5] = __builtin_amdgcn_s_memrealtime(); }
+    const int cg0 = blockIdx.z * a.cg_per_wg;
+    const int NSTAGE = a.cg_per_wg * 3;                // channel-chunk groups x 3 kernel rows
+    auto ring = [&](int k) -> char* { return k < 2 ? Bs + k * G::B_PAD * 16 : As + (k - 2) * G::B_PAD * 16; };
+    auto dma_stage = [&](int stage, int k) {           // the weights of `stage` (one kernel row of one 32-channel group: B_UNITS straight 16-byte copies) -> ring buffer k
+        const int cg = cg0 + stage / 3, dyy = stage % 3;
+        const unsigned dst = (unsigned)(uintptr_t)ring(k) + 16u * 64u * (unsigned)wave;
+#pragma unroll
+        for (int i = 0; i < B_N; ++i)
+            dma_unit(UnitSrc{a.wu, kWholeBuf, 16u * (unsigned)(t + 256 * i), 16u * (unsigned)((cg * NCW * 9 + G::ST * dyy) * HDS_BU)}, dst + 16u * 256u * (unsigned)i);
+    };
+    if constexpr (kDma) {                              // the first two stages' weights go out in front of everything else
+        dma_stage(0, 0);
+        dma_stage(NSTAGE > 1 ? 1 : 0, 1);
+    }
+    // The gradient halo's loads go out HERE, in front of the parameter loop (round 6: per-workgroup stamps showed 7.5k cycles from the
+    // kernel's first instruction to these loads being ISSUED - the table loads of the parameter loop, the recorded maxima's scalar loads
+    // and the kernel arguments each cost a dependent memory round trip in front of them - and another 2k until they had landed)
+    const char* g_n = static_cast<const char*>(a.g.g) + (int64_t)GSZ * n * a.pl.HWp * a.g.ldg;
+    const char* x_n = a.g.x ? static_cast<const char*>(a.g.x) + (int64_t)XSZ * n * a.pl.HWp * a.g.ldx : nullptr;
+    // ... and in front of them the stream's recorded gradient maxima (operand kind 3, materialised GS): their vector loads used to sit
+    // behind the parameter loop with a vmcnt(0) of their own - a third round trip
+    u32x4 am4[kAmaxRep / 4];
+    if constexpr (OP == 3) {
+        if (!a.g.x) {
+#pragma unroll
+            for (int r = 0; r < kAmaxRep / 4; ++r) am4[r] = *reinterpret_cast<const u32x4*>(a.g.amax + (int64_t)n * kAmaxRep + 4 * r);
+        }
+    }
+    float4 rv[A_N], rx[A_N];
+#pragma unroll
+    for (int i = 0; i < A_N; ++i) {                // every load in flight before the first LDS store
+        const int idx = t + 256 * i;
+        const int hp = idx / SPP, q = idx % SPP;                        // halo pixel, 16-byte slot (E channels) of its 32
+        const int hy = hp / G::W, hx = hp - hy * G::W;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = idx < G::PX * SPP && (unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W;
+        const int64_t pix = ok ? iy * a.pl.W + ix : 0;                 // unconditional loads, clamped address
+        rv[i] = ld16(g_n, (int64_t)GSZ * (pix * a.g.ldg + E * q));
+        if (x_n) rx[i] = ld16(x_n, (int64_t)XSZ * (pix * a.g.ldx + E * q));
+    }
+    __builtin_amdgcn_sched_barrier(0);
     for (int k = t; k < C; k += 256) {                  // norm2 parameters of this stream (layer table of the forward)
         const float invstd = tab_invstd(a.bt, n)[k];
         prm[k] = a.bt.gamma[k] * invstd;
@@ -553,9 +601,15 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
     // operand kind 3: scale of the gradient operand and inverse of the (gradient x weight) scale - from the stream's recorded maximum
     // (materialised GS), or, when the BN backward is applied on load (a.g.x set), from the largest magnitude of THIS workgroup's halo
     ActScale gsc{1.f, 1.f};
-    if constexpr (OP == 3) { if (!a.g.x) { gsc = amax_scale(a.g.amax + (int64_t)n * kAmaxRep); gsc.inv *= pack_inv_scale(a.wu); } }
-    const int cg0 = blockIdx.z * a.cg_per_wg;
-    const int NSTAGE = a.cg_per_wg * 3;                // channel-chunk groups x 3 kernel rows
+    if constexpr (OP == 3) {
+        if (!a.g.x) {
+            unsigned m = 0;
+#pragma unroll
+            for (int r = 0; r < kAmaxRep / 4; ++r) m = max(max(m, max(am4[r].x, am4[r].y)), max(am4[r].z, am4[r].w));
+            gsc = scale_of_max(m);
+            gsc.inv *= pack_inv_scale(a.wu);
+        }
+    }
     // Weight stages: stage = cgroup * 3 + kernel row (a cgroup holds NCW chunks, a stage the row's three taps of each: they are
     // contiguous in the pack).  Two LDS buffers; the loads of stage s + 1 are issued at the top of stage s, fly under its 36 MFMAs
     // per wave and are stored at its end - ONE barrier per kernel row (round 3: one per tap - 1.6k cycles per stage for 0.77k
@@ -575,22 +629,15 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
         for (int i = 0; i < B_N; ++i) rb[i] = bload_u4(a.wu, kWholeBuf, b_voff[i], 16u * (unsigned)((cg * NCW * 9 + ST * dy) * HDS_BU));
     };
     // gradient halo (zero outside the image), split at the store
-    const char* g_n = static_cast<const char*>(a.g.g) + (int64_t)GSZ * n * a.pl.HWp * a.g.ldg;
-    const char* x_n = a.g.x ? static_cast<const char*>(a.g.x) + (int64_t)XSZ * n * a.pl.HWp * a.g.ldx : nullptr;
     {
-        float4 rv[A_N], rx[A_N];
-#pragma unroll
-        for (int i = 0; i < A_N; ++i) {            // every load in flight before the first LDS store
-            const int idx = t + 256 * i;
-            const int hp = idx / SPP, q = idx % SPP;                        // halo pixel, 16-byte slot (E channels) of its 32
-            const int hy = hp / G::W, hx = hp - hy * G::W;
-            const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-            const bool ok = idx < G::PX * SPP && (unsigned)iy < (unsigned)a.pl.H && (unsigned)ix < (unsigned)a.pl.W;
-            const int64_t pix = ok ? iy * a.pl.W + ix : 0;                 // unconditional loads, clamped address
-            rv[i] = ld16(g_n, (int64_t)GSZ * (pix * a.g.ldg + E * q));
-            if (x_n) rx[i] = ld16(x_n, (int64_t)XSZ * (pix * a.g.ldx + E * q));
-        }
+#ifdef SMG_TRACE_INIT
+        if (trace) trace[1] = smg_stamp();
+#endif
         __syncthreads();                           // gp (and prm) visible
+#ifdef SMG_TRACE_INIT
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (trace) trace[2] = smg_stamp();
+#endif
         if constexpr (OP == 3) {
             if (x_n) {                             // (launch-uniform) BN backward on load: the halo's own maximum sets the scale
                 float vmax = 0.f;
@@ -650,10 +697,16 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
 #pragma unroll
     for (int m = 0; m < MT; ++m) abase[m] = G::row(wq, m, l31) * G::W + G::col(l31);
 
-    g_load(0);
-    s_store(0);
+    if constexpr (!kDma) {
+        g_load(0);
+        s_store(0);
+    }
     __syncthreads();
+#ifdef SMG_TRACE_INIT
+    if (trace) trace[3] = smg_stamp();
+#else
     if (trace) trace[1] = __builtin_amdgcn_s_memtime();
+#endif
     // TS = 16 (round 6): the wave's two tiles are the row pairs (4 wq + m, 4 wq + m + 2) (HaloGeo::rowi), and its whole gradient operand
     // - four row-pair fragments (pair i = halo rows 4 wq + i, 4 wq + i + 2; halo columns 0..15) and one edge fragment (columns 16, 17
     // of the four pairs) per piece and k16-step, 80 registers - is read from the LDS halo ONCE.  Tap (dy, dx) of tile m takes pair
@@ -673,7 +726,17 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
                 for (int i = 0; i < 4; ++i) P[i][ks][pc] = *reinterpret_cast<const u32x4*>(pl_ + (pbase + i * G::W) * 16);
                 Eg[ks][pc] = *reinterpret_cast<const u32x4*>(pl_ + ebase * 16);
             }
+        if constexpr (kDma) {
+            // every wave holds its fragments: the halo's LDS area becomes ring buffers 2 and 3
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            dma_stage(NSTAGE > 2 ? 2 : NSTAGE - 1, 2);
+            dma_stage(NSTAGE > 3 ? 3 : NSTAGE - 1, 3);
+        }
     }
+#ifdef SMG_TRACE_INIT
+    if (trace) trace[4] = smg_stamp();
+#endif
     f32x16 acc[MT];
     // Mask / xhat source of this wave's output tile (32 output channels from c0), prefetched: one row segment (a pixel's four
     // consecutive channels, 16 / 8 bytes per lane; finish_acc_rows turns it into accumulator layout) per four accumulator rows,
@@ -698,6 +761,15 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
       sfor<0, 3>([&](auto DY) {
         constexpr int dy = decltype(DY)::value;
         const int stage = s3 + dy, buf = stage & 1;
+        if constexpr (kDma) {
+            // Ring of NB = 4 buffers, stage s in buffer s % 4, requested three stages ahead.  Behind this wait at most the two younger
+            // stages' requests (3 per wave and stage) are still out - the ones of stages s + 1, s + 2; vmcnt counts in order, and any
+            // other vector memory operation the compiler put behind them only makes the wait stricter - and behind the barrier every
+            // wave's pieces of stage s have landed AND every wave has left stage s - 1, whose buffer takes stage s + 3.
+            dma_wait<2 * B_N>();
+            dma_barrier();
+            if (stage > 0) dma_stage(stage + 3 < NSTAGE ? stage + 3 : NSTAGE - 1, (stage + 3) & 3);      // (tail: dead re-requests of the last stage into buffers nobody reads again)
+        } else
         g_load(stage + 1 < NSTAGE ? stage + 1 : NSTAGE - 1);             // (tail: a clamped re-load, stored dead)
         if (dy < 2) {                                     // (compile-time after unrolling) the group's mask segments: half behind each of the first two rows' weight loads
             constexpr int SEGS = MT * 4;
@@ -708,7 +780,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
         constexpr int dx = decltype(DX)::value;
         // output pixel (ry, rx), tap (dy, dx) reads g at halo (ry + 2 - dy, rx + 2 - dx)
         const int toff = (2 - dy) * G::W + (2 - dx);
-        const char* Bw = Bs + (buf * G::B_PAD + (wc * ST + dx) * HDS_BU) * 16;
+        const char* Bw = kDma ? ring(stage & 3) + ((wc * ST + dx) * HDS_BU) * 16 : Bs + (buf * G::B_PAD + (wc * ST + dx) * HDS_BU) * 16;
         auto fa = [&](int m, int ks, int pc) -> u32x4 {
             return *reinterpret_cast<const u32x4*>(As + ((pc * 4 + 2 * ks + half) * LDH + abase[m] + toff) * 16);
         };
@@ -792,9 +864,11 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
                     for (int m = 0; m < MT; ++m) acc[m] = mfma_bf16(af[ks][m][PA[g]], bf[ks][PB[g]], acc[m]);
         }
         });   // dx
-        s_store(buf ^ 1);                               // that buffer was last read one stage ago, behind that stage's barrier (at the very end: a dead store)
+        if constexpr (!kDma) s_store(buf ^ 1);          // that buffer was last read one stage ago, behind that stage's barrier (at the very end: a dead store)
         if (dy == 2) {
+#ifndef SMG_TRACE_INIT
             if (trace && s3 == 0) trace[2] = __builtin_amdgcn_s_memtime();
+#endif
             // epilogue of this wave's output-channel chunk: ReLU mask, store dy, BN(norm2) backward sums
             const int c = ((cg0 + stage / 3) * NCW + wc) * 32 + l31;
             const float sc = prm[c], be = prm[C + c], mean = prm[2 * C + c], invstd = prm[3 * C + c];
@@ -837,12 +911,19 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
                 const int ch = ((cg0 + stage / 3) * NCW + j) * 32 + cc;
                 atomicAdd((q ? a.o2 : a.o1) + (int64_t)n * a.ostride + ch + stat_rep(), (double)tot);
             }
+#ifndef SMG_TRACE_INIT
             if (trace && s3 == 0) trace[3] = __builtin_amdgcn_s_memtime();
+#endif
         }
-        __syncthreads();
+        if constexpr (!kDma) __syncthreads();
       });
     }
+    if constexpr (kDma) dma_wait<0>();                  // no request may still be on its way into this workgroup's LDS when it ends
+#ifdef SMG_TRACE_INIT
+    if (trace) trace[6] = __builtin_amdgcn_s_memrealtime();
+#else
     if (trace) { trace[4] = __builtin_amdgcn_s_memtime(); trace[6] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 
@@ -900,9 +981,27 @@ static __global__ __launch_bounds__(256, kHaloWgradWaves) void conv3x3_halo_wgra
     const int gz = (slot / ncg) * 8 + xcd;             // (tile group, stream) index
     if (gz >= a.groups * a.streams) return;
     const int n = gz / a.groups, bx = gz - n * a.groups, cc0 = (slot % ncg) * 32;
-    ActScale gsc{1.f, 1.f};                             // operand kind 3: scale of this stream's gradient operand; inverse of (gradient x activation) scale
+    // operand kind 3: scale of this stream's gradient operand (from its recorded maxima) and inverse of the (gradient x activation) scale.
+    // The maxima's loads go out here and are looked at behind the first tile's loads (round 6: amax_scale's own vmcnt(0) in front of
+    // everything else was one more dependent memory round trip per workgroup - the 8 x 8 launches are ONE workgroup life long).
+    u32x4 am4[kAmaxRep / 4];
     float sa = 1.f;
-    if constexpr (OP == 3) { gsc = amax_scale(a.g.amax + (int64_t)n * kAmaxRep); gsc.inv *= a.asc[1]; sa = a.asc[0]; }
+    if constexpr (OP == 3) {
+#pragma unroll
+        for (int r = 0; r < kAmaxRep / 4; ++r) am4[r] = *reinterpret_cast<const u32x4*>(a.g.amax + (int64_t)n * kAmaxRep + 4 * r);
+        sa = a.asc[0];
+    }
+    auto grad_scale = [&]() -> ActScale {
+        ActScale g{1.f, 1.f};
+        if constexpr (OP == 3) {
+            unsigned m = 0;
+#pragma unroll
+            for (int r = 0; r < kAmaxRep / 4; ++r) m = max(max(m, max(am4[r].x, am4[r].y)), max(am4[r].z, am4[r].w));
+            g = scale_of_max(m);
+            g.inv *= a.asc[1];
+        }
+        return g;
+    };
     if (t < 32) {
         prm[t] = tab_mean(a.bt, n)[cc0 + t];
         prm[32 + t] = a.bt.gamma[cc0 + t] * tab_invstd(a.bt, n)[cc0 + t] * sa;
@@ -953,6 +1052,7 @@ static __global__ __launch_bounds__(256, kHaloWgradWaves) void conv3x3_halo_wgra
                     if (x_n) rgx[i] = ld16(x_n, (int64_t)XSZ * (pix * a.g.ldx + E * q));
                 }
             }
+            const ActScale gsc = grad_scale();       // (behind this tile's loads; a few VALU per tile)
 #pragma unroll
             for (int i = 0; i < B_N; ++i) {
                 const int idx = t + 256 * i;
@@ -1040,6 +1140,7 @@ static __global__ __launch_bounds__(256, kHaloWgradWaves) void conv3x3_halo_wgra
         }
     }
     // flush: per tap, fold the four waves' tiles through LDS and add into the gradient
+    const ActScale gsc = grad_scale();
     float* red = smem;                                  // [4][16][64]
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
