@@ -290,7 +290,8 @@ def compact_line(out):
     cb = out.get("cpu_baseline")
     if cb:
         c["cpu_baseline"] = {k: _r(cb[k]) for k in ("value", "unit", "cores", "kind", "seconds_per_pass", "physical_cores", "sweep_fwd_seconds") if k in cb}
-        c["cpu_baseline"]["sample"] = cb.get("sample", "")[:160]
+        sm = cb.get("sample", "")
+        c["cpu_baseline"]["sample"] = sm[:sm.index(" | ")] if " | " in sm[:170] else sm[:160]
     for k in ("pass_tflops_algorithmic", "host_enqueue_ms_per_step", "ms_per_step_host_inputs", "sweep_fwd_ms", "train_step_ms", "train_step_host_enqueue_ms", "train_step_graph_ms",
               "train_step_kernel_ms", "train_step_launches", "forward_1rot_ms", "launches_per_step", "allreduce_overlapped", "allreduce_exposed_ms_per_step",
               "allreduce_ms", "allreduce_bytes", "allreduce_backend", "rccl_world", "device_count", "devices_seen"):
@@ -762,10 +763,11 @@ def main():
             best = min(secs, key=lambda k: secs[k])
             out["cpu_baseline"] = {
                 "value": 1.0 / secs[best], "unit": "passes/s", "cores": best, "kind": "port",
-                "sample": ("%s (rotation, mask) training samples at %d threads, reference schedule (batch 1, masked stream per sample, fwd + Huber "
-                           "+ bwd + Adam per sample, PyTorch CPU fp32)%s; thread setting = best of %s (1 sample each)"
+                # (first 160 characters go into the compact line: keep the facts up front)
+                "sample": ("%s (rotation, mask) samples, %d threads, reference schedule (batch 1, masked stream per sample, fwd+Huber+bwd+Adam each), "
+                           "PyTorch CPU fp32%s | thread setting = best of %s (1 sample each)"
                            % ("one full pass: 16" if args.cpu_samples >= R else "%d of the 16" % args.cpu_samples, best,
-                              "" if args.cpu_samples >= R else ", extrapolated x%g" % (R / args.cpu_samples), sorted(probe))),
+                              "" if args.cpu_samples >= R else ", x%g" % (R / args.cpu_samples), sorted(probe))),
                 "seconds_per_pass": secs[best], "physical_cores": pc, "logical_cpus": os.cpu_count(),
                 # (detail file only) the one-sample probes of the thread settings; threads = physical cores is among
                 # them - on this 2-socket host oneDNN oversubscribes itself there (230-310 s per pass): an artefact, not a baseline

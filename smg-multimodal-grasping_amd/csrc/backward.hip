@@ -1,6 +1,10 @@
 // backward.hip - the backward walk: replaces loss.backward() of Trainer.backprop (code/trainer.py:350-351).
 #include "engine.h"
 
+#ifndef SMG_D3_TH8
+#define SMG_D3_TH8 1      // dev A/B: 0 = the 3x3 data gradient of the big planes on 16 x 16 tiles (rounds 2-5)
+#endif
+
 // ------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------
@@ -343,7 +347,9 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                 a.wu = e->packed_u + e->pk_hd[b][i]; a.bt = bn_table(e, e->sb_tab[b][i], e->max_streams, 0, kBottleneck, P + d.n2.w, P + d.n2.b);
                 BY(e, ESZ(e) * NS * pl.HW * (kGrowth + 2 * kBottleneck));      // gradient in, mask source in, dy out
                 ProfScope ps(e, st, K_D3, 2.0 * NS * pl.HW * 9 * kBottleneck * kGrowth);
-                TraceScope ts(st, K_D3, halo_tile(pl, NS) == 16 ? dim3(((pl.H + 15) / 16) * ((pl.W + 15) / 16), NS) : dim3(((pl.H + 7) / 8) * ((pl.W + 7) / 8), NS, kBottleneck / 64));
+                const bool th8 = SMG_D3_TH8 && halo_tile(pl, NS) == 16 && e->prec == 0 && kSplitOp == 3 && pl.H % 8 == 0 && pl.W % 16 == 0;
+                TraceScope ts(st, K_D3, th8 ? dim3((pl.H / 8) * ((pl.W + 15) / 16), NS)
+                                            : halo_tile(pl, NS) == 16 ? dim3(((pl.H + 15) / 16) * ((pl.W + 15) / 16), NS) : dim3(((pl.H + 7) / 8) * ((pl.W + 7) / 8), NS, kBottleneck / 64));
                 if (halo_tile(pl, NS) == 16) {
                     static bool raised[64][3] = {};          // the 16x16 kernel needs more than the default 64 KB of dynamic LDS
                     if (!raised[e->device & 63][e->prec]) {
@@ -352,6 +358,11 @@ int do_backward(smg_engine* e, const smg_net* net, const float* dq, hipStream_t 
                         raised[e->device & 63][e->prec] = true;
                     }
                     a.tiles_x = (pl.W + 15) / 16; a.cg_per_wg = kBottleneck / 32;
+                    if (th8) {
+                        // 16 x 8 tiles (halo.cuh): one MFMA tile per wave, 52.7 KB of LDS - three workgroups per CU instead of two
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_dgrad_kernel<16, 0, false, 8>), dim3((pl.H / 8) * a.tiles_x, NS), dim3(256),
+                                           (HaloDgradSGeo<16, 0, 8>::smem_bytes(kBottleneck)), st, a);
+                    } else
                     if (pl.H % 16 || pl.W % 16) {      // tiles hang over the edge: the bounds-checked instantiation
                         PREC_DISPATCH(e, hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_halo_dgrad_kernel<16, PREC, true>), dim3(((pl.H + 15) / 16) * a.tiles_x, NS), dim3(256),
                                            (HaloDgradSGeo<16, PREC>::smem_bytes(kBottleneck)), st, a));

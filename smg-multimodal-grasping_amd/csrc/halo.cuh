@@ -37,22 +37,29 @@ namespace smg { constexpr int kHaloFwdWaves = 2, kHaloWgradWaves = 2; }
 
 namespace smg {
 
-template <int TS>
+template <int TS, int TH_ = TS>
 struct HaloGeo {
     static_assert(TS == 16 || TS == 8, "tile side");
-    static constexpr int T = TS, W = TS + 2, PX = W * W, NPIX = TS * TS;
-    static constexpr int MT = TS == 16 ? 2 : 1;        // 32-pixel MFMA tiles per wave
+    static_assert(TH_ == TS || (TS == 16 && TH_ == 8), "tile height: square, or 16 wide x 8 high");
+    static constexpr int T = TS, TH = TH_, W = TS + 2, HH = TH + 2, PX = W * HH, NPIX = TS * TH;
+    static constexpr int MT = NPIX == 256 ? 2 : 1;     // 32-pixel MFMA tiles per wave
     static constexpr int WQ = NPIX / (32 * MT);        // waves that split the pixels (4 / 2)
     static constexpr int WX = 4 / WQ;                  // the other wave factor (1 / 2)
     static constexpr int ROWS = 32 / TS;               // pixel rows per MFMA tile (2 / 4)
+    static constexpr int RP = MT + 2;                  // row pairs a wave's register-resident fragments span (rowi): 4 (16 x 16) / 3 (16 x 8)
+    static constexpr int RSTEP = TS == 16 ? (TH == 16 ? 2 : 4) : 0;      // distance of the two rows of a pair
     // pixel (row, col) inside the tile of MFMA-tile row i (0..31) of tile m of pixel-wave wq
     __device__ static __forceinline__ int row(int wq, int m, int i) { return (wq * MT + m) * ROWS + i / TS; }
     __device__ static __forceinline__ int col(int i) { return i % TS; }
     // TS = 16, kernels that derive their activation fragments in registers (round 6): the two pixel rows of a wave's tile m are rows
     // 4 wq + m and 4 wq + m + 2 - INTERLEAVED with the other tile's - so that the fragment of kernel row dy of tile m, input rows
     // (4 wq + m + dy, 4 wq + m + dy + 2), is the row pair i = m + dy of FOUR pairs (i = 0..3) that serve all six (tile, kernel row)
-    // combinations of the wave (consecutive rows would need six)
-    __device__ static __forceinline__ int rowi(int wq, int m, int i) { return TS == 16 ? 4 * wq + m + 2 * (i / TS) : row(wq, m, i); }
+    // combinations of the wave (consecutive rows would need six).  16 x 8 tiles (one MFMA tile per wave): rows wq and wq + 4, pairs
+    // i = dy of THREE.
+    __device__ static __forceinline__ int rowi(int wq, int m, int i) {
+        return TS == 16 ? (TH == 16 ? 4 * wq + m + 2 * (i / TS) : wq + 4 * (i / TS)) : row(wq, m, i);
+    }
+    __device__ static __forceinline__ int pair0(int wq) { return TH == 16 ? 4 * wq : wq; }      // first halo row of the wave's pair 0
 };
 
 // compile-time loop: f(integral_constant<int, B>) ... f(integral_constant<int, N - 1>) (DPP controls must be immediates)
@@ -507,25 +514,30 @@ struct Halo3x3DgradArgs {
 // barrier per stage, prefetched into registers under the stage's MFMAs.  A stage is two k16-steps (32 gradient channels)
 // per pixel tile; after the ninth tap of a chunk the epilogue applies the ReLU mask and collects the norm2 sums.
 // ------------------------------------------------------------------------------------
-template <int TS, int PREC> struct HaloDgradSGeo : HaloGeo<TS> {
-    using G = HaloGeo<TS>;
+template <int TS, int PREC, int TH = TS> struct HaloDgradSGeo : HaloGeo<TS, TH> {
+    using G = HaloGeo<TS, TH>;
     static constexpr int NP = np_of(bwd_op(PREC));
     static constexpr int BU = NP * 4 * 32;                               // weight units per (tap, 32-channel chunk): 384 / 256 / 128
     static constexpr int LDH = G::PX;
-    static constexpr int A_UNITS = NP * 4 * LDH;
+    static constexpr int A_UNITS_ = NP * 4 * LDH;
     static constexpr int A_N = (G::PX * (PREC ? 4 : 8) + 255) / 256;     // 16-byte slots per thread (32 gradient channels per pixel)
     static constexpr int NCW = G::WX;                                    // output-channel chunks per stage
     static constexpr int ST = 3;                                         // taps per stage: one kernel row (a stage per tap spent more on its barrier than on its 12 MFMAs)
     static constexpr int B_UNITS = NCW * ST * BU;                        // per buffer
     static constexpr int B_N = (B_UNITS + 255) / 256;
     static constexpr int B_PAD = B_N * 256;                              // units per buffer incl. the padding the last copy round touches
+    // (16 x 8 tiles: the halo area is rounded up to two ring buffers - it hosts buffers 2 and 3 of the weights' LDS-DMA ring once the
+    //  gradient fragments are in registers; 52.7 KB, three workgroups per CU)
+    static constexpr int A_UNITS = (TH != TS && A_UNITS_ < 2 * B_PAD) ? 2 * B_PAD : A_UNITS_;
     __host__ __device__ static constexpr int smem_bytes(int C) { return (A_UNITS + 2 * B_PAD) * 16 + (4 * C + 256 + 128) * 4; }
 };
 
-template <int TS, int PREC = 0, bool RAG = false>
-static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const Halo3x3DgradArgs a) {
+// TH = 8 with TS = 16 (round 6): 16 x 8 tiles, one MFMA tile per wave - half the accumulators, fragments and mask prefetch per wave,
+// 52.7 KB of LDS: THREE workgroups per CU where the 16 x 16 form (252 registers, 66 KB) holds two.
+template <int TS, int PREC = 0, bool RAG = false, int TH = TS>
+static __global__ __launch_bounds__(256, TH == TS ? 2 : 3) void conv3x3_halo_dgrad_kernel(const Halo3x3DgradArgs a) {
     constexpr bool kEdge = TS == 8 || RAG;
-    using G = HaloDgradSGeo<TS, PREC>;
+    using G = HaloDgradSGeo<TS, PREC, TH>;
     using GT = grd_t<PREC>;
     using XT = act_t<PREC>;
     constexpr int OP = bwd_op(PREC), NP = G::NP, HDS_BU = G::BU, GSZ = GT::size, XSZ = XT::size, E = 16 / GSZ, SPP = 32 / E;   // SPP: slots per pixel
@@ -543,7 +555,7 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
     const int wq = wave % G::WQ, wc = wave / G::WQ;     // pixel slice, output-channel chunk of the stage
     const int n = blockIdx.y;
     const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
-    const int y0 = ty * TS, x0 = tx * TS;
+    const int y0 = ty * TH, x0 = tx * TS;
     const int C = a.C;
     // dev stamps (SMG_TRACE_KIND=5): start | halo staged | first output-channel group's 9 stages | its epilogue | end
     unsigned long long* trace = (g_smg_trace && t == 0) ? g_smg_trace + 8 * ((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) : nullptr;
@@ -712,18 +724,19 @@ static __global__ __launch_bounds__(256, 2) void conv3x3_halo_dgrad_kernel(const
     // of the four pairs) per piece and k16-step, 80 registers - is read from the LDS halo ONCE.  Tap (dy, dx) of tile m takes pair
     // m + 2 - dy shifted left by 2 - dx lanes (dpp_col_shift): the stages read nothing but weights from LDS (12 instead of 36
     // ds_read_b128 per kernel row).
-    constexpr int RP = kRegFrag ? 4 : 1;
+    constexpr int RP = kRegFrag ? G::RP : 1;
     u32x4 P[RP][2][NP], Eg[2][NP];
     if constexpr (kRegFrag) {
-        const int pbase = (4 * wq + 2 * (l31 >> 4)) * G::W + (l31 & 15);
-        const int ebase = (4 * wq + (((lane & 15) >> 1) & 3) + 2 * (l31 >> 4)) * G::W + 16 + (lane & 1);
+        const int ej = ((lane & 15) >> 1) < RP ? ((lane & 15) >> 1) : RP - 1;      // edge fragment: lanes 2 j, 2 j + 1 of a DPP row carry pair j
+        const int pbase = (G::pair0(wq) + G::RSTEP * (l31 >> 4)) * G::W + (l31 & 15);
+        const int ebase = (G::pair0(wq) + ej + G::RSTEP * (l31 >> 4)) * G::W + 16 + (lane & 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc) {
                 const char* pl_ = As + ((pc * 4 + 2 * ks + half) * LDH) * 16;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) P[i][ks][pc] = *reinterpret_cast<const u32x4*>(pl_ + (pbase + i * G::W) * 16);
+                for (int i = 0; i < RP; ++i) P[i][ks][pc] = *reinterpret_cast<const u32x4*>(pl_ + (pbase + i * G::W) * 16);
                 Eg[ks][pc] = *reinterpret_cast<const u32x4*>(pl_ + ebase * 16);
             }
         if constexpr (kDma) {

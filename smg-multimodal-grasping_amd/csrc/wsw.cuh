@@ -158,13 +158,22 @@ static __global__ __launch_bounds__(512, 1) void conv1x1_wgrad_ws_kernel(const W
                     for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f16(af[g == 1 ? 1 : 0][i], bf[g == 0 ? 1 : 0][j], acc[i][j]);
         }
     };
-    // the accumulators carry the scale of the 64-pixel block being reduced: at a block boundary bring them to the next block's
+    // the accumulators carry the scale of the 64-pixel block being reduced: at a block boundary bring them to the next block's.
+    // A block whose scale lies kSkipBinades or more ABOVE the accumulators' (its largest gradient that many binades below the previous
+    // block's) is skipped instead: the upward factor could push the sums past fp32's range (advisor, round 5), and such a block's
+    // products sit below the last bit of any sum of comparable terms (an fp32 chain would lose them the same way; where every earlier
+    // term of an output happened to be zero the plain chain keeps them - an error of 2^-64 of the larger blocks' magnitude).
+    constexpr int kSkipBinades = 64;
     float cur_inv = sinv[0];
+    bool skip = false;                       // (workgroup-uniform: sinv is the same for every lane)
     auto rescale = [&](int kt) {             // end of k-tile kt
         const int nx = (kt + 1) * G::BK;
         if (nx % kScaleBlock || kt + 1 >= KT) return;
         const float inv = sinv[nx / kScaleBlock];
-        if (inv != cur_inv) {
+        // (positive powers of two: exponent fields.  Not behind a block of scale 1 - that is what a block of zeros carries, and the sums
+        //  it leaves are rescaled for whatever follows)
+        skip = cur_inv != 1.f && (int)(__float_as_uint(cur_inv) >> 23) - (int)(__float_as_uint(inv) >> 23) >= kSkipBinades;
+        if (inv != cur_inv && !skip) {
             const float f = cur_inv * __uint_as_float((254u << 23) - __float_as_uint(inv));      // cur_inv / inv, exact
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -179,12 +188,14 @@ static __global__ __launch_bounds__(512, 1) void conv1x1_wgrad_ws_kernel(const W
     if (role == 0) {
         int kt = 0;
         for (; kt + 2 <= KT; kt += 2) {
-            compute(0); rescale(kt);
+            if (!skip) compute(0);
+            rescale(kt);
             __syncthreads();
-            compute(1); rescale(kt + 1);
+            if (!skip) compute(1);
+            rescale(kt + 1);
             __syncthreads();
         }
-        if (kt < KT) { compute(0); __syncthreads(); }
+        if (kt < KT) { if (!skip) compute(0); __syncthreads(); }
     } else {
         g_load(KT > 2 ? 2 : KT - 1, ra[0], rb[0]);         // slot 0 is free again (tile 0 is in LDS)
         int kt = 0;
