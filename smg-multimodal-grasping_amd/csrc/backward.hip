@@ -2,7 +2,7 @@
 #include "engine.h"
 
 #ifndef SMG_D3_TH8
-#define SMG_D3_TH8 1      // dev A/B: 0 = the 3x3 data gradient of the big planes on 16 x 16 tiles (rounds 2-5)
+#define SMG_D3_TH8 0      // dev A/B: 1 = the 3x3 data gradient of the big planes on 16 x 8 tiles, three workgroups per CU (round 6: built, parity green, measured SLOWER - DESIGN.md section 5.0)
 #endif
 
 // ------------------------------------------------------------------------------------
