@@ -45,8 +45,8 @@ SPLIT_TERMS_PLAIN = 6                 # ... of the classes that stay on the thre
 PLAIN_CLASSES = ("stem7x7_fwd", "transition_wgrad", "transition_dgrad", "stem_wgrad", "head_conv0_wgrad", "head_conv0_dgrad")
 PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / SPLIT_TERMS
 PEAK_HBM_GBS = 8000.0                 # HBM3E peak (MI355X_MICROARCH.md; ~6300 achievable)
-PMC_FILE = "pmc_r05_hbm_traffic.json"                     # tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes
-SERIAL_CSV = "rocprof_r05_kernel_stats_serialized.csv"    # rocprofv3 --kernel-trace --stats of `bench.py --train-only --serialize`
+PMC_FILE = "pmc_r06_hbm_traffic.json"                     # tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes
+SERIAL_CSV = "rocprof_r06_kernel_stats_serialized.csv"    # rocprofv3 --kernel-trace --stats of `bench.py --train-only --serialize`
 PASS5_GFLOP = 36767.6                 # S=1824, R=32 fwd+bwd pass, masked stream de-duplicated
 # rocprofv3 kernel-name fragments that make up each class of roofline.per_kernel (profiles/*kernel_stats*.csv)
 # (reduce_partials_kernel serves every weight gradient that goes through partial tiles - one launch per dense layer reduces its 3x3 AND
