@@ -546,7 +546,6 @@ static __global__ __launch_bounds__(256, TH == TS ? 2 : 3) void conv3x3_halo_dgr
     // ... and with the halo out of LDS after the prologue, the weights of the stages stream through a RING of four LDS buffers by LDS-DMA
     // (two behind the halo, two in the halo's own area once the fragments are in registers), three stages ahead of the MFMAs - see below
     constexpr bool kDma = kRegFrag && G::NCW == 1 && G::B_UNITS % 256 == 0 && 2 * G::B_PAD <= G::A_UNITS && SMG_HALO_DMA;
-    constexpr int NB = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* As = reinterpret_cast<char*>(smem);                            // [piece][k8][LDH] units
     char* Bs = As + G::A_UNITS * 16;                                     // [2][NCW][3 taps][piece][k8][32] units
@@ -775,7 +774,7 @@ static __global__ __launch_bounds__(256, TH == TS ? 2 : 3) void conv3x3_halo_dgr
         constexpr int dy = decltype(DY)::value;
         const int stage = s3 + dy, buf = stage & 1;
         if constexpr (kDma) {
-            // Ring of NB = 4 buffers, stage s in buffer s % 4, requested three stages ahead.  Behind this wait at most the two younger
+            // Ring of four buffers, stage s in buffer s % 4, requested three stages ahead.  Behind this wait at most the two younger
             // stages' requests (3 per wave and stage) are still out - the ones of stages s + 1, s + 2; vmcnt counts in order, and any
             // other vector memory operation the compiler put behind them only makes the wait stricter - and behind the barrier every
             // wave's pieces of stage s have landed AND every wave has left stage s - 1, whose buffer takes stage s + 3.

@@ -163,6 +163,9 @@ static __global__ __launch_bounds__(512, 1) void conv1x1_wgrad_ws_kernel(const W
     // block's) is skipped instead: the upward factor could push the sums past fp32's range (advisor, round 5), and such a block's
     // products sit below the last bit of any sum of comparable terms (an fp32 chain would lose them the same way; where every earlier
     // term of an output happened to be zero the plain chain keeps them - an error of 2^-64 of the larger blocks' magnitude).
+    // (The generic kernel - few-stream calls, block 1's first layer - keeps the plain rescale: the same skip as a workgroup-uniform branch
+    //  around its MFMA block measured +2 % on the single-sample step, 5.55-5.61 -> 5.68-5.71 ms; its factor overflows only when two
+    //  neighbouring 64-pixel blocks of one stream differ by ~90 binades.)
     constexpr int kSkipBinades = 64;
     float cur_inv = sinv[0];
     bool skip = false;                       // (workgroup-uniform: sinv is the same for every lane)
