@@ -223,6 +223,7 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                     a.wu = e->packed_u + e->pk_hf[b][i]; a.asc = asc_n2(e, b, (int)i);
                     BY(e, ESZ(e) * ns * pl.HW * (kBottleneck + kGrowth));
                     ProfScope ps(e, cs, K_C3, 2.0 * ns * pl.HW * 9 * kBottleneck * kGrowth);
+                    TraceScope ts(cs, K_C3, dim3(banded_grid(halo_tile(pl, ns) == 16 ? ((pl.H + 15) / 16) * ((pl.W + 15) / 16) : ((pl.H + 7) / 8) * ((pl.W + 7) / 8), ns)));      // dev stamps: SMG_TRACE_KIND=2
                     if (halo_tile(pl, ns) == 8) {
                         // small planes: the wave-specialised form (halo.cuh; 17.1 -> 15.2 us per launch.  At TS = 16 it measures
                         // 67.8 -> 62.8 us serialised and nothing on the step - two forward chains already fill each other's gaps there)

@@ -171,6 +171,14 @@ static __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : kHaloFwdWaves) void
     const int tap0 = (G::WX > 1 && wk) ? 5 : 0, tap1 = (G::WX > 1 && !wk) ? 5 : 9;
     int n, tile;
     if (!banded_tile(a.n_tiles, a.streams, tile, n)) return;
+    // dev stamps (SMG_TRACE_KIND=2): start | prologue (parameters, first chunk staged) | first chunk's taps | chunk loop | epilogue
+    // (instrumentation build -DSMG_TRACE_FWD3 only: round 5 measured 10 % for live stamps in this kernel)
+#ifdef SMG_TRACE_FWD3
+    unsigned long long* trace = (g_smg_trace && threadIdx.x == 0) ? g_smg_trace + 8 * (size_t)blockIdx.x : nullptr;
+    if (trace) { trace[0] = smg_stamp(); trace[5] = __builtin_amdgcn_s_memrealtime(); }
+#else
+    constexpr unsigned long long* trace = nullptr;
+#endif
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int y0 = ty * TS, x0 = tx * TS;
     const int C = a.C, kq = t & 3;                           // this thread's 16-byte slot inside every chunk (E channels)
@@ -397,9 +405,11 @@ static __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : kHaloFwdWaves) void
             __syncthreads();         // this chunk is read, the next one is in the other buffer
         }
     } else {
+        if (trace) trace[1] = smg_stamp();
         for (int ch = 0; ch < NCH; ++ch) {
             if (ch + 1 < NCH) g_load(ch + 1, Set0{});
             taps_of_chunk();
+            if (trace && ch == 0) trace[2] = smg_stamp();
             __syncthreads();                          // every wave is done reading this chunk
             if (ch + 1 < NCH) {
                 s_store(ch + 1, As, Bs, Set0{});
@@ -407,6 +417,7 @@ static __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : kHaloFwdWaves) void
             }
         }
     }
+    if (trace) trace[3] = smg_stamp();
     if constexpr (G::WX > 1) {                    // fold the tap-split partial tiles into the wk == 0 waves
         float* r = smem + (wq * 16) * 64 + lane;  // [WQ][16][64], MT == 1
         if (wk > 0) {
@@ -466,6 +477,7 @@ static __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : kHaloFwdWaves) void
         const double tot = red[q * 128 + c] + red[q * 128 + 32 + c] + red[q * 128 + 64 + c] + red[q * 128 + 96 + c];
         atomicAdd((q ? a.dsq : a.dsum) + (int64_t)n * a.dstride + a.dcoff + c + fstat_rep(), tot);
     }
+    if (trace) { trace[4] = smg_stamp(); trace[6] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 
