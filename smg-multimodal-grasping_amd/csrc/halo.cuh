@@ -554,7 +554,10 @@ static __global__ __launch_bounds__(256, TH == TS ? 2 : 3) void conv3x3_halo_dgr
     using XT = act_t<PREC>;
     constexpr int OP = bwd_op(PREC), NP = G::NP, HDS_BU = G::BU, GSZ = GT::size, XSZ = XT::size, E = 16 / GSZ, SPP = 32 / E;   // SPP: slots per pixel
     constexpr int MT = G::MT, NCW = G::NCW, A_N = G::A_N, B_N = G::B_N, LDH = G::LDH;
-    constexpr bool kRegFrag = TS == 16 && OP != 0 && SMG_HALO_REGFRAG;                       // gradient fragments resident in registers: four row pairs + DPP column shifts (below)
+    // gradient fragments resident in registers: four row pairs + DPP column shifts (below).  Precision mode 0 only: in the 16-bit modes the
+    // resident fragments take the bounds-checked instantiation from 161 to 169 registers - two waves per SIMD instead of three, 62.9 -> 70.6 us
+    // per launch on config 5's planes - and gain nothing where they fit (45.6 us both ways on config 3's)
+    constexpr bool kRegFrag = TS == 16 && OP == 3 && SMG_HALO_REGFRAG;
     // ... and with the halo out of LDS after the prologue, the weights of the stages stream through a RING of four LDS buffers by LDS-DMA
     // (two behind the halo, two in the halo's own area once the fragments are in registers), three stages ahead of the MFMAs - see below
     constexpr bool kDma = kRegFrag && G::NCW == 1 && G::B_UNITS % 256 == 0 && 2 * G::B_PAD <= G::A_UNITS && SMG_HALO_DMA;
