@@ -31,6 +31,9 @@ namespace smg { constexpr int kHaloFwdWaves = 2, kHaloWgradWaves = 2; }
 #ifndef SMG_HALO_REGFRAG
 #define SMG_HALO_REGFRAG 1      // dev A/B: 0 = every activation fragment of the TS = 16 forward / data gradient read from LDS (rounds 2-5)
 #endif
+#ifndef SMG_D3_ST8
+#define SMG_D3_ST8 1            // dev A/B: 3 = the 8 x 8 data gradient stages a whole kernel row's weights (rounds 4-5: 65 KB of LDS, two workgroups per CU)
+#endif
 #ifndef SMG_HALO_DMA
 #define SMG_HALO_DMA 1          // dev A/B: 0 = the TS = 16 data gradient's weights register-staged through two LDS buffers, one stage ahead (rounds 2-5)
 #endif
@@ -534,7 +537,11 @@ template <int TS, int PREC, int TH = TS> struct HaloDgradSGeo : HaloGeo<TS, TH> 
     static constexpr int A_UNITS_ = NP * 4 * LDH;
     static constexpr int A_N = (G::PX * (PREC ? 4 : 8) + 255) / 256;     // 16-byte slots per thread (32 gradient channels per pixel)
     static constexpr int NCW = G::WX;                                    // output-channel chunks per stage
-    static constexpr int ST = 3;                                         // taps per stage: one kernel row (a stage per tap spent more on its barrier than on its 12 MFMAs)
+    // taps per stage.  16 x 16 tiles: one kernel row (a stage per tap spent more on its barrier than on its 12 MFMAs).  8 x 8 tiles: ONE tap
+    // (round 6) - two buffers of a whole row's weights for 64 output channels made 65 KB of LDS, two workgroups per CU, and the 850
+    // workgroups of a 17-stream launch on the 40^2 planes ran in TWO rounds (per-workgroup stamps: the second starts 10 us in; span 18.5-20.8 us
+    // for lives of 8-9); a tap per stage is 33 KB - four per CU, one round.
+    static constexpr int ST = TS == 8 ? SMG_D3_ST8 : 3;
     static constexpr int B_UNITS = NCW * ST * BU;                        // per buffer
     static constexpr int B_N = (B_UNITS + 255) / 256;
     static constexpr int B_PAD = B_N * 256;                              // units per buffer incl. the padding the last copy round touches
@@ -547,7 +554,7 @@ template <int TS, int PREC, int TH = TS> struct HaloDgradSGeo : HaloGeo<TS, TH> 
 // TH = 8 with TS = 16 (round 6): 16 x 8 tiles, one MFMA tile per wave - half the accumulators, fragments and mask prefetch per wave,
 // 52.7 KB of LDS: THREE workgroups per CU where the 16 x 16 form (252 registers, 66 KB) holds two.
 template <int TS, int PREC = 0, bool RAG = false, int TH = TS>
-static __global__ __launch_bounds__(256, TH == TS ? 2 : 3) void conv3x3_halo_dgrad_kernel(const Halo3x3DgradArgs a) {
+static __global__ __launch_bounds__(256, TS == 8 ? 4 : (TH == TS ? 2 : 3)) void conv3x3_halo_dgrad_kernel(const Halo3x3DgradArgs a) {
     constexpr bool kEdge = TS == 8 || RAG;
     using G = HaloDgradSGeo<TS, PREC, TH>;
     using GT = grd_t<PREC>;
@@ -575,10 +582,11 @@ static __global__ __launch_bounds__(256, TH == TS ? 2 : 3) void conv3x3_halo_dgr
     unsigned long long* trace = (g_smg_trace && t == 0) ? g_smg_trace + 8 * ((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) : nullptr;
     if (trace) { trace[0] = __builtin_amdgcn_s_memtime(); trace[5] = __builtin_amdgcn_s_memrealtime(); }
     const int cg0 = blockIdx.z * a.cg_per_wg;
-    const int NSTAGE = a.cg_per_wg * 3;                // channel-chunk groups x 3 kernel rows
+    constexpr int SPR = 3 / G::ST;                     // stages per kernel row: 1 (a row's three taps per stage) or 3 (a tap per stage, 8 x 8 tiles)
+    const int NSTAGE = a.cg_per_wg * 3 * SPR;          // channel-chunk groups x kernel rows x stages per row
     auto ring = [&](int k) -> char* { return k < 2 ? Bs + k * G::B_PAD * 16 : As + (k - 2) * G::B_PAD * 16; };
     auto dma_stage = [&](int stage, int k) {           // the weights of `stage` (one kernel row of one 32-channel group: B_UNITS straight 16-byte copies) -> ring buffer k
-        const int cg = cg0 + stage / 3, dyy = stage % 3;
+        const int cg = cg0 + stage / 3, dyy = stage % 3;      // (ring form: TS = 16, a kernel row per stage)
         const unsigned dst = (unsigned)(uintptr_t)ring(k) + 16u * 64u * (unsigned)wave;
 #pragma unroll
         for (int i = 0; i < B_N; ++i)
@@ -650,9 +658,9 @@ static __global__ __launch_bounds__(256, TH == TS ? 2 : 3) void conv3x3_halo_dgr
         b_voff[i] = 16u * (unsigned)(j * 9 * HDS_BU + rem);
     }
     auto g_load = [&](int stage) {
-        const int cg = cg0 + stage / 3, dy = stage % 3;
+        const int cg = cg0 + stage / (3 * SPR), tap0 = (stage % (3 * SPR)) * ST;       // first tap of the stage
 #pragma unroll
-        for (int i = 0; i < B_N; ++i) rb[i] = bload_u4(a.wu, kWholeBuf, b_voff[i], 16u * (unsigned)((cg * NCW * 9 + ST * dy) * HDS_BU));
+        for (int i = 0; i < B_N; ++i) rb[i] = bload_u4(a.wu, kWholeBuf, b_voff[i], 16u * (unsigned)((cg * NCW * 9 + tap0) * HDS_BU));
     };
     // gradient halo (zero outside the image), split at the store
     {
@@ -779,15 +787,16 @@ static __global__ __launch_bounds__(256, TH == TS ? 2 : 3) void conv3x3_halo_dgr
         if constexpr (std::is_same<XT, e_f32>::value) xq[m][g] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.mbuf) + idx);
         else xq[m][g] = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(a.mbuf) + idx);
     };
-    for (int s3 = 0; s3 < NSTAGE; s3 += 3) {           // one output-channel group (three kernel rows) per trip
+    for (int s3 = 0; s3 < NSTAGE; s3 += 3 * SPR) {     // one output-channel group (three kernel rows) per trip
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-      const int cmask0 = ((cg0 + s3 / 3) * NCW + wc) * 32;
+      const int cmask0 = ((cg0 + s3 / (3 * SPR)) * NCW + wc) * 32;
       sfor<0, 3>([&](auto DY) {
-        constexpr int dy = decltype(DY)::value;
-        const int stage = s3 + dy, buf = stage & 1;
+       sfor<0, SPR>([&](auto SUB) {
+        constexpr int dy = decltype(DY)::value, sub = decltype(SUB)::value;
+        const int stage = s3 + dy * SPR + sub, buf = stage & 1;
         if constexpr (kDma) {
             // Ring of four buffers, stage s in buffer s % 4, requested three stages ahead.  Behind this wait at most the two younger
             // stages' requests (3 per wave and stage) are still out - the ones of stages s + 1, s + 2; vmcnt counts in order, and any
@@ -798,16 +807,16 @@ static __global__ __launch_bounds__(256, TH == TS ? 2 : 3) void conv3x3_halo_dgr
             if (stage > 0) dma_stage(stage + 3 < NSTAGE ? stage + 3 : NSTAGE - 1, (stage + 3) & 3);      // (tail: dead re-requests of the last stage into buffers nobody reads again)
         } else
         g_load(stage + 1 < NSTAGE ? stage + 1 : NSTAGE - 1);             // (tail: a clamped re-load, stored dead)
-        if (dy < 2) {                                     // (compile-time after unrolling) the group's mask segments: half behind each of the first two rows' weight loads
+        if (dy < 2 && sub == 0) {                         // (compile-time after unrolling) the group's mask segments: half behind each of the first two rows' weight loads
             constexpr int SEGS = MT * 4;
 #pragma unroll
             for (int sg = 0; sg < SEGS / 2; ++sg) { const int q = dy * (SEGS / 2) + sg; load_mask_seg(cmask0, q / 4, q % 4); }
         }
-        sfor<0, 3>([&](auto DX) {
-        constexpr int dx = decltype(DX)::value;
+        sfor<0, ST>([&](auto DX) {
+        constexpr int dxi = decltype(DX)::value, dx = sub * ST + dxi;      // tap inside the stage, kernel column
         // output pixel (ry, rx), tap (dy, dx) reads g at halo (ry + 2 - dy, rx + 2 - dx)
         const int toff = (2 - dy) * G::W + (2 - dx);
-        const char* Bw = kDma ? ring(stage & 3) + ((wc * ST + dx) * HDS_BU) * 16 : Bs + (buf * G::B_PAD + (wc * ST + dx) * HDS_BU) * 16;
+        const char* Bw = kDma ? ring(stage & 3) + ((wc * ST + dxi) * HDS_BU) * 16 : Bs + (buf * G::B_PAD + (wc * ST + dxi) * HDS_BU) * 16;
         auto fa = [&](int m, int ks, int pc) -> u32x4 {
             return *reinterpret_cast<const u32x4*>(As + ((pc * 4 + 2 * ks + half) * LDH + abase[m] + toff) * 16);
         };
@@ -892,12 +901,12 @@ static __global__ __launch_bounds__(256, TH == TS ? 2 : 3) void conv3x3_halo_dgr
         }
         });   // dx
         if constexpr (!kDma) s_store(buf ^ 1);          // that buffer was last read one stage ago, behind that stage's barrier (at the very end: a dead store)
-        if (dy == 2) {
+        if (dy == 2 && sub == SPR - 1) {
 #ifndef SMG_TRACE_INIT
             if (trace && s3 == 0) trace[2] = __builtin_amdgcn_s_memtime();
 #endif
             // epilogue of this wave's output-channel chunk: ReLU mask, store dy, BN(norm2) backward sums
-            const int c = ((cg0 + stage / 3) * NCW + wc) * 32 + l31;
+            const int c = ((cg0 + stage / (3 * SPR)) * NCW + wc) * 32 + l31;
             const float sc = prm[c], be = prm[C + c], mean = prm[2 * C + c], invstd = prm[3 * C + c];
             float s1 = 0.f, s2 = 0.f;
             auto finish = [&](rawq_t<XT> (&xq)[MT][4]) {
@@ -935,7 +944,7 @@ static __global__ __launch_bounds__(256, TH == TS ? 2 : 3) void conv3x3_halo_dgr
                 float tot = 0.f;
 #pragma unroll
                 for (int w = 0; w < G::WQ; ++w) tot += red[q * 128 + (j * G::WQ + w) * 32 + cc];
-                const int ch = ((cg0 + stage / 3) * NCW + j) * 32 + cc;
+                const int ch = ((cg0 + stage / (3 * SPR)) * NCW + j) * 32 + cc;
                 atomicAdd((q ? a.o2 : a.o1) + (int64_t)n * a.ostride + ch + stat_rep(), (double)tot);
             }
 #ifndef SMG_TRACE_INIT
@@ -943,6 +952,7 @@ static __global__ __launch_bounds__(256, TH == TS ? 2 : 3) void conv3x3_halo_dgr
 #endif
         }
         if constexpr (!kDma) __syncthreads();
+       });
       });
     }
     if constexpr (kDma) dma_wait<0>();                  // no request may still be on its way into this workgroup's LDS when it ends
