@@ -42,11 +42,8 @@ struct WsGeoT {
 
 using WsGeo = WsGeoT<np_of(fwd_op(0))>;
 
-#ifndef SMG_C1WS_WAVES
-#define SMG_C1WS_WAVES 8        // waves per SIMD the register allocator is held to: 8 = 64 VGPRs, FOUR 512-thread workgroups per CU (dev A/B: 1 = rounds 3-5's 65 VGPRs, three per CU)
-#endif
 template <int PREC = 0>
-static __global__ __launch_bounds__(512, SMG_C1WS_WAVES) void conv1x1_fwd_ws_kernel(const Fwd1x1WsArgs a) {
+static __global__ __launch_bounds__(512, 1) void conv1x1_fwd_ws_kernel(const Fwd1x1WsArgs a) {
     static_assert(PREC == 0, "fp32 storage only");
     using G = WsGeo;
     constexpr int OP = fwd_op(PREC), NP = G::NP;
