@@ -2,6 +2,9 @@
 // (code/models.py:361-586, :72-296) for one (trunk, head).
 #include "engine.h"
 
+#ifndef SMG_C1WS_BN
+#define SMG_C1WS_BN 128     // dev A/B: 64 = two 64-column workgroups per 64-row tile (rounds 3-5)
+#endif
 #ifndef SMG_FWD16_WS
 #define SMG_FWD16_WS 0
 #endif
@@ -194,17 +197,19 @@ int do_forward(smg_engine* e, const smg_net* net, int trunk_id, int head_id, con
                         a.tw_mean = const_cast<float*>(t1.mean); a.tw_invstd = const_cast<float*>(t1.invstd);
                         a.wp = e->packed_u + e->pk_c1[b][i]; a.N = kBottleneck; a.asc = asc_n1(e, b, (int)i);
                         a.dst = bt; a.ldd = kBottleneck; a.dsum = bsum; a.dsq = bsq; a.dstride = kBottleneck;
-                        const int nM = ns * pl.HWp / 64, nN = kBottleneck / 64;
+                        constexpr int WBN = SMG_C1WS_BN;                     // 128: one workgroup per 64-row tile covers all 128 output columns (ws.cuh)
+                        using WG_ = WsGeoT<np_of(fwd_op(0)), WBN>;
+                        const int nM = ns * pl.HWp / 64, nN = kBottleneck / WBN;
                         a.tm = TileMap{nM, nN, 0};
                         BY(e, ESZ(e) * ns * pl.HW * (d.cin + kBottleneck));
                         ProfScope ps(e, cs, K_C1, 2.0 * ns * pl.HW * d.cin * kBottleneck);
-                        const size_t smem = WsGeo::smem_bytes(d.cin);
+                        const size_t smem = WG_::smem_bytes(d.cin);
                         static bool raised[64] = {};
                         if (!raised[e->device & 63]) {
-                            (void)hipFuncSetAttribute((const void*)conv1x1_fwd_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                            (void)hipFuncSetAttribute((const void*)conv1x1_fwd_ws_kernel<0, WBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                             raised[e->device & 63] = true;
                         }
-                        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_fwd_ws_kernel<0>), dim3(tile_grid(a.tm)), dim3(512), smem, cs, a);
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1x1_fwd_ws_kernel<0, WBN>), dim3(tile_grid(a.tm)), dim3(512), smem, cs, a);
                     } else
                     if (pl.HWp % 128 == 0 && wg128 >= small_wgs) run(CfgP128x128{});
                     else if (wg64 < small_wgs) run(CfgP32x64{});

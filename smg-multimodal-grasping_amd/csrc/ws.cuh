@@ -28,10 +28,11 @@ struct Fwd1x1WsArgs {
     TileMap tm;                                    // XCD-aware order: the N tiles of one M tile are consecutive on one XCD
 };
 
-template <int NP_>
+template <int NP_, int BN_ = 64>
 struct WsGeoT {
     static constexpr int NP = NP_;                                    // pieces per operand (3: bf16 split, 2: fp16 split)
-    static constexpr int BM = 64, BN = 64, BK = 32, K8 = BK / 8;
+    static constexpr int BM = 64, BN = BN_, BK = 32, K8 = BK / 8;
+    static constexpr int TN = BN / 64;                                // 32-column accumulator tiles per consumer wave (2 x 2 waves)
     static constexpr int LDUA = BM + 2, LDUB = BN;                    // A rows padded as in GemmCfg (64 / BK units)
     static constexpr int A_BYTES = NP * K8 * LDUA * 16, B_BYTES = NP * K8 * LDUB * 16;
     static constexpr int A_N = BM * (BK / 4) / 256;                   // 2 float4 per producer thread
@@ -41,11 +42,17 @@ struct WsGeoT {
 };
 
 using WsGeo = WsGeoT<np_of(fwd_op(0))>;
+// BN = 128 (round 6): ONE workgroup per 64-row tile covers all 128 output columns - the activations are loaded, BN + ReLU'd and split
+// once instead of once per 64-column tile (the producers' instruction work per output halves; the small planes' waves are
+// issue-bound), each consumer wave carries two accumulator tiles.  62 KB of LDS at K = 992: two per CU,
+// 425 workgroups of a 17-stream 40^2 launch in one round.
+using WsGeo128 = WsGeoT<np_of(fwd_op(0)), 128>;
 
-template <int PREC = 0>
+template <int PREC = 0, int BN = 64>
 static __global__ __launch_bounds__(512, 1) void conv1x1_fwd_ws_kernel(const Fwd1x1WsArgs a) {
     static_assert(PREC == 0, "fp32 storage only");
-    using G = WsGeo;
+    using G = WsGeoT<np_of(fwd_op(0)), BN>;
+    constexpr int TN = G::TN;
     constexpr int OP = fwd_op(PREC), NP = G::NP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* As = reinterpret_cast<char*>(smem);
@@ -130,33 +137,42 @@ static __global__ __launch_bounds__(512, 1) void conv1x1_fwd_ws_kernel(const Fwd
     __syncthreads();
 
     // ---- consumers: accumulator and fragment geometry (2 x 2 waves, one 32 x 32 tile each)
-    f32x16 acc;
+    f32x16 acc[TN];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32 * TN;
     auto compute = [&](int buf) {
         const char* A = As + buf * G::A_BYTES;
         const char* B = Bs + buf * G::B_BYTES;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int k8 = 2 * s + half;
-            u32x4 af[NPIECE], bf[NPIECE];
+            u32x4 af[NPIECE], bf[TN][NPIECE];
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc) {
                 af[pc] = *reinterpret_cast<const u32x4*>(A + ((pc * G::K8 + k8) * G::LDUA + wm0 + l31) * 16);
-                bf[pc] = *reinterpret_cast<const u32x4*>(B + ((pc * G::K8 + k8) * G::LDUB + wn0 + l31) * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j][pc] = *reinterpret_cast<const u32x4*>(B + ((pc * G::K8 + k8) * G::LDUB + wn0 + 32 * j + l31) * 16);
             }
-            if constexpr (OP == 3) {
-                acc = mfma_f16(af[0], bf[1], acc);
-                acc = mfma_f16(af[1], bf[0], acc);
-                acc = mfma_f16(af[0], bf[0], acc);
+            if constexpr (OP == 3) {             // term groups outermost, tiles innermost: consecutive MFMAs never share an accumulator (TN = 2)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[j] = mfma_f16(af[0], bf[j][1], acc[j]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[j] = mfma_f16(af[1], bf[j][0], acc[j]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[j] = mfma_f16(af[0], bf[j][0], acc[j]);
             } else {
-                acc = mfma_bf16(af[0], bf[2], acc);
-                acc = mfma_bf16(af[2], bf[0], acc);
-                acc = mfma_bf16(af[1], bf[1], acc);
-                acc = mfma_bf16(af[0], bf[1], acc);
-                acc = mfma_bf16(af[1], bf[0], acc);
-                acc = mfma_bf16(af[0], bf[0], acc);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[j] = mfma_bf16(af[0], bf[j][2], acc[j]);
+                    acc[j] = mfma_bf16(af[2], bf[j][0], acc[j]);
+                    acc[j] = mfma_bf16(af[1], bf[j][1], acc[j]);
+                    acc[j] = mfma_bf16(af[0], bf[j][1], acc[j]);
+                    acc[j] = mfma_bf16(af[1], bf[j][0], acc[j]);
+                    acc[j] = mfma_bf16(af[0], bf[j][0], acc[j]);
+                }
             }
         }
     };
@@ -187,57 +203,67 @@ static __global__ __launch_bounds__(512, 1) void conv1x1_fwd_ws_kernel(const Fwd
     }
 
     // ---- epilogue (consumers): raw output + per-(stream, channel) sum / sum of squares (fp64)
-    double v0 = 0.0, v1 = 0.0;
+    double v0[TN], v1[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) v0[j] = v1[j] = 0.0;
     if (role == 0) {
         if constexpr (OP == 3) {               // products of scaled operands: exact power-of-two correction
             const float inv = a.asc[1] * pack_inv_scale(a.wp);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] *= inv;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] *= inv;
         }
-        const int cj = wn0 + l31, col = n0 + cj;
-        if (pbase + G::BM <= a.pl.HW) {
-            // whole tile inside the plane: shifted fp32 sums per 16-row strip, widened once (see FwdConvP::epilogue)
-            float* tb = a.dst + (int64_t)m0 * a.ldd + n0;
-            unsigned o = (unsigned)((wm0 + 4 * half) * a.ldd + cj);
-            const float s = acc[0];
-            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float x = acc[r];
-                tb[o] = x;
-                o += (r & 3) == 3 ? 5u * (unsigned)a.ldd : (unsigned)a.ldd;
-                const float dx = x - s;
-                s1 += dx;
-                s2 = fmaf(dx, dx, s2);
-            }
-            const double sd = (double)s, s1d = (double)s1;
-            v0 = s1d + 16.0 * sd;
-            v1 = (double)s2 + 2.0 * sd * s1d + 16.0 * sd * sd;
-        } else {
+        for (int j = 0; j < TN; ++j) {
+            const int cj = wn0 + 32 * j + l31, col = n0 + cj;
+            if (pbase + G::BM <= a.pl.HW) {
+                // whole tile inside the plane: shifted fp32 sums per 16-row strip, widened once (see FwdConvP::epilogue)
+                float* tb = a.dst + (int64_t)m0 * a.ldd + n0;
+                unsigned o = (unsigned)((wm0 + 4 * half) * a.ldd + cj);
+                const float s = acc[j][0];
+                float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (pbase + row < a.pl.HW) {
-                    const float x = acc[r];
-                    a.dst[(int64_t)(m0 + row) * a.ldd + col] = x;
-                    const double xd = (double)x;
-                    v0 += xd;
-                    v1 += xd * xd;
+                for (int r = 0; r < 16; ++r) {
+                    const float x = acc[j][r];
+                    tb[o] = x;
+                    o += (r & 3) == 3 ? 5u * (unsigned)a.ldd : (unsigned)a.ldd;
+                    const float dx = x - s;
+                    s1 += dx;
+                    s2 = fmaf(dx, dx, s2);
+                }
+                const double sd = (double)s, s1d = (double)s1;
+                v0[j] = s1d + 16.0 * sd;
+                v1[j] = (double)s2 + 2.0 * sd * s1d + 16.0 * sd * sd;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (pbase + row < a.pl.HW) {
+                        const float x = acc[j][r];
+                        a.dst[(int64_t)(m0 + row) * a.ldd + col] = x;
+                        const double xd = (double)x;
+                        v0[j] += xd;
+                        v1[j] += xd * xd;
+                    }
                 }
             }
+            v0[j] += __shfl_xor(v0[j], 32);
+            v1[j] += __shfl_xor(v1[j], 32);
         }
-        v0 += __shfl_xor(v0, 32);
-        v1 += __shfl_xor(v1, 32);
     }
-    double* red = reinterpret_cast<double*>(smem);       // [2 quantities][2 row-waves][64 columns]
+    double* red = reinterpret_cast<double*>(smem);       // [2 quantities][2 row-waves][BN columns]
     if (role == 0 && half == 0) {
-        red[((0 * 2) + (wave >> 1)) * 64 + wn0 + l31] = v0;
-        red[((1 * 2) + (wave >> 1)) * 64 + wn0 + l31] = v1;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            red[((0 * 2) + (wave >> 1)) * G::BN + wn0 + 32 * j + l31] = v0[j];
+            red[((1 * 2) + (wave >> 1)) * G::BN + wn0 + 32 * j + l31] = v1[j];
+        }
     }
     __syncthreads();
-    if (t < 128) {
-        const int q = t >> 6, c = t & 63;
-        const double tot = red[(q * 2) * 64 + c] + red[(q * 2 + 1) * 64 + c];
+    if (t < 2 * G::BN) {
+        const int q = t / G::BN, c = t % G::BN;
+        const double tot = red[(q * 2) * G::BN + c] + red[(q * 2 + 1) * G::BN + c];
         atomicAdd((q ? a.dsq : a.dsum) + (int64_t)n * a.dstride + n0 + c + fstat_rep(), tot);
     }
 }
