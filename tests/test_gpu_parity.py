@@ -1895,7 +1895,8 @@ def test_bench_rccl_world1_line(gpu):
     assert out["allreduce_overlapped"] is True and out["allreduce_ms"] > 0 and out["allreduce_bytes"] == 4 * (6953856 + 160896)
 
 
-def test_weight_gradient_chunks_never_start_in_the_plane_padding(gpu):
+@pytest.mark.parametrize("size,rots", [(232, [1, 6, 10, 13]), (256, [3, 11])])
+def test_weight_gradient_chunks_never_start_in_the_plane_padding(gpu, size, rots):
     """A 232^2 heightmap -> S = 672: dense block 1's 168^2 = 28 224-pixel planes are padded to 28 288 rows (make_plane pads planes
     of 8192+ pixels to multiples of 128), so HWp - HW = 64 - a whole weight-gradient chunk granule.  Chunks sized from HWp put the
     last chunk of a stream wholly into the padding for 5 streams (chunk 448, 64 per stream: the 64th starts at row 28 224 = HW);
@@ -1903,8 +1904,10 @@ def test_weight_gradient_chunks_never_start_in_the_plane_padding(gpu):
     (advisor, round 5: static reading, S = 640 and S = 1824 were not affected).  pick_chunk now sizes chunks over the valid rows.
     Detector: under "deterministic" the conv weight gradients of a 5-stream call must be bit-identical before and after an
     unrelated call whose gradients are 1000x larger (stale partial tiles of that call would be added), and every 1x1 weight
-    gradient of dense block 1 must match the sum of the single-rotation calls (two streams each: the atomics form, no partial
-    tiles)."""
+    gradient of dense block 1 and every transition's weight gradient must match the sum of the single-rotation calls (two streams
+    each: the 1x1 weight gradients there take the atomics form, no partial tiles).
+    Second case, a 256^2 heightmap -> S = 736 with 3 streams: 184^2 planes padded by 64 rows, 92^2 = 8464-pixel planes by 112 - the
+    advisor's transition-1 weight gradient case (two column tiles, 64-row chunks)."""
     from trainer import Trainer
     import synthetic
     tr = Trainer('reinforcement', 0.5, False, None, False)
@@ -1912,9 +1915,9 @@ def test_weight_gradient_chunks_never_start_in_the_plane_padding(gpu):
     tr.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     tr.model.gnum_rotations = tr.model.snum_rotations = 16
     tr.optimizer.lr = 0.0
-    depth, masks = synthetic.heightmap_scene(11, size=232)
-    depth_b, masks_b = synthetic.heightmap_scene(12, size=232)
-    rots = [1, 6, 10, 13]
+    depth, masks = synthetic.heightmap_scene(11, size=size)
+    depth_b, masks_b = synthetic.heightmap_scene(12, size=size)
+    S = {232: 672, 256: 736}[size]
     with torch.no_grad():
         q = tr.model.run(0, [rots], 16, heightmaps=torch.from_numpy(np.stack([depth, depth * masks[0]])).cuda(), mean=tr.image_mean, std=tr.image_std)
     q0 = q.reshape(len(rots), -1)[:, 0].double().cpu().numpy()
@@ -1926,7 +1929,7 @@ def test_weight_gradient_chunks_never_start_in_the_plane_padding(gpu):
     def run(d, m, labels):
         tr.train_batch(d, m, 0, rots, labels)
         return {n: p.grad.clone() for n, p in conv}
-    eng = engine_of(tr.model, 672)
+    eng = engine_of(tr.model, S)
     try:
         eng.set_option("deterministic", 1)
         g_a = run(depth, depth * masks[0], labels_small)
@@ -1944,9 +1947,10 @@ def test_weight_gradient_chunks_never_start_in_the_plane_padding(gpu):
         gsum = g if gsum is None else {n: gsum[n] + g[n] for n in g}
     worst = 0.0
     for n in g_a:
-        if ".conv1." not in n or "denseblock1" not in n:
+        if not ((".conv1." in n and "denseblock1" in n) or ".transition" in n):
             continue
         rel = float((g_a[n].double() - gsum[n]).norm() / gsum[n].norm())
         worst = max(worst, rel)
         assert rel <= 3e-2, (n, rel)
-    print("S=672, 5 streams, deterministic: dense block 1's 1x1 weight gradients vs the sum of single-rotation calls: worst relative error %.2e" % worst)
+    print("S=%d, %d streams, deterministic: dense block 1's 1x1 and the transitions' weight gradients vs the sum of single-rotation calls: worst relative error %.2e"
+          % (S, len(rots) + 1, worst))
